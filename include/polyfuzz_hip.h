@@ -1,0 +1,211 @@
+/*
+ * polyfuzz_hip.h -- C ABI of libpolyfuzz_hip.so, the MI355X (gfx950) engine
+ * behind PolyFuzz's TFIDF / EditDistance matchers.
+ *
+ * The reference (MaartenGr/PolyFuzz v0.4.3) is pure Python and has no FFI of
+ * its own; the entry points below are what a binding for its hot path would
+ * bind.  Each one cites the reference interface it replaces (file:line under
+ * the reference tree).  Conventions:
+ *   - plain pointers and sizes only; no torch / numpy types;
+ *   - every function returns 0 on success or a negative pfz_status; the
+ *     message of the last failure on the calling thread is pfz_last_error();
+ *   - host ("_host" / upload / download) entry points take caller-owned host
+ *     buffers; every other buffer is device memory owned by an opaque handle;
+ *   - all device work of a context is issued on that context's own HIP stream;
+ *     calls return after enqueueing unless documented otherwise
+ *     (downloads and pfz_ctx_sync block);
+ *   - "no match" is idx = -1, score = 0.
+ * There is NO CPU fallback anywhere behind this ABI: without a gfx950 device
+ * pfz_ctx_create fails with PFZ_ERR_NO_DEVICE.
+ */
+#ifndef POLYFUZZ_HIP_H
+#define POLYFUZZ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFZ_VERSION 100 /* 0.1.0 */
+
+typedef enum pfz_status {
+    PFZ_OK = 0,
+    PFZ_ERR_INVALID = -1,     /* bad argument */
+    PFZ_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    PFZ_ERR_HIP = -3,         /* a HIP runtime call failed (see pfz_last_error) */
+    PFZ_ERR_UNSUPPORTED = -4, /* valid request outside what the kernels cover */
+    PFZ_ERR_NOMEM = -5,
+    PFZ_ERR_RCCL = -6
+} pfz_status;
+
+typedef struct pfz_ctx pfz_ctx;       /* one device + one stream + scratch */
+typedef struct pfz_csr pfz_csr;       /* device-resident CSR matrix (fp32 values, sorted indices) */
+typedef struct pfz_index pfz_index;   /* device-resident inverted index of a to-side CSR */
+typedef struct pfz_topn pfz_topn;     /* device-resident (idx int32, score fp32)[n_rows][ntop] */
+typedef struct pfz_strings pfz_strings; /* device-resident packed string list */
+typedef struct pfz_tfidf pfz_tfidf;   /* fitted vectoriser: vocabulary + idf (+ to-side matrix/index) */
+
+/* ---- library / context -------------------------------------------------- */
+int pfz_version(void);
+const char *pfz_last_error(void);
+/* number of HIP devices, 0 if none (never an error) */
+int pfz_device_count(void);
+int pfz_ctx_create(int device, pfz_ctx **out);
+void pfz_ctx_destroy(pfz_ctx *ctx);
+int pfz_ctx_sync(pfz_ctx *ctx);
+/* device properties of the context: name (<=255 chars), CU count, HBM bytes */
+int pfz_ctx_info(pfz_ctx *ctx, char *name256, int32_t *n_cu, int64_t *hbm_bytes);
+
+/* HIP-event timers on the context's stream (used by bench.py for the live
+ * per-kernel timing the roofline is computed from).  slot in [0, 64). */
+int pfz_event_record(pfz_ctx *ctx, int32_t slot);
+/* blocks until both events completed */
+int pfz_event_elapsed_ms(pfz_ctx *ctx, int32_t slot_begin, int32_t slot_end, float *ms);
+/* per-kernel profile: when enabled, every launch of the named hot kernels is
+ * bracketed by its own event pair (adds a little launch overhead). */
+int pfz_prof_enable(pfz_ctx *ctx, int32_t on);
+int pfz_prof_reset(pfz_ctx *ctx);
+/* total ms and launch count of kernel `name` since the last reset (blocks). */
+int pfz_prof_get(pfz_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
+
+/* ---- CSR matrices --------------------------------------------------------
+ * The layout scipy.sparse.csr_matrix uses for TfidfVectorizer output
+ * (reference _tfidf.py:110-111): indptr[n_rows+1], indices[nnz] sorted per
+ * row, data[nnz].  Values are converted to fp32 by the caller. */
+int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols,
+                   const int64_t *indptr, const int32_t *indices, const float *data,
+                   pfz_csr **out);
+int pfz_csr_shape(const pfz_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+/* blocks; any of the three output pointers may be NULL */
+int pfz_csr_download(pfz_ctx *ctx, const pfz_csr *m, int64_t *indptr, int32_t *indices, float *data);
+void pfz_csr_free(pfz_csr *m);
+
+/* ---- K3: sparse cosine top-n ---------------------------------------------
+ * Replaces sparse_dot_topn.awesome_cossim_topn(from, to.T, top_n+1, min_sim)
+ * as called at reference polyfuzz/models/_utils.py:82, fused with the
+ * diagonal removal of _utils.py:84-87 and the per-row top-n extraction of
+ * _utils.py:89-91,128-146.
+ *
+ * pfz_index_build: device-side inverted index (n-gram id -> postings, split
+ * by to-row block) of the to-side matrix; built once per fit and kept
+ * resident (reference keeps self.tf_idf_to, _tfidf.py:110).  */
+int pfz_index_build(pfz_ctx *ctx, const pfz_csr *to_matrix, pfz_index **out);
+void pfz_index_free(pfz_index *ix);
+/* bytes of postings + offset table (for the bench's byte accounting) */
+int pfz_index_info(const pfz_index *ix, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
+                   int64_t *block_cols, int64_t *n_blocks, int64_t *table_bytes);
+
+int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out);
+void pfz_topn_free(pfz_topn *t);
+/* blocks; out_idx / out_val are [n_rows * ntop] row-major host buffers */
+int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *out_val);
+/* raw device pointers (for an RCCL all-gather issued by the caller) */
+int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int64_t *n_rows, int32_t *ntop);
+
+/* For every from-row i: the ntop largest cosine scores C[i][j] = sum_k
+ * A[i][k] * B[j][k] with C[i][j] > lower_bound (strict, as sparse_dot_topn),
+ * ordered by (score desc, j asc).  Accumulation is fp32, per (i,j) in
+ * ascending k.  exclude_diag != 0 drops j == i + diag_offset (self-match,
+ * _utils.py:84-87; diag_offset = global index of from-row 0 when the from
+ * side is a row shard).  lower_bound < 0 is treated as 0 (non-positive scores
+ * are "no match" in the reference's output contract, _utils.py:122-123).
+ * 1 <= ntop <= 128.  Enqueues on the context stream. */
+int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,
+                    int32_t ntop, float lower_bound, int32_t exclude_diag, int64_t diag_offset,
+                    pfz_topn *out);
+
+/* One-shot host convenience: upload both CSR matrices, build the index, run
+ * pfz_cossim_topn, download.  Blocks. */
+int pfz_cossim_topn_host(pfz_ctx *ctx,
+                         int64_t n_from, int64_t n_to, int64_t n_cols,
+                         const int64_t *from_indptr, const int32_t *from_indices, const float *from_data,
+                         const int64_t *to_indptr, const int32_t *to_indices, const float *to_data,
+                         int32_t ntop, float lower_bound, int32_t exclude_diag,
+                         int32_t *out_idx, float *out_val);
+
+/* ---- K1/K2: char-n-gram TF-IDF vectorisation ------------------------------
+ * Replaces TfidfVectorizer(min_df=1, analyzer=TFIDF._create_ngrams)
+ * .fit/.transform as used at reference _tfidf.py:102-118 (sklearn
+ * feature_extraction/text.py: vocabulary = sorted distinct n-grams, tf = raw
+ * count, idf = ln((1+n)/(1+df))+1, rows L2-normalised).
+ *
+ * Strings are passed as code units of `char_width` bytes (1: Latin-1/ASCII
+ * code points, 4: UTF-32 code points), concatenated, with n+1 offsets (in
+ * code units).  Cleaning (reference _tfidf.py:142-146) of ASCII input is done
+ * on the device; the host must pre-clean strings that contain non-ASCII code
+ * points (str.lower() is Unicode-aware) and pass clean = 0 for those. */
+int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, int64_t n_strings,
+                       int32_t char_width, pfz_strings **out);
+void pfz_strings_free(pfz_strings *s);
+
+typedef struct pfz_tfidf_params {
+    int32_t ngram_lo, ngram_hi;   /* inclusive, reference n_gram_range */
+    int32_t clean;                /* reference clean_string (ASCII fast path) */
+    int32_t remove_space_ngrams;  /* reference remove_space_ngrams */
+} pfz_tfidf_params;
+
+/* Fit the vocabulary and idf on the concatenation docs_a + docs_b (either may
+ * be NULL) -- reference: fit(to_list + from_list), _tfidf.py:109,114. */
+int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params,
+                  const pfz_strings *docs_a, const pfz_strings *docs_b, pfz_tfidf **out);
+void pfz_tfidf_free(pfz_tfidf *v);
+/* vocabulary size, number of fitted documents */
+int pfz_tfidf_info(const pfz_tfidf *v, int64_t *vocab_size, int64_t *n_docs, int32_t *code_bits);
+/* blocks; codes[vocab] = packed n-gram codes in vocabulary (column) order,
+ * idf[vocab] fp64, df[vocab].  Any pointer may be NULL. */
+int pfz_tfidf_export(pfz_ctx *ctx, const pfz_tfidf *v, uint64_t *codes, double *idf, int64_t *df);
+/* Re-create a fitted vectoriser from exported state (joblib load path). */
+int pfz_tfidf_import(pfz_ctx *ctx, const pfz_tfidf_params *params, int64_t vocab_size, int64_t n_docs,
+                     int32_t code_bits, const uint64_t *codes, const double *idf, pfz_tfidf **out);
+/* Vectorise a string list with a fitted vocabulary (out-of-vocabulary n-grams
+ * are ignored, sklearn text.py:1271-1273).  Enqueues; result resident. */
+int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *docs, pfz_csr **out);
+
+/* ---- K4: all-pairs Indel ratio + row arg-max ------------------------------
+ * Replaces the hot loop of EditDistance._calculate_edit_distance
+ * (reference polyfuzz/models/_distance.py:89-102) with scorer =
+ * rapidfuzz.fuzz.ratio (_distance.py:4,32): for every from-string the FIRST
+ * to-string with the maximal ratio (np.argmax, _distance.py:99) and that
+ * ratio as float64 = (1 - (|a|+|b|-2*LCS)/(|a|+|b|)) * 100 (100 when both
+ * are empty).  self_match != 0 restates list.remove(from_string)
+ * (_distance.py:93-96): the first to-entry EQUAL to the from-string is not a
+ * candidate.  opt_matrix_dev, if non-NULL, is a device buffer of
+ * n_from*n_to floats receiving every ratio (skipped entry = -1).
+ * Host output buffers; blocks. */
+int pfz_indel_argmax(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
+                     int32_t self_match, int64_t from_begin, int64_t from_end,
+                     int32_t *out_idx, double *out_score);
+/* same, results left on the device / full matrix to a host buffer */
+int pfz_indel_matrix_host(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
+                          int64_t from_begin, int64_t from_end, float *out_matrix);
+
+/* ---- K5: dense cosine top-n -----------------------------------------------
+ * Replaces cosine_similarity on dense embedding matrices
+ * (reference _utils.py:74-77,95; Embeddings.match _embeddings.py:127-133):
+ * rows are L2-normalised on the device (true cosine, as the sklearn branch),
+ * fp32 MFMA product, fused per-row top-n. Host buffers; blocks. */
+int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
+                               const float *to_vec, int64_t n_to, int64_t dim,
+                               int32_t ntop, float lower_bound, int32_t exclude_diag,
+                               int32_t *out_idx, float *out_val);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) ----------------------
+ * The from-side is row-sharded, the to-side replicated; the only exchange is
+ * the all-gather of per-shard results.  Bootstrap: rank 0 calls
+ * pfz_comm_unique_id, the 128-byte id is broadcast by the host launcher
+ * (torch.distributed / MPI / a file), every rank calls pfz_comm_init. */
+typedef struct pfz_comm pfz_comm;
+int pfz_comm_unique_id(uint8_t id128[128]);
+int pfz_comm_init(pfz_ctx *ctx, const uint8_t id128[128], int32_t rank, int32_t world, pfz_comm **out);
+void pfz_comm_destroy(pfz_comm *c);
+/* all-gather equal-sized shards of top-n results: `local` holds rows
+ * [rank*rows_per_rank, (rank+1)*rows_per_rank); `global` has world *
+ * rows_per_rank rows.  Enqueues on the context stream. */
+int pfz_comm_allgather_topn(pfz_comm *c, const pfz_topn *local, pfz_topn *global);
+int pfz_comm_barrier(pfz_comm *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYFUZZ_HIP_H */

@@ -1,0 +1,313 @@
+"""ctypes binding of libpolyfuzz_hip.so (the C ABI of include/polyfuzz_hip.h).
+
+No torch, no fallback: if the library is missing or no gfx950 device is visible
+the calls raise -- the host layer never computes similarities itself.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from . import _build
+
+c_i32, c_i64, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+c_vp = ctypes.c_void_p
+P = ctypes.POINTER
+
+
+class PfzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libpolyfuzz_hip error {code}: {msg}")
+        self.code = code
+
+
+class PfzUnsupported(PfzError, NotImplementedError):
+    pass
+
+
+class PfzNoDevice(PfzError):
+    pass
+
+
+class TfidfParams(ctypes.Structure):
+    _fields_ = [("ngram_lo", c_i32), ("ngram_hi", c_i32), ("clean", c_i32), ("remove_space_ngrams", c_i32)]
+
+
+# every symbol include/polyfuzz_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "pfz_version": (ctypes.c_int, []),
+    "pfz_last_error": (ctypes.c_char_p, []),
+    "pfz_device_count": (ctypes.c_int, []),
+    "pfz_ctx_create": (ctypes.c_int, [ctypes.c_int, P(c_vp)]),
+    "pfz_ctx_destroy": (None, [c_vp]),
+    "pfz_ctx_sync": (ctypes.c_int, [c_vp]),
+    "pfz_ctx_info": (ctypes.c_int, [c_vp, ctypes.c_char_p, P(c_i32), P(c_i64)]),
+    "pfz_event_record": (ctypes.c_int, [c_vp, c_i32]),
+    "pfz_event_elapsed_ms": (ctypes.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
+    "pfz_prof_enable": (ctypes.c_int, [c_vp, c_i32]),
+    "pfz_prof_reset": (ctypes.c_int, [c_vp]),
+    "pfz_prof_get": (ctypes.c_int, [c_vp, ctypes.c_char_p, P(c_f64), P(c_i64)]),
+    "pfz_csr_upload": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
+    "pfz_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
+    "pfz_csr_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pfz_csr_free": (None, [c_vp]),
+    "pfz_index_build": (ctypes.c_int, [c_vp, c_vp, P(c_vp)]),
+    "pfz_index_free": (None, [c_vp]),
+    "pfz_index_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
+    "pfz_topn_alloc": (ctypes.c_int, [c_vp, c_i64, c_i32, P(c_vp)]),
+    "pfz_topn_free": (None, [c_vp]),
+    "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "pfz_topn_device_ptrs": (ctypes.c_int, [c_vp, P(c_vp), P(c_vp), P(c_i64), P(c_i32)]),
+    "pfz_cossim_topn": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_f32, c_i32, c_i64, c_vp]),
+    "pfz_cossim_topn_host": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            c_i32, c_f32, c_i32, c_vp, c_vp]),
+    "pfz_strings_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, P(c_vp)]),
+    "pfz_strings_free": (None, [c_vp]),
+    "pfz_tfidf_fit": (ctypes.c_int, [c_vp, P(TfidfParams), c_vp, c_vp, P(c_vp)]),
+    "pfz_tfidf_free": (None, [c_vp]),
+    "pfz_tfidf_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i32)]),
+    "pfz_tfidf_export": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pfz_tfidf_import": (ctypes.c_int, [c_vp, P(TfidfParams), c_i64, c_i64, c_i32, c_vp, c_vp, P(c_vp)]),
+    "pfz_tfidf_transform": (ctypes.c_int, [c_vp, c_vp, c_vp, P(c_vp)]),
+    "pfz_indel_argmax": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp]),
+    "pfz_indel_matrix_host": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "pfz_dense_cossim_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
+                                                  c_vp, c_vp]),
+    "pfz_comm_unique_id": (ctypes.c_int, [c_vp]),
+    "pfz_comm_init": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_vp)]),
+    "pfz_comm_destroy": (None, [c_vp]),
+    "pfz_comm_allgather_topn": (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    "pfz_comm_barrier": (ctypes.c_int, [c_vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libpolyfuzz_hip.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950).  polyfuzz_amd has no CPU fallback.")
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = load().pfz_last_error().decode("utf-8", "replace")
+    if rc == -4:
+        raise PfzUnsupported(rc, msg)
+    if rc == -2:
+        raise PfzNoDevice(rc, msg)
+    raise PfzError(rc, msg)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_vp)
+
+
+def device_count():
+    return int(load().pfz_device_count())
+
+
+class Context:
+    """One HIP device + stream.  `Context.default()` is a per-process singleton on
+    device POLYFUZZ_HIP_DEVICE (or LOCAL_RANK, or 0)."""
+    _default = None
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("POLYFUZZ_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self.lib = load()
+        h = c_vp()
+        check(self.lib.pfz_ctx_create(int(device), ctypes.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    @classmethod
+    def default(cls):
+        if cls._default is None:
+            cls._default = cls()
+        return cls._default
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pfz_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.pfz_ctx_sync(self.h))
+
+    def info(self):
+        name = ctypes.create_string_buffer(256)
+        ncu, mem = c_i32(), c_i64()
+        check(self.lib.pfz_ctx_info(self.h, name, ctypes.byref(ncu), ctypes.byref(mem)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    # timers ---------------------------------------------------------------
+    def event_record(self, slot):
+        check(self.lib.pfz_event_record(self.h, slot))
+
+    def event_elapsed_ms(self, a, b):
+        ms = c_f32()
+        check(self.lib.pfz_event_elapsed_ms(self.h, a, b, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def prof_enable(self, on=True):
+        check(self.lib.pfz_prof_enable(self.h, int(bool(on))))
+
+    def prof_reset(self):
+        check(self.lib.pfz_prof_reset(self.h))
+
+    def prof_get(self, name):
+        ms, n = c_f64(), c_i64()
+        check(self.lib.pfz_prof_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+
+class _Handle:
+    _free = None
+
+    def __init__(self, ctx, h):
+        self.ctx = ctx
+        self.h = h
+
+    def free(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            getattr(self.ctx.lib, self._free)(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceCSR(_Handle):
+    _free = "pfz_csr_free"
+
+    @classmethod
+    def upload(cls, ctx, indptr, indices, data, n_cols):
+        indptr = np.ascontiguousarray(indptr, np.int64)
+        indices = np.ascontiguousarray(indices, np.int32)
+        data = np.ascontiguousarray(data, np.float32)
+        h = c_vp()
+        check(ctx.lib.pfz_csr_upload(ctx.h, len(indptr) - 1, int(n_cols), _ptr(indptr), _ptr(indices), _ptr(data),
+                                     ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_scipy(cls, ctx, m):
+        m = m.tocsr()
+        if not m.has_sorted_indices:
+            m = m.sorted_indices()
+        return cls.upload(ctx, m.indptr, m.indices, m.data, m.shape[1])
+
+    @property
+    def shape(self):
+        r, c, z = c_i64(), c_i64(), c_i64()
+        check(self.ctx.lib.pfz_csr_shape(self.h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(z)))
+        return r.value, c.value, z.value
+
+    def download(self):
+        n_rows, n_cols, nnz = self.shape
+        indptr = np.empty(n_rows + 1, np.int64)
+        indices = np.empty(nnz, np.int32)
+        data = np.empty(nnz, np.float32)
+        check(self.ctx.lib.pfz_csr_download(self.ctx.h, self.h, _ptr(indptr), _ptr(indices), _ptr(data)))
+        return indptr, indices, data, n_cols
+
+
+class DeviceIndex(_Handle):
+    _free = "pfz_index_free"
+
+    @classmethod
+    def build(cls, ctx, to_csr):
+        h = c_vp()
+        check(ctx.lib.pfz_index_build(ctx.h, to_csr.h, ctypes.byref(h)))
+        return cls(ctx, h)
+
+    def info(self):
+        v = [c_i64() for _ in range(6)]
+        check(self.ctx.lib.pfz_index_info(self.h, *[ctypes.byref(x) for x in v]))
+        keys = ("n_rows", "n_cols", "nnz", "block_cols", "n_blocks", "table_bytes")
+        return dict(zip(keys, (x.value for x in v)))
+
+
+class DeviceTopN(_Handle):
+    _free = "pfz_topn_free"
+
+    @classmethod
+    def alloc(cls, ctx, n_rows, ntop):
+        h = c_vp()
+        check(ctx.lib.pfz_topn_alloc(ctx.h, int(n_rows), int(ntop), ctypes.byref(h)))
+        t = cls(ctx, h)
+        t.n_rows, t.ntop = int(n_rows), int(ntop)
+        return t
+
+    def download(self):
+        idx = np.empty((self.n_rows, self.ntop), np.int32)
+        val = np.empty((self.n_rows, self.ntop), np.float32)
+        check(self.ctx.lib.pfz_topn_download(self.ctx.h, self.h, _ptr(idx), _ptr(val)))
+        return idx, val
+
+    def device_ptrs(self):
+        pi, pv = c_vp(), c_vp()
+        check(self.ctx.lib.pfz_topn_device_ptrs(self.h, ctypes.byref(pi), ctypes.byref(pv), None, None))
+        return pi.value, pv.value
+
+
+def cossim_topn(ctx, index, from_csr, ntop, lower_bound, exclude_diag=False, diag_offset=0, out=None):
+    """Enqueue K3; returns the (device-resident) DeviceTopN."""
+    n_rows = from_csr.shape[0]
+    if out is None:
+        out = DeviceTopN.alloc(ctx, n_rows, ntop)
+    check(ctx.lib.pfz_cossim_topn(ctx.h, index.h, from_csr.h, int(ntop), float(lower_bound),
+                                  int(bool(exclude_diag)), int(diag_offset), out.h))
+    return out
+
+
+def cossim_topn_host(ctx, from_csr3, to_csr3, n_cols, ntop, lower_bound, exclude_diag=False):
+    """One-shot: (indptr, indices, data) host triples in, (idx, val) host arrays out."""
+    fp, fi, fv = from_csr3
+    tp, ti, tv = to_csr3
+    fp = np.ascontiguousarray(fp, np.int64)
+    fi = np.ascontiguousarray(fi, np.int32)
+    fv = np.ascontiguousarray(fv, np.float32)
+    tp = np.ascontiguousarray(tp, np.int64)
+    ti = np.ascontiguousarray(ti, np.int32)
+    tv = np.ascontiguousarray(tv, np.float32)
+    n_from, n_to = len(fp) - 1, len(tp) - 1
+    idx = np.empty((n_from, ntop), np.int32)
+    val = np.empty((n_from, ntop), np.float32)
+    check(ctx.lib.pfz_cossim_topn_host(ctx.h, n_from, n_to, int(n_cols), _ptr(fp), _ptr(fi), _ptr(fv),
+                                       _ptr(tp), _ptr(ti), _ptr(tv), int(ntop), float(lower_bound),
+                                       int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
+    return idx, val

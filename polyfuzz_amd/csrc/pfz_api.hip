@@ -1,0 +1,444 @@
+// Context, error reporting, timers, CSR / top-n containers and the shared
+// device scan of libpolyfuzz_hip.so.
+#include "pfz_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace pfz {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    if (e == hipErrorOutOfMemory) return PFZ_ERR_NOMEM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return PFZ_ERR_NO_DEVICE;
+    return PFZ_ERR_HIP;
+}
+
+int ensure_scratch(pfz_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return PFZ_OK;
+    if (ctx->scratch) {
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        PFZ_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    size_t want = bytes + bytes / 4 + 4096;
+    PFZ_HIP(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+    return PFZ_OK;
+}
+
+ProfScope::ProfScope(pfz_ctx *c, const char *n) : ctx(c), name(n)
+{
+    if (!ctx->prof) return;
+    auto take = [&]() -> hipEvent_t {
+        if (!ctx->event_pool.empty()) {
+            hipEvent_t ev = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+            return ev;
+        }
+        hipEvent_t ev = nullptr;
+        (void)hipEventCreate(&ev);
+        return ev;
+    };
+    b = take();
+    e = take();
+    (void)hipEventRecord(b, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!ctx->prof || !b || !e) return;
+    (void)hipEventRecord(e, ctx->stream);
+    ProfEntry &pe = ctx->prof_entries[name];
+    pe.begin.push_back(b);
+    pe.end.push_back(e);
+}
+
+static void prof_fold(pfz_ctx *ctx, ProfEntry &pe)
+{
+    for (size_t i = 0; i < pe.begin.size(); ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(pe.end[i]);
+        if (hipEventElapsedTime(&ms, pe.begin[i], pe.end[i]) == hipSuccess) {
+            pe.total_ms += ms;
+            pe.launches += 1;
+        }
+        ctx->event_pool.push_back(pe.begin[i]);
+        ctx->event_pool.push_back(pe.end[i]);
+    }
+    pe.begin.clear();
+    pe.end.clear();
+}
+
+// ---- multi-block exclusive scan (int32) -----------------------------------
+// Three launches: per-tile sums, scan of the tile sums (one workgroup), tile
+// re-scan with the carried-in base.  Tile = 256 threads x 16 items.
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 16;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ inline int32_t wave_incl_scan(int32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan across the 256 threads of a workgroup; returns the prefix of
+// this thread, *total = workgroup sum.
+__device__ inline int32_t block_excl_scan(int32_t v, int32_t *lds4, int32_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    int32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        int32_t s = lds4[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const int32_t *__restrict__ in, int64_t n,
+                                                                 int32_t *__restrict__ tile_sums)
+{
+    __shared__ int32_t lds4[kScanThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        int64_t p = base + i;
+        if (p < n) s += in[p];
+    }
+    int32_t tot;
+    (void)block_excl_scan(s, lds4, &tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_sums(int32_t *__restrict__ tile_sums, int64_t n_tiles,
+                                                            int32_t *__restrict__ grand_total)
+{
+    __shared__ int32_t lds4[kScanThreads / 64];
+    int32_t carry = 0;
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += kScanThreads) {
+        int64_t p = t0 + threadIdx.x;
+        int32_t v = (p < n_tiles) ? tile_sums[p] : 0;
+        int32_t tot;
+        int32_t ex = block_excl_scan(v, lds4, &tot);
+        if (p < n_tiles) tile_sums[p] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(int32_t *__restrict__ data, int64_t n,
+                                                             const int32_t *__restrict__ tile_sums)
+{
+    __shared__ int32_t lds4[kScanThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int32_t v[kScanItems];
+    int32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        int64_t p = base + i;
+        v[i] = (p < n) ? data[p] : 0;
+        s += v[i];
+    }
+    int32_t tot;
+    int32_t ex = block_excl_scan(s, lds4, &tot) + tile_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        int64_t p = base + i;
+        if (p < n) data[p] = ex;
+        ex += v[i];
+    }
+}
+
+int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n)
+{
+    if (n <= 0) {
+        PFZ_HIP(hipMemsetAsync(data, 0, sizeof(int32_t), ctx->stream));
+        return PFZ_OK;
+    }
+    const int64_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    PFZ_TRY(ensure_scratch(ctx, (size_t)n_tiles * sizeof(int32_t)));
+    int32_t *tile_sums = (int32_t *)ctx->scratch;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(kScanThreads), 0, ctx->stream, data, n, tile_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, ctx->stream, tile_sums, n_tiles, data + n);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(kScanThreads), 0, ctx->stream, data, n, tile_sums);
+    PFZ_HIP(hipGetLastError());
+    return PFZ_OK;
+}
+
+}  // namespace pfz
+
+using namespace pfz;
+
+extern "C" {
+
+int pfz_version(void) { return PFZ_VERSION; }
+
+const char *pfz_last_error(void) { return pfz::g_err; }
+
+int pfz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pfz_ctx_create(int device, pfz_ctx **out)
+{
+    PFZ_REQUIRE(out != nullptr, "pfz_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("pfz_ctx_create: no HIP device visible (hipGetDeviceCount -> %d, %s); "
+                  "libpolyfuzz_hip has no CPU fallback", (int)e, hipGetErrorString(e));
+        return PFZ_ERR_NO_DEVICE;
+    }
+    PFZ_REQUIRE(device >= 0 && device < n, "pfz_ctx_create: device %d out of range [0,%d)", device, n);
+    PFZ_HIP(hipSetDevice(device));
+    pfz_ctx *ctx = new pfz_ctx();
+    ctx->device = device;
+    PFZ_HIP(hipGetDeviceProperties(&ctx->prop, device));
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("pfz_ctx_create: device %d is %s; this library ships gfx950 code objects only",
+                  device, ctx->prop.gcnArchName);
+        delete ctx;
+        return PFZ_ERR_NO_DEVICE;
+    }
+    PFZ_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (int i = 0; i < kEventSlots; ++i) PFZ_HIP(hipEventCreate(&ctx->events[i]));
+    *out = ctx;
+    return PFZ_OK;
+}
+
+void pfz_ctx_destroy(pfz_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->prof_entries) prof_fold(ctx, kv.second);
+    for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < kEventSlots; ++i)
+        if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pfz_ctx_sync(pfz_ctx *ctx)
+{
+    PFZ_REQUIRE(ctx, "pfz_ctx_sync: ctx is NULL");
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    return PFZ_OK;
+}
+
+int pfz_ctx_info(pfz_ctx *ctx, char *name256, int32_t *n_cu, int64_t *hbm_bytes)
+{
+    PFZ_REQUIRE(ctx, "pfz_ctx_info: ctx is NULL");
+    if (name256) snprintf(name256, 256, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    return PFZ_OK;
+}
+
+int pfz_event_record(pfz_ctx *ctx, int32_t slot)
+{
+    PFZ_REQUIRE(ctx && slot >= 0 && slot < kEventSlots, "pfz_event_record: bad slot %d", slot);
+    PFZ_HIP(hipEventRecord(ctx->events[slot], ctx->stream));
+    return PFZ_OK;
+}
+
+int pfz_event_elapsed_ms(pfz_ctx *ctx, int32_t a, int32_t b, float *ms)
+{
+    PFZ_REQUIRE(ctx && ms && a >= 0 && a < kEventSlots && b >= 0 && b < kEventSlots, "pfz_event_elapsed_ms: bad args");
+    PFZ_HIP(hipEventSynchronize(ctx->events[a]));
+    PFZ_HIP(hipEventSynchronize(ctx->events[b]));
+    PFZ_HIP(hipEventElapsedTime(ms, ctx->events[a], ctx->events[b]));
+    return PFZ_OK;
+}
+
+int pfz_prof_enable(pfz_ctx *ctx, int32_t on)
+{
+    PFZ_REQUIRE(ctx, "pfz_prof_enable: ctx is NULL");
+    ctx->prof = on != 0;
+    return PFZ_OK;
+}
+
+int pfz_prof_reset(pfz_ctx *ctx)
+{
+    PFZ_REQUIRE(ctx, "pfz_prof_reset: ctx is NULL");
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->prof_entries) {
+        prof_fold(ctx, kv.second);
+        kv.second.total_ms = 0.0;
+        kv.second.launches = 0;
+    }
+    return PFZ_OK;
+}
+
+int pfz_prof_get(pfz_ctx *ctx, const char *name, double *total_ms, int64_t *launches)
+{
+    PFZ_REQUIRE(ctx && name, "pfz_prof_get: bad args");
+    auto it = ctx->prof_entries.find(name);
+    if (it == ctx->prof_entries.end()) {
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = 0;
+        return PFZ_OK;
+    }
+    prof_fold(ctx, it->second);
+    if (total_ms) *total_ms = it->second.total_ms;
+    if (launches) *launches = it->second.launches;
+    return PFZ_OK;
+}
+
+// ---- CSR -------------------------------------------------------------------
+
+int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *indptr,
+                   const int32_t *indices, const float *data, pfz_csr **out)
+{
+    PFZ_REQUIRE(ctx && out && indptr, "pfz_csr_upload: NULL argument");
+    PFZ_REQUIRE(n_rows >= 0 && n_cols >= 0, "pfz_csr_upload: negative shape");
+    const int64_t nnz = indptr[n_rows];
+    PFZ_REQUIRE(indptr[0] == 0 && nnz >= 0, "pfz_csr_upload: indptr must start at 0");
+    if (nnz >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31) - 1) {
+        set_error("pfz_csr_upload: nnz=%lld / n_rows=%lld exceed the int32 device layout", (long long)nnz, (long long)n_rows);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    PFZ_REQUIRE(nnz == 0 || (indices && data), "pfz_csr_upload: NULL indices/data");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    pfz_csr *m = new pfz_csr();
+    m->ctx = ctx;
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    m->nnz = nnz;
+    std::vector<int32_t> ip32((size_t)n_rows + 1);
+    for (int64_t i = 0; i <= n_rows; ++i) {
+        if (i > 0 && indptr[i] < indptr[i - 1]) {
+            delete m;
+            set_error("pfz_csr_upload: indptr not monotone at row %lld", (long long)i);
+            return PFZ_ERR_INVALID;
+        }
+        ip32[(size_t)i] = (int32_t)indptr[i];
+    }
+    PFZ_HIP(hipMalloc(&m->indptr, (size_t)(n_rows + 1) * sizeof(int32_t)));
+    PFZ_HIP(hipMalloc(&m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
+    PFZ_HIP(hipMalloc(&m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
+    PFZ_HIP(hipMemcpyAsync(m->indptr, ip32.data(), (size_t)(n_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz > 0) {
+        PFZ_HIP(hipMemcpyAsync(m->indices, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        PFZ_HIP(hipMemcpyAsync(m->data, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));  // ip32 is a temporary
+    *out = m;
+    return PFZ_OK;
+}
+
+int pfz_csr_shape(const pfz_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
+{
+    PFZ_REQUIRE(m, "pfz_csr_shape: NULL matrix");
+    if (n_rows) *n_rows = m->n_rows;
+    if (n_cols) *n_cols = m->n_cols;
+    if (nnz) *nnz = m->nnz;
+    return PFZ_OK;
+}
+
+int pfz_csr_download(pfz_ctx *ctx, const pfz_csr *m, int64_t *indptr, int32_t *indices, float *data)
+{
+    PFZ_REQUIRE(ctx && m, "pfz_csr_download: NULL argument");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (indptr) {
+        std::vector<int32_t> ip32((size_t)m->n_rows + 1);
+        PFZ_HIP(hipMemcpy(ip32.data(), m->indptr, ip32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ip32.size(); ++i) indptr[i] = ip32[i];
+    }
+    if (indices && m->nnz > 0) PFZ_HIP(hipMemcpy(indices, m->indices, (size_t)m->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (data && m->nnz > 0) PFZ_HIP(hipMemcpy(data, m->data, (size_t)m->nnz * sizeof(float), hipMemcpyDeviceToHost));
+    return PFZ_OK;
+}
+
+void pfz_csr_free(pfz_csr *m)
+{
+    if (!m) return;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->indptr) (void)hipFree(m->indptr);
+    if (m->indices) (void)hipFree(m->indices);
+    if (m->data) (void)hipFree(m->data);
+    delete m;
+}
+
+// ---- top-n result container -------------------------------------------------
+
+int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out)
+{
+    PFZ_REQUIRE(ctx && out && n_rows >= 0 && ntop >= 1, "pfz_topn_alloc: bad args");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    pfz_topn *t = new pfz_topn();
+    t->ctx = ctx;
+    t->n_rows = n_rows;
+    t->ntop = ntop;
+    size_t n = (size_t)(n_rows > 0 ? n_rows : 1) * (size_t)ntop;
+    PFZ_HIP(hipMalloc(&t->idx, n * sizeof(int32_t)));
+    PFZ_HIP(hipMalloc(&t->val, n * sizeof(float)));
+    *out = t;
+    return PFZ_OK;
+}
+
+void pfz_topn_free(pfz_topn *t)
+{
+    if (!t) return;
+    if (t->ctx) (void)hipSetDevice(t->ctx->device);
+    if (t->idx) (void)hipFree(t->idx);
+    if (t->val) (void)hipFree(t->val);
+    delete t;
+}
+
+int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *out_val)
+{
+    PFZ_REQUIRE(ctx && t, "pfz_topn_download: NULL argument");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    size_t n = (size_t)t->n_rows * (size_t)t->ntop;
+    if (n == 0) return PFZ_OK;
+    if (out_idx) PFZ_HIP(hipMemcpy(out_idx, t->idx, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_val) PFZ_HIP(hipMemcpy(out_val, t->val, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PFZ_OK;
+}
+
+int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int64_t *n_rows, int32_t *ntop)
+{
+    PFZ_REQUIRE(t, "pfz_topn_device_ptrs: NULL argument");
+    if (idx_dev) *idx_dev = t->idx;
+    if (val_dev) *val_dev = t->val;
+    if (n_rows) *n_rows = t->n_rows;
+    if (ntop) *ntop = t->ntop;
+    return PFZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+"""GPU parity of K3 (sparse cosine top-n) against the oracle and the reference goldens.
+
+Bar: indices bit-exact against the oracle's canonical order (score desc, col
+asc) except where the float64 oracle itself separates two candidates by less
+than NEAR_TIE (fp32 accumulation cannot resolve those); scores within 1e-5.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_topn_parity, vectorize_pair, random_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, a3, b3, n_col, ntop, lb, diag=False):
+    from polyfuzz_amd import _lib
+    return _lib.cossim_topn_host(ctx, a3, b3, n_col, ntop, lb, diag)
+
+
+def test_readme_lists(ctx, oracle_mod):
+    fl = ["apple", "apples", "appl", "recal", "house", "similarity"]
+    tl = ["apple", "apples", "mouse"]
+    a3, b3, n_col = vectorize_pair(oracle_mod, fl, tl)
+    idx, val = _run(ctx, a3, b3, n_col, 3, 0.0)
+    # known answers: SURVEY.md §8c / reference README.md:88-95
+    np.testing.assert_array_equal(idx[:, 0], [0, 1, 0, -1, 2, -1])
+    np.testing.assert_allclose(val[:, 0], [1.0, 1.0, 0.783751479, 0.0, 0.587926596, 0.0], atol=1e-6)
+    np.testing.assert_array_equal(idx[:, 1], [1, 0, 1, -1, -1, -1])
+    np.testing.assert_allclose(val[:3, 1], [0.777651595, 0.777651595, 0.609485588], atol=1e-6)
+    assert (idx[:, 2] == -1).all()
+    # strict lower bound 0.75: house->mouse (0.588) disappears
+    idx, val = _run(ctx, a3, b3, n_col, 1, 0.75)
+    np.testing.assert_array_equal(idx[:, 0], [0, 1, 0, -1, -1, -1])
+
+
+@pytest.mark.parametrize("ntop,lb", [(5, 0.0), (1, 0.0), (5, 0.75), (10, 0.3)])
+def test_company_c2_vs_oracle(ctx, oracle_mod, golden, ntop, lb):
+    fl = golden["company_c2_lists"]["from_list"]
+    tl = golden["company_c2_lists"]["to_list"]
+    a3, b3, n_col = vectorize_pair(oracle_mod, fl, tl, cache_key="c2")
+    idx, val = _run(ctx, a3, b3, n_col, ntop, lb)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col, ntop, lb)
+    assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, n_col)
+
+
+def test_company_c2_vs_reference_golden(ctx, oracle_mod, golden):
+    """Against the reference's own run (tests/golden/make_golden.py): canonical top-5 of its dense matrix."""
+    fl = golden["company_c2_lists"]["from_list"]
+    tl = golden["company_c2_lists"]["to_list"]
+    a3, b3, n_col = vectorize_pair(oracle_mod, fl, tl, cache_key="c2")
+    assert n_col == int(golden["npz"]["c2_vocab_size"][0])
+    idx, val = _run(ctx, a3, b3, n_col, 5, 0.0)
+    assert_topn_parity(idx, val, golden["npz"]["c2_canon_idx"], golden["npz"]["c2_canon_val"],
+                       oracle_mod, a3, b3, n_col)
+    # the reference's printed (3-dp rounded) scores
+    np.testing.assert_allclose(np.round(val.astype(np.float64), 3), golden["npz"]["c2_ref_sim"], atol=1.01e-3)
+
+
+def test_company_self_match(ctx, oracle_mod, golden):
+    sl = golden["company_self_list"]["from_list"]
+    a3, b3, n_col = vectorize_pair(oracle_mod, sl, None)
+    idx, val = _run(ctx, a3, a3, n_col, 3, 0.0, diag=True)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, a3, n_col, 3, 0.0, exclude_diag=True)
+    assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, a3, n_col, exclude_diag=True)
+    assert (idx[:, 0] != np.arange(len(sl))).all()
+    assert_topn_parity(idx, val, golden["npz"]["self_canon_idx"], golden["npz"]["self_canon_val"],
+                       oracle_mod, a3, a3, n_col, exclude_diag=True)
+
+
+@pytest.mark.parametrize("n_a,n_b,n_col,dens,ntop", [
+    (1, 1, 5, 0.9, 1), (3, 5000, 40, 0.2, 7), (257, 2049, 300, 0.05, 4), (64, 4097, 64, 0.5, 128),
+    (100, 70, 2000, 0.09, 3),   # rows with > 64 n-grams
+])
+def test_random_csr_shapes(ctx, oracle_mod, n_a, n_b, n_col, dens, ntop):
+    rng = np.random.default_rng(n_a * 7 + n_b)
+    a3 = random_csr(rng, n_a, n_col, dens)
+    b3 = random_csr(rng, n_b, n_col, dens)
+    idx, val = _run(ctx, a3, b3, n_col, ntop, 0.1)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col, ntop, 0.1)
+    assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, n_col)
+
+
+def test_empty_and_degenerate(ctx, oracle_mod):
+    rng = np.random.default_rng(3)
+    b3 = random_csr(rng, 50, 30, 0.2)
+    # from-side with empty rows
+    a3 = random_csr(rng, 20, 30, 0.2, empty_rows=[0, 7, 19])
+    idx, val = _run(ctx, a3, b3, 30, 2, 0.0)
+    assert (idx[[0, 7, 19]] == -1).all() and (val[[0, 7, 19]] == 0).all()
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, 30, 2, 0.0)
+    assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, 30)
+    # empty to-side
+    e3 = (np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float64))
+    idx, val = _run(ctx, a3, e3, 30, 2, 0.0)
+    assert idx.shape == (20, 2) and (idx == -1).all()
+    # empty from-side
+    idx, val = _run(ctx, e3, b3, 30, 2, 0.0)
+    assert idx.shape == (0, 2)
+    # duplicated to-rows: exact ties resolve to the lower column
+    dup = (np.concatenate([b3[0], b3[0][1:] + b3[0][-1]]), np.concatenate([b3[1], b3[1]]),
+           np.concatenate([b3[2], b3[2]]))
+    idx, val = _run(ctx, a3, dup, 30, 4, 0.0)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, dup, 30, 4, 0.0)
+    np.testing.assert_array_equal(idx, exp_idx)
+
+
+def test_bad_arguments(ctx):
+    from polyfuzz_amd import _lib, PfzError
+    e3 = (np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    with pytest.raises(PfzError):
+        _lib.cossim_topn_host(ctx, e3, e3, 4, 0, 0.0)
+    with pytest.raises(NotImplementedError):
+        _lib.cossim_topn_host(ctx, e3, e3, 4, 1000, 0.0)
