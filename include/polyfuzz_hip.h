@@ -150,14 +150,17 @@ typedef struct pfz_tfidf_params {
 int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params,
                   const pfz_strings *docs_a, const pfz_strings *docs_b, pfz_tfidf **out);
 void pfz_tfidf_free(pfz_tfidf *v);
-/* vocabulary size, number of fitted documents */
+/* vocabulary size, number of fitted documents, bits of the packed n-gram code */
 int pfz_tfidf_info(const pfz_tfidf *v, int64_t *vocab_size, int64_t *n_docs, int32_t *code_bits);
-/* blocks; codes[vocab] = packed n-gram codes in vocabulary (column) order,
- * idf[vocab] fp64, df[vocab].  Any pointer may be NULL. */
-int pfz_tfidf_export(pfz_ctx *ctx, const pfz_tfidf *v, uint64_t *codes, double *idf, int64_t *df);
-/* Re-create a fitted vectoriser from exported state (joblib load path). */
+/* blocks; ngrams[vocab * ngram_hi] = the vocabulary in column order, each
+ * n-gram as ngram_hi UTF-32 code points (shorter n-grams 0-padded on the
+ * right) -- independent of the device-side code packing; idf[vocab] fp64
+ * (sklearn idf_), df[vocab].  Any pointer may be NULL. */
+int pfz_tfidf_export(pfz_ctx *ctx, const pfz_tfidf *v, uint32_t *ngrams, double *idf, int64_t *df);
+/* Re-create a fitted vectoriser from exported state (joblib load path,
+ * reference polyfuzz.py:429-457).  ngrams must be sorted as exported. */
 int pfz_tfidf_import(pfz_ctx *ctx, const pfz_tfidf_params *params, int64_t vocab_size, int64_t n_docs,
-                     int32_t code_bits, const uint64_t *codes, const double *idf, pfz_tfidf **out);
+                     const uint32_t *ngrams, const double *idf, pfz_tfidf **out);
 /* Vectorise a string list with a fitted vocabulary (out-of-vocabulary n-grams
  * are ignored, sklearn text.py:1271-1273).  Enqueues; result resident. */
 int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *docs, pfz_csr **out);
@@ -168,17 +171,19 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
  * rapidfuzz.fuzz.ratio (_distance.py:4,32): for every from-string the FIRST
  * to-string with the maximal ratio (np.argmax, _distance.py:99) and that
  * ratio as float64 = (1 - (|a|+|b|-2*LCS)/(|a|+|b|)) * 100 (100 when both
- * are empty).  self_match != 0 restates list.remove(from_string)
- * (_distance.py:93-96): the first to-entry EQUAL to the from-string is not a
- * candidate.  opt_matrix_dev, if non-NULL, is a device buffer of
- * n_from*n_to floats receiving every ratio (skipped entry = -1).
- * Host output buffers; blocks. */
+ * are empty).  skip_idx (host, one entry per from-string of the whole list, or
+ * NULL) restates list.remove(from_string) of the self-match path
+ * (_distance.py:93-96): skip_idx[i] is the index of the FIRST to-entry equal
+ * to from-string i (-1: none) and is not a candidate for row i.
+ * Rows [from_begin, from_end) are scored (a row shard); out_idx / out_score
+ * are host buffers of from_end - from_begin entries.  Blocks. */
 int pfz_indel_argmax(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
-                     int32_t self_match, int64_t from_begin, int64_t from_end,
+                     const int32_t *skip_idx, int64_t from_begin, int64_t from_end,
                      int32_t *out_idx, double *out_score);
-/* same, results left on the device / full matrix to a host buffer */
+/* every ratio of rows [from_begin, from_end) x all to-strings as float64,
+ * row-major host buffer (test / small-input entry point).  Blocks. */
 int pfz_indel_matrix_host(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
-                          int64_t from_begin, int64_t from_end, float *out_matrix);
+                          int64_t from_begin, int64_t from_end, double *out_matrix);
 
 /* ---- K5: dense cosine top-n -----------------------------------------------
  * Replaces cosine_similarity on dense embedding matrices

@@ -68,9 +68,9 @@ SIGNATURES = {
     "pfz_tfidf_free": (None, [c_vp]),
     "pfz_tfidf_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i32)]),
     "pfz_tfidf_export": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "pfz_tfidf_import": (ctypes.c_int, [c_vp, P(TfidfParams), c_i64, c_i64, c_i32, c_vp, c_vp, P(c_vp)]),
+    "pfz_tfidf_import": (ctypes.c_int, [c_vp, P(TfidfParams), c_i64, c_i64, c_vp, c_vp, P(c_vp)]),
     "pfz_tfidf_transform": (ctypes.c_int, [c_vp, c_vp, c_vp, P(c_vp)]),
-    "pfz_indel_argmax": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp]),
+    "pfz_indel_argmax": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "pfz_indel_matrix_host": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "pfz_dense_cossim_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                   c_vp, c_vp]),
@@ -310,4 +310,126 @@ def cossim_topn_host(ctx, from_csr3, to_csr3, n_cols, ntop, lower_bound, exclude
     check(ctx.lib.pfz_cossim_topn_host(ctx.h, n_from, n_to, int(n_cols), _ptr(fp), _ptr(fi), _ptr(fv),
                                        _ptr(tp), _ptr(ti), _ptr(tv), int(ntop), float(lower_bound),
                                        int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
+    return idx, val
+
+
+# ---- strings / vectoriser -------------------------------------------------------
+
+def pack_strings(strings):
+    """list[str] -> (code units ndarray, offsets int64[n+1], char_width).
+
+    1-byte code units (Latin-1) when every code point is <= 0xFF, UTF-32 otherwise."""
+    n = len(strings)
+    lens = np.fromiter((len(s) for s in strings), np.int64, n)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    joined = "".join(strings)
+    try:
+        raw = joined.encode("latin-1")
+        chars = np.frombuffer(raw, np.uint8)
+        width = 1
+    except UnicodeEncodeError:
+        raw = joined.encode("utf-32-le", "surrogatepass")
+        chars = np.frombuffer(raw, np.uint32)
+        width = 4
+    if len(chars) != off[-1]:
+        raise ValueError("string packing length mismatch")
+    return chars, off, width
+
+
+class DeviceStrings(_Handle):
+    _free = "pfz_strings_free"
+
+    @classmethod
+    def upload(cls, ctx, strings):
+        chars, off, width = pack_strings(strings)
+        h = c_vp()
+        check(ctx.lib.pfz_strings_upload(ctx.h, _ptr(chars) if len(chars) else None, _ptr(off), len(strings), width,
+                                         ctypes.byref(h)))
+        s = cls(ctx, h)
+        s.n = len(strings)
+        s.char_width = width
+        return s
+
+
+class DeviceTfidf(_Handle):
+    _free = "pfz_tfidf_free"
+
+    @classmethod
+    def fit(cls, ctx, params, docs_a, docs_b=None):
+        h = c_vp()
+        rc = ctx.lib.pfz_tfidf_fit(ctx.h, ctypes.byref(params), docs_a.h if docs_a is not None else None,
+                                   docs_b.h if docs_b is not None else None, ctypes.byref(h))
+        if rc == -1 and b"empty vocabulary" in ctx.lib.pfz_last_error():
+            raise ValueError("empty vocabulary; perhaps the documents only contain stop words")
+        check(rc)
+        v = cls(ctx, h)
+        v.params = params
+        return v
+
+    @classmethod
+    def from_state(cls, ctx, params, ngrams, idf, n_docs):
+        ngrams = np.ascontiguousarray(ngrams, np.uint32)
+        idf = np.ascontiguousarray(idf, np.float64)
+        h = c_vp()
+        check(ctx.lib.pfz_tfidf_import(ctx.h, ctypes.byref(params), len(idf), int(n_docs), _ptr(ngrams), _ptr(idf),
+                                       ctypes.byref(h)))
+        v = cls(ctx, h)
+        v.params = params
+        return v
+
+    def info(self):
+        vs, nd, cb = c_i64(), c_i64(), c_i32()
+        check(self.ctx.lib.pfz_tfidf_info(self.h, ctypes.byref(vs), ctypes.byref(nd), ctypes.byref(cb)))
+        return {"vocab": vs.value, "n_docs": nd.value, "code_bits": cb.value}
+
+    def export(self):
+        """-> (ngrams uint32[vocab, ngram_hi], idf float64[vocab], df int64[vocab])"""
+        i = self.info()
+        hi = self.params.ngram_hi
+        ngrams = np.empty((i["vocab"], hi), np.uint32)
+        idf = np.empty(i["vocab"], np.float64)
+        df = np.empty(i["vocab"], np.int64)
+        check(self.ctx.lib.pfz_tfidf_export(self.ctx.h, self.h, _ptr(ngrams), _ptr(idf), _ptr(df)))
+        return ngrams, idf, df
+
+    def transform(self, docs):
+        h = c_vp()
+        check(self.ctx.lib.pfz_tfidf_transform(self.ctx.h, self.h, docs.h, ctypes.byref(h)))
+        return DeviceCSR(self.ctx, h)
+
+
+# ---- edit distance / dense ---------------------------------------------------------
+
+def indel_argmax(ctx, from_dev, to_dev, skip_idx=None, begin=0, end=None):
+    """K4: (first arg-max index int32[n], ratio float64[n]) of from-rows [begin, end)."""
+    end = from_dev.n if end is None else end
+    n = end - begin
+    idx = np.empty(n, np.int32)
+    score = np.empty(n, np.float64)
+    if skip_idx is not None:
+        skip_idx = np.ascontiguousarray(skip_idx, np.int32)
+        if len(skip_idx) != from_dev.n:
+            raise ValueError("skip_idx must have one entry per from-string")
+    check(ctx.lib.pfz_indel_argmax(ctx.h, from_dev.h, to_dev.h, _ptr(skip_idx), int(begin), int(end),
+                                   _ptr(idx), _ptr(score)))
+    return idx, score
+
+
+def indel_matrix(ctx, from_dev, to_dev, begin=0, end=None):
+    end = from_dev.n if end is None else end
+    out = np.empty((end - begin, to_dev.n), np.float64)
+    check(ctx.lib.pfz_indel_matrix_host(ctx.h, from_dev.h, to_dev.h, int(begin), int(end), _ptr(out)))
+    return out
+
+
+def dense_cossim_topn_host(ctx, from_vec, to_vec, ntop, lower_bound, exclude_diag=False):
+    a = np.ascontiguousarray(from_vec, np.float32)
+    b = np.ascontiguousarray(to_vec, np.float32)
+    if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError(f"dense cosine needs two 2-D arrays with equal width, got {a.shape} and {b.shape}")
+    idx = np.empty((a.shape[0], ntop), np.int32)
+    val = np.empty((a.shape[0], ntop), np.float32)
+    check(ctx.lib.pfz_dense_cossim_topn_host(ctx.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], int(ntop),
+                                             float(lower_bound), int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
     return idx, val

@@ -1,0 +1,797 @@
+// K1/K2 -- character-n-gram TF-IDF vectorisation on the device.
+//
+// Replaces TfidfVectorizer(min_df=1, analyzer=TFIDF._create_ngrams).fit /
+// .transform as used by reference polyfuzz/models/_tfidf.py:102-118, with the
+// analyzer of _tfidf.py:120-146 (clean -> sliding n-char windows, windows
+// containing ' ' dropped).  sklearn semantics restated (feature_extraction/
+// text.py): vocabulary = distinct n-grams in sorted order (column id = rank,
+// :1194-1199), tf = raw count (:1247-1310), out-of-vocabulary n-grams ignored at
+// transform (:1271-1273), idf = ln((1+n_docs)/(1+df))+1 (:1662-1679), value =
+// tf*idf, rows L2-normalised sequentially in float64 (:1716-1722).
+//
+// Device representation
+//   n-gram code : the n characters, each mapped to a small rank (1..S, 0 = pad)
+//                 of w bits, packed big-endian and left-aligned into
+//                 ngram_hi*w <= 36 bits.  Numeric order of codes == Python's
+//                 lexicographic order of the n-gram strings (shorter prefix
+//                 first), so "rank of the code among the distinct codes" is
+//                 exactly sklearn's column id.
+//   vocabulary  : presence bitmap over the code space (2^code_bits bits; 32 KiB
+//                 for cleaned 3-grams, HBM-sized for long n-grams) + an int32
+//                 rank prefix per 256-bit group: column id = prefix[g] +
+//                 popcount of the lower bits -- no sort, no hash, no search.
+//   per string  : a slot range of len*R uint64 in HBM (R = number of n values),
+//                 holding first the codes, then in place the sorted distinct
+//                 (column id, tf) pairs.
+// Kernels: k_extract (thread per string: clean + window + emit + mark bitmap),
+// k_group_popc (+ scan), k_rows_short (wave per string: 64-lane bitonic sort,
+// ballot run-lengths, df atomics), k_rows_long (workgroup per long string),
+// k_idf, k_finalize (thread per string: fp64 tf*idf, sequential L2 norm, CSR).
+// All of it is HBM-streaming work over a few MB; none of it is MFMA-shaped.
+#include "pfz_internal.h"
+
+#include <algorithm>
+#include <atomic>
+
+namespace pfz {
+
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr int kLongMax = 4096;     // n-grams per string sorted in LDS by k_rows_long
+constexpr int kMaxCodeBits = 36;
+
+static std::atomic<uint64_t> g_gen{1};
+
+struct VocabView {
+    const uint32_t *bitmap;
+    const int32_t *prefix;
+};
+
+// column id of a code, or kInvalid when the code is not in the vocabulary
+__device__ inline uint32_t vocab_rank(const VocabView &v, uint64_t code)
+{
+    const uint64_t g = code >> 8;
+    const uint32_t wi = (uint32_t)(code >> 5) & 7u;
+    const uint32_t *words = v.bitmap + g * 8;
+    const uint32_t word = words[wi];
+    const uint32_t bit = (uint32_t)code & 31u;
+    if (!((word >> bit) & 1u)) return kInvalid;
+    uint32_t r = (uint32_t)v.prefix[g] + __popc(word & ((1u << bit) - 1u));
+    for (uint32_t j = 0; j < wi; ++j) r += __popc(words[j]);
+    return r;
+}
+
+struct ExtractParams {
+    int32_t lo, hi, clean, remove_space, w;
+    int64_t alpha_len;
+};
+
+// ---------------------------------------------------------------------------
+// k_extract: one thread per string.
+// ---------------------------------------------------------------------------
+template <int CW>
+__global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_v, const int64_t *__restrict__ off,
+                                                  int64_t n, ExtractParams P, const uint32_t *__restrict__ alpha_map,
+                                                  uint64_t *__restrict__ slots, int32_t *__restrict__ row_cnt,
+                                                  uint32_t *__restrict__ bitmap)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = off[i], e = off[i + 1];
+    const int R = P.hi - P.lo + 1;
+    uint64_t *out = slots + b * R;
+    const int w = P.w;
+    const uint64_t full_mask = (1ull << (P.hi * w)) - 1ull;
+    uint64_t win = 0;
+    int run = 0, cnt = 0;
+    bool pending_space = false, any = false;
+
+    auto feed = [&](uint32_t m, bool breaks) {
+        win = ((win << w) | m) & full_mask;
+        run = breaks ? 0 : (run < P.hi ? run + 1 : P.hi);
+        for (int nn = P.lo; nn <= P.hi; ++nn) {
+            if (run >= nn) {
+                const uint64_t code = (win & ((1ull << (nn * w)) - 1ull)) << ((P.hi - nn) * w);
+                out[cnt++] = code;
+                if (bitmap) atomicOr(&bitmap[code >> 5], 1u << ((uint32_t)code & 31u));
+            }
+        }
+    };
+
+    for (int64_t p = b; p < e; ++p) {
+        uint32_t c = CW == 1 ? (uint32_t)((const uint8_t *)chars_v)[p] : ((const uint32_t *)chars_v)[p];
+        if (P.clean) {
+            // reference _tfidf.py:142-146 on code points <= 0xFF: lower(), keep
+            // [a-z0-9 ], collapse runs of ' ', strip
+            if (c >= 'A' && c <= 'Z') c += 32;
+            if (c == ' ') {
+                if (any) pending_space = true;
+                continue;
+            }
+            const bool letter = c >= 'a' && c <= 'z';
+            const bool digit = c >= '0' && c <= '9';
+            if (!letter && !digit) continue;
+            if (pending_space) {
+                feed(1u, P.remove_space != 0);
+                pending_space = false;
+            }
+            any = true;
+            feed(letter ? c - 'a' + 12u : c - '0' + 2u, false);
+        } else {
+            const uint32_t m = (int64_t)c < P.alpha_len ? alpha_map[c] : 0u;
+            feed(m, m == 0u || (P.remove_space && c == ' '));
+        }
+    }
+    row_cnt[i] = cnt;
+}
+
+template <int CW>
+__global__ __launch_bounds__(256) void k_alpha_mark(const void *__restrict__ chars_v, int64_t n_units,
+                                                     uint32_t *__restrict__ present)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_units; p += (int64_t)gridDim.x * 256) {
+        uint32_t c = CW == 1 ? (uint32_t)((const uint8_t *)chars_v)[p] : ((const uint32_t *)chars_v)[p];
+        if (c < 0x110000u) atomicOr(&present[c >> 5], 1u << (c & 31u));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_group_popc(const uint32_t *__restrict__ bitmap, int64_t n_groups,
+                                                     int32_t *__restrict__ prefix)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint4 *w4 = (const uint4 *)(bitmap + g * 8);
+    const uint4 a = w4[0], b = w4[1];
+    prefix[g] = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) +
+                __popc(b.w);
+}
+
+__global__ __launch_bounds__(256) void k_set_bits(const uint64_t *__restrict__ codes, int64_t n,
+                                                   uint32_t *__restrict__ bitmap)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t code = codes[i];
+    atomicOr(&bitmap[code >> 5], 1u << ((uint32_t)code & 31u));
+}
+
+// codes of the vocabulary in column order
+__global__ __launch_bounds__(256) void k_export_codes(const uint32_t *__restrict__ bitmap,
+                                                       const int32_t *__restrict__ prefix, int64_t n_groups,
+                                                       uint64_t *__restrict__ codes)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    if (prefix[g + 1] == prefix[g]) return;
+    int64_t o = prefix[g];
+    for (int j = 0; j < 8; ++j) {
+        uint32_t word = bitmap[g * 8 + j];
+        while (word) {
+            const int bit = __builtin_ctz(word);
+            word &= word - 1;
+            codes[o++] = ((uint64_t)g << 8) | (uint64_t)(j * 32 + bit);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_rows_short: one wave per string with <= 64 n-grams.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ off, int64_t n, int32_t R,
+                                                     VocabView V, uint64_t *__restrict__ slots,
+                                                     const int32_t *__restrict__ row_cnt,
+                                                     int32_t *__restrict__ row_nnz, int32_t *__restrict__ df)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int cnt = row_cnt[row];
+    if (cnt > 64) return;  // k_rows_long
+    if (cnt == 0) {
+        if (lane == 0) row_nnz[row] = 0;
+        return;
+    }
+    uint64_t *base = slots + off[row] * R;
+    uint32_t key = kInvalid;
+    if (lane < cnt) key = vocab_rank(V, base[lane]);
+    // 64-lane bitonic sort, ascending
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t o = __shfl_xor(key, j, 64);
+            const bool asc = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            const uint32_t mn = key < o ? key : o, mx = key < o ? o : key;
+            key = (lower == asc) ? mn : mx;
+        }
+    }
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool valid = key != kInvalid;
+    const bool head = valid && (lane == 0 || key != prev);
+    const uint64_t H = __ballot(head);
+    const int nvalid = __popcll(__ballot(valid));
+    if (head) {
+        const int pos = __popcll(H & ((1ull << lane) - 1ull));
+        const uint64_t above = lane == 63 ? 0ull : (H >> (lane + 1));
+        const int next = above ? lane + 1 + __builtin_ctzll(above) : nvalid;
+        base[pos] = ((uint64_t)(uint32_t)(next - lane) << 32) | key;   // (.x = id, .y = tf) little-endian
+        if (df) atomicAdd(&df[key], 1);
+    }
+    if (lane == 0) row_nnz[row] = __popcll(H);
+}
+
+// ---------------------------------------------------------------------------
+// k_rows_long: one workgroup per string with > 64 n-grams.
+//   cnt <= kLongMax : keys sorted in LDS; otherwise in a global scratch slab.
+// ---------------------------------------------------------------------------
+// Sort + run-length encode one long string.  KEYS is either an LDS array or a
+// global scratch slab; the body is instantiated once per address space (a
+// runtime-selected flat pointer is avoided on purpose).
+template <typename KEYS>
+__device__ inline void rows_long_body(KEYS keys, int cnt, const VocabView &V, uint64_t *base, int32_t *row_nnz_out,
+                                      int32_t *df, int *sh_heads, int *sh_valid)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int npow2 = 128;
+    while (npow2 < cnt) npow2 <<= 1;
+    for (int t = threadIdx.x; t < npow2; t += 256) keys[t] = t < cnt ? vocab_rank(V, base[t]) : kInvalid;
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < npow2; t += 256) {
+                const int x = t ^ j;
+                if (x > t) {
+                    const bool asc = (t & k) == 0;
+                    const uint32_t a = keys[t], b = keys[x];
+                    if ((a > b) == asc) {
+                        keys[t] = b;
+                        keys[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // run-length encode: wave 0 walks the sorted keys, writes (id, start)
+    uint2 *out = (uint2 *)base;
+    if (wave == 0) {
+        int nheads = 0, nvalid = 0;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int t = c0 + lane;
+            uint32_t key = kInvalid, prev = kInvalid;
+            if (t < cnt) key = keys[t];
+            if (t > 0 && t < cnt) prev = keys[t - 1];
+            const bool valid = key != kInvalid;
+            const bool head = valid && (t == 0 || key != prev);
+            const uint64_t H = __ballot(head);
+            if (head) {
+                out[nheads + __popcll(H & ((1ull << lane) - 1ull))] = make_uint2(key, (uint32_t)t);
+                if (df) atomicAdd(&df[key], 1);
+            }
+            nheads += __popcll(H);
+            nvalid += __popcll(__ballot(valid));
+        }
+        if (lane == 0) {
+            *sh_heads = nheads;
+            *sh_valid = nvalid;
+            *row_nnz_out = nheads;
+        }
+    }
+    __syncthreads();
+    const int nheads = *sh_heads, nvalid = *sh_valid;
+    for (int c0 = 0; c0 < nheads; c0 += 256) {   // start -> tf, chunk by chunk (read, barrier, write)
+        const int p = c0 + threadIdx.x;
+        uint32_t tf = 0;
+        if (p < nheads) tf = (p + 1 < nheads ? out[p + 1].y : (uint32_t)nvalid) - out[p].y;
+        __syncthreads();
+        if (p < nheads) out[p].y = tf;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rows_long(const int64_t *__restrict__ off, int64_t n, int32_t R, VocabView V,
+                                                    uint64_t *__restrict__ slots,
+                                                    const int32_t *__restrict__ row_cnt,
+                                                    int32_t *__restrict__ row_nnz, int32_t *__restrict__ df,
+                                                    uint32_t *__restrict__ giant_scratch, int64_t giant_stride)
+{
+    __shared__ uint32_t lds_keys[kLongMax];
+    __shared__ int sh_heads, sh_valid;
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const int cnt = row_cnt[row];
+        if (cnt <= 64) continue;
+        uint64_t *base = slots + off[row] * R;
+        if (cnt <= kLongMax)
+            rows_long_body(&lds_keys[0], cnt, V, base, row_nnz + row, df, &sh_heads, &sh_valid);
+        else
+            rows_long_body(giant_scratch + (int64_t)blockIdx.x * giant_stride, cnt, V, base, row_nnz + row, df,
+                           &sh_heads, &sh_valid);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_idf(const int32_t *__restrict__ df, int64_t vocab, double n_docs,
+                                              double *__restrict__ idf)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= vocab) return;
+    // sklearn text.py:1662-1679 (smooth_idf): ln((1+n)/(1+df)) + 1
+    idf[k] = log((n_docs + 1.0) / ((double)df[k] + 1.0)) + 1.0;
+}
+
+// one thread per string: tf*idf in float64, sequential sum of squares in index
+// order, sqrt, divide (sklearn inplace_csr_row_normalize_l2), round to fp32.
+__global__ __launch_bounds__(256) void k_finalize(const int64_t *__restrict__ off, int64_t n, int32_t R,
+                                                   const uint64_t *__restrict__ slots,
+                                                   const int32_t *__restrict__ indptr, const double *__restrict__ idf,
+                                                   int32_t *__restrict__ indices, float *__restrict__ data)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const uint2 *in = (const uint2 *)(slots + off[row] * R);
+    const int o = indptr[row], nn = indptr[row + 1] - o;
+    double ss = 0.0;
+    for (int t = 0; t < nn; ++t) {
+        const uint2 e = in[t];
+        const double v = __dmul_rn((double)e.y, idf[e.x]);
+        ss = __dadd_rn(ss, __dmul_rn(v, v));
+    }
+    const double nrm = sqrt(ss);
+    for (int t = 0; t < nn; ++t) {
+        const uint2 e = in[t];
+        double v = __dmul_rn((double)e.y, idf[e.x]);
+        if (ss != 0.0) v = v / nrm;
+        indices[o + t] = (int32_t)e.x;
+        data[o + t] = (float)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy_i32(const int32_t *__restrict__ src, int64_t n, int32_t *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------
+static inline unsigned grid_for(int64_t n, int per_block = 256) { return (unsigned)((n + per_block - 1) / per_block); }
+
+static int bits_for(uint64_t max_value)
+{
+    int b = 1;
+    while ((max_value >> b) != 0) ++b;
+    return b;
+}
+
+static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool mark)
+{
+    const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
+    const size_t need = (size_t)(s->n_units > 0 ? s->n_units : 1) * (size_t)R;
+    if (s->slots_cap < need) {
+        if (s->slots) PFZ_HIP(hipFree(s->slots));
+        s->slots = nullptr;
+        PFZ_HIP(hipMalloc(&s->slots, need * sizeof(uint64_t)));
+        s->slots_cap = need;
+    }
+    if (!s->row_cnt) PFZ_HIP(hipMalloc(&s->row_cnt, (size_t)(s->n + 1) * 2 * sizeof(int32_t)));
+    if (s->n == 0) return PFZ_OK;
+    ExtractParams P{v->params.ngram_lo, v->params.ngram_hi, v->params.clean, v->params.remove_space_ngrams,
+                    v->bits_per_char, v->alpha_map_len};
+    ProfScope ps(ctx, "k1_extract");
+    if (s->char_width == 1)
+        hipLaunchKernelGGL(k_extract<1>, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->chars, s->offsets, s->n, P,
+                           v->alpha_map, s->slots, s->row_cnt, mark ? v->bitmap : nullptr);
+    else
+        hipLaunchKernelGGL(k_extract<4>, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->chars, s->offsets, s->n, P,
+                           v->alpha_map, s->slots, s->row_cnt, mark ? v->bitmap : nullptr);
+    PFZ_HIP(hipGetLastError());
+    return PFZ_OK;
+}
+
+static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool count_df)
+{
+    if (s->n == 0) return PFZ_OK;
+    const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
+    VocabView V{v->bitmap, v->prefix};
+    int32_t *row_nnz = s->row_cnt + (s->n + 1);
+    int32_t *df = count_df ? v->df : nullptr;
+    {
+        ProfScope ps(ctx, "k2_rows_short");
+        hipLaunchKernelGGL(k_rows_short, dim3(grid_for(s->n, 4)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, V,
+                           s->slots, s->row_cnt, row_nnz, df);
+    }
+    if (s->max_len * R > 64) {
+        const int64_t max_cnt = s->max_len * R;
+        unsigned grid = (unsigned)std::min<int64_t>(s->n, 2048);
+        uint32_t *giant = nullptr;
+        int64_t stride = 0;
+        if (max_cnt > kLongMax) {
+            grid = (unsigned)std::min<int64_t>(s->n, 64);
+            stride = 128;
+            while (stride < max_cnt) stride <<= 1;
+            PFZ_TRY(ensure_scratch(ctx, (size_t)grid * (size_t)stride * sizeof(uint32_t)));
+            giant = (uint32_t *)ctx->scratch;
+        }
+        ProfScope ps(ctx, "k2_rows_long");
+        hipLaunchKernelGGL(k_rows_long, dim3(grid), dim3(256), 0, ctx->stream, s->offsets, s->n, R, V, s->slots,
+                           s->row_cnt, row_nnz, df, giant, stride);
+    }
+    PFZ_HIP(hipGetLastError());
+    return PFZ_OK;
+}
+
+static int build_prefix(pfz_ctx *ctx, pfz_tfidf *v)
+{
+    hipLaunchKernelGGL(k_group_popc, dim3(grid_for(v->n_groups)), dim3(256), 0, ctx->stream, v->bitmap, v->n_groups,
+                       v->prefix);
+    PFZ_TRY(exclusive_scan_i32(ctx, v->prefix, v->n_groups));
+    int32_t total = 0;
+    PFZ_HIP(hipMemcpyAsync(&total, v->prefix + v->n_groups, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    v->vocab = total;
+    return PFZ_OK;
+}
+
+static int alloc_vocab_space(pfz_ctx *ctx, pfz_tfidf *v)
+{
+    const int64_t n_bits = std::max<int64_t>((int64_t)1 << v->code_bits, 256);
+    v->n_groups = n_bits / 256;
+    PFZ_HIP(hipMalloc(&v->bitmap, (size_t)(n_bits / 8)));
+    PFZ_HIP(hipMalloc(&v->prefix, (size_t)(v->n_groups + 1) * sizeof(int32_t)));
+    PFZ_HIP(hipMemsetAsync(v->bitmap, 0, (size_t)(n_bits / 8), ctx->stream));
+    return PFZ_OK;
+}
+
+static int check_params(const pfz_tfidf_params *p)
+{
+    PFZ_REQUIRE(p, "pfz_tfidf: params is NULL");
+    PFZ_REQUIRE(p->ngram_lo >= 1 && p->ngram_hi >= p->ngram_lo, "pfz_tfidf: bad n_gram_range (%d, %d)", p->ngram_lo,
+                p->ngram_hi);
+    return PFZ_OK;
+}
+
+static int set_alphabet(pfz_ctx *ctx, pfz_tfidf *v, const std::vector<uint32_t> &sorted_cps)
+{
+    v->alphabet = sorted_cps;
+    const uint64_t S = sorted_cps.size();
+    v->bits_per_char = bits_for(S > 0 ? S : 1);
+    v->code_bits = v->bits_per_char * v->params.ngram_hi;
+    if (v->code_bits > kMaxCodeBits) {
+        set_error("pfz_tfidf: n_gram_range upper bound %d with an alphabet of %llu symbols needs %d-bit n-gram codes; "
+                  "this build supports up to %d bits (e.g. cleaned strings up to 6-grams, 255 symbols up to 4-grams)",
+                  v->params.ngram_hi, (unsigned long long)S, v->code_bits, kMaxCodeBits);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    const uint32_t max_cp = S ? sorted_cps.back() : 0;
+    std::vector<uint32_t> map((size_t)max_cp + 1, 0u);
+    for (size_t r = 0; r < sorted_cps.size(); ++r) map[sorted_cps[r]] = (uint32_t)r + 1u;
+    v->alpha_map_len = (int64_t)map.size();
+    PFZ_HIP(hipMalloc(&v->alpha_map, map.size() * sizeof(uint32_t)));
+    PFZ_HIP(hipMemcpy(v->alpha_map, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return PFZ_OK;
+}
+
+// cleaned alphabet: ' ' 0-9 a-z  -> ranks 1..37
+static inline uint32_t clean_rank_to_cp(uint32_t m) { return m == 1 ? ' ' : (m <= 11 ? '0' + (m - 2) : 'a' + (m - 12)); }
+static inline uint32_t clean_cp_to_rank(uint32_t c)
+{
+    if (c == ' ') return 1;
+    if (c >= '0' && c <= '9') return c - '0' + 2;
+    if (c >= 'a' && c <= 'z') return c - 'a' + 12;
+    return 0;
+}
+
+}  // namespace pfz
+
+using namespace pfz;
+
+extern "C" {
+
+int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, int64_t n, int32_t char_width,
+                       pfz_strings **out)
+{
+    PFZ_REQUIRE(ctx && out && offsets && n >= 0, "pfz_strings_upload: bad arguments");
+    PFZ_REQUIRE(char_width == 1 || char_width == 4, "pfz_strings_upload: char_width must be 1 or 4 (got %d)", char_width);
+    PFZ_REQUIRE(offsets[0] == 0, "pfz_strings_upload: offsets[0] must be 0");
+    int64_t max_len = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        PFZ_REQUIRE(len >= 0, "pfz_strings_upload: offsets not monotone at %lld", (long long)i);
+        if (len > max_len) max_len = len;
+    }
+    const int64_t n_units = offsets[n];
+    PFZ_REQUIRE(n_units == 0 || chars, "pfz_strings_upload: chars is NULL");
+    if (n >= ((int64_t)1 << 31) - 2 || n_units >= ((int64_t)1 << 40)) {
+        set_error("pfz_strings_upload: list too large (%lld strings, %lld code units)", (long long)n, (long long)n_units);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    PFZ_HIP(hipSetDevice(ctx->device));
+    pfz_strings *s = new pfz_strings();
+    s->ctx = ctx;
+    s->n = n;
+    s->n_units = n_units;
+    s->char_width = char_width;
+    s->max_len = max_len;
+    s->h_off.assign(offsets, offsets + n + 1);
+    if (n_units > 0) s->h_chars.assign((const uint8_t *)chars, (const uint8_t *)chars + (size_t)n_units * (size_t)char_width);
+    PFZ_HIP(hipMalloc(&s->chars, (size_t)(n_units > 0 ? n_units : 1) * (size_t)char_width + 16));
+    PFZ_HIP(hipMalloc(&s->offsets, (size_t)(n + 1) * sizeof(int64_t)));
+    if (n_units > 0)
+        PFZ_HIP(hipMemcpyAsync(s->chars, chars, (size_t)n_units * (size_t)char_width, hipMemcpyHostToDevice, ctx->stream));
+    PFZ_HIP(hipMemcpyAsync(s->offsets, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    *out = s;
+    return PFZ_OK;
+}
+
+void pfz_strings_free(pfz_strings *s)
+{
+    if (!s) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->chars) (void)hipFree(s->chars);
+    if (s->offsets) (void)hipFree(s->offsets);
+    if (s->slots) (void)hipFree(s->slots);
+    if (s->row_cnt) (void)hipFree(s->row_cnt);
+    delete s;
+}
+
+void pfz_tfidf_free(pfz_tfidf *v)
+{
+    if (!v) return;
+    if (v->ctx) (void)hipSetDevice(v->ctx->device);
+    if (v->alpha_map) (void)hipFree(v->alpha_map);
+    if (v->bitmap) (void)hipFree(v->bitmap);
+    if (v->prefix) (void)hipFree(v->prefix);
+    if (v->df) (void)hipFree(v->df);
+    if (v->idf) (void)hipFree(v->idf);
+    delete v;
+}
+
+int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params, const pfz_strings *docs_a_c, const pfz_strings *docs_b_c,
+                  pfz_tfidf **out)
+{
+    PFZ_REQUIRE(ctx && out, "pfz_tfidf_fit: NULL argument");
+    PFZ_TRY(check_params(params));
+    PFZ_REQUIRE(docs_a_c || docs_b_c, "pfz_tfidf_fit: no documents");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    // the n-gram cache lives inside the (otherwise read-only) string lists
+    pfz_strings *lists[2] = {const_cast<pfz_strings *>(docs_a_c), const_cast<pfz_strings *>(docs_b_c)};
+    if (lists[0] == lists[1]) lists[1] = nullptr;
+    pfz_tfidf *v = new pfz_tfidf();
+    struct Guard {
+        pfz_tfidf *p;
+        ~Guard() { if (p) pfz_tfidf_free(p); }
+    } guard{v};
+    v->ctx = ctx;
+    v->params = *params;
+    v->gen = g_gen.fetch_add(1);
+
+    if (params->clean) {
+        for (pfz_strings *s : lists)
+            if (s && s->char_width != 1) {
+                set_error("pfz_tfidf_fit: clean=1 runs on 1-byte code units only; pre-clean wide strings on the host");
+                return PFZ_ERR_INVALID;
+            }
+        v->bits_per_char = 6;
+        v->code_bits = 6 * params->ngram_hi;
+        if (v->code_bits > kMaxCodeBits) {
+            set_error("pfz_tfidf_fit: n_gram_range upper bound %d needs %d-bit codes; this build supports up to %d-grams "
+                      "of cleaned strings", params->ngram_hi, v->code_bits, kMaxCodeBits / 6);
+            return PFZ_ERR_UNSUPPORTED;
+        }
+    } else {
+        // alphabet = distinct code units of the fitted documents, in code-point order
+        const size_t words = 0x110000 / 32;
+        PFZ_TRY(ensure_scratch(ctx, words * sizeof(uint32_t)));
+        uint32_t *present = (uint32_t *)ctx->scratch;
+        PFZ_HIP(hipMemsetAsync(present, 0, words * sizeof(uint32_t), ctx->stream));
+        for (pfz_strings *s : lists) {
+            if (!s || s->n_units == 0) continue;
+            const unsigned grid = (unsigned)std::min<int64_t>((s->n_units + 255) / 256, 4096);
+            if (s->char_width == 1)
+                hipLaunchKernelGGL(k_alpha_mark<1>, dim3(grid), dim3(256), 0, ctx->stream, s->chars, s->n_units, present);
+            else
+                hipLaunchKernelGGL(k_alpha_mark<4>, dim3(grid), dim3(256), 0, ctx->stream, s->chars, s->n_units, present);
+        }
+        std::vector<uint32_t> h(words);
+        PFZ_HIP(hipMemcpyAsync(h.data(), present, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> cps;
+        for (size_t wi = 0; wi < words; ++wi) {
+            uint32_t word = h[wi];
+            while (word) {
+                const int bit = __builtin_ctz(word);
+                word &= word - 1;
+                cps.push_back((uint32_t)(wi * 32 + bit));
+            }
+        }
+        PFZ_TRY(set_alphabet(ctx, v, cps));
+    }
+    PFZ_TRY(alloc_vocab_space(ctx, v));
+    for (pfz_strings *s : lists)
+        if (s) PFZ_TRY(run_extract(ctx, v, s, true));
+    PFZ_TRY(build_prefix(ctx, v));
+    if (v->vocab == 0) {
+        // sklearn text.py:1282-1285
+        set_error("empty vocabulary; perhaps the documents only contain stop words");
+        return PFZ_ERR_INVALID;
+    }
+    PFZ_HIP(hipMalloc(&v->df, (size_t)v->vocab * sizeof(int32_t)));
+    PFZ_HIP(hipMalloc(&v->idf, (size_t)v->vocab * sizeof(double)));
+    PFZ_HIP(hipMemsetAsync(v->df, 0, (size_t)v->vocab * sizeof(int32_t), ctx->stream));
+    v->n_docs = 0;
+    for (pfz_strings *s : lists) {
+        if (!s) continue;
+        PFZ_TRY(run_rows(ctx, v, s, true));
+        s->cache_gen = v->gen;
+        v->n_docs += s->n;
+    }
+    hipLaunchKernelGGL(k_idf, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, v->df, v->vocab, (double)v->n_docs,
+                       v->idf);
+    PFZ_HIP(hipGetLastError());
+    guard.p = nullptr;
+    *out = v;
+    return PFZ_OK;
+}
+
+int pfz_tfidf_info(const pfz_tfidf *v, int64_t *vocab_size, int64_t *n_docs, int32_t *code_bits)
+{
+    PFZ_REQUIRE(v, "pfz_tfidf_info: NULL vectoriser");
+    if (vocab_size) *vocab_size = v->vocab;
+    if (n_docs) *n_docs = v->n_docs;
+    if (code_bits) *code_bits = v->code_bits;
+    return PFZ_OK;
+}
+
+int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *docs_c, pfz_csr **out)
+{
+    PFZ_REQUIRE(ctx && v && docs_c && out, "pfz_tfidf_transform: NULL argument");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    pfz_strings *s = const_cast<pfz_strings *>(docs_c);
+    if (v->params.clean && s->char_width != 1) {
+        set_error("pfz_tfidf_transform: clean=1 runs on 1-byte code units only; pre-clean wide strings on the host");
+        return PFZ_ERR_INVALID;
+    }
+    if (s->cache_gen != v->gen) {
+        PFZ_TRY(run_extract(ctx, v, s, false));
+        PFZ_TRY(run_rows(ctx, v, s, false));
+        s->cache_gen = v->gen;
+    }
+    const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
+    pfz_csr *m = new pfz_csr();
+    m->ctx = ctx;
+    m->n_rows = s->n;
+    m->n_cols = v->vocab;
+    PFZ_HIP(hipMalloc(&m->indptr, (size_t)(s->n + 1) * sizeof(int32_t)));
+    int32_t nnz = 0;
+    if (s->n > 0) {
+        const int32_t *row_nnz = s->row_cnt + (s->n + 1);
+        hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, row_nnz, s->n, m->indptr);
+        PFZ_TRY(exclusive_scan_i32(ctx, m->indptr, s->n));
+        PFZ_HIP(hipMemcpyAsync(&nnz, m->indptr + s->n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        PFZ_HIP(hipMemsetAsync(m->indptr, 0, sizeof(int32_t), ctx->stream));
+    }
+    m->nnz = nnz;
+    PFZ_HIP(hipMalloc(&m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
+    PFZ_HIP(hipMalloc(&m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
+    if (s->n > 0 && nnz > 0) {
+        ProfScope ps(ctx, "k2_finalize");
+        hipLaunchKernelGGL(k_finalize, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
+                           m->indptr, v->idf, m->indices, m->data);
+    }
+    PFZ_HIP(hipGetLastError());
+    *out = m;
+    return PFZ_OK;
+}
+
+int pfz_tfidf_export(pfz_ctx *ctx, const pfz_tfidf *v, uint32_t *ngrams, double *idf, int64_t *df)
+{
+    PFZ_REQUIRE(ctx && v, "pfz_tfidf_export: NULL argument");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (idf && v->vocab > 0) PFZ_HIP(hipMemcpy(idf, v->idf, (size_t)v->vocab * sizeof(double), hipMemcpyDeviceToHost));
+    if (df && v->vocab > 0) {
+        std::vector<int32_t> h((size_t)v->vocab);
+        PFZ_HIP(hipMemcpy(h.data(), v->df, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); ++i) df[i] = h[i];
+    }
+    if (ngrams && v->vocab > 0) {
+        uint64_t *d_codes = nullptr;
+        PFZ_HIP(hipMalloc(&d_codes, (size_t)v->vocab * sizeof(uint64_t)));
+        hipLaunchKernelGGL(k_export_codes, dim3(grid_for(v->n_groups)), dim3(256), 0, ctx->stream, v->bitmap, v->prefix,
+                           v->n_groups, d_codes);
+        std::vector<uint64_t> codes((size_t)v->vocab);
+        hipError_t e = hipMemcpyAsync(codes.data(), d_codes, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_codes);
+        PFZ_HIP(e);
+        const int hi = v->params.ngram_hi, w = v->bits_per_char;
+        const uint64_t cmask = (1ull << w) - 1ull;
+        for (size_t i = 0; i < codes.size(); ++i)
+            for (int p = 0; p < hi; ++p) {
+                const uint32_t m = (uint32_t)((codes[i] >> ((hi - 1 - p) * w)) & cmask);
+                uint32_t cp = 0;
+                if (m != 0) cp = v->params.clean ? clean_rank_to_cp(m) : v->alphabet[m - 1];
+                ngrams[i * hi + p] = cp;
+            }
+    }
+    return PFZ_OK;
+}
+
+int pfz_tfidf_import(pfz_ctx *ctx, const pfz_tfidf_params *params, int64_t vocab, int64_t n_docs, const uint32_t *ngrams,
+                     const double *idf, pfz_tfidf **out)
+{
+    PFZ_REQUIRE(ctx && out && ngrams && idf && vocab > 0, "pfz_tfidf_import: bad arguments");
+    PFZ_TRY(check_params(params));
+    PFZ_HIP(hipSetDevice(ctx->device));
+    pfz_tfidf *v = new pfz_tfidf();
+    struct Guard {
+        pfz_tfidf *p;
+        ~Guard() { if (p) pfz_tfidf_free(p); }
+    } guard{v};
+    v->ctx = ctx;
+    v->params = *params;
+    v->gen = g_gen.fetch_add(1);
+    v->n_docs = n_docs;
+    const int hi = params->ngram_hi;
+    if (params->clean) {
+        v->bits_per_char = 6;
+        v->code_bits = 6 * hi;
+        if (v->code_bits > kMaxCodeBits) {
+            set_error("pfz_tfidf_import: %d-grams of cleaned strings exceed the %d-bit code space", hi, kMaxCodeBits);
+            return PFZ_ERR_UNSUPPORTED;
+        }
+    } else {
+        std::vector<uint32_t> cps;
+        for (int64_t i = 0; i < vocab * hi; ++i)
+            if (ngrams[i]) cps.push_back(ngrams[i]);
+        std::sort(cps.begin(), cps.end());
+        cps.erase(std::unique(cps.begin(), cps.end()), cps.end());
+        PFZ_TRY(set_alphabet(ctx, v, cps));
+    }
+    const int w = v->bits_per_char;
+    std::vector<uint64_t> codes((size_t)vocab);
+    for (int64_t i = 0; i < vocab; ++i) {
+        uint64_t code = 0;
+        for (int p = 0; p < hi; ++p) {
+            const uint32_t cp = ngrams[i * hi + p];
+            uint32_t m = 0;
+            if (cp != 0) {
+                if (params->clean) {
+                    m = clean_cp_to_rank(cp);
+                } else {
+                    auto it = std::lower_bound(v->alphabet.begin(), v->alphabet.end(), cp);
+                    m = (uint32_t)(it - v->alphabet.begin()) + 1u;
+                }
+                PFZ_REQUIRE(m != 0, "pfz_tfidf_import: n-gram %lld has a character outside the cleaned alphabet", (long long)i);
+            }
+            code = (code << w) | m;
+        }
+        PFZ_REQUIRE(i == 0 || code > codes[(size_t)i - 1], "pfz_tfidf_import: vocabulary not in sorted order at %lld", (long long)i);
+        codes[(size_t)i] = code;
+    }
+    PFZ_TRY(alloc_vocab_space(ctx, v));
+    uint64_t *d_codes = nullptr;
+    PFZ_HIP(hipMalloc(&d_codes, (size_t)vocab * sizeof(uint64_t)));
+    hipError_t e = hipMemcpyAsync(d_codes, codes.data(), (size_t)vocab * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_set_bits, dim3(grid_for(vocab)), dim3(256), 0, ctx->stream, d_codes, vocab, v->bitmap);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(d_codes);
+    PFZ_HIP(e);
+    PFZ_TRY(build_prefix(ctx, v));
+    PFZ_REQUIRE(v->vocab == vocab, "pfz_tfidf_import: %lld distinct n-grams, expected %lld", (long long)v->vocab, (long long)vocab);
+    PFZ_HIP(hipMalloc(&v->df, (size_t)vocab * sizeof(int32_t)));
+    PFZ_HIP(hipMalloc(&v->idf, (size_t)vocab * sizeof(double)));
+    PFZ_HIP(hipMemsetAsync(v->df, 0, (size_t)vocab * sizeof(int32_t), ctx->stream));
+    PFZ_HIP(hipMemcpy(v->idf, idf, (size_t)vocab * sizeof(double), hipMemcpyHostToDevice));
+    guard.p = nullptr;
+    *out = v;
+    return PFZ_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace pfz {
@@ -61,6 +62,13 @@ ProfScope::ProfScope(pfz_ctx *c, const char *n) : ctx(c), name(n)
 
 ProfScope::~ProfScope()
 {
+    static const bool debug_sync = getenv("PFZ_DEBUG_SYNC") != nullptr;
+    if (debug_sync) {  // developer aid: localise an asynchronous device fault to a kernel
+        fprintf(stderr, "[pfz] %s ...", name);
+        fflush(stderr);
+        hipError_t err = hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, " %s\n", hipGetErrorString(err));
+    }
     if (!ctx->prof || !b || !e) return;
     (void)hipEventRecord(e, ctx->stream);
     ProfEntry &pe = ctx->prof_entries[name];

@@ -89,13 +89,39 @@ struct pfz_topn {
 struct pfz_strings {
     pfz_ctx *ctx = nullptr;
     int64_t n = 0, n_units = 0;
-    int32_t char_width = 1;
-    void *chars = nullptr;     // device
-    int64_t *offsets = nullptr;  // device [n+1]
+    int32_t char_width = 1;      // bytes per code unit: 1 or 4
+    void *chars = nullptr;       // device [n_units]
+    int64_t *offsets = nullptr;  // device [n+1], in code units
     int64_t max_len = 0;
-    uint32_t max_code = 0;
-    // host mirrors (small; used for planning)
-    std::vector<int64_t> h_offsets;
+    // host mirror (a few MB): used by the host-side planning of K4
+    std::vector<uint8_t> h_chars;    // n_units * char_width bytes
+    std::vector<int64_t> h_off;      // n + 1
+    // n-gram cache of the vectoriser (see k1_vectorize.hip): per-string slot
+    // ranges holding first the packed n-gram codes, then (column id, tf) pairs
+    uint64_t cache_gen = 0;      // pfz_tfidf::gen the cache was made for (0 = none)
+    uint64_t *slots = nullptr;   // device [n_units * R]
+    size_t slots_cap = 0;        // in uint64 entries
+    int32_t *row_cnt = nullptr;  // device [n + 1]: n-grams, then distinct ids per string
+};
+
+struct pfz_tfidf {
+    pfz_ctx *ctx = nullptr;
+    pfz_tfidf_params params;
+    uint64_t gen = 0;            // unique id of this fit (cache tag)
+    int32_t bits_per_char = 0;   // w
+    int32_t code_bits = 0;       // ngram_hi * w  (<= 36)
+    // alphabet: code unit -> rank+1 (0 = not in alphabet).  clean=1 uses the
+    // fixed [ 0-9a-z] alphabet and no table.
+    uint32_t *alpha_map = nullptr;   // device [alpha_map_len]
+    int64_t alpha_map_len = 0;
+    std::vector<uint32_t> alphabet;  // host: sorted code points, rank r -> alphabet[r]
+    // vocabulary as a presence bitmap over codes + rank prefix per 256-bit group
+    uint32_t *bitmap = nullptr;      // device [2^code_bits / 32]
+    int32_t *prefix = nullptr;       // device [n_groups + 1]
+    int64_t n_groups = 0;
+    int64_t vocab = 0, n_docs = 0;
+    int32_t *df = nullptr;           // device [vocab]
+    double *idf = nullptr;           // device [vocab]
 };
 
 namespace pfz {

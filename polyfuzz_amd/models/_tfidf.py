@@ -1,0 +1,219 @@
+"""TFIDF -- the reference's character-n-gram TF-IDF matcher
+(polyfuzz/models/_tfidf.py:15-146) on the MI355X engine.
+
+Same constructor, same `.match(from_list, to_list=None, re_train=True)`, same
+DataFrame contract.  Everything between receiving the lists and assembling the
+DataFrame -- cleaning, n-gram extraction, vocabulary, tf/idf, L2 normalisation
+(K1/K2), the to-side inverted index and the fused cosine top-n (K3) -- runs on
+the device through the C ABI; the fitted vocabulary, idf and to-side index stay
+resident in HBM between `match(..., re_train=False)` calls (reference
+polyfuzz.py:234-240, "production" path).
+"""
+import re
+from typing import List, Tuple
+
+import numpy as np
+import pandas as pd
+from scipy.sparse import csr_matrix
+
+from .. import _lib
+from ._base import BaseMatcher
+from ._utils import topn_to_frame, _METHODS
+
+
+def _clean_string(string: str) -> str:
+    """ Only keep alphanumerical characters (reference _tfidf.py:142-146); host
+    path for strings with code points > 0xFF, where str.lower() can map into ASCII """
+    string = re.sub(r'[^A-Za-z0-9 ]+', '', string.lower())
+    string = re.sub(r'\s+', ' ', string).strip()
+    return string
+
+
+def _is_latin1(strings) -> bool:
+    try:
+        "".join(strings).encode("latin-1")
+        return True
+    except UnicodeEncodeError:
+        return False
+
+
+class HipTfidfVectorizer:
+    """What `TFIDF.vectorizer` holds after a fit: the device-resident vocabulary +
+    idf, with the read-only parts of sklearn's TfidfVectorizer surface
+    (vocabulary_, idf_, get_feature_names_out, transform)."""
+
+    def __init__(self, owner, dev):
+        self._owner = owner
+        self._dev = dev
+        self._state = None
+
+    def _export(self):
+        if self._state is None:
+            ngrams, idf, df = self._dev.export()
+            names = ["".join(chr(c) for c in row if c) for row in ngrams.tolist()]
+            self._state = (ngrams, idf, df, names)
+        return self._state
+
+    @property
+    def idf_(self):
+        return self._export()[1]
+
+    @property
+    def vocabulary_(self):
+        return {g: i for i, g in enumerate(self._export()[3])}
+
+    def get_feature_names_out(self):
+        return np.array(self._export()[3], dtype=object)
+
+    def transform(self, raw_documents) -> csr_matrix:
+        docs = self._owner._upload(list(raw_documents))
+        return _download_csr(self._dev.transform(docs))
+
+
+def _download_csr(dev_csr) -> csr_matrix:
+    indptr, indices, data, n_cols = dev_csr.download()
+    return csr_matrix((data.astype(np.float64), indices, indptr), shape=(len(indptr) - 1, n_cols))
+
+
+class TFIDF(BaseMatcher):
+    """
+    A character based n-gram TF-IDF to approximate edit distance
+
+    Arguments (reference _tfidf.py:17-39, unchanged):
+        n_gram_range: The n_gram_range on a character-level
+        clean_string: Whether to clean the string such that only alphanumerical characters are kept
+        min_similarity: The minimum similarity between strings, otherwise return 0 similarity
+        top_n: The number of matches you want returned
+        cosine_method: "sparse" (default; honours min_similarity), "sklearn", "knn" (ignore it, as the
+                       reference does) -- all run the HIP kernel
+        model_id: The name of the particular instance, used when comparing models
+        remove_space_ngrams: Remove n-grams that contain a space
+    """
+    def __init__(self,
+                 n_gram_range: Tuple[int, int] = (3, 3),
+                 clean_string: bool = True,
+                 min_similarity: float = 0.75,
+                 top_n: int = 1,
+                 cosine_method: str = "sparse",
+                 model_id: str = None,
+                 remove_space_ngrams=True):
+        super().__init__(model_id)
+        self.type = "TF-IDF"
+        self.n_gram_range = n_gram_range
+        self.clean_string = clean_string
+        self.min_similarity = min_similarity
+        self.cosine_method = cosine_method
+        self.top_n = top_n
+        self.remove_space_ngrams = remove_space_ngrams
+        self._dev_vec = None        # _lib.DeviceTfidf
+        self._dev_to = None         # _lib.DeviceCSR of the to-side
+        self._dev_index = None      # _lib.DeviceIndex of the to-side
+        self._vectorizer = None
+        self._host_state = None     # picklable copy (see __getstate__)
+
+    # ---- reference attributes ------------------------------------------------
+    @property
+    def vectorizer(self):
+        self._restore()
+        return self._vectorizer
+
+    @property
+    def tf_idf_to(self):
+        self._restore()
+        return None if self._dev_to is None else _download_csr(self._dev_to)
+
+    # ---- API -------------------------------------------------------------------
+    def match(self,
+              from_list: List[str],
+              to_list: List[str] = None,
+              re_train: bool = True) -> pd.DataFrame:
+        """ Match two lists of strings to each other and return the most similar strings
+        (reference _tfidf.py:68-100) """
+        if self.cosine_method not in _METHODS:
+            raise ValueError(f"cosine_method must be one of {_METHODS}")
+        ctx = _lib.Context.default()
+        from_dev, to_dev = self._extract_tf_idf(from_list, to_list, re_train)
+        top_n = self.top_n
+        if to_list is not None and top_n > len(set(to_list)):     # _utils.py:54-56
+            top_n = len(set(to_list))
+        self_match = to_list is None
+        lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
+        idx, val = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower,
+                                    exclude_diag=self_match).download()
+        names = list(from_list) if self_match else to_list
+        return topn_to_frame(idx, val, from_list, names, top_n)
+
+    # ---- internals ---------------------------------------------------------------
+    def _params(self):
+        lo, hi = int(self.n_gram_range[0]), int(self.n_gram_range[1])
+        return _lib.TfidfParams(lo, hi, int(bool(self.clean_string)), int(bool(self.remove_space_ngrams)))
+
+    def _upload(self, strings):
+        ctx = _lib.Context.default()
+        if self.clean_string and not _is_latin1(strings):
+            # cleaning is idempotent, so the device's clean pass leaves these untouched
+            strings = [_clean_string(s) for s in strings]
+        return _lib.DeviceStrings.upload(ctx, strings)
+
+    def _extract_tf_idf(self, from_list, to_list=None, re_train=True):
+        """ reference _tfidf.py:102-118: fit on to_list + from_list (or from_list alone), keep the
+        to-side matrix; with re_train=False reuse the fitted vocabulary and to-side """
+        ctx = _lib.Context.default()
+        self._restore()
+        if to_list:
+            from_s = self._upload(from_list)
+            if re_train:
+                to_s = self._upload(to_list)
+                self._fit(ctx, to_s, from_s)
+                self._set_to_side(ctx, self._dev_vec.transform(to_s))
+            self._require_fitted()
+            return self._dev_vec.transform(from_s), self._dev_to
+        if re_train:
+            from_s = self._upload(from_list)
+            self._fit(ctx, from_s, None)
+            self._set_to_side(ctx, self._dev_vec.transform(from_s))
+        self._require_fitted()
+        return self._dev_to, self._dev_to
+
+    def _fit(self, ctx, docs_a, docs_b):
+        self._dev_vec = _lib.DeviceTfidf.fit(ctx, self._params(), docs_a, docs_b)
+        self._vectorizer = HipTfidfVectorizer(self, self._dev_vec)
+        self._host_state = None
+
+    def _set_to_side(self, ctx, dev_csr):
+        self._dev_to = dev_csr
+        self._dev_index = _lib.DeviceIndex.build(ctx, dev_csr)
+
+    def _require_fitted(self):
+        if self._dev_vec is None or self._dev_index is None:
+            raise ValueError("This TFIDF instance is not fitted yet: call match(..., re_train=True) first")
+
+    # ---- persistence (joblib.dump / load, reference polyfuzz.py:429-457) ---------
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items()
+                 if k not in ("_dev_vec", "_dev_to", "_dev_index", "_vectorizer", "_host_state")}
+        host = self._host_state
+        if host is None and self._dev_vec is not None:
+            ngrams, idf, _ = self._dev_vec.export()
+            host = {"ngrams": ngrams, "idf": idf, "n_docs": self._dev_vec.info()["n_docs"],
+                    "params": tuple(getattr(self._dev_vec.params, f) for f, _ in _lib.TfidfParams._fields_),
+                    "to_csr": None if self._dev_to is None else self._dev_to.download()}
+        state["_host_state"] = host
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._dev_vec = self._dev_to = self._dev_index = self._vectorizer = None
+
+    def _restore(self):
+        """Re-create the device state of an unpickled matcher on first use."""
+        if self._dev_vec is not None or self._host_state is None:
+            return
+        ctx = _lib.Context.default()
+        h = self._host_state
+        self._dev_vec = _lib.DeviceTfidf.from_state(ctx, _lib.TfidfParams(*h["params"]), h["ngrams"], h["idf"],
+                                                    h["n_docs"])
+        self._vectorizer = HipTfidfVectorizer(self, self._dev_vec)
+        if h["to_csr"] is not None:
+            indptr, indices, data, n_cols = h["to_csr"]
+            self._set_to_side(ctx, _lib.DeviceCSR.upload(ctx, indptr, indices, data, n_cols))

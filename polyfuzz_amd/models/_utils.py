@@ -1,0 +1,80 @@
+"""cosine_similarity -- the similarity operator of the reference
+(polyfuzz/models/_utils.py:15-125) on the MI355X engine.
+
+Same signature and output contract; every back-end name the reference accepts
+("sparse", "sklearn", "knn") runs the HIP kernel (K3 for sparse input, K5 for
+dense ndarray input) -- they differ only in what the reference makes them differ
+in: "sparse" honours `min_similarity` (strict >), "sklearn"/"knn" ignore it
+(_utils.py:62-68,95 vs :82).  There is no CPU path.
+"""
+from typing import List
+
+import numpy as np
+import pandas as pd
+from scipy.sparse import issparse
+
+from .. import _lib
+
+_METHODS = ("sparse", "sklearn", "knn", "hip")
+
+
+def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_list: List[str],
+                  top_n: int) -> pd.DataFrame:
+    """(idx, score) arrays -> the reference's DataFrame (_utils.py:104-125):
+    columns From, To, Similarity[, To_2, Similarity_2 ...]; scores rounded to 3
+    decimals (_utils.py:70,102,143); Similarity < 0.001 -> 0.0 and To -> None."""
+    n = len(from_list)
+    to_arr = np.empty(len(to_list) + 1, dtype=object)
+    to_arr[:len(to_list)] = to_list
+    to_arr[len(to_list)] = None
+    data = {"From": pd.Series(list(from_list), dtype=object)}
+    for r in range(top_n):
+        sim = np.round(val[:, r].astype(np.float64), 3) if n else np.zeros(0, np.float64)
+        j = idx[:, r].astype(np.int64) if n else np.zeros(0, np.int64)
+        none = (sim < 0.001) | (j < 0)
+        sim = np.where(none, 0.0, sim)
+        j = np.where(none, len(to_list), j)
+        data["To" if r == 0 else f"To_{r + 1}"] = pd.Series(to_arr[j], dtype=object)
+        data["Similarity" if r == 0 else f"Similarity_{r + 1}"] = sim
+    return pd.DataFrame(data)
+
+
+def _to_device_csr(ctx, m):
+    if issparse(m):
+        return _lib.DeviceCSR.from_scipy(ctx, m)
+    raise TypeError(f"expected a scipy sparse matrix, got {type(m)!r}")
+
+
+def cosine_similarity(from_vector,
+                      to_vector,
+                      from_list: List[str],
+                      to_list: List[str],
+                      min_similarity: float = 0.75,
+                      top_n: int = 1,
+                      method: str = "sparse") -> pd.DataFrame:
+    """ Calculate similarity between two matrices/vectors and return best matches
+
+    Arguments mirror reference _utils.py:15-21.  `from_vector` / `to_vector` are
+    scipy sparse matrices (TF-IDF) or dense ndarrays (embeddings); `to_list=None`
+    means self-match: the diagonal is excluded (_utils.py:84-87, 97-98).
+    """
+    if method not in _METHODS:
+        raise ValueError(f"method must be one of {_METHODS}, got {method!r}")
+    if to_list is not None:
+        if top_n > len(set(to_list)):          # _utils.py:54-56
+            top_n = len(set(to_list))
+    self_match = to_list is None
+    lower = float(min_similarity) if method in ("sparse", "hip") else 0.0
+    ctx = _lib.Context.default()
+
+    if isinstance(from_vector, np.ndarray) or isinstance(to_vector, np.ndarray):
+        idx, val = _lib.dense_cossim_topn_host(ctx, np.asarray(from_vector), np.asarray(to_vector), max(top_n, 1),
+                                               lower, self_match)
+    else:
+        a = _to_device_csr(ctx, from_vector)
+        b = a if to_vector is from_vector else _to_device_csr(ctx, to_vector)
+        index = _lib.DeviceIndex.build(ctx, b)
+        idx, val = _lib.cossim_topn(ctx, index, a, max(top_n, 1), lower, exclude_diag=self_match).download()
+    if self_match:
+        to_list = list(from_list)
+    return topn_to_frame(idx, val, from_list, to_list, top_n)

@@ -1,0 +1,87 @@
+"""GPU parity of K4 (all-pairs Indel ratio + first arg-max) against the oracle's plain-DP LCS."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrix(ctx, fl, tl):
+    from polyfuzz_amd import _lib
+    f = _lib.DeviceStrings.upload(ctx, fl)
+    t = _lib.DeviceStrings.upload(ctx, tl)
+    return _lib.indel_matrix(ctx, f, t), _lib.indel_argmax(ctx, f, t)
+
+
+def test_readme_matrix_known_answers(ctx):
+    fl = ["apple", "apples", "appl", "recal", "house", "similarity"]
+    tl = ["apple", "apples", "mouse"]
+    m, (idx, score) = _matrix(ctx, fl, tl)
+    exp = np.array([[100, 90.909091, 20], [90.909091, 100, 18.181818], [88.888889, 80, 0], [40, 36.363636, 20],
+                    [20, 18.181818, 80], [13.333333, 12.5, 13.333333]])
+    np.testing.assert_allclose(m, exp, atol=1e-6)
+    np.testing.assert_array_equal(idx, [0, 1, 0, 0, 2, 0])       # first maximum wins (rows 3 and 5 tie)
+
+
+def test_titles_bit_exact_vs_oracle(ctx, oracle_mod, golden):
+    t = golden["titles_lists"]
+    fl, tl = t["from_list"], t["to_list"]
+    m, (idx, score) = _matrix(ctx, fl, tl)
+    e_idx, e_score, e_m = oracle_mod.indel_argmax(fl, tl, want_matrix=True)
+    np.testing.assert_array_equal(m, e_m)            # float64, same formula: bit-exact
+    np.testing.assert_array_equal(idx, e_idx)
+    np.testing.assert_array_equal(score, e_score)
+    np.testing.assert_array_equal(idx, golden["npz"]["titles_idx_norm0"])
+    np.testing.assert_array_equal(score, golden["npz"]["titles_sim_norm0"])
+
+
+def test_word_classes_and_edge_lengths(ctx, oracle_mod):
+    rng = np.random.default_rng(11)
+    alpha = "abcdefgh "
+    lens_f = [0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 256, 257, 400, 512, 700, 1024]
+    lens_t = [0, 1, 3, 17, 32, 64, 100, 130, 300, 600, 1500] + list(rng.integers(1, 40, 120))
+    mk = lambda n: "".join(alpha[i] for i in rng.integers(0, len(alpha), n))
+    fl, tl = [mk(n) for n in lens_f], [mk(int(n)) for n in lens_t]
+    m, (idx, score) = _matrix(ctx, fl, tl)
+    e_idx, e_score, e_m = oracle_mod.indel_argmax(fl, tl, want_matrix=True)
+    np.testing.assert_array_equal(m, e_m)
+    np.testing.assert_array_equal(idx, e_idx)
+    np.testing.assert_array_equal(score, e_score)
+    assert m[0, 0] == 100.0          # both empty
+
+
+def test_wide_alphabet_16bit_symbols(ctx, oracle_mod):
+    rng = np.random.default_rng(5)
+    cps = list(range(0x4E00, 0x4E00 + 400)) + list(range(0x41, 0x5B))     # > 255 distinct symbols
+    mk = lambda n: "".join(chr(cps[i]) for i in rng.integers(0, len(cps), n))
+    fl = [mk(int(n)) for n in rng.integers(0, 50, 40)]
+    tl = [mk(int(n)) for n in rng.integers(0, 50, 150)] + fl[:5]
+    m, (idx, score) = _matrix(ctx, fl, tl)
+    e_idx, e_score, e_m = oracle_mod.indel_argmax(fl, tl, want_matrix=True)
+    np.testing.assert_array_equal(m, e_m)
+    np.testing.assert_array_equal(idx, e_idx)
+
+
+def test_self_match_removes_first_equal(ctx, oracle_mod, golden):
+    from polyfuzz_amd import _lib
+    dup = golden["titles_self_list"]["from_list"]
+    first = {}
+    for j, s in enumerate(dup):
+        first.setdefault(s, j)
+    skip = np.array([first[s] for s in dup], np.int32)
+    f = _lib.DeviceStrings.upload(ctx, dup)
+    idx, score = _lib.indel_argmax(ctx, f, f, skip)
+    e_idx, e_score = oracle_mod.indel_argmax(dup, dup, self_match=True)
+    np.testing.assert_array_equal(idx, e_idx)
+    np.testing.assert_array_equal(score, e_score)
+    np.testing.assert_array_equal(score, golden["npz"]["titles_self_sim"])
+    assert [dup[j] for j in idx] == list(golden["npz"]["titles_self_to"])
+    # row shard
+    idx2, score2 = _lib.indel_argmax(ctx, f, f, skip, 40, 90)
+    np.testing.assert_array_equal(idx2, idx[40:90])
+
+
+def test_too_long_from_string_is_loud(ctx):
+    from polyfuzz_amd import _lib
+    f = _lib.DeviceStrings.upload(ctx, ["a" * 1025])
+    with pytest.raises(NotImplementedError):
+        _lib.indel_argmax(ctx, f, f)

@@ -1,0 +1,117 @@
+"""End-to-end parity of the drop-in matchers (polyfuzz_amd.models.TFIDF / EditDistance)
+against DataFrames produced by the REFERENCE itself (tests/golden/, make_golden.py)."""
+import io
+import pickle
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp_frame(df, rec, sim_atol=1.01e-3):
+    assert list(df.columns) == list(rec.keys())
+    for c in df.columns:
+        got = df[c].tolist()
+        if "Similarity" in c:
+            np.testing.assert_allclose(np.array(got, float), np.array(rec[c], float), atol=sim_atol)
+        else:
+            assert [None if (isinstance(v, float) and v != v) else v for v in got] == rec[c], c
+
+
+def test_readme_cases_match_reference_frames(golden):
+    from polyfuzz_amd.models import TFIDF
+    rc = golden["readme_cases"]
+    fl, tl = rc["from_list"], rc["to_list"]
+    n = 0
+    for case in rc["cases"]:
+        kw = dict(case["kwargs"])
+        if "n_gram_range" in kw:
+            kw["n_gram_range"] = tuple(kw["n_gram_range"])
+            if kw["n_gram_range"][1] > 5 and not kw.get("clean_string", True):
+                continue            # 6-grams of uncleaned text exceed the 36-bit code space (loud error, tested elsewhere)
+        m = TFIDF(cosine_method="sklearn", **kw)      # goldens were made with the reference's sklearn back-end
+        df = m.match(fl) if case["self"] else m.match(fl, tl)
+        _cmp_frame(df, case["df"])
+        n += 1
+    assert n >= 18
+
+
+def test_readme_sparse_semantics_min_similarity():
+    from polyfuzz_amd.models import TFIDF
+    fl = ["apple", "apples", "appl", "recal", "house", "similarity"]
+    tl = ["apple", "apples", "mouse"]
+    df = TFIDF().match(fl, tl)      # defaults: min_similarity 0.75, "sparse" -> strict lower bound honoured
+    assert df["To"].tolist() == ["apple", "apples", "apple", None, None, None]
+    np.testing.assert_allclose(df["Similarity"], [1.0, 1.0, 0.784, 0, 0, 0], atol=1e-9)
+    df = TFIDF(min_similarity=0, top_n=2).match(fl)      # self-match, SURVEY §8c
+    assert df["To"].tolist()[:3] == ["apples", "apple", "apple"]
+    np.testing.assert_allclose(df["Similarity"][:3], [0.787, 0.787, 0.767], atol=1e-9)
+    np.testing.assert_allclose(df["Similarity_2"][:3], [0.767, 0.604, 0.604], atol=1e-9)
+
+
+def test_fit_transform_and_pickle(golden):
+    from polyfuzz_amd.models import TFIDF
+    rc = golden["readme_cases"]
+    fl, tl = rc["from_list"], rc["to_list"]
+    m = TFIDF(cosine_method="sklearn", min_similarity=0, top_n=1)
+    m.match(fl, tl)
+    new_from = rc["transform"]["new_from"]
+    _cmp_frame(m.match(new_from, tl, re_train=False), rc["transform"]["df"])
+    assert m.vectorizer.get_feature_names_out()[0] == "app" and m.tf_idf_to.shape == (3, 19)
+    m2 = pickle.loads(pickle.dumps(m))
+    _cmp_frame(m2.match(new_from, tl, re_train=False), rc["transform"]["df"])
+    assert m2.vectorizer.vocabulary_ == m.vectorizer.vocabulary_
+
+
+def test_company_c2_frame_vs_reference(golden):
+    from polyfuzz_amd.models import TFIDF
+    fl = golden["company_c2_lists"]["from_list"]
+    tl = golden["company_c2_lists"]["to_list"]
+    df = TFIDF(cosine_method="sklearn", min_similarity=0, top_n=5).match(fl, tl)
+    ref_sim = golden["npz"]["c2_ref_sim"]
+    canon = golden["npz"]["c2_canon_idx"]
+    pos = {}
+    for i, s in enumerate(tl):
+        pos.setdefault(s, i)
+    bad = 0
+    for r in range(5):
+        sc = "Similarity" if r == 0 else f"Similarity_{r + 1}"
+        tc = "To" if r == 0 else f"To_{r + 1}"
+        np.testing.assert_allclose(df[sc].to_numpy(), ref_sim[:, r], atol=1.01e-3)
+        got = np.array([-1 if t is None else pos[t] for t in df[tc].tolist()])
+        exp = np.where(ref_sim[:, r] < 0.001, -1, canon[:, r])
+        bad += int((got != exp).sum())
+    assert bad <= 0.002 * 5 * len(fl)      # only near-ties in the reference's own float64 scores may differ
+
+
+def test_edit_distance_frames(golden):
+    from polyfuzz_amd.models import EditDistance
+    rc = golden["readme_cases"]
+    fl, tl = rc["from_list"], rc["to_list"]
+    for case in rc["edit_distance"]:
+        m = EditDistance(normalize=case["normalize"])
+        df = m.match(fl) if case["self"] else m.match(fl, tl)
+        _cmp_frame(df, case["df"], sim_atol=1e-12)
+    t = golden["titles_lists"]
+    for norm in (True, False):
+        df = EditDistance(normalize=norm).match(t["from_list"], t["to_list"])
+        np.testing.assert_allclose(df["Similarity"].to_numpy(), golden["npz"][f"titles_sim_norm{int(norm)}"], atol=1e-12)
+        assert df["To"].tolist() == [t["to_list"][j] for j in golden["npz"][f"titles_idx_norm{int(norm)}"]]
+    with pytest.raises(NotImplementedError):
+        EditDistance(scorer=lambda a, b: 0.0)
+
+
+def test_cosine_similarity_operator_sparse_input(oracle_mod):
+    from scipy.sparse import csr_matrix
+    from polyfuzz_amd.models import cosine_similarity
+    from tests.helpers import vectorize_pair
+    fl = ["apple", "apples", "appl", "recal", "house", "similarity"]
+    tl = ["apple", "apples", "mouse"]
+    a3, b3, n_col = vectorize_pair(oracle_mod, fl, tl)
+    A = csr_matrix((a3[2], a3[1], a3[0]), shape=(6, n_col))
+    B = csr_matrix((b3[2], b3[1], b3[0]), shape=(3, n_col))
+    df = cosine_similarity(A, B, fl, tl, min_similarity=0, top_n=5)
+    assert list(df.columns) == ["From", "To", "Similarity", "To_2", "Similarity_2", "To_3", "Similarity_3"]
+    assert df["To"].tolist() == ["apple", "apples", "apple", None, "mouse", None]

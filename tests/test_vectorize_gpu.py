@@ -1,0 +1,107 @@
+"""GPU parity of K1/K2 (device TF-IDF vectorisation) against the oracle restatement of
+sklearn's TfidfVectorizer + the reference analyzer (oracle/tfidf_oracle.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+README_FROM = ["apple", "apples", "appl", "recal", "house", "similarity"]
+README_TO = ["apple", "apples", "mouse"]
+
+
+def _device_vectorize(ctx, from_list, to_list, lo, hi, clean, remove_space=True):
+    from polyfuzz_amd import _lib
+    params = _lib.TfidfParams(lo, hi, int(clean), int(remove_space))
+    f = _lib.DeviceStrings.upload(ctx, from_list)
+    t = _lib.DeviceStrings.upload(ctx, to_list) if to_list is not None else None
+    vec = _lib.DeviceTfidf.fit(ctx, params, t if t is not None else f, f if t is not None else None)
+    out = [vec.transform(f).download()]
+    if t is not None:
+        out.append(vec.transform(t).download())
+    return vec, out
+
+
+def _check_csr(dev, exp, n_col):
+    indptr, indices, data, ncols = dev
+    e_indptr, e_indices, e_data = exp
+    assert ncols == n_col
+    np.testing.assert_array_equal(indptr, e_indptr)
+    np.testing.assert_array_equal(indices, e_indices)
+    np.testing.assert_allclose(data, e_data, rtol=0, atol=2e-7)
+    return float((data == e_data.astype(np.float32)).mean()) if len(data) else 1.0
+
+
+@pytest.mark.parametrize("rng", [(1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (3, 3), (3, 5)])
+@pytest.mark.parametrize("clean", [True, False])
+def test_readme_lists_all_ranges(ctx, oracle_mod, rng, clean):
+    vec, (a, b) = _device_vectorize(ctx, README_FROM, README_TO, rng[0], rng[1], clean)
+    o = oracle_mod.TfidfOracle(n_gram_range=rng, clean=clean).fit(README_TO + README_FROM)
+    _check_csr(a, o.transform(README_FROM), len(o.vocabulary))
+    _check_csr(b, o.transform(README_TO), len(o.vocabulary))
+    ngrams, idf, df = vec.export()
+    names = ["".join(chr(c) for c in row if c) for row in ngrams.tolist()]
+    assert names == o.vocabulary
+    np.testing.assert_array_equal(df, o.df)
+    np.testing.assert_allclose(idf, o.idf, rtol=1e-15)
+
+
+def test_company_c2(ctx, oracle_mod, golden):
+    fl = golden["company_c2_lists"]["from_list"]
+    tl = golden["company_c2_lists"]["to_list"]
+    vec, (a, b) = _device_vectorize(ctx, fl, tl, 3, 3, True)
+    o = oracle_mod.TfidfOracle().fit(tl + fl)
+    assert len(o.vocabulary) == int(golden["npz"]["c2_vocab_size"][0])
+    exact_a = _check_csr(a, o.transform(fl), len(o.vocabulary))
+    exact_b = _check_csr(b, o.transform(tl), len(o.vocabulary))
+    assert a[0][-1] == golden["npz"]["c2_nnz"][0] and b[0][-1] == golden["npz"]["c2_nnz"][1]
+    assert min(exact_a, exact_b) > 0.999   # fp32(float64 value) bit-for-bit on (nearly) every entry
+
+
+def test_self_fit_and_messy_strings(ctx, oracle_mod):
+    docs = ["  Hello,   World!! ", "A\tB  C\nD", "", "   ", "a", "ab", "abc", "ABC abc AbC", "x" * 70 + " " + "yz" * 40,
+            "1st & 2nd St.", "trailing   ", "Ünited été", "a  b", "..."]
+    for clean in (True, False):
+        for rs in (True, False):
+            vec, (a,) = _device_vectorize(ctx, docs, None, 2, 3, clean, rs)
+            o = oracle_mod.TfidfOracle(n_gram_range=(2, 3), clean=clean, remove_space_ngrams=rs).fit(docs)
+            _check_csr(a, o.transform(docs), len(o.vocabulary))
+
+
+def test_wide_characters_and_long_rows(ctx, oracle_mod, golden):
+    t = golden["titles_lists"]
+    fl, tl = t["from_list"], t["to_list"]
+    long_docs = ["".join(chr(97 + (i * 7 + j) % 26) for j in range(300 + 40 * i)) for i in range(6)]
+    long_docs.append("ab" * 3000)            # > 4096 n-grams: the global-scratch path of k_rows_long
+    fl = fl + long_docs
+    vec, (a, b) = _device_vectorize(ctx, fl, tl, 3, 3, False)
+    o = oracle_mod.TfidfOracle(clean=False).fit(tl + fl)
+    _check_csr(a, o.transform(fl), len(o.vocabulary))
+    _check_csr(b, o.transform(tl), len(o.vocabulary))
+
+
+def test_transform_out_of_vocabulary_and_roundtrip(ctx, oracle_mod):
+    from polyfuzz_amd import _lib
+    fit_docs = ["apple pie", "apple tart", "cherry pie"]
+    new_docs = ["apple strudel", "zzz qqq", "", "pie"]
+    for clean in (True, False):
+        params = _lib.TfidfParams(3, 3, int(clean), 1)
+        vec = _lib.DeviceTfidf.fit(ctx, params, _lib.DeviceStrings.upload(ctx, fit_docs), None)
+        o = oracle_mod.TfidfOracle(clean=clean).fit(fit_docs)
+        got = vec.transform(_lib.DeviceStrings.upload(ctx, new_docs)).download()
+        _check_csr(got, o.transform(new_docs), len(o.vocabulary))
+        ngrams, idf, df = vec.export()
+        vec2 = _lib.DeviceTfidf.from_state(ctx, params, ngrams, idf, vec.info()["n_docs"])
+        got2 = vec2.transform(_lib.DeviceStrings.upload(ctx, new_docs)).download()
+        for x, y in zip(got, got2):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_errors(ctx):
+    from polyfuzz_amd import _lib
+    s = _lib.DeviceStrings.upload(ctx, ["", "  ", "ab"])
+    with pytest.raises(ValueError, match="empty vocabulary"):
+        _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 3, 1, 1), s, None)
+    with pytest.raises(NotImplementedError):
+        _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 7, 1, 1), s, None)
+    with pytest.raises(_lib.PfzError):
+        _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 2, 1, 1), s, None)
