@@ -5,16 +5,18 @@ Workload (BASELINE.json metric: "TF-IDF cosine 100k x 100k"): char-3-gram TF-IDF
 cosine top-5, min_similarity 0, 100 000 synthetic company-name-like from-strings
 against 100 000 to-strings per GPU (polyfuzz_amd.synth: token recombination of
 the real company-name statistics; the reference's data files are HTTP downloads
-and are not on the GPU box).  One "step" = one pass of the hot path with the
-string lists already resident in HBM: vectorise both lists, build the to-side
-inverted index, run the fused cosine top-n kernel (everything `TFIDF.match`
-does between receiving the lists and assembling the DataFrame).
+and do not exist on the GPU box).  One "step" = one pass of the hot path with the
+string lists already resident in HBM: fit vocabulary+idf on to+from, vectorise
+both lists, build the to-side inverted index, run the fused cosine top-n --
+everything `TFIDF.match` does between receiving the lists and assembling the
+DataFrame (reference _tfidf.py:93-98, _utils.py:54-102).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU):
-the from-side is row-sharded -- every rank owns its own 100k from-rows -- and the
-to-side is replicated ("weak" scaling; the shards are independent, the only
-exchange is the RCCL all-gather of the per-shard top-n results, which is part of
-the timed step).  torch is used for rendezvous/barrier only, never in the data path.
+Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): the
+from-side is row-sharded -- every rank owns its own 100k from-rows -- and the
+to-side is replicated ("weak" scaling).  The fit is exact across ranks (RCCL
+all-gather of vocabulary bitmaps, all-reduce of df) and the per-shard top-n blocks
+are all-gathered; both exchanges are inside the timed step.  torch is used for
+rendezvous / barrier / the max-over-ranks only, never in the data path.
 
 Prints ONE JSON line on rank 0.
 """
@@ -33,20 +35,57 @@ N_FROM = 100_000
 N_TO = 100_000
 TOP_N = 5
 MIN_SIM = 0.0
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-from", type=int, default=N_FROM)
     ap.add_argument("--n-to", type=int, default=N_TO)
     ap.add_argument("--top-n", type=int, default=TOP_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
+
+
+def cpu_baseline_and_check(job, idx, val, seconds):
+    """Time the oracle (single-thread C restatement of the reference's sparse cosine
+    top-n -- polyfuzz calls sparse_dot_topn single-threaded, _utils.py:82) on a bounded
+    sample of the same from-rows, and use its output as the parity spot check."""
+    import oracle
+    oracle.build_native()
+    a3, b3, n_col = job.host_matrices()
+    n_from = len(a3[0]) - 1
+    probe = min(200, n_from)
+    t0 = time.perf_counter()
+    oracle.cossim_topn(a3, b3, n_col, job.top_n, job.min_similarity, rows=(0, probe))
+    per_row = (time.perf_counter() - t0) / max(probe, 1)
+    rows = int(max(probe, min(n_from, seconds / max(per_row, 1e-9))))
+    t0 = time.perf_counter()
+    e_idx, e_val = oracle.cossim_topn(a3, b3, n_col, job.top_n, job.min_similarity, rows=(0, rows))
+    dt = time.perf_counter() - t0
+    base = {"value": rows * float(job.n_to) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {rows} of {n_from} from-rows x all {job.n_to} to-rows, oracle/cossim_topn.c "
+                      f"(Gustavson + strict bound + top-{job.top_n}), {dt:.1f} s on 1 of {os.cpu_count()} host cores; "
+                      "vectorisation not included"}
+    g_idx, g_val = idx[:rows], val[:rows].astype(np.float64)
+    max_err = float(np.abs(g_val - e_val).max()) if rows else 0.0
+    mism = np.nonzero((g_idx != e_idx).any(axis=1))[0]
+    # an index mismatch is a real error unless the float64 oracle itself has the two scores within 2e-6
+    hard = 0
+    for i in mism[:2000]:
+        dense = oracle.cossim_dense(a3, b3, n_col, rows=(int(i), int(i) + 1))[0]
+        for r in range(job.top_n):
+            if g_idx[i, r] != e_idx[i, r]:
+                s = dense[g_idx[i, r]] if g_idx[i, r] >= 0 else 0.0
+                if abs(s - e_val[i, r]) >= 2e-6:
+                    hard += 1
+    check = {"rows_checked": rows, "max_abs_score_err": max_err, "rows_with_index_diff": int(len(mism)),
+             "index_diffs_not_near_ties": hard, "ok": bool(max_err <= 1e-5 and hard == 0)}
+    return base, check
 
 
 def main():
@@ -59,7 +98,7 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    dist = None
+    dist = torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -67,24 +106,23 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import polyfuzz_amd
-    from polyfuzz_amd import engine, synth
+    from polyfuzz_amd import _lib, pipeline, synth
 
     ctx = polyfuzz_amd.Context(local_rank)
     info = ctx.info()
+    comm = _lib.Comm.from_torch_distributed(ctx, dist) if world > 1 else None
 
-    # ---- inputs: replicated to-list, per-rank from-shard -----------------------
+    # ---- inputs: replicated to-list, per-rank from-shard (resident in HBM before timing) ----
     to_list = synth.company_names(args.n_to, seed=5678)
     from_list = synth.company_names(args.n_from, seed=1234 + rank)
-
-    job = engine.TfidfMatchJob(ctx, from_list, to_list, top_n=args.top_n, min_similarity=MIN_SIM,
-                               world=world, rank=rank, dist=dist)
+    job = pipeline.TfidfMatchJob(ctx, from_list, to_list, top_n=args.top_n, min_similarity=MIN_SIM, comm=comm)
 
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
             dist.barrier()
             torch.cuda.synchronize()
+            ctx.sync()
 
     for _ in range(args.warmup):
         job.step()
@@ -94,33 +132,31 @@ def main():
     t0 = time.perf_counter()
     ctx.event_record(0)
     for _ in range(args.steps):
-        job.step()
+        result = job.step()
     ctx.event_record(1)
     barrier()
-    t1 = time.perf_counter()
+    wall = time.perf_counter() - t0
     ctx.prof_enable(False)
-    wall = t1 - t0
     if dist is not None:
-        import torch
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
-    stats = job.stats()                      # nnz, madds, vocab ...
-    k3_ms, k3_launches = ctx.prof_get("k3_cossim_topn")
-    kernel_ms = {name: ctx.prof_get(name)[0] / max(1, args.steps) for name in engine.PROFILED_KERNELS}
-    gpu_ms = ctx.event_elapsed_ms(0, 1)
-
-    pairs_per_step = float(args.n_from) * float(args.n_to) * world
-    value = pairs_per_step * args.steps / wall
-
     out = None
     if rank == 0:
+        stats = job.stats()
+        k3_ms, k3_launches = ctx.prof_get("k3_cossim_topn")
+        kernel_ms = {name: round(ctx.prof_get(name)[0] / max(1, args.steps), 4) for name in pipeline.PROFILED_KERNELS}
+        gpu_ms = ctx.event_elapsed_ms(0, 1)
+        pairs_per_step = float(args.n_from) * float(args.n_to) * world
+        value = pairs_per_step * args.steps / wall
         k3_avg_s = (k3_ms / max(1, k3_launches)) * 1e-3
+        # algorithmic bytes of one K3 launch (SURVEY.md §8d / DESIGN.md): one 8-byte posting per
+        # multiply-add + the from-side CSR once + the (idx, score) results once
         bytes_alg = 8.0 * stats["madds"] + 8.0 * stats["nnz_from"] + 8.0 * args.n_from * args.top_n
         achieved = bytes_alg / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0
         out = {
-            "metric": "string-pairs/sec, TF-IDF cosine top-n",
+            "metric": "string-pairs/sec, TF-IDF cosine top-n (+ top-1 match latency = ms_per_step)",
             "value": value,
             "unit": "pairs/s",
             "n_gpus": world,
@@ -134,16 +170,15 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"TF-IDF char-3-gram cosine top-{args.top_n}, min_similarity {MIN_SIM}, "
-                            f"{args.n_from}x{args.n_to} synthetic company-name-like strings per GPU "
+                            f"{args.n_from} x {args.n_to} synthetic company-name-like strings per GPU "
                             f"(from-side row-sharded, to-side replicated)",
                 "n_from_per_gpu": args.n_from, "n_to": args.n_to, "top_n": args.top_n,
                 "vocab": stats["vocab"], "nnz_from": stats["nnz_from"], "nnz_to": stats["nnz_to"],
-                "multiply_adds": stats["madds"],
+                "multiply_adds_per_gpu": stats["madds"],
                 "step": job.step_description(),
                 "parallelism": f"row-shard x{world}",
                 "device": info["name"],
             },
-            "top1_latency_ms": wall / args.steps * 1e3,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,
             "kernel_ms_per_step": kernel_ms,
             "roofline": {
@@ -160,9 +195,8 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = engine.cpu_baseline(job, seconds=args.cpu_seconds)
-        # parity spot check of the last step's result against the oracle (not timed)
-        out["parity_check"] = engine.spot_check(job)
+            idx, val = result.download()
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline_and_check(job, idx, val, args.cpu_seconds)
     barrier()
     if dist is not None:
         dist.destroy_process_group()

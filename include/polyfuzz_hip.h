@@ -44,7 +44,8 @@ typedef struct pfz_csr pfz_csr;       /* device-resident CSR matrix (fp32 values
 typedef struct pfz_index pfz_index;   /* device-resident inverted index of a to-side CSR */
 typedef struct pfz_topn pfz_topn;     /* device-resident (idx int32, score fp32)[n_rows][ntop] */
 typedef struct pfz_strings pfz_strings; /* device-resident packed string list */
-typedef struct pfz_tfidf pfz_tfidf;   /* fitted vectoriser: vocabulary + idf (+ to-side matrix/index) */
+typedef struct pfz_tfidf pfz_tfidf;   /* fitted vectoriser: vocabulary + idf */
+typedef struct pfz_comm pfz_comm;     /* RCCL communicator bound to a context (one process per GPU) */
 
 /* ---- library / context -------------------------------------------------- */
 int pfz_version(void);
@@ -200,7 +201,6 @@ int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_fr
  * the all-gather of per-shard results.  Bootstrap: rank 0 calls
  * pfz_comm_unique_id, the 128-byte id is broadcast by the host launcher
  * (torch.distributed / MPI / a file), every rank calls pfz_comm_init. */
-typedef struct pfz_comm pfz_comm;
 int pfz_comm_unique_id(uint8_t id128[128]);
 int pfz_comm_init(pfz_ctx *ctx, const uint8_t id128[128], int32_t rank, int32_t world, pfz_comm **out);
 void pfz_comm_destroy(pfz_comm *c);
@@ -209,6 +209,15 @@ void pfz_comm_destroy(pfz_comm *c);
  * rows_per_rank rows.  Enqueues on the context stream. */
 int pfz_comm_allgather_topn(pfz_comm *c, const pfz_topn *local, pfz_topn *global);
 int pfz_comm_barrier(pfz_comm *c);
+int pfz_comm_info(const pfz_comm *c, int32_t *rank, int32_t *world);
+/* pfz_tfidf_fit over a corpus that is split across the ranks of `comm`:
+ * `replicated` (may be NULL) is identical on every rank and counted once --
+ * the to-list -- and `local_shard` is this rank's part of the from-list.  The
+ * vocabulary is the union over ranks (all-gather of the code bitmaps) and df /
+ * n_docs are all-reduced, so every rank ends with the SAME fitted vectoriser
+ * the single-GPU fit on the concatenated lists would produce. */
+int pfz_tfidf_fit_sharded(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params,
+                          const pfz_strings *replicated, const pfz_strings *local_shard, pfz_tfidf **out);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,8 @@ SIGNATURES = {
     "pfz_comm_destroy": (None, [c_vp]),
     "pfz_comm_allgather_topn": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "pfz_comm_barrier": (ctypes.c_int, [c_vp]),
+    "pfz_comm_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
+    "pfz_tfidf_fit_sharded": (ctypes.c_int, [c_vp, c_vp, P(TfidfParams), c_vp, c_vp, P(c_vp)]),
 }
 
 _lib = None
@@ -433,3 +435,56 @@ def dense_cossim_topn_host(ctx, from_vec, to_vec, ntop, lower_bound, exclude_dia
     check(ctx.lib.pfz_dense_cossim_topn_host(ctx.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], int(ntop),
                                              float(lower_bound), int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
     return idx, val
+
+
+# ---- multi-GPU (one process per GPU, RCCL) -------------------------------------------
+
+class Comm(_Handle):
+    """RCCL communicator bound to a Context.  Bootstrap: rank 0 creates the 128-byte
+    unique id, the launcher broadcasts it (torch.distributed / MPI / file)."""
+    _free = "pfz_comm_destroy"
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_uint8 * 128)()
+        check(load().pfz_comm_unique_id(ctypes.cast(buf, c_vp)))
+        return bytes(buf)
+
+    @classmethod
+    def init(cls, ctx, uid, rank, world):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(uid)
+        h = c_vp()
+        check(ctx.lib.pfz_comm_init(ctx.h, ctypes.cast(buf, c_vp), int(rank), int(world), ctypes.byref(h)))
+        c = cls(ctx, h)
+        c.rank, c.world = int(rank), int(world)
+        return c
+
+    @classmethod
+    def from_torch_distributed(cls, ctx, dist):
+        """Bootstrap through an initialised torch.distributed process group (rendezvous only)."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.init(ctx, box[0], rank, world)
+
+    def barrier(self):
+        check(self.ctx.lib.pfz_comm_barrier(self.h))
+
+    def allgather_topn(self, local, out=None):
+        if out is None:
+            out = DeviceTopN.alloc(self.ctx, local.n_rows * self.world, local.ntop)
+        check(self.ctx.lib.pfz_comm_allgather_topn(self.h, local.h, out.h))
+        return out
+
+
+def tfidf_fit_sharded(ctx, comm, params, replicated, local_shard):
+    h = c_vp()
+    rc = ctx.lib.pfz_tfidf_fit_sharded(ctx.h, comm.h, ctypes.byref(params),
+                                       replicated.h if replicated is not None else None,
+                                       local_shard.h if local_shard is not None else None, ctypes.byref(h))
+    if rc == -1 and b"empty vocabulary" in ctx.lib.pfz_last_error():
+        raise ValueError("empty vocabulary; perhaps the documents only contain stop words")
+    check(rc)
+    v = DeviceTfidf(ctx, h)
+    v.params = params
+    return v

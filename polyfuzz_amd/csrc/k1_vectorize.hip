@@ -369,12 +369,12 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
     const size_t need = (size_t)(s->n_units > 0 ? s->n_units : 1) * (size_t)R;
     if (s->slots_cap < need) {
-        if (s->slots) PFZ_HIP(hipFree(s->slots));
+        if (s->slots) pool_free(s->slots);
         s->slots = nullptr;
-        PFZ_HIP(hipMalloc(&s->slots, need * sizeof(uint64_t)));
+        PFZ_TRY(pool_alloc(ctx, &s->slots, need * sizeof(uint64_t)));
         s->slots_cap = need;
     }
-    if (!s->row_cnt) PFZ_HIP(hipMalloc(&s->row_cnt, (size_t)(s->n + 1) * 2 * sizeof(int32_t)));
+    if (!s->row_cnt) PFZ_TRY(pool_alloc(ctx, &s->row_cnt, (size_t)(s->n + 1) * 2 * sizeof(int32_t)));
     if (s->n == 0) return PFZ_OK;
     ExtractParams P{v->params.ngram_lo, v->params.ngram_hi, v->params.clean, v->params.remove_space_ngrams,
                     v->bits_per_char, v->alpha_map_len};
@@ -437,8 +437,8 @@ static int alloc_vocab_space(pfz_ctx *ctx, pfz_tfidf *v)
 {
     const int64_t n_bits = std::max<int64_t>((int64_t)1 << v->code_bits, 256);
     v->n_groups = n_bits / 256;
-    PFZ_HIP(hipMalloc(&v->bitmap, (size_t)(n_bits / 8)));
-    PFZ_HIP(hipMalloc(&v->prefix, (size_t)(v->n_groups + 1) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &v->bitmap, (size_t)(n_bits / 8)));
+    PFZ_TRY(pool_alloc(ctx, &v->prefix, (size_t)(v->n_groups + 1) * sizeof(int32_t)));
     PFZ_HIP(hipMemsetAsync(v->bitmap, 0, (size_t)(n_bits / 8), ctx->stream));
     return PFZ_OK;
 }
@@ -467,8 +467,9 @@ static int set_alphabet(pfz_ctx *ctx, pfz_tfidf *v, const std::vector<uint32_t> 
     std::vector<uint32_t> map((size_t)max_cp + 1, 0u);
     for (size_t r = 0; r < sorted_cps.size(); ++r) map[sorted_cps[r]] = (uint32_t)r + 1u;
     v->alpha_map_len = (int64_t)map.size();
-    PFZ_HIP(hipMalloc(&v->alpha_map, map.size() * sizeof(uint32_t)));
-    PFZ_HIP(hipMemcpy(v->alpha_map, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PFZ_TRY(pool_alloc(ctx, &v->alpha_map, map.size() * sizeof(uint32_t)));
+    PFZ_HIP(hipMemcpyAsync(v->alpha_map, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));   // `map` is a temporary
     return PFZ_OK;
 }
 
@@ -515,8 +516,8 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
     s->max_len = max_len;
     s->h_off.assign(offsets, offsets + n + 1);
     if (n_units > 0) s->h_chars.assign((const uint8_t *)chars, (const uint8_t *)chars + (size_t)n_units * (size_t)char_width);
-    PFZ_HIP(hipMalloc(&s->chars, (size_t)(n_units > 0 ? n_units : 1) * (size_t)char_width + 16));
-    PFZ_HIP(hipMalloc(&s->offsets, (size_t)(n + 1) * sizeof(int64_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->chars, (size_t)(n_units > 0 ? n_units : 1) * (size_t)char_width + 16));
+    PFZ_TRY(pool_alloc(ctx, &s->offsets, (size_t)(n + 1) * sizeof(int64_t)));
     if (n_units > 0)
         PFZ_HIP(hipMemcpyAsync(s->chars, chars, (size_t)n_units * (size_t)char_width, hipMemcpyHostToDevice, ctx->stream));
     PFZ_HIP(hipMemcpyAsync(s->offsets, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
@@ -529,10 +530,10 @@ void pfz_strings_free(pfz_strings *s)
 {
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
-    if (s->chars) (void)hipFree(s->chars);
-    if (s->offsets) (void)hipFree(s->offsets);
-    if (s->slots) (void)hipFree(s->slots);
-    if (s->row_cnt) (void)hipFree(s->row_cnt);
+    if (s->chars) pool_free(s->chars);
+    if (s->offsets) pool_free(s->offsets);
+    if (s->slots) pool_free(s->slots);
+    if (s->row_cnt) pool_free(s->row_cnt);
     delete s;
 }
 
@@ -540,17 +541,33 @@ void pfz_tfidf_free(pfz_tfidf *v)
 {
     if (!v) return;
     if (v->ctx) (void)hipSetDevice(v->ctx->device);
-    if (v->alpha_map) (void)hipFree(v->alpha_map);
-    if (v->bitmap) (void)hipFree(v->bitmap);
-    if (v->prefix) (void)hipFree(v->prefix);
-    if (v->df) (void)hipFree(v->df);
-    if (v->idf) (void)hipFree(v->idf);
+    if (v->alpha_map) pool_free(v->alpha_map);
+    if (v->bitmap) pool_free(v->bitmap);
+    if (v->prefix) pool_free(v->prefix);
+    if (v->df) pool_free(v->df);
+    if (v->idf) pool_free(v->idf);
     delete v;
 }
 
-int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params, const pfz_strings *docs_a_c, const pfz_strings *docs_b_c,
-                  pfz_tfidf **out)
+}  // extern "C"
+
+// OR `world` bitmaps of n_words words each (gathered back to back) into dst
+__global__ __launch_bounds__(256) void k_or_reduce(const uint32_t *__restrict__ gathered, int64_t n_words, int world,
+                                                    uint32_t *__restrict__ dst)
 {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * 256) {
+        uint32_t v = 0;
+        for (int r = 0; r < world; ++r) v |= gathered[(int64_t)r * n_words + i];
+        dst[i] = v;
+    }
+}
+
+// Fit on docs_a (identical on every rank of `comm`, counted once) + docs_b (this
+// rank's shard).  comm == NULL: single-GPU fit on docs_a + docs_b.
+static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params, const pfz_strings *docs_a_c,
+                    const pfz_strings *docs_b_c, pfz_tfidf **out)
+{
+    const int world = comm_world(comm), rank = comm_rank(comm);
     PFZ_REQUIRE(ctx && out, "pfz_tfidf_fit: NULL argument");
     PFZ_TRY(check_params(params));
     PFZ_REQUIRE(docs_a_c || docs_b_c, "pfz_tfidf_fit: no documents");
@@ -583,7 +600,7 @@ int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params, const pfz_string
     } else {
         // alphabet = distinct code units of the fitted documents, in code-point order
         const size_t words = 0x110000 / 32;
-        PFZ_TRY(ensure_scratch(ctx, words * sizeof(uint32_t)));
+        PFZ_TRY(ensure_scratch(ctx, (size_t)(world + 1) * words * sizeof(uint32_t)));
         uint32_t *present = (uint32_t *)ctx->scratch;
         PFZ_HIP(hipMemsetAsync(present, 0, words * sizeof(uint32_t), ctx->stream));
         for (pfz_strings *s : lists) {
@@ -593,6 +610,11 @@ int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params, const pfz_string
                 hipLaunchKernelGGL(k_alpha_mark<1>, dim3(grid), dim3(256), 0, ctx->stream, s->chars, s->n_units, present);
             else
                 hipLaunchKernelGGL(k_alpha_mark<4>, dim3(grid), dim3(256), 0, ctx->stream, s->chars, s->n_units, present);
+        }
+        if (world > 1) {   // union of the ranks' alphabets
+            uint32_t *gathered = present + words;
+            PFZ_TRY(comm_allgather_bytes(comm, present, gathered, words * sizeof(uint32_t)));
+            hipLaunchKernelGGL(k_or_reduce, dim3(64), dim3(256), 0, ctx->stream, gathered, (int64_t)words, world, present);
         }
         std::vector<uint32_t> h(words);
         PFZ_HIP(hipMemcpyAsync(h.data(), present, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -611,21 +633,53 @@ int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params, const pfz_string
     PFZ_TRY(alloc_vocab_space(ctx, v));
     for (pfz_strings *s : lists)
         if (s) PFZ_TRY(run_extract(ctx, v, s, true));
+    if (world > 1) {   // vocabulary = union of the ranks' n-gram sets
+        const int64_t n_words = v->n_groups * 8;
+        if (v->code_bits > 30) {
+            set_error("pfz_tfidf_fit_sharded: %d-bit n-gram codes: the bitmap all-gather is limited to 30 bits", v->code_bits);
+            return PFZ_ERR_UNSUPPORTED;
+        }
+        PFZ_TRY(ensure_scratch(ctx, (size_t)world * (size_t)n_words * sizeof(uint32_t)));
+        uint32_t *gathered = (uint32_t *)ctx->scratch;
+        PFZ_TRY(comm_allgather_bytes(comm, v->bitmap, gathered, (size_t)n_words * sizeof(uint32_t)));
+        const unsigned grid = (unsigned)std::min<int64_t>((n_words + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_or_reduce, dim3(grid), dim3(256), 0, ctx->stream, gathered, n_words, world, v->bitmap);
+    }
     PFZ_TRY(build_prefix(ctx, v));
     if (v->vocab == 0) {
         // sklearn text.py:1282-1285
         set_error("empty vocabulary; perhaps the documents only contain stop words");
         return PFZ_ERR_INVALID;
     }
-    PFZ_HIP(hipMalloc(&v->df, (size_t)v->vocab * sizeof(int32_t)));
-    PFZ_HIP(hipMalloc(&v->idf, (size_t)v->vocab * sizeof(double)));
+    PFZ_TRY(pool_alloc(ctx, &v->df, (size_t)v->vocab * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &v->idf, (size_t)v->vocab * sizeof(double)));
     PFZ_HIP(hipMemsetAsync(v->df, 0, (size_t)v->vocab * sizeof(int32_t), ctx->stream));
     v->n_docs = 0;
-    for (pfz_strings *s : lists) {
+    int64_t local_docs = 0;
+    for (int li = 0; li < 2; ++li) {
+        pfz_strings *s = lists[li];
         if (!s) continue;
-        PFZ_TRY(run_rows(ctx, v, s, true));
+        // the replicated list (docs_a) is counted by rank 0 only
+        const bool counts = (li == 1) || rank == 0 || world == 1;
+        PFZ_TRY(run_rows(ctx, v, s, counts));
         s->cache_gen = v->gen;
-        v->n_docs += s->n;
+        if (counts) local_docs += s->n;
+    }
+    v->n_docs = local_docs;
+    if (world > 1) {
+        PFZ_TRY(comm_allreduce_sum_i32(comm, v->df, (size_t)v->vocab));
+        int64_t *d_n = nullptr;
+        PFZ_TRY(pool_alloc(ctx, &d_n, sizeof(int64_t)));
+        hipError_t e = hipMemcpyAsync(d_n, &local_docs, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        int rc = PFZ_OK;
+        if (e == hipSuccess) rc = comm_allreduce_sum_i64(comm, d_n, 1);
+        int64_t total = 0;
+        if (e == hipSuccess && rc == PFZ_OK) e = hipMemcpyAsync(&total, d_n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == PFZ_OK) e = hipStreamSynchronize(ctx->stream);
+        pool_free(d_n);
+        PFZ_TRY(rc);
+        PFZ_HIP(e);
+        v->n_docs = total;
     }
     hipLaunchKernelGGL(k_idf, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, v->df, v->vocab, (double)v->n_docs,
                        v->idf);
@@ -633,6 +687,22 @@ int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params, const pfz_string
     guard.p = nullptr;
     *out = v;
     return PFZ_OK;
+}
+
+extern "C" {
+
+int pfz_tfidf_fit(pfz_ctx *ctx, const pfz_tfidf_params *params, const pfz_strings *docs_a, const pfz_strings *docs_b,
+                  pfz_tfidf **out)
+{
+    return fit_impl(ctx, nullptr, params, docs_a, docs_b, out);
+}
+
+int pfz_tfidf_fit_sharded(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params, const pfz_strings *replicated,
+                          const pfz_strings *local_shard, pfz_tfidf **out)
+{
+    PFZ_REQUIRE(comm, "pfz_tfidf_fit_sharded: NULL communicator");
+    PFZ_REQUIRE(replicated != local_shard || !replicated, "pfz_tfidf_fit_sharded: the replicated and the sharded list must differ");
+    return fit_impl(ctx, comm, params, replicated, local_shard, out);
 }
 
 int pfz_tfidf_info(const pfz_tfidf *v, int64_t *vocab_size, int64_t *n_docs, int32_t *code_bits)
@@ -663,7 +733,7 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
     m->ctx = ctx;
     m->n_rows = s->n;
     m->n_cols = v->vocab;
-    PFZ_HIP(hipMalloc(&m->indptr, (size_t)(s->n + 1) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &m->indptr, (size_t)(s->n + 1) * sizeof(int32_t)));
     int32_t nnz = 0;
     if (s->n > 0) {
         const int32_t *row_nnz = s->row_cnt + (s->n + 1);
@@ -675,8 +745,8 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
         PFZ_HIP(hipMemsetAsync(m->indptr, 0, sizeof(int32_t), ctx->stream));
     }
     m->nnz = nnz;
-    PFZ_HIP(hipMalloc(&m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
-    PFZ_HIP(hipMalloc(&m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
     if (s->n > 0 && nnz > 0) {
         ProfScope ps(ctx, "k2_finalize");
         hipLaunchKernelGGL(k_finalize, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
@@ -700,13 +770,13 @@ int pfz_tfidf_export(pfz_ctx *ctx, const pfz_tfidf *v, uint32_t *ngrams, double 
     }
     if (ngrams && v->vocab > 0) {
         uint64_t *d_codes = nullptr;
-        PFZ_HIP(hipMalloc(&d_codes, (size_t)v->vocab * sizeof(uint64_t)));
+        PFZ_TRY(pool_alloc(ctx, &d_codes, (size_t)v->vocab * sizeof(uint64_t)));
         hipLaunchKernelGGL(k_export_codes, dim3(grid_for(v->n_groups)), dim3(256), 0, ctx->stream, v->bitmap, v->prefix,
                            v->n_groups, d_codes);
         std::vector<uint64_t> codes((size_t)v->vocab);
         hipError_t e = hipMemcpyAsync(codes.data(), d_codes, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_codes);
+        pool_free(d_codes);
         PFZ_HIP(e);
         const int hi = v->params.ngram_hi, w = v->bits_per_char;
         const uint64_t cmask = (1ull << w) - 1ull;
@@ -775,20 +845,21 @@ int pfz_tfidf_import(pfz_ctx *ctx, const pfz_tfidf_params *params, int64_t vocab
     }
     PFZ_TRY(alloc_vocab_space(ctx, v));
     uint64_t *d_codes = nullptr;
-    PFZ_HIP(hipMalloc(&d_codes, (size_t)vocab * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &d_codes, (size_t)vocab * sizeof(uint64_t)));
     hipError_t e = hipMemcpyAsync(d_codes, codes.data(), (size_t)vocab * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_set_bits, dim3(grid_for(vocab)), dim3(256), 0, ctx->stream, d_codes, vocab, v->bitmap);
         e = hipStreamSynchronize(ctx->stream);
     }
-    (void)hipFree(d_codes);
+    pool_free(d_codes);
     PFZ_HIP(e);
     PFZ_TRY(build_prefix(ctx, v));
     PFZ_REQUIRE(v->vocab == vocab, "pfz_tfidf_import: %lld distinct n-grams, expected %lld", (long long)v->vocab, (long long)vocab);
-    PFZ_HIP(hipMalloc(&v->df, (size_t)vocab * sizeof(int32_t)));
-    PFZ_HIP(hipMalloc(&v->idf, (size_t)vocab * sizeof(double)));
+    PFZ_TRY(pool_alloc(ctx, &v->df, (size_t)vocab * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &v->idf, (size_t)vocab * sizeof(double)));
     PFZ_HIP(hipMemsetAsync(v->df, 0, (size_t)vocab * sizeof(int32_t), ctx->stream));
-    PFZ_HIP(hipMemcpy(v->idf, idf, (size_t)vocab * sizeof(double), hipMemcpyHostToDevice));
+    PFZ_HIP(hipMemcpyAsync(v->idf, idf, (size_t)vocab * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
     guard.p = nullptr;
     *out = v;
     return PFZ_OK;

@@ -278,8 +278,8 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     ix->nnz = B->nnz;
     ix->block_cols = kC;
     ix->n_blocks = (int32_t)nb;
-    PFZ_HIP(hipMalloc(&ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
-    PFZ_HIP(hipMalloc(&ix->post, (size_t)(B->nnz > 0 ? B->nnz : 1) * sizeof(int2)));
+    PFZ_TRY(pool_alloc(ctx, &ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)(B->nnz > 0 ? B->nnz : 1) * sizeof(int2)));
     PFZ_HIP(hipMemsetAsync(ix->tab, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
     if (B->n_rows > 0 && B->nnz > 0) {
         const unsigned grid = (unsigned)((B->n_rows * 16 + 255) / 256);
@@ -306,8 +306,8 @@ void pfz_index_free(pfz_index *ix)
 {
     if (!ix) return;
     if (ix->ctx) (void)hipSetDevice(ix->ctx->device);
-    if (ix->tab) (void)hipFree(ix->tab);
-    if (ix->post) (void)hipFree(ix->post);
+    if (ix->tab) pool_free(ix->tab);
+    if (ix->post) pool_free(ix->post);
     delete ix;
 }
 

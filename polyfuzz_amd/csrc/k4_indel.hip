@@ -181,9 +181,10 @@ static inline uint32_t unit_at(const pfz_strings *s, int64_t p)
 }
 
 struct DevBuf {
+    pfz_ctx *ctx = nullptr;
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { PFZ_HIP(hipMalloc(&p, bytes > 0 ? bytes : 16)); return PFZ_OK; }
+    ~DevBuf() { if (p) pool_free(p); }
+    int alloc(size_t bytes) { return pool_alloc(ctx, &p, bytes > 0 ? bytes : 16); }
     template <typename T> int upload(const std::vector<T> &v, hipStream_t st)
     {
         PFZ_TRY(alloc(v.size() * sizeof(T)));
@@ -305,6 +306,9 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, c
         }
 
     DevBuf d_a, d_aoff, d_packed, d_goff, d_gsteps, d_blen, d_borig, d_skip, d_oidx, d_oscore, d_matrix, d_rows[6];
+    for (DevBuf *b : {&d_a, &d_aoff, &d_packed, &d_goff, &d_gsteps, &d_blen, &d_borig, &d_skip, &d_oidx, &d_oscore,
+                      &d_matrix, &d_rows[0], &d_rows[1], &d_rows[2], &d_rows[3], &d_rows[4], &d_rows[5]})
+        b->ctx = ctx;
     PFZ_TRY(d_a.upload(a_ids, ctx->stream));
     PFZ_TRY(d_aoff.upload(F->h_off, ctx->stream));
     PFZ_TRY(d_packed.upload(packed, ctx->stream));

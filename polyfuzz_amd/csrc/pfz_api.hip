@@ -7,6 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 namespace pfz {
 
 static thread_local char g_err[1024] = "";
@@ -39,6 +42,82 @@ int ensure_scratch(pfz_ctx *ctx, size_t bytes)
     size_t want = bytes + bytes / 4 + 4096;
     PFZ_HIP(hipMalloc(&ctx->scratch, want));
     ctx->scratch_bytes = want;
+    return PFZ_OK;
+}
+
+// ---- caching allocator -------------------------------------------------------
+static std::mutex g_pool_mu;
+static std::unordered_map<void *, std::pair<pfz_ctx *, size_t>> g_pool_owner;  // live block -> (ctx, class size)
+
+static size_t size_class(size_t bytes)
+{
+    if (bytes < 512) return 512;
+    size_t p2 = 512;
+    while (p2 * 2 <= bytes) p2 *= 2;       // p2 <= bytes < 2*p2
+    for (int j = 0; j <= 4; ++j) {
+        const size_t c = p2 + (p2 / 4) * j;  // p2, 1.25, 1.5, 1.75, 2 x p2
+        if (c >= bytes) return c;
+    }
+    return p2 * 2;
+}
+
+int pool_alloc_raw(pfz_ctx *ctx, void **p, size_t bytes)
+{
+    const size_t cls = size_class(bytes);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = ctx->pool_free_lists.find(cls);
+    if (it != ctx->pool_free_lists.end() && !it->second.empty()) {
+        *p = it->second.back();
+        it->second.pop_back();
+        ctx->pool_cached_bytes -= cls;
+    } else {
+        hipError_t e = hipMalloc(p, cls);
+        if (e == hipErrorOutOfMemory && ctx->pool_cached_bytes > 0) {   // give the cache back and retry once
+            (void)hipStreamSynchronize(ctx->stream);
+            for (auto &kv : ctx->pool_free_lists) {
+                for (void *q : kv.second) (void)hipFree(q);
+                kv.second.clear();
+            }
+            ctx->pool_cached_bytes = 0;
+            e = hipMalloc(p, cls);
+        }
+        if (e != hipSuccess) {
+            *p = nullptr;
+            return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+        }
+    }
+    g_pool_owner[*p] = {ctx, cls};
+    ctx->pool_live_bytes += cls;
+    return PFZ_OK;
+}
+
+void pool_free(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_owner.find(p);
+    if (it == g_pool_owner.end()) {   // not ours (should not happen): hand it to the runtime
+        (void)hipFree(p);
+        return;
+    }
+    pfz_ctx *ctx = it->second.first;
+    const size_t cls = it->second.second;
+    g_pool_owner.erase(it);
+    ctx->pool_free_lists[cls].push_back(p);
+    ctx->pool_cached_bytes += cls;
+    ctx->pool_live_bytes -= cls;
+}
+
+int pool_release(pfz_ctx *ctx)
+{
+    PFZ_HIP(hipSetDevice(ctx->device));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &kv : ctx->pool_free_lists) {
+        for (void *q : kv.second) (void)hipFree(q);
+        kv.second.clear();
+    }
+    ctx->pool_cached_bytes = 0;
     return PFZ_OK;
 }
 
@@ -255,6 +334,18 @@ void pfz_ctx_destroy(pfz_ctx *ctx)
     for (int i = 0; i < kEventSlots; ++i)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)pool_release(ctx);
+    {   // blocks still owned by live handles of this context: free them, the handles become inert
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto it = g_pool_owner.begin(); it != g_pool_owner.end();) {
+            if (it->second.first == ctx) {
+                (void)hipFree(it->first);
+                it = g_pool_owner.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -354,9 +445,9 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
         }
         ip32[(size_t)i] = (int32_t)indptr[i];
     }
-    PFZ_HIP(hipMalloc(&m->indptr, (size_t)(n_rows + 1) * sizeof(int32_t)));
-    PFZ_HIP(hipMalloc(&m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
-    PFZ_HIP(hipMalloc(&m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &m->indptr, (size_t)(n_rows + 1) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
     PFZ_HIP(hipMemcpyAsync(m->indptr, ip32.data(), (size_t)(n_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (nnz > 0) {
         PFZ_HIP(hipMemcpyAsync(m->indices, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -395,9 +486,9 @@ void pfz_csr_free(pfz_csr *m)
 {
     if (!m) return;
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
-    if (m->indptr) (void)hipFree(m->indptr);
-    if (m->indices) (void)hipFree(m->indices);
-    if (m->data) (void)hipFree(m->data);
+    if (m->indptr) pool_free(m->indptr);
+    if (m->indices) pool_free(m->indices);
+    if (m->data) pool_free(m->data);
     delete m;
 }
 
@@ -412,8 +503,8 @@ int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out)
     t->n_rows = n_rows;
     t->ntop = ntop;
     size_t n = (size_t)(n_rows > 0 ? n_rows : 1) * (size_t)ntop;
-    PFZ_HIP(hipMalloc(&t->idx, n * sizeof(int32_t)));
-    PFZ_HIP(hipMalloc(&t->val, n * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &t->idx, n * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &t->val, n * sizeof(float)));
     *out = t;
     return PFZ_OK;
 }
@@ -422,8 +513,8 @@ void pfz_topn_free(pfz_topn *t)
 {
     if (!t) return;
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
-    if (t->idx) (void)hipFree(t->idx);
-    if (t->val) (void)hipFree(t->val);
+    if (t->idx) pool_free(t->idx);
+    if (t->val) pool_free(t->val);
     delete t;
 }
 

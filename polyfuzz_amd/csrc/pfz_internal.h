@@ -57,6 +57,9 @@ struct pfz_ctx {
     // reusable scratch (grown on demand, never inside a timed region after warm-up)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // caching allocator state: size class -> free blocks
+    std::map<size_t, std::vector<void *>> pool_free_lists;
+    size_t pool_cached_bytes = 0, pool_live_bytes = 0;
 };
 
 struct pfz_csr {
@@ -135,6 +138,25 @@ struct ProfScope {
     ProfScope(pfz_ctx *c, const char *n);
     ~ProfScope();
 };
+
+// Caching device allocator of a context (pfz_api.hip).  hipMalloc/hipFree are
+// slow and hipFree synchronises the device, so blocks are size-classed and
+// recycled; every block is only ever touched by work on the owning context's
+// stream, which makes stream order the only ordering that is needed.
+int pool_alloc_raw(pfz_ctx *ctx, void **p, size_t bytes);
+template <typename T> inline int pool_alloc(pfz_ctx *ctx, T **p, size_t bytes)
+{
+    return pool_alloc_raw(ctx, (void **)p, bytes);
+}
+void pool_free(void *p);           // returns the block to its context's cache
+int pool_release(pfz_ctx *ctx);    // hipFree every cached block (blocks)
+
+// RCCL helpers (pfz_comm.hip); all enqueue on the communicator's context stream
+int comm_rank(const pfz_comm *c);
+int comm_world(const pfz_comm *c);
+int comm_allgather_bytes(pfz_comm *c, const void *send, void *recv, size_t bytes_per_rank);
+int comm_allreduce_sum_i32(pfz_comm *c, int32_t *buf, size_t n);
+int comm_allreduce_sum_i64(pfz_comm *c, int64_t *buf, size_t n);
 
 // exclusive scan of n int32 counters in place, total written to in[n]
 // (array must have n+1 slots).  Enqueues on ctx->stream.

@@ -1,0 +1,82 @@
+"""Device-resident TF-IDF match job: the hot path of `TFIDF.match` with the string
+lists already in HBM and the result left in HBM.
+
+One `step()` = everything the reference does between receiving the lists and
+building the DataFrame (reference polyfuzz/models/_tfidf.py:93-98 ->
+_utils.py:54-102): fit the vocabulary/idf on to + from, vectorise both lists,
+build the to-side inverted index, run the fused cosine top-n.
+
+Multi-GPU (one process per GPU): the from-list is row-sharded (each rank holds
+its shard), the to-list is replicated.  The fit is exact: vocabulary bitmaps are
+all-gathered and document frequencies all-reduced over RCCL, so every rank ends
+with the vectoriser a single-GPU fit on the concatenated lists would produce;
+the per-shard top-n blocks are all-gathered into the full result on every rank.
+"""
+import numpy as np
+
+from . import _lib
+
+PROFILED_KERNELS = ("k1_extract", "k2_rows_short", "k2_rows_long", "k2_finalize", "k_index_count",
+                    "k_index_fill", "k3_cossim_topn")
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous row shard [begin, end) of rank: sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class TfidfMatchJob:
+    def __init__(self, ctx, from_shard, to_list, top_n=1, min_similarity=0.0, n_gram_range=(3, 3),
+                 clean_string=True, remove_space_ngrams=True, comm=None, self_match=False, shard_offset=0):
+        self.ctx = ctx
+        self.comm = comm
+        self.top_n = int(top_n)
+        self.min_similarity = float(min_similarity)
+        self.self_match = bool(self_match)
+        self.shard_offset = int(shard_offset)
+        self.params = _lib.TfidfParams(int(n_gram_range[0]), int(n_gram_range[1]), int(bool(clean_string)),
+                                       int(bool(remove_space_ngrams)))
+        self.n_from = len(from_shard)
+        self.n_to = len(to_list)
+        self.from_dev = _lib.DeviceStrings.upload(ctx, from_shard)
+        self.to_dev = _lib.DeviceStrings.upload(ctx, to_list)
+        self.local = _lib.DeviceTopN.alloc(ctx, self.n_from, self.top_n)
+        self.gathered = None
+        if comm is not None and comm.world > 1:
+            self.gathered = _lib.DeviceTopN.alloc(ctx, self.n_from * comm.world, self.top_n)
+        self.vec = self.from_csr = self.to_csr = self.index = None
+
+    def step(self):
+        ctx = self.ctx
+        if self.comm is not None and self.comm.world > 1:
+            self.vec = _lib.tfidf_fit_sharded(ctx, self.comm, self.params, self.to_dev, self.from_dev)
+        else:
+            self.vec = _lib.DeviceTfidf.fit(ctx, self.params, self.to_dev, self.from_dev)
+        self.to_csr = self.vec.transform(self.to_dev)
+        self.index = _lib.DeviceIndex.build(ctx, self.to_csr)
+        self.from_csr = self.vec.transform(self.from_dev)
+        _lib.cossim_topn(ctx, self.index, self.from_csr, self.top_n, self.min_similarity,
+                         exclude_diag=self.self_match, diag_offset=self.shard_offset, out=self.local)
+        if self.gathered is not None:
+            self.comm.allgather_topn(self.local, self.gathered)
+        return self.gathered if self.gathered is not None else self.local
+
+    def step_description(self):
+        return ("fit vocabulary+idf on to+from (K1/K2), vectorise both lists, build the to-side inverted index, "
+                "fused cosine top-n (K3)" + ("; all-gather of the per-shard results (RCCL)" if self.gathered else ""))
+
+    # ---- host-side accounting (never inside the timed region) ---------------------
+    def host_matrices(self):
+        """(from CSR triple, to CSR triple, n_cols) of the last step as float64 host arrays."""
+        fp, fi, fv, n_cols = self.from_csr.download()
+        tp, ti, tv, _ = self.to_csr.download()
+        return (fp, fi, fv.astype(np.float64)), (tp, ti, tv.astype(np.float64)), n_cols
+
+    def stats(self):
+        (fp, fi, _), (tp, ti, _), n_cols = self.host_matrices()
+        df_from = np.bincount(fi, minlength=n_cols).astype(np.float64)
+        df_to = np.bincount(ti, minlength=n_cols).astype(np.float64)
+        return {"vocab": int(n_cols), "nnz_from": int(fp[-1]), "nnz_to": int(tp[-1]),
+                "madds": float((df_from * df_to).sum())}

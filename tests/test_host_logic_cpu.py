@@ -1,0 +1,71 @@
+"""Host-side logic that needs no GPU: string packing, DataFrame contract, shard planning, synthetic data."""
+import numpy as np
+import pandas as pd
+import pytest
+
+
+def test_pack_strings_widths():
+    from polyfuzz_amd._lib import pack_strings
+    chars, off, w = pack_strings(["ab", "", "cdé"])
+    assert w == 1 and chars.dtype == np.uint8 and off.tolist() == [0, 2, 2, 5] and chars[-1] == 0xE9
+    chars, off, w = pack_strings(["ab", "한글", ""])
+    assert w == 4 and chars.dtype == np.uint32 and off.tolist() == [0, 2, 4, 4] and chars[2] == ord("한")
+    chars, off, w = pack_strings([])
+    assert len(chars) == 0 and off.tolist() == [0]
+
+
+def test_topn_to_frame_contract():
+    """reference _utils.py:104-125: column order, 3-dp rounding, < 0.001 -> 0.0 / None, -1 -> None."""
+    from polyfuzz_amd.models._utils import topn_to_frame
+    idx = np.array([[1, 0], [0, -1], [-1, -1]], np.int32)
+    val = np.array([[0.78375, 0.0004], [1.0, 0.0], [0.0, 0.0]], np.float32)
+    df = topn_to_frame(idx, val, ["a", "b", "c"], ["x", "y"], 2)
+    assert list(df.columns) == ["From", "To", "Similarity", "To_2", "Similarity_2"]
+    assert df["To"].tolist() == ["y", "x", None] and df["To_2"].tolist() == [None, None, None]
+    np.testing.assert_allclose(df["Similarity"], [0.784, 1.0, 0.0])
+    assert df["Similarity_2"].tolist() == [0.0, 0.0, 0.0]
+    assert df["Similarity"].dtype == np.float64 and df["From"].tolist() == ["a", "b", "c"]
+
+
+def test_clean_string_matches_oracle(oracle_mod):
+    from polyfuzz_amd.models._tfidf import _clean_string
+    for s in ["  Hello,   World!! ", "A\tB  C\nD", "İstanbul", "Ünited", "", "K2 — the 2nd"]:
+        assert _clean_string(s) == oracle_mod.clean_string(s)
+
+
+def test_edit_distance_scorer_gate():
+    from polyfuzz_amd.models import EditDistance, BaseMatcher
+    assert isinstance(EditDistance(), BaseMatcher) and EditDistance().type == "EditDistance"
+    with pytest.raises(NotImplementedError):
+        EditDistance(scorer=len)
+
+    class ratio:       # looks like rapidfuzz.fuzz.ratio
+        __name__ = "ratio"
+        __module__ = "rapidfuzz.fuzz"
+    EditDistance(scorer=ratio())
+
+
+def test_base_matcher_is_abstract():
+    from polyfuzz_amd.models import BaseMatcher, TFIDF
+    with pytest.raises(TypeError):
+        BaseMatcher()
+    m = TFIDF(n_gram_range=(2, 3), min_similarity=0.5, top_n=3, model_id="m")
+    assert (m.type, m.model_id, m.top_n, m.cosine_method) == ("TF-IDF", "m", 3, "sparse")
+
+
+def test_shard_bounds_cover_everything():
+    from polyfuzz_amd.pipeline import shard_bounds
+    for n in (0, 1, 7, 100, 100003):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(n, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [e - b for b, e in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_names_are_deterministic_and_name_like():
+    from polyfuzz_amd import synth
+    a, b = synth.company_names(500, 7), synth.company_names(500, 7)
+    assert a == b and a != synth.company_names(500, 8)
+    assert 15 < np.mean([len(s) for s in a]) < 35
