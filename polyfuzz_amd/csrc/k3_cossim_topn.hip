@@ -38,6 +38,7 @@ namespace pfz {
 constexpr int kC = 2048;    // to-rows per block == fp32 accumulators per wave (8 KiB LDS)
 constexpr int kCap = 256;   // candidate keys per wave (2 KiB LDS)
 constexpr int kMaxTop = 128;
+constexpr int kSlots = 8;    // posting chunks (64 entries each) in flight per wave
 
 // ---------------------------------------------------------------------------
 // inverted-index build
@@ -132,11 +133,50 @@ __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
     __syncthreads();
 }
 
-__device__ inline void scatter_list(float *acc, const int2 *__restrict__ post, int ss, int ee, float aa, int lane)
+// Scatter every non-empty (k,b) posting list of one from-row chunk into acc.
+//   m       : wave-uniform mask of the lanes whose list [s,e) is non-empty
+//   s, e, a : per lane -- lane l owns n-gram k_l of the row: its posting range in
+//             this block and the row's value for that n-gram
+// Lists are taken in ascending lane (= ascending n-gram id) order and cut into
+// 64-entry chunks.  U chunks form a round: all U global loads of a round are
+// issued before the first is consumed (the kernel is latency-bound otherwise:
+// SQ_WAIT_ANY was 76 % of wave cycles with one load in flight), then the chunks
+// are applied strictly in order with a plain LDS read-add-write each.  That is
+// safe because a to-row occurs at most once per list (no two lanes of one
+// instruction share an address) and the LDS executes a wave's operations in
+// program order (a later list reads what an earlier one wrote); it is used
+// instead of ds_add_f32 because the LDS float atomic retires ~1 lane per clock.
+template <int U>
+__device__ inline void scatter_lists(float *acc, const int2 *__restrict__ post, uint64_t m, int s, int e, float a,
+                                     int lane)
 {
-    for (int q = ss + lane; q < ee; q += 64) {
-        int2 pe = post[q];
-        atomicAdd(&acc[pe.x], aa * __int_as_float(pe.y));
+    int cur_q = 0, cur_e = 0;   // wave-uniform: next entry / end of the list being cut
+    float cur_a = 0.f;
+    while (m != 0 || cur_q < cur_e) {
+        int2 pe[U];
+        float pa[U];
+        bool pv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (cur_q >= cur_e && m != 0) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                cur_q = __builtin_amdgcn_readlane(s, src);
+                cur_e = __builtin_amdgcn_readlane(e, src);
+                cur_a = readlane_f(a, src);
+            }
+            const int q = cur_q + lane;
+            pv[u] = q < cur_e;
+            pa[u] = cur_a;
+            pe[u] = make_int2(0, 0);
+            if (pv[u]) pe[u] = post[q];
+            cur_q += 64;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pv[u]) acc[pe[u].x] = acc[pe[u].x] + pa[u] * __int_as_float(pe[u].y);
+            __builtin_amdgcn_wave_barrier();   // keep the compiler from reordering LDS accesses across chunks
+        }
     }
 }
 
@@ -163,32 +203,29 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
         st.cnt = 0;
         st.thr = lower_bound;
 
-        // registers for the first 64 n-grams of the row (covers almost every row)
-        int k0 = 0, cur0 = 0;
+        // registers for the first 64 n-grams of the row (covers almost every row);
+        // the offset-table entry of the next block is always one block ahead in flight
+        int k0 = 0, cur0 = 0, nxt0 = 0;
         float a0 = 0.f;
         const bool have0 = lane < nnz;
+        const int32_t *trow = tab;
         if (have0) {
             k0 = a_idx[p0 + lane];
             a0 = a_val[p0 + lane];
-            cur0 = tab[(int64_t)k0 * nb];
+            trow = tab + (int64_t)k0 * nb;
+            cur0 = trow[0];
+            nxt0 = trow[1];
         }
 
         for (int b = 0; b < nb; ++b) {
             bool touched = false;
             {
-                int s = cur0, e = cur0;
-                if (have0) {
-                    e = tab[(int64_t)k0 * nb + b + 1];
-                    cur0 = e;
-                }
-                uint64_t m = __ballot(e > s);
+                const int s = cur0, e = have0 ? nxt0 : cur0;
+                cur0 = e;
+                if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];   // prefetch for block b+1 (tab has V*nb+2 slots)
+                const uint64_t m = __ballot(e > s);
                 touched = m != 0;
-                while (m) {
-                    const int src = __builtin_ctzll(m);
-                    m &= m - 1;
-                    scatter_list(acc, post, __builtin_amdgcn_readlane(s, src), __builtin_amdgcn_readlane(e, src),
-                                 readlane_f(a0, src), lane);
-                }
+                scatter_lists<kSlots>(acc, post, m, s, e, a0, lane);
             }
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
                 int s = 0, e = 0;
@@ -199,14 +236,9 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
                     s = tab[(int64_t)k * nb + b];
                     e = tab[(int64_t)k * nb + b + 1];
                 }
-                uint64_t m = __ballot(e > s);
+                const uint64_t m = __ballot(e > s);
                 touched |= m != 0;
-                while (m) {
-                    const int src = __builtin_ctzll(m);
-                    m &= m - 1;
-                    scatter_list(acc, post, __builtin_amdgcn_readlane(s, src), __builtin_amdgcn_readlane(e, src),
-                                 readlane_f(a, src), lane);
-                }
+                scatter_lists<kSlots>(acc, post, m, s, e, a, lane);
             }
             if (!touched) continue;
             __syncthreads();  // order the LDS adds before the sweep's reads (single wave: no cost)
