@@ -74,7 +74,33 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
                                                   uint64_t *__restrict__ slots, int32_t *__restrict__ row_cnt,
                                                   uint32_t *__restrict__ bitmap)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // The 256 strings of a workgroup are contiguous in the packed buffer: stage their
+    // characters into LDS with coalesced 4-byte loads (a per-thread byte walk over
+    // global memory costs one uncoalesced load per character), then walk from LDS.
+    constexpr int kStageBytes = 24 * 1024;
+    __shared__ uint32_t stage[kStageBytes / 4];
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int64_t i_end = i0 + 256 < n ? i0 + 256 : n;
+    const int64_t byte0 = off[i0] * CW, byte1 = off[i_end] * CW;
+    const int64_t base4 = byte0 & ~(int64_t)3;                 // 4-byte aligned start
+    const bool staged = byte1 - base4 <= kStageBytes;
+    if (staged) {
+        const uint32_t *src = (const uint32_t *)((const uint8_t *)chars_v + base4);
+        const int words = (int)((byte1 - base4 + 3) >> 2);     // the buffer is padded by 16 bytes
+        for (int t = threadIdx.x; t < words; t += 256) stage[t] = src[t];
+    }
+    __syncthreads();
+    // (two explicit address spaces; a pointer selected at run time between LDS and global
+    // would become a flat pointer)
+    auto fetch = [&](int64_t p) -> uint32_t {
+        if (staged) {
+            const int o = (int)(p * CW - base4);
+            return CW == 1 ? (uint32_t)((const uint8_t *)stage)[o] : stage[o >> 2];
+        }
+        return CW == 1 ? (uint32_t)((const uint8_t *)chars_v)[p] : ((const uint32_t *)chars_v)[p];
+    };
+
+    const int64_t i = i0 + threadIdx.x;
     if (i >= n) return;
     const int64_t b = off[i], e = off[i + 1];
     const int R = P.hi - P.lo + 1;
@@ -98,7 +124,7 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
     };
 
     for (int64_t p = b; p < e; ++p) {
-        uint32_t c = CW == 1 ? (uint32_t)((const uint8_t *)chars_v)[p] : ((const uint32_t *)chars_v)[p];
+        uint32_t c = fetch(p);
         if (P.clean) {
             // reference _tfidf.py:142-146 on code points <= 0xFF: lower(), keep
             // [a-z0-9 ], collapse runs of ' ', strip

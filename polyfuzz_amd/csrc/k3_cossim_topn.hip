@@ -6,72 +6,83 @@
 //
 // Data layout in HBM
 //   from side : CSR (indptr int32, indices int32 sorted, data fp32)
-//   to side   : inverted index.  The to-rows are cut into blocks of kC rows;
-//               for n-gram id k and block b the postings (local to-row, fp32
-//               value) are post[tab[k*nb+b] .. tab[k*nb+b+1]).  tab is one
-//               int32 array of V*nb+1 offsets, so a from-row walks block b of
-//               all its n-grams by reading two neighbouring offsets each.
+//   to side   : inverted index.  The to-rows are cut into blocks of C rows
+//               (C = 1024 / 2048 / 4096); for n-gram id k and block b the
+//               postings (byte offset of the to-row's accumulator, fp32 value)
+//               are post[tab[k*nb+b] .. tab[k*nb+b+1]).  tab is one int32 array
+//               of V*nb+1 offsets, so a from-row walks block b of all its
+//               n-grams by streaming along one table row per n-gram.
 //
-// Kernel (one wave == one workgroup == one from-row at a time)
-//   for each to-block b (ascending):
-//     for each n-gram k of the row (ascending id): the 64 lanes stride over the
-//       (k,b) postings and ds_add_f32 a*b into acc[local to-row] (LDS, kC fp32).
-//       Within one (k,b) list every to-row is unique, so there are no
-//       same-address collisions inside an instruction, and LDS operations of
-//       one wave execute in order: every accumulator receives its terms in
-//       ascending k -- the Gustavson order of the CPU reference -- and the
-//       result is bit-reproducible.
-//     sweep: lanes read acc as float4, write zeros back, and push entries with
-//       score > threshold into a per-wave candidate buffer (64-bit keys
-//       score_bits<<32 | ~col, so an unsigned max is "score desc, col asc").
-//       When the buffer fills, the wave keeps its ntop best (rounds of
-//       wave-max) and raises the threshold to the ntop-th score.
-//   The final compaction leaves the sorted top-n; lanes write (idx, score).
+// Arithmetic: fixed point.  Every product a*b is computed in fp32, scaled by
+// S = 2^30 / (norm bound) and truncated to int32; the accumulators are int32 and
+// are updated with ds_add_u32.  Integer addition is associative, so the sum does
+// not depend on the order in which postings arrive: results are bit-reproducible,
+// exact ties (duplicate to-strings) stay exact ties, and the kernel is free to
+// process postings in whatever order fills the lanes best.  |sum/S - exact| is
+// below 13 * 2^-30 + fp32 product rounding (~3e-8), far inside the 1e-5 budget.
+// (Measured on MI355X, tools/ubench/lds_atomic.hip: ds_add_u32 6.6 lanes/clk/CU,
+// plain LDS read+fadd+write 3.6, ds_add_f32 0.31 -- the float atomic is unusable.)
 //
-// Roofline: the kernel is bound by the LDS scatter-add + sweep and by the
-// posting stream out of L2 / Infinity Cache; the algorithmic HBM-side bytes
-// are 8 B per multiply-add (one posting) + 8 B per from-nnz + 8 B per result.
+// Kernel (one wave == one workgroup == one from-row at a time; the hardware
+// dispatcher load-balances the very skewed rows)
+//   for each to-block b:
+//     scatter: lane l owns n-gram l of the row and its (k,b) posting range; the
+//       ranges are cut into 64-entry chunks, numbered across all lists, and dealt
+//       round-robin to the W waves of the workgroup, kSlots chunk loads in flight
+//       per wave (see scatter_block).
+//     sweep: lanes read acc as int4 pairs, write zeros back, and test the max of
+//       8 sums against the running threshold (v_max3_i32); survivors go to a
+//       per-wave candidate buffer as 64-bit keys sum<<32 | ~col, so an unsigned
+//       max is "score desc, col asc".  When the buffer fills the wave keeps its
+//       ntop best (rounds of wave-max) and raises the threshold to the ntop-th sum.
+//   The final compaction leaves the sorted top-n; lanes write (idx, sum/S).
+//
+// Roofline: bound by LDS atomics + sweep and by instruction issue; HBM traffic is
+// ~1/3 of the algorithmic bytes (8 B per multiply-add + 8 B per from-nnz + 8 B
+// per result) because the index (tens of MB) lives in L2 / Infinity Cache.
 #include "pfz_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
 
 namespace pfz {
 
-constexpr int kC = 2048;    // to-rows per block == fp32 accumulators per wave (8 KiB LDS)
-constexpr int kCap = 256;   // candidate keys per wave (2 KiB LDS)
+constexpr int kCap = 256;        // candidate keys per wave (2 KiB LDS)
 constexpr int kMaxTop = 128;
-constexpr int kSlots = 8;    // posting chunks (64 entries each) in flight per wave
+constexpr int kSlots = 8;        // 64-entry posting chunks in flight per wave
 
 // ---------------------------------------------------------------------------
-// inverted-index build
+// inverted-index build (block size = 1 << c_shift to-rows)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_index_count(const int32_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices, int32_t n_rows,
-                                                      int32_t nb, int32_t *__restrict__ tab1 /* tab + 1 */)
+                                                      int32_t nb, int32_t c_shift, int32_t *__restrict__ tab1 /* tab + 1 */)
 {
     // one 16-lane group per to-row: rows have ~13 entries
     const int gid = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
     if (gid >= n_rows) return;
     const int p0 = indptr[gid], p1 = indptr[gid + 1];
-    const int b = gid / kC;
+    const int b = gid >> c_shift;
     for (int p = p0 + sub; p < p1; p += 16) atomicAdd(&tab1[(int64_t)indices[p] * nb + b], 1);
 }
 
 __global__ __launch_bounds__(256) void k_index_fill(const int32_t *__restrict__ indptr,
                                                      const int32_t *__restrict__ indices,
                                                      const float *__restrict__ data, int32_t n_rows, int32_t nb,
-                                                     int32_t *__restrict__ tab1, int2 *__restrict__ post)
+                                                     int32_t c_shift, int32_t *__restrict__ tab1,
+                                                     int2 *__restrict__ post)
 {
     const int gid = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
     if (gid >= n_rows) return;
     const int p0 = indptr[gid], p1 = indptr[gid + 1];
-    const int b = gid / kC;
-    const int local = gid - b * kC;
+    const int b = gid >> c_shift;
+    const int local = gid - (b << c_shift);
     for (int p = p0 + sub; p < p1; p += 16) {
-        // the order inside one (k,b) list is irrelevant to the results: every
-        // to-row occurs at most once per list
+        // the order inside one (k,b) list is irrelevant to the results (integer sums)
         int pos = atomicAdd(&tab1[(int64_t)indices[p] * nb + b], 1);
-        post[pos] = make_int2(local, __float_as_int(data[p]));
+        post[pos] = make_int2(local * 4, __float_as_int(data[p]));   // .x = byte offset into acc
     }
 }
 
@@ -90,27 +101,51 @@ __device__ inline uint64_t wave_max_u64(uint64_t v)
     return v;
 }
 
+// The workgroup is ONE wave: its LDS operations execute in program order, so
+// cross-lane hand-offs through LDS need no hardware barrier -- only the compiler
+// must not reorder across the hand-off.  (__syncthreads() would also drain vmcnt
+// to 0 and stall on every posting load in flight.)
+__device__ inline void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // compiler-level ordering, no instruction
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ inline float readlane_f(float v, int src)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+__device__ inline int max3i(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// acc += trunc(as * b) at byte offset off
+__device__ inline void acc_add(int *acc, int off, float as, int bbits)
+{
+    const int v = (int)(as * __int_as_float(bbits));
+    atomicAdd((int *)((char *)acc + off), v);
+}
+
 struct TopState {
-    int cnt;     // wave-uniform number of keys in cand[]
-    float thr;   // accept score > thr
+    int cnt;   // wave-uniform number of keys in cand[]
+    int thr;   // accept sum > thr
 };
 
 // Keep the ntop best of cand[0..cnt) sorted at cand[0..keep).
 __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
 {
-    __syncthreads();
+    wave_sync();
     uint64_t e[kCap / 64];
 #pragma unroll
     for (int i = 0; i < kCap / 64; ++i) {
         int p = lane + 64 * i;
         e[i] = p < st.cnt ? cand[p] : 0ull;
     }
-    __syncthreads();
+    wave_sync();
     const int keep = st.cnt < ntop ? st.cnt : ntop;
     uint64_t best = 0;
     for (int r = 0; r < keep; ++r) {
@@ -125,165 +160,248 @@ __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
     }
     st.cnt = keep;
     if (keep == ntop) {
-        // from now on only scores >= the ntop-th best can matter
-        uint32_t bits = (uint32_t)(best >> 32);
-        float t = __uint_as_float(bits - 1u);
+        // from now on only sums >= the ntop-th best can matter
+        const int t = (int)(uint32_t)(best >> 32) - 1;
         st.thr = t > st.thr ? t : st.thr;
     }
-    __syncthreads();
+    wave_sync();
 }
 
-// Scatter every non-empty (k,b) posting list of one from-row chunk into acc.
-//   m       : wave-uniform mask of the lanes whose list [s,e) is non-empty
-//   s, e, a : per lane -- lane l owns n-gram k_l of the row: its posting range in
-//             this block and the row's value for that n-gram
-// Lists are taken in ascending lane (= ascending n-gram id) order and cut into
-// 64-entry chunks.  U chunks form a round: all U global loads of a round are
-// issued before the first is consumed (the kernel is latency-bound otherwise:
-// SQ_WAIT_ANY was 76 % of wave cycles with one load in flight), then the chunks
-// are applied strictly in order with a plain LDS read-add-write each.  That is
-// safe because a to-row occurs at most once per list (no two lanes of one
-// instruction share an address) and the LDS executes a wave's operations in
-// program order (a later list reads what an earlier one wrote); it is used
-// instead of ds_add_f32 because the LDS float atomic retires ~1 lane per clock.
-template <int U>
-__device__ inline void scatter_lists(float *acc, const int2 *__restrict__ post, uint64_t m, int s, int e, float a,
-                                     int lane)
+// push the entries of one int4 (columns j0..j0+3) that beat the threshold
+__device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0, int self_col, int ntop, int lane)
 {
-    int cur_q = 0, cur_e = 0;   // wave-uniform: next entry / end of the list being cut
-    float cur_a = 0.f;
-    while (m != 0 || cur_q < cur_e) {
-        int2 pe[U];
-        float pa[U];
-        bool pv[U];
+    const int vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (cur_q >= cur_e && m != 0) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                cur_q = __builtin_amdgcn_readlane(s, src);
-                cur_e = __builtin_amdgcn_readlane(e, src);
-                cur_a = readlane_f(a, src);
-            }
-            const int q = cur_q + lane;
-            pv[u] = q < cur_e;
-            pa[u] = cur_a;
-            pe[u] = make_int2(0, 0);
-            if (pv[u]) pe[u] = post[q];
-            cur_q += 64;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (pv[u]) acc[pe[u].x] = acc[pe[u].x] + pa[u] * __int_as_float(pe[u].y);
-            __builtin_amdgcn_wave_barrier();   // keep the compiler from reordering LDS accesses across chunks
+    for (int c = 0; c < 4; ++c) {
+        const int j = j0 + c;
+        const bool pred = vv[c] > st.thr && j != self_col;
+        const uint64_t mk = __ballot(pred);
+        if (mk) {
+            const int pos = st.cnt + __popcll(mk & ((1ull << lane) - 1ull));
+            if (pred) cand[pos] = ((uint64_t)(uint32_t)vv[c] << 32) | (uint32_t)(~j);
+            st.cnt += __popcll(mk);
+            if (st.cnt > kCap - 64) compact(cand, st, ntop, lane);
         }
     }
 }
 
-__global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
+// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads()
+// would also drain vmcnt and expose the latency of the offset-table prefetch.
+__device__ inline void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Read, clear and filter this wave's share of one block of accumulators: int4
+// slots [i_begin, i_begin + N4) of the block whose first column is col0.
+template <int N4>
+__device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int i_begin, int col0, int self_col,
+                                   int ntop, int lane)
+{
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    static_assert(N4 % 128 == 0, "a wave sweeps whole 128-slot steps");
+#pragma unroll 2
+    for (int t = 0; t < N4 / 128; ++t) {
+        const int i0 = i_begin + t * 128 + lane, i1 = i0 + 64;
+        const int4 v0 = acc4[i0], v1 = acc4[i1];
+        acc4[i0] = zero4;
+        acc4[i1] = zero4;
+        const int mx = max3i(max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y), max3i(v1.z, v1.w, v1.w));
+        if (__ballot(mx > st.thr)) {
+            push4(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
+            push4(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane);
+        }
+    }
+}
+
+// Scatter this wave's share of the (k,b) posting lists of up to 64 n-grams of one
+// from-row into the workgroup's accumulators.
+//   s, e : per lane, the lane's posting range in this block (e == s: nothing)
+//   as   : per lane, the row's value for the lane's n-gram times the fixed-point scale
+// The lists are cut into 64-entry chunks and the chunks numbered g = 0..T-1 across
+// all lists (inclusive prefix `pin` of the per-lane chunk counts).  Because the sums
+// are integers the order is free, so chunk g simply belongs to wave g % W, and a
+// wave finds the list of ANY chunk number in O(1): owner lane = number of lanes
+// whose prefix is <= g (one v_cmp + s_bcnt1).  kSlots chunk loads are in flight per
+// wave, regardless of list boundaries.
+template <int W>
+__device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, int s, int e, float as, int lane,
+                                     int wave)
+{
+    const int nch = (e - s + 63) >> 6;
+    int pin = nch;                                  // inclusive scan over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(pin, d, 64);
+        if (lane >= d) pin += o;
+    }
+    // entry index of chunk g of the lane's list = qbase + g*64 + lane
+    const int qbase = s - (pin - nch) * 64;
+    const int total = __builtin_amdgcn_readlane(pin, 63);
+    const char *post_bytes = (const char *)post;
+    for (int g0 = wave; g0 < total; g0 += W * kSlots) {
+        int2 pe[kSlots];
+        float pa[kSlots];
+        bool ok[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            const int g = g0 + j * W;                                   // wave-uniform chunk number
+            int src = __popcll(__ballot(pin <= g));                    // lane that owns chunk g
+            src = src > 63 ? 63 : src;                                  // g >= total: lane 63's list, q >= its end
+            const int ee = __builtin_amdgcn_readlane(e, src);
+            const int q = __builtin_amdgcn_readlane(qbase, src) + g * 64 + lane;
+            pa[j] = readlane_f(as, src);
+            ok[j] = q < ee;
+            // unconditional load (idle lanes re-read entry 0): a branch around the load would make
+            // the compiler wait for every load separately.  32-bit unsigned byte offset from the
+            // uniform base -> SGPR-base addressing, no 64-bit address arithmetic per lane.
+            const uint32_t off = ok[j] ? (uint32_t)q * 8u : 0u;
+            pe[j] = *(const int2 *)(post_bytes + off);
+        }
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j)
+            if (ok[j]) acc_add(acc, pe[j].x, pa[j], pe[j].y);
+    }
+}
+
+
+// C to-rows per block, W waves per workgroup; the workgroup owns one from-row at a time.
+template <int C, int W>
+__global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
     const int32_t *__restrict__ a_indptr, const int32_t *__restrict__ a_idx, const float *__restrict__ a_val,
     int32_t n_a, const int32_t *__restrict__ tab, const int2 *__restrict__ post, int32_t nb, int32_t ntop,
-    float lower_bound, int32_t exclude_diag, int64_t diag_offset, int32_t *__restrict__ out_idx,
-    float *__restrict__ out_val)
+    int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset,
+    int32_t *__restrict__ out_idx, float *__restrict__ out_val, int32_t ablate, int32_t n_slices,
+    uint64_t *__restrict__ part_keys)
 {
-    __shared__ __attribute__((aligned(16))) float acc[kC];
-    __shared__ __attribute__((aligned(16))) uint64_t cand[kCap];
-    const int lane = threadIdx.x;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int t = 0; t < kC / 256; ++t) *(float4 *)&acc[(t * 64 + lane) * 4] = zero4;
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) int acc[C];
+    __shared__ __attribute__((aligned(16))) uint64_t cand_all[W][kCap];
+    __shared__ int cnt_all[W];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tell the compiler it is wave-uniform
+    uint64_t *cand = cand_all[wave];
+    int4 *acc4 = (int4 *)acc;
+    constexpr int N4 = C / 4 / W;   // int4 slots swept by one wave
+    for (int t = threadIdx.x; t < C / 4; t += W * 64) acc4[t] = make_int4(0, 0, 0, 0);
+    lds_barrier();
 
-    for (int row = blockIdx.x; row < n_a; row += gridDim.x) {
+    // Work item = (from-row, to-slice).  The to-blocks are cut into n_slices contiguous
+    // ranges and item i works on slice i % n_slices: workgroups are dispatched round-robin
+    // over the 8 XCDs (observed, not relied on for correctness), so each XCD's L2 keeps
+    // seeing the same eighth of the inverted index instead of thrashing through all of it.
+    const int per_slice = (nb + n_slices - 1) / n_slices;
+    for (int item = blockIdx.x; item < n_a * n_slices; item += gridDim.x) {
+        const int row = item / n_slices, slice = item - row * n_slices;
+        const int b_lo = slice * per_slice, b_hi = min(nb, b_lo + per_slice);
         const int p0 = a_indptr[row], p1 = a_indptr[row + 1];
         const int nnz = p1 - p0;
         const int64_t self_col64 = (int64_t)row + diag_offset;
         const int self_col = (exclude_diag && self_col64 >= 0 && self_col64 < 0x7fffffff) ? (int)self_col64 : -1;
-        TopState st;
+        TopState st;   // per wave: the best of the columns this wave sweeps
         st.cnt = 0;
-        st.thr = lower_bound;
+        st.thr = thr0;
 
         // registers for the first 64 n-grams of the row (covers almost every row);
         // the offset-table entry of the next block is always one block ahead in flight
-        int k0 = 0, cur0 = 0, nxt0 = 0;
-        float a0 = 0.f;
+        int cur0 = 0, nxt0 = 0;
+        float as0 = 0.f;
         const bool have0 = lane < nnz;
         const int32_t *trow = tab;
         if (have0) {
-            k0 = a_idx[p0 + lane];
-            a0 = a_val[p0 + lane];
-            trow = tab + (int64_t)k0 * nb;
-            cur0 = trow[0];
-            nxt0 = trow[1];
+            as0 = a_val[p0 + lane] * scale;
+            trow = tab + (int64_t)a_idx[p0 + lane] * nb;
+            cur0 = trow[b_lo];
+            nxt0 = trow[b_lo + 1];
         }
 
-        for (int b = 0; b < nb; ++b) {
-            bool touched = false;
-            {
-                const int s = cur0, e = have0 ? nxt0 : cur0;
-                cur0 = e;
-                if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];   // prefetch for block b+1 (tab has V*nb+2 slots)
-                const uint64_t m = __ballot(e > s);
-                touched = m != 0;
-                scatter_lists<kSlots>(acc, post, m, s, e, a0, lane);
-            }
+        for (int b = b_lo; b < b_hi; ++b) {
+            const int s = cur0, e = have0 ? nxt0 : cur0;
+            cur0 = e;
+            if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];   // prefetch for block b+1 (tab has V*nb+2 slots)
+            bool touched = __ballot(e > s) != 0;    // identical in every wave of the workgroup
+            if (touched && ablate != 1) scatter_block<W>(acc, post, s, e, as0, lane, wave);
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
-                int s = 0, e = 0;
-                float a = 0.f;
+                int s2 = 0, e2 = 0;
+                float as2 = 0.f;
                 if (c0 + lane < p1) {
                     const int k = a_idx[c0 + lane];
-                    a = a_val[c0 + lane];
-                    s = tab[(int64_t)k * nb + b];
-                    e = tab[(int64_t)k * nb + b + 1];
+                    as2 = a_val[c0 + lane] * scale;
+                    s2 = tab[(int64_t)k * nb + b];
+                    e2 = tab[(int64_t)k * nb + b + 1];
                 }
-                const uint64_t m = __ballot(e > s);
-                touched |= m != 0;
-                scatter_lists<kSlots>(acc, post, m, s, e, a, lane);
-            }
-            if (!touched) continue;
-            __syncthreads();  // order the LDS adds before the sweep's reads (single wave: no cost)
-
-            const int col0 = b * kC;
-#pragma unroll 2
-            for (int t = 0; t < kC / 256; ++t) {
-                const int e0 = (t * 64 + lane) * 4;
-                const float4 v = *(const float4 *)&acc[e0];
-                *(float4 *)&acc[e0] = zero4;
-                const float thr = st.thr;
-                const bool any = (v.x > thr) | (v.y > thr) | (v.z > thr) | (v.w > thr);
-                if (__ballot(any)) {
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int j = col0 + e0 + c;
-                        const bool pred = vv[c] > st.thr && j != self_col;
-                        const uint64_t mk = __ballot(pred);
-                        if (mk) {
-                            const int pos = st.cnt + __popcll(mk & ((1ull << lane) - 1ull));
-                            if (pred) cand[pos] = ((uint64_t)__float_as_uint(vv[c]) << 32) | (uint32_t)(~j);
-                            st.cnt += __popcll(mk);
-                            if (st.cnt > kCap - 64) compact(cand, st, ntop, lane);
-                        }
-                    }
+                if (__ballot(e2 > s2)) {
+                    touched = true;
+                    scatter_block<W>(acc, post, s2, e2, as2, lane, wave);
                 }
             }
-            __syncthreads();
+            if (touched && ablate != 2) {
+                lds_barrier();     // every wave's updates of this block are in acc
+                sweep_block<N4>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane);
+                lds_barrier();     // acc is zero again
+            }
         }
 
+        // merge the waves' candidates: wave 0 folds the others' top-n into its own
         compact(cand, st, ntop, lane);
-        for (int r = lane; r < ntop; r += 64) {
-            int32_t oi = -1;
-            float ov = 0.f;
-            if (r < st.cnt) {
-                const uint64_t key = cand[r];
-                oi = (int32_t)(~(uint32_t)key);
-                ov = __uint_as_float((uint32_t)(key >> 32));
+        if (lane == 0) cnt_all[wave] = st.cnt;
+        lds_barrier();
+        if (wave == 0) {
+            for (int w = 1; w < W; ++w) {
+                const int cw = cnt_all[w];
+                for (int r = lane; r < cw; r += 64) cand[st.cnt + r] = cand_all[w][r];
+                st.cnt += cw;
+                compact(cand, st, ntop, lane);
             }
-            out_idx[(int64_t)row * ntop + r] = oi;
-            out_val[(int64_t)row * ntop + r] = ov;
+            for (int r = lane; r < ntop; r += 64) {
+                const uint64_t key = r < st.cnt ? cand[r] : 0ull;
+                if (n_slices > 1) {   // partial result of this slice; k3_merge_slices finishes the row
+                    part_keys[((int64_t)row * n_slices + slice) * ntop + r] = key;
+                } else {
+                    out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
+                    out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * inv_scale : 0.f;
+                }
+            }
         }
-        __syncthreads();
+        lds_barrier();   // cand_all is reused by the next item
     }
+}
+
+// Merge the n_slices partial top-n key lists of every from-row (one wave per row).
+__global__ __launch_bounds__(256) void k3_merge_slices(const uint64_t *__restrict__ part_keys, int32_t n_a,
+                                                       int32_t n_slices, int32_t ntop, float inv_scale,
+                                                       int32_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][kCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= n_a) return;
+    uint64_t *cand = cand_all[wave];
+    TopState st;
+    st.cnt = 0;
+    st.thr = 0;
+    for (int sl = 0; sl < n_slices; ++sl) {
+        const uint64_t *src = part_keys + ((int64_t)row * n_slices + sl) * ntop;
+        for (int r0 = 0; r0 < ntop; r0 += 64) {     // keys are sorted, zeros (= no entry) at the end
+            const int r = r0 + lane;
+            const uint64_t key = r < ntop ? src[r] : 0ull;
+            const uint64_t mk = __ballot(key != 0ull);
+            if (key) cand[st.cnt + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+            st.cnt += __popcll(mk);
+            if (st.cnt > kCap - 64) compact(cand, st, ntop, lane);
+        }
+    }
+    compact(cand, st, ntop, lane);
+    for (int r = lane; r < ntop; r += 64) {
+        const uint64_t key = r < st.cnt ? cand[r] : 0ull;
+        out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
+        out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * inv_scale : 0.f;
+    }
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
 }
 
 }  // namespace pfz
@@ -296,8 +414,19 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
 {
     PFZ_REQUIRE(ctx && B && out, "pfz_index_build: NULL argument");
     PFZ_HIP(hipSetDevice(ctx->device));
-    const int64_t nb = (B->n_rows + kC - 1) / kC;
+    // tuning knob: to-rows per block.  Measured at 100k x 100k (tools/sweep_k3.sh): 2048 rows x 2 waves
+    // is the best point -- larger blocks fill the 64-entry chunks better but cost occupancy (LDS).
+    int block = env_int("PFZ_K3_BLOCK", 2048);
+    if (block != 2048 && block != 4096 && block != 8192) block = 2048;
+    int c_shift = 0;
+    while ((1 << c_shift) < block) ++c_shift;
+    const int64_t nb = (B->n_rows + block - 1) / block;
     const int64_t slots = B->n_cols * nb;
+    if (B->nnz >= ((int64_t)1 << 29)) {
+        set_error("pfz_index_build: %lld postings exceed the 4 GiB the kernel addresses with 32-bit offsets",
+                  (long long)B->nnz);
+        return PFZ_ERR_UNSUPPORTED;
+    }
     if (slots >= ((int64_t)1 << 31) - 2) {
         set_error("pfz_index_build: vocabulary %lld x %lld to-blocks exceeds the int32 offset table",
                   (long long)B->n_cols, (long long)nb);
@@ -308,8 +437,9 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     ix->n_rows = B->n_rows;
     ix->n_cols = B->n_cols;
     ix->nnz = B->nnz;
-    ix->block_cols = kC;
+    ix->block_cols = block;
     ix->n_blocks = (int32_t)nb;
+    ix->max_norm = B->max_norm;
     PFZ_TRY(pool_alloc(ctx, &ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)(B->nnz > 0 ? B->nnz : 1) * sizeof(int2)));
     PFZ_HIP(hipMemsetAsync(ix->tab, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
@@ -318,7 +448,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
         {
             ProfScope ps(ctx, "k_index_count");
             hipLaunchKernelGGL(k_index_count, dim3(grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
-                               (int32_t)B->n_rows, (int32_t)nb, ix->tab + 1);
+                               (int32_t)B->n_rows, (int32_t)nb, c_shift, ix->tab + 1);
         }
         // counts sit at tab[1 + i]; exclusive scan of tab[1..] -> tab[1+i] = start(i)
         PFZ_TRY(exclusive_scan_i32(ctx, ix->tab + 1, slots));
@@ -326,7 +456,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
             ProfScope ps(ctx, "k_index_fill");
             // the fill advances tab[1+i] to end(i) = start(i+1); tab[0] = 0 = start(0)
             hipLaunchKernelGGL(k_index_fill, dim3(grid), dim3(256), 0, ctx->stream, B->indptr, B->indices, B->data,
-                               (int32_t)B->n_rows, (int32_t)nb, ix->tab + 1, ix->post);
+                               (int32_t)B->n_rows, (int32_t)nb, c_shift, ix->tab + 1, ix->post);
         }
         PFZ_HIP(hipGetLastError());
     }
@@ -373,13 +503,59 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     if (A->n_rows == 0) return PFZ_OK;
     PFZ_HIP(hipSetDevice(ctx->device));
     if (lower_bound < 0.f) lower_bound = 0.f;
-    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 16 * 64;
-    const unsigned grid = (unsigned)(A->n_rows < max_grid ? A->n_rows : max_grid);
+    // fixed-point scale: |sum| <= ||a|| * ||b|| (Cauchy-Schwarz) must stay below 2^31
+    const double bound = (double)A->max_norm * (double)ix->max_norm * 1.0001 + 1e-30;
+    int k = 30;
+    while (k > -60 && ldexp(bound, k) >= 2147483000.0) --k;
+    while (k < 60 && ldexp(bound, k + 1) < 1073741824.0) ++k;   // tiny norms: use the full range
+    const float scale = (float)ldexp(1.0, k), inv_scale = (float)ldexp(1.0, -k);
+    const double thr_d = floor((double)lower_bound * (double)scale);
+    const int32_t thr0 = thr_d >= 2147483000.0 ? 2147483000 : (int32_t)thr_d;
+    // to-side slices: one per XCD when there are enough blocks (tuning knob PFZ_K3_SLICES)
+    // (measured: slicing LOSES at 100k x 100k -- 7.4 ms -> 9.9 ms with 8 slices -- because every slice
+    // restarts the top-n threshold and pays the row set-up again; it stays off by default)
+    int n_slices = env_int("PFZ_K3_SLICES", 1);
+    n_slices = n_slices < 1 ? 1 : (n_slices > ix->n_blocks ? (ix->n_blocks > 0 ? ix->n_blocks : 1) : n_slices);
+    uint64_t *part = nullptr;
+    if (n_slices > 1) {
+        PFZ_TRY(ensure_scratch(ctx, (size_t)A->n_rows * (size_t)n_slices * (size_t)ntop * sizeof(uint64_t)));
+        part = (uint64_t *)ctx->scratch;
+    }
+    const int64_t items = A->n_rows * n_slices;
+    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 16 * 64 * 8;
+    const unsigned grid = (unsigned)(items < max_grid ? items : max_grid / n_slices * n_slices);
+    const int waves = env_int("PFZ_K3_WAVES", 2);   // tuning knob: waves per workgroup (= per from-row)
+    const int variant = ix->block_cols * 100 + waves;
+    const int ablate = env_int("PFZ_K3_ABLATE", 0);   // timing experiments only: 1 = no scatter, 2 = no sweep
     {
         ProfScope ps(ctx, "k3_cossim_topn");
-        hipLaunchKernelGGL(k3_cossim_topn_kernel, dim3(grid), dim3(64), 0, ctx->stream, A->indptr, A->indices, A->data,
-                           (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ntop, lower_bound, exclude_diag,
-                           diag_offset, out->idx, out->val);
+#define PFZ_K3_CASE(CC, WW)                                                                                        \
+    case CC * 100 + WW:                                                                                            \
+        hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, WW>), dim3(grid), dim3(WW * 64), 0, ctx->stream, A->indptr,  \
+                           A->indices, A->data, (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ntop, thr0,   \
+                           scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate, n_slices, part); \
+        break;
+        switch (variant) {
+            PFZ_K3_CASE(2048, 1)
+            PFZ_K3_CASE(2048, 2)
+            PFZ_K3_CASE(2048, 4)
+            PFZ_K3_CASE(4096, 1)
+            PFZ_K3_CASE(4096, 2)
+            PFZ_K3_CASE(4096, 4)
+            PFZ_K3_CASE(4096, 8)
+            PFZ_K3_CASE(8192, 2)
+            PFZ_K3_CASE(8192, 4)
+            PFZ_K3_CASE(8192, 8)
+        default:
+            set_error("pfz_cossim_topn: no kernel for block size %d with %d waves", ix->block_cols, waves);
+            return PFZ_ERR_INVALID;
+        }
+#undef PFZ_K3_CASE
+    }
+    if (n_slices > 1) {
+        ProfScope ps(ctx, "k3_merge_slices");
+        hipLaunchKernelGGL(k3_merge_slices, dim3((unsigned)((A->n_rows + 3) / 4)), dim3(256), 0, ctx->stream, part,
+                           (int32_t)A->n_rows, n_slices, ntop, inv_scale, out->idx, out->val);
     }
     PFZ_HIP(hipGetLastError());
     return PFZ_OK;

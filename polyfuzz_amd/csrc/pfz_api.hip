@@ -436,6 +436,20 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
     m->n_rows = n_rows;
     m->n_cols = n_cols;
     m->nnz = nnz;
+    {   // largest row norm (the caller's matrix need not be normalised, reference _utils.py:74-82)
+        double mx = 0.0;
+        for (int64_t i = 0; i < n_rows; ++i) {
+            double ss = 0.0;
+            for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) ss += (double)data[p] * (double)data[p];
+            if (!(ss == ss) || ss > 1e60) {
+                delete m;
+                set_error("pfz_csr_upload: row %lld has a non-finite or huge norm", (long long)i);
+                return PFZ_ERR_INVALID;
+            }
+            if (ss > mx) mx = ss;
+        }
+        m->max_norm = (float)(sqrt(mx) * 1.000001);
+    }
     std::vector<int32_t> ip32((size_t)n_rows + 1);
     for (int64_t i = 0; i <= n_rows; ++i) {
         if (i > 0 && indptr[i] < indptr[i - 1]) {

@@ -68,6 +68,7 @@ struct pfz_csr {
     int32_t *indptr = nullptr;   // [n_rows + 1], nnz < 2^31
     int32_t *indices = nullptr;  // [nnz]
     float *data = nullptr;       // [nnz]
+    float max_norm = 1.f;        // upper bound of the rows' L2 norms (sizes K3's fixed-point scale)
 };
 
 // Inverted index of the to-side: for n-gram id k and to-row block b (block =
@@ -78,7 +79,8 @@ struct pfz_index {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     int32_t block_cols = 0, n_blocks = 0;
     int32_t *tab = nullptr;  // [n_cols * n_blocks + 1]
-    int2 *post = nullptr;    // [nnz]  .x = to-row - b*block_cols, .y = fp32 bits
+    int2 *post = nullptr;    // [nnz]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
+    float max_norm = 1.f;    // of the indexed matrix' rows
 };
 
 struct pfz_topn {
