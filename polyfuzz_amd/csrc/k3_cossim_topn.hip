@@ -7,7 +7,7 @@
 // Data layout in HBM
 //   from side : CSR (indptr int32, indices int32 sorted, data fp32)
 //   to side   : inverted index.  The to-rows are cut into blocks of C rows
-//               (C = 1024 / 2048 / 4096); for n-gram id k and block b the
+//               (C = 2048 / 4096 / 8192); for n-gram id k and block b the
 //               postings (byte offset of the to-row's accumulator, fp32 value)
 //               are post[tab[k*nb+b] .. tab[k*nb+b+1]).  tab is one int32 array
 //               of V*nb+1 offsets, so a from-row walks block b of all its
@@ -23,7 +23,7 @@
 // (Measured on MI355X, tools/ubench/lds_atomic.hip: ds_add_u32 6.6 lanes/clk/CU,
 // plain LDS read+fadd+write 3.6, ds_add_f32 0.31 -- the float atomic is unusable.)
 //
-// Kernel (one wave == one workgroup == one from-row at a time; the hardware
+// Kernel (one workgroup of W waves == one from-row at a time; the hardware
 // dispatcher load-balances the very skewed rows)
 //   for each to-block b:
 //     scatter: lane l owns n-gram l of the row and its (k,b) posting range; the
