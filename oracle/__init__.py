@@ -22,5 +22,6 @@ Pinning status (see DESIGN.md "Oracle"):
   EditDistance class run with the restated scorer.
 """
 from .tfidf_oracle import (clean_string, create_ngrams, TfidfOracle)      # noqa: F401
+from .dense import dense_cossim, dense_cossim_topn   # noqa: F401
 from .native import (cossim_topn, cossim_dense, indel_ratio, indel_argmax,  # noqa: F401
                      build as build_native)

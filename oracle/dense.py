@@ -1,0 +1,36 @@
+"""
+oracle/dense.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+float64 restatement of the dense branch of the reference's cosine_similarity operator
+(polyfuzz/models/_utils.py:94-102 -> sklearn.metrics.pairwise.cosine_similarity,
+sklearn/metrics/pairwise.py:1683+: normalize(X) . normalize(Y)^T with zero rows left
+at zero), followed by the canonical top-n (score desc, column asc), scores > lower_bound.
+"""
+import numpy as np
+
+
+def dense_cossim(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    na = np.sqrt((a * a).sum(1))
+    nb = np.sqrt((b * b).sum(1))
+    na[na == 0] = 1.0
+    nb[nb == 0] = 1.0
+    return (a / na[:, None]) @ (b / nb[:, None]).T
+
+
+def dense_cossim_topn(a, b, ntop, lower_bound=0.0, exclude_diag=False):
+    d = dense_cossim(a, b)
+    if exclude_diag:
+        np.fill_diagonal(d, -np.inf)
+    n, m = d.shape
+    idx = np.full((n, ntop), -1, np.int32)
+    val = np.zeros((n, ntop), np.float64)
+    lb = max(lower_bound, 0.0)
+    for i in range(n):
+        order = np.lexsort((np.arange(m), -d[i]))[:ntop]
+        keep = d[i, order] > lb
+        k = int(keep.sum())
+        idx[i, :k] = order[:k]
+        val[i, :k] = d[i, order[:k]]
+    return idx, val

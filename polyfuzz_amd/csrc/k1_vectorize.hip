@@ -118,7 +118,13 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
             if (run >= nn) {
                 const uint64_t code = (win & ((1ull << (nn * w)) - 1ull)) << ((P.hi - nn) * w);
                 out[cnt++] = code;
-                if (bitmap) atomicOr(&bitmap[code >> 5], 1u << ((uint32_t)code & 31u));
+                if (bitmap) {
+                    // test before set: almost every n-gram occurrence finds its bit already there, and the
+                    // hot words ('inc', 'llc', ...) would otherwise serialise thousands of atomics
+                    uint32_t *wp = &bitmap[code >> 5];
+                    const uint32_t bit = 1u << ((uint32_t)code & 31u);
+                    if (!(*(volatile uint32_t *)wp & bit)) atomicOr(wp, bit);
+                }
             }
         }
     };

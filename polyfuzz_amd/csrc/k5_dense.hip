@@ -1,0 +1,297 @@
+// K5 -- dense cosine top-n for embedding matrices (fp32 MFMA).
+//
+// Replaces the dense branches of the reference's cosine_similarity operator
+// (polyfuzz/models/_utils.py:74-77,95-102; called with precomputed vectors from
+// Embeddings.match, _embeddings.py:127-133): cosine = normalize(A) . normalize(B)^T
+// (sklearn.metrics.pairwise.cosine_similarity), then the top-n of every row,
+// diagonal excluded for self-match.
+//
+// Plan (sized for 288 GB of HBM rather than for cleverness):
+//   k5_inv_norms   : 1/||row|| for both matrices (wave per row).
+//   k5_gemm_panel  : S[P x n_to] = A_panel . B^T, scaled by both inverse norms;
+//                    128x128x32 workgroup tiles, 4 waves x (2x2) v_mfma_f32_32x32x2_f32
+//                    -- exact fp32 products at the fp32 peak rate; operands staged
+//                    through LDS ([row][k], leading dimension 33: conflict-free
+//                    ds_read_b32 of the MFMA fragments).  The panel of scores IS
+//                    written to HBM: at d = 768 that is 8 B of traffic per 1536
+//                    flops, 6x below the machine balance, so the GEMM stays
+//                    MFMA-bound and the top-n logic stays out of its epilogue.
+//   k5_row_topn    : wave per row streams its scores (float4), threshold filter,
+//                    64-bit keys score_bits<<32 | ~col, compaction by wave-max rounds
+//                    (same scheme as K3), writes (idx, score) by (score desc, col asc).
+// The panel height P is chosen so the score panel is <= ~8 GiB.
+#include "pfz_internal.h"
+
+#include <algorithm>
+
+namespace pfz {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 128;   // workgroup tile (rows of A x rows of B)
+constexpr int kBK = 32;      // k-depth staged per step
+constexpr int kLd = kBK + 1; // LDS leading dimension
+constexpr int kCap5 = 256;
+
+__global__ __launch_bounds__(256) void k5_inv_norms(const float *__restrict__ x, int64_t n, int64_t d,
+                                                     float *__restrict__ inv)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *p = x + row * d;
+    double ss = 0.0;
+    for (int64_t k = lane; k < d; k += 64) ss += (double)p[k] * (double)p[k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) inv[row] = ss > 0.0 ? (float)(1.0 / sqrt(ss)) : 0.f;   // zero rows stay zero (sklearn normalize)
+}
+
+// S[(i - a0) * ld + j] = inv_a[i] * inv_b[j] * sum_k A[i][k] * B[j][k]   for i in [a0, a1), j in [0, n_b)
+__global__ __launch_bounds__(256) void k5_gemm_panel(const float *__restrict__ A, const float *__restrict__ B,
+                                                      const float *__restrict__ inv_a, const float *__restrict__ inv_b,
+                                                      int64_t a0, int64_t a1, int64_t n_b, int64_t d,
+                                                      float *__restrict__ S, int64_t ld)
+{
+    __shared__ float As[kTile * kLd];
+    __shared__ float Bs[kTile * kLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = a0 + (int64_t)blockIdx.y * kTile;   // first A row of the tile
+    const int64_t col0 = (int64_t)blockIdx.x * kTile;        // first B row of the tile
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;   // the wave's 64x64 corner inside the tile
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging map: thread t -> 4 consecutive k of one row, 4 rows apart in steps of 32 rows
+    const int lr = tid >> 3;          // 0..31
+    const int lk = (tid & 7) * 4;     // 0,4,..,28
+    for (int64_t k0 = 0; k0 < d; k0 += kBK) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = lr + p * 32;
+            const int64_t ga = row0 + r, gb = col0 + r;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (ga < a1) {
+                const float *src = A + ga * d + k0 + lk;
+                if (k0 + lk + 3 < d && ((d & 3) == 0)) va = *(const float4 *)src;
+                else {
+                    if (k0 + lk + 0 < d) va.x = src[0];
+                    if (k0 + lk + 1 < d) va.y = src[1];
+                    if (k0 + lk + 2 < d) va.z = src[2];
+                    if (k0 + lk + 3 < d) va.w = src[3];
+                }
+            }
+            if (gb < n_b) {
+                const float *src = B + gb * d + k0 + lk;
+                if (k0 + lk + 3 < d && ((d & 3) == 0)) vb = *(const float4 *)src;
+                else {
+                    if (k0 + lk + 0 < d) vb.x = src[0];
+                    if (k0 + lk + 1 < d) vb.y = src[1];
+                    if (k0 + lk + 2 < d) vb.z = src[2];
+                    if (k0 + lk + 3 < d) vb.w = src[3];
+                }
+            }
+            float *da = As + r * kLd + lk, *db = Bs + r * kLd + lk;
+            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
+            db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < kBK; kk += 2) {
+            // MFMA 32x32x2 fragments: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]
+            const int kq = kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(wm + i * 32 + (lane & 31)) * kLd + kq];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(wn + j * 32 + (lane & 31)) * kLd + kq];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t col = col0 + wn + j * 32 + (lane & 31);
+        const float sb = col < n_b ? inv_b[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a1 && col < ld) S[(row - a0) * ld + col] = acc[i][j][r] * inv_a[row] * sb;
+            }
+        }
+    }
+}
+
+__device__ inline uint64_t wave_max_u64_5(uint64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, d, 64);
+        uint32_t hi = __shfl_xor((uint32_t)(v >> 32), d, 64);
+        uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// One wave per score row: top-n of the scores > thr.
+__global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, int64_t ld, int64_t a0, int64_t a1,
+                                                    int64_t n_b, int32_t ntop, float lower_bound, int32_t exclude_diag,
+                                                    int32_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][kCap5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = a0 + (int64_t)blockIdx.x * 4 + wave;
+    if (row >= a1) return;
+    uint64_t *cand = cand_all[wave];
+    const float *s = S + (row - a0) * ld;
+    const int64_t self_col = exclude_diag ? row : -1;
+    int cnt = 0;
+    float thr = lower_bound;
+
+    auto compact = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint64_t e[kCap5 / 64];
+#pragma unroll
+        for (int i = 0; i < kCap5 / 64; ++i) e[i] = lane + 64 * i < cnt ? cand[lane + 64 * i] : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        const int keep = cnt < ntop ? cnt : ntop;
+        uint64_t best = 0;
+        for (int r = 0; r < keep; ++r) {
+            uint64_t m = e[0];
+#pragma unroll
+            for (int i = 1; i < kCap5 / 64; ++i) m = e[i] > m ? e[i] : m;
+            best = wave_max_u64_5(m);
+#pragma unroll
+            for (int i = 0; i < kCap5 / 64; ++i)
+                if (e[i] == best) e[i] = 0ull;
+            if (lane == 0) cand[r] = best;
+        }
+        cnt = keep;
+        if (keep == ntop) {
+            const float t = __uint_as_float((uint32_t)(best >> 32) - 1u);   // accept >= the ntop-th score
+            thr = t > thr ? t : thr;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int64_t c0 = 0; c0 < ld; c0 += 256) {
+        const int64_t c = c0 + lane * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < ld) v = *(const float4 *)(s + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        if (!__ballot(mx > thr)) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t j = c + q;
+            const bool pred = vv[q] > thr && j < n_b && j != self_col;
+            const uint64_t mk = __ballot(pred);
+            if (mk) {
+                const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+                if (pred) cand[pos] = ((uint64_t)__float_as_uint(vv[q]) << 32) | (uint32_t)(~(uint32_t)j);
+                cnt += __popcll(mk);
+                if (cnt > kCap5 - 64) compact();
+            }
+        }
+    }
+    compact();
+    for (int r = lane; r < ntop; r += 64) {
+        const uint64_t key = r < cnt ? cand[r] : 0ull;
+        out_idx[row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
+        out_val[row * ntop + r] = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;
+    }
+}
+
+}  // namespace pfz
+
+using namespace pfz;
+
+extern "C" {
+
+int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,
+                               int64_t dim, int32_t ntop, float lower_bound, int32_t exclude_diag, int32_t *out_idx,
+                               float *out_val)
+{
+    PFZ_REQUIRE(ctx && out_idx && out_val, "pfz_dense_cossim_topn_host: NULL argument");
+    PFZ_REQUIRE(n_from >= 0 && n_to >= 0 && dim >= 1, "pfz_dense_cossim_topn_host: bad shape");
+    PFZ_REQUIRE(ntop >= 1, "pfz_dense_cossim_topn_host: ntop must be >= 1");
+    PFZ_REQUIRE(lower_bound == lower_bound, "pfz_dense_cossim_topn_host: lower_bound is NaN");
+    if (ntop > 128) {
+        set_error("pfz_dense_cossim_topn_host: ntop=%d exceeds the kernel's limit of 128", ntop);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    if (n_to >= ((int64_t)1 << 31) - 256) {
+        set_error("pfz_dense_cossim_topn_host: n_to too large for int32 indices");
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    if (n_from == 0) return PFZ_OK;
+    PFZ_REQUIRE(from_vec && (n_to == 0 || to_vec), "pfz_dense_cossim_topn_host: NULL matrix");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    if (lower_bound < 0.f) lower_bound = 0.f;   // non-positive similarities are "no match" (_utils.py:122-123)
+    const bool same = to_vec == from_vec && n_to == n_from;
+
+    struct Buf {
+        void *p = nullptr;
+        ~Buf() { if (p) pool_free(p); }
+    } dA, dB, dIa, dIb, dS, dOi, dOv;
+    const size_t a_bytes = (size_t)n_from * (size_t)dim * sizeof(float);
+    const size_t b_bytes = (size_t)(n_to > 0 ? n_to : 1) * (size_t)dim * sizeof(float);
+    PFZ_TRY(pool_alloc(ctx, &dA.p, a_bytes));
+    PFZ_HIP(hipMemcpyAsync(dA.p, from_vec, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!same) {
+        PFZ_TRY(pool_alloc(ctx, &dB.p, b_bytes));
+        if (n_to > 0) PFZ_HIP(hipMemcpyAsync(dB.p, to_vec, (size_t)n_to * (size_t)dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const float *A = (const float *)dA.p, *B = same ? A : (const float *)dB.p;
+    PFZ_TRY(pool_alloc(ctx, &dIa.p, (size_t)n_from * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &dIb.p, (size_t)(n_to > 0 ? n_to : 1) * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &dOi.p, (size_t)n_from * ntop * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &dOv.p, (size_t)n_from * ntop * sizeof(float)));
+    hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_from + 3) / 4)), dim3(256), 0, ctx->stream, A, n_from, dim, (float *)dIa.p);
+    if (n_to > 0)
+        hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_to + 3) / 4)), dim3(256), 0, ctx->stream, B, n_to, dim, (float *)dIb.p);
+
+    const int64_t ld = ((n_to + 255) / 256) * 256;                      // whole float4 x 64-lane steps
+    int64_t panel = ld > 0 ? ((int64_t)8 << 30) / (ld * 4) : n_from;     // <= 8 GiB of scores
+    panel = std::max<int64_t>(kTile, std::min<int64_t>(panel / kTile * kTile, ((n_from + kTile - 1) / kTile) * kTile));
+    if (ld > 0) PFZ_TRY(pool_alloc(ctx, &dS.p, (size_t)panel * (size_t)ld * sizeof(float)));
+    for (int64_t a0 = 0; a0 < n_from; a0 += panel) {
+        const int64_t a1 = std::min(n_from, a0 + panel);
+        if (ld > 0) {
+            ProfScope ps(ctx, "k5_gemm_panel");
+            dim3 grid((unsigned)(ld / kTile), (unsigned)((a1 - a0 + kTile - 1) / kTile));
+            hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, A, B, (const float *)dIa.p,
+                               (const float *)dIb.p, a0, a1, n_to, dim, (float *)dS.p, ld);
+        }
+        {
+            ProfScope ps(ctx, "k5_row_topn");
+            hipLaunchKernelGGL(k5_row_topn, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ctx->stream,
+                               (const float *)dS.p, ld, a0, a1, n_to, ntop, lower_bound, exclude_diag,
+                               (int32_t *)dOi.p, (float *)dOv.p);
+        }
+    }
+    PFZ_HIP(hipGetLastError());
+    PFZ_HIP(hipMemcpyAsync(out_idx, dOi.p, (size_t)n_from * ntop * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PFZ_HIP(hipMemcpyAsync(out_val, dOv.p, (size_t)n_from * ntop * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    return PFZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""GPU parity of K5 (dense cosine top-n, fp32 MFMA) against the float64 oracle and against DataFrames the
+REFERENCE produced from its own embedding fixtures (tests/golden/dense_golden.*)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _check(idx, val, e_idx, e_val, dense, tol=1e-5):
+    np.testing.assert_allclose(val, e_val, rtol=0, atol=tol)
+    bad = np.nonzero((idx != e_idx).any(axis=1))[0]
+    for i in bad:                       # only float64 near-ties may swap
+        for r in range(idx.shape[1]):
+            if idx[i, r] != e_idx[i, r]:
+                s = dense[i, idx[i, r]] if idx[i, r] >= 0 else 0.0
+                assert abs(s - e_val[i, r]) < 4e-6, (i, r, idx[i], e_idx[i])
+    assert len(bad) <= max(1, len(idx) // 100)
+
+
+@pytest.mark.parametrize("n_a,n_b,d,ntop", [(6, 3, 300, 2), (1, 1, 1, 1), (130, 257, 768, 5), (300, 1000, 33, 10),
+                                            (513, 129, 64, 128)])
+def test_random_dense_vs_oracle(ctx, oracle_mod, n_a, n_b, d, ntop):
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(n_a + n_b + d)
+    a = rng.standard_normal((n_a, d)).astype(np.float32)
+    b = rng.standard_normal((n_b, d)).astype(np.float32)
+    if n_b > 10:
+        b[3] = a[0] * 2.5            # an exact-direction duplicate: cosine 1
+        b[7] = 0                     # zero row: cosine 0 with everything
+    idx, val = _lib.dense_cossim_topn_host(ctx, a, b, ntop, 0.0)
+    e_idx, e_val = oracle_mod.dense_cossim_topn(a, b, ntop, 0.0)
+    _check(idx, val, e_idx, e_val, oracle_mod.dense_cossim(a, b))
+    if n_b > 10:
+        assert idx[0, 0] == 3 and abs(val[0, 0] - 1.0) < 1e-6
+
+
+def test_self_match_and_lower_bound(ctx, oracle_mod):
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((400, 96)).astype(np.float32)
+    a[100:110] = a[:10] + 0.05 * rng.standard_normal((10, 96)).astype(np.float32)      # near-duplicates
+    idx, val = _lib.dense_cossim_topn_host(ctx, a, a, 3, 0.2, exclude_diag=True)
+    e_idx, e_val = oracle_mod.dense_cossim_topn(a, a, 3, 0.2, exclude_diag=True)
+    _check(idx, val, e_idx, e_val, oracle_mod.dense_cossim(a, a))
+    assert (idx[:, 0] != np.arange(400)).all() and (idx[:10, 0] == np.arange(100, 110)).all()
+
+
+def test_reference_embedding_fixtures(golden_dense):
+    """cosine_similarity operator on the reference's unit-norm 300-d fixtures == the reference's own frames."""
+    from polyfuzz_amd.models import cosine_similarity
+    g, cases = golden_dense
+    for case in cases["cases"]:
+        to_list = None if case["self"] else cases["to_list"]
+        b = g["from_vec"] if case["self"] else g["to_vec"]
+        df = cosine_similarity(g["from_vec"], b, cases["from_list"], to_list, min_similarity=0.0,
+                               top_n=case["top_n"], method="sklearn")
+        assert list(df.columns) == list(case["df"].keys())
+        for c in df.columns:
+            got = df[c].tolist()
+            if "Similarity" in c:
+                np.testing.assert_allclose(np.array(got, float), np.array(case["df"][c], float), atol=1.01e-3)
+            else:
+                assert got == case["df"][c], c
+
+
+@pytest.fixture(scope="module")
+def golden_dense():
+    g = np.load(os.path.join(HERE, "golden", "dense_golden.npz"))
+    with open(os.path.join(HERE, "golden", "dense_golden.json")) as f:
+        return g, json.load(f)
