@@ -1,0 +1,105 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent properties
+(the float64 oracle takes minutes at these sizes, so it is only run on a random sample of rows)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def headline(ctx):
+    """TF-IDF cosine top-5, 100k names self-match (SURVEY §8d "Headline") on synthetic names."""
+    from polyfuzz_amd import _lib, synth
+    names = synth.company_names(100_000, seed=4321)
+    s = _lib.DeviceStrings.upload(ctx, names)
+    vec = _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 3, 1, 1), s, None)
+    a = vec.transform(s)
+    ix = _lib.DeviceIndex.build(ctx, a)
+    idx, val = _lib.cossim_topn(ctx, ix, a, 5, 0.0, exclude_diag=True).download()
+    idx2, val2 = _lib.cossim_topn(ctx, ix, a, 5, 0.0, exclude_diag=True).download()
+    return names, a, idx, val, idx2, val2
+
+
+def test_headline_properties(headline):
+    names, a, idx, val, idx2, val2 = headline
+    n = len(names)
+    np.testing.assert_array_equal(idx, idx2)                 # idempotent / bit-reproducible
+    np.testing.assert_array_equal(val, val2)
+    assert (val <= 1.0 + 1e-6).all() and (val >= 0).all()
+    assert (np.diff(val, axis=1) <= 0).all()                 # sorted by score
+    assert ((idx == -1) == (val == 0)).all()
+    assert (idx != np.arange(n)[:, None]).all()              # diagonal excluded
+    valid = idx >= 0
+    srt = np.sort(np.where(valid, idx, -np.arange(1, 6)[None, :]), axis=1)
+    assert (np.diff(srt, axis=1) != 0).all()                 # distinct candidates per row
+    # ties are broken by ascending index
+    tie = (np.diff(val, axis=1) == 0) & valid[:, 1:]
+    assert (idx[:, 1:][tie] > idx[:, :-1][tie]).all()
+    # symmetry of the integer sums: if j is i's best match, i reaches j with the same score
+    best = idx[:, 0]
+    has = best >= 0
+    rows = np.nonzero(has)[0]
+    back = idx[best[rows]]
+    hit = (back == rows[:, None])
+    rr, cc = np.nonzero(hit)
+    assert len(rr) > 0.3 * len(rows)
+    np.testing.assert_array_equal(val[best[rows[rr]], cc], val[rows[rr], 0])
+
+
+def test_headline_duplicates_tie_exactly(headline):
+    names, a, idx, val, _, _ = headline
+    first = {}
+    dups = []
+    for i, s in enumerate(names):
+        if s in first:
+            dups.append((first[s], i))
+        else:
+            first[s] = i
+    assert len(dups) > 100
+    indptr = a.download()[0]
+    nnz = np.diff(indptr)
+    for i, j in dups[:2000]:
+        if nnz[i] == 0:        # names without any 3-gram ("A B", "R"): no vector, no match
+            assert val[i, 0] == 0 and val[j, 0] == 0
+            continue
+        # identical strings: each is the other's perfect match and their remaining neighbours coincide
+        assert val[i, 0] >= 1.0 - 1e-6 and val[j, 0] >= 1.0 - 1e-6
+        ni = [(v, k) for v, k in zip(val[i], idx[i]) if k not in (i, j)]
+        nj = [(v, k) for v, k in zip(val[j], idx[j]) if k not in (i, j)]
+        assert ni[:3] == nj[:3]
+
+
+def test_headline_sample_vs_oracle(headline, oracle_mod):
+    names, a, idx, val, _, _ = headline
+    ap, ai, av, ncol = a.download()
+    a3 = (ap, ai, av.astype(np.float64))
+    rows = np.random.default_rng(0).choice(len(names), 60, replace=False)
+    for i in rows:
+        e_idx, e_val = oracle_mod.cossim_topn(a3, a3, ncol, 5, 0.0, exclude_diag=True, rows=(int(i), int(i) + 1))
+        np.testing.assert_allclose(val[i], e_val[0], atol=1e-5)
+        if not np.array_equal(idx[i], e_idx[0]):
+            d = np.abs(np.diff(e_val[0]))
+            assert (d < 2e-6).any(), (i, idx[i], e_idx[0], e_val[0])
+
+
+def test_edit_distance_20k_properties(ctx, oracle_mod):
+    """EditDistance config (SURVEY §8d C3 shape: 20k x 20k titles-like strings)."""
+    from polyfuzz_amd import _lib, synth
+    fl = [s[:40] for s in synth.company_names(20_000, seed=11)]
+    tl = [s[:40] for s in synth.company_names(20_000, seed=12)]
+    tl[5000] = fl[77]                                     # a planted exact match
+    f, t = _lib.DeviceStrings.upload(ctx, fl), _lib.DeviceStrings.upload(ctx, tl)
+    idx, score = _lib.indel_argmax(ctx, f, t)
+    idx2, score2 = _lib.indel_argmax(ctx, f, t)
+    np.testing.assert_array_equal(idx, idx2)
+    np.testing.assert_array_equal(score, score2)
+    assert (score >= 0).all() and (score <= 100).all() and (idx >= 0).all()
+    assert score[77] == 100.0 and tl[idx[77]] == fl[77]
+    rows = np.random.default_rng(1).choice(len(fl), 25, replace=False)
+    for i in rows:
+        e_idx, e_score = oracle_mod.indel_argmax(fl, tl, rows=(int(i), int(i) + 1))
+        assert idx[i] == e_idx[0] and score[i] == e_score[0]
+    # symmetry of the ratio on a row shard
+    m = _lib.indel_matrix(ctx, f, t, 0, 64)
+    mt = _lib.indel_matrix(ctx, t, f, 0, 64)
+    np.testing.assert_array_equal(m[:, :64], mt[:, :64].T)
