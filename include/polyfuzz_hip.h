@@ -99,6 +99,8 @@ int pfz_index_info(const pfz_index *ix, int64_t *n_rows, int64_t *n_cols, int64_
 
 int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out);
 void pfz_topn_free(pfz_topn *t);
+/* set every entry to "no match" (idx -1, score 0); enqueues */
+int pfz_topn_clear(pfz_ctx *ctx, pfz_topn *t);
 /* blocks; out_idx / out_val are [n_rows * ntop] row-major host buffers */
 int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *out_val);
 /* raw device pointers (for an RCCL all-gather issued by the caller) */
@@ -111,7 +113,9 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
  * _utils.py:84-87; diag_offset = global index of from-row 0 when the from
  * side is a row shard).  lower_bound < 0 is treated as 0 (non-positive scores
  * are "no match" in the reference's output contract, _utils.py:122-123).
- * 1 <= ntop <= 128.  Enqueues on the context stream. */
+ * 1 <= ntop <= 128.  `out` may have MORE rows than the from-matrix (a padded
+ * shard buffer for the equal-sized all-gather): the extra rows are not touched.
+ * Enqueues on the context stream. */
 int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,
                     int32_t ntop, float lower_bound, int32_t exclude_diag, int64_t diag_offset,
                     pfz_topn *out);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pfz_topn_alloc": (ctypes.c_int, [c_vp, c_i64, c_i32, P(c_vp)]),
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "pfz_topn_clear": (ctypes.c_int, [c_vp, c_vp]),
     "pfz_topn_device_ptrs": (ctypes.c_int, [c_vp, P(c_vp), P(c_vp), P(c_i64), P(c_i32)]),
     "pfz_cossim_topn": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_f32, c_i32, c_i64, c_vp]),
     "pfz_cossim_topn_host": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -280,6 +281,9 @@ class DeviceTopN(_Handle):
         check(self.ctx.lib.pfz_topn_download(self.ctx.h, self.h, _ptr(idx), _ptr(val)))
         return idx, val
 
+    def clear(self):
+        check(self.ctx.lib.pfz_topn_clear(self.ctx.h, self.h))
+
     def device_ptrs(self):
         pi, pv = c_vp(), c_vp()
         check(self.ctx.lib.pfz_topn_device_ptrs(self.h, ctypes.byref(pi), ctypes.byref(pv), None, None))
@@ -288,9 +292,8 @@ class DeviceTopN(_Handle):
 
 def cossim_topn(ctx, index, from_csr, ntop, lower_bound, exclude_diag=False, diag_offset=0, out=None):
     """Enqueue K3; returns the (device-resident) DeviceTopN."""
-    n_rows = from_csr.shape[0]
     if out is None:
-        out = DeviceTopN.alloc(ctx, n_rows, ntop)
+        out = DeviceTopN.alloc(ctx, from_csr.shape[0], ntop)
     check(ctx.lib.pfz_cossim_topn(ctx.h, index.h, from_csr.h, int(ntop), float(lower_bound),
                                   int(bool(exclude_diag)), int(diag_offset), out.h))
     return out

@@ -49,7 +49,7 @@ namespace pfz {
 
 constexpr int kCap = 256;        // candidate keys per wave (2 KiB LDS)
 constexpr int kMaxTop = 128;
-constexpr int kSlots = 8;        // 64-entry posting chunks in flight per wave
+constexpr int kSlots = 8;        // 64-entry posting chunks in flight per wave (12 measured slower)
 
 // ---------------------------------------------------------------------------
 // inverted-index build (block size = 1 << c_shift to-rows)
@@ -497,7 +497,7 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     }
     PFZ_REQUIRE(A->n_cols == ix->n_cols, "pfz_cossim_topn: from-matrix has %lld columns, index has %lld",
                 (long long)A->n_cols, (long long)ix->n_cols);
-    PFZ_REQUIRE(out->n_rows == A->n_rows && out->ntop == ntop, "pfz_cossim_topn: result buffer is %lldx%d, need %lldx%d",
+    PFZ_REQUIRE(out->n_rows >= A->n_rows && out->ntop == ntop, "pfz_cossim_topn: result buffer is %lldx%d, need %lldx%d",
                 (long long)out->n_rows, out->ntop, (long long)A->n_rows, ntop);
     PFZ_REQUIRE(lower_bound == lower_bound, "pfz_cossim_topn: lower_bound is NaN");
     if (A->n_rows == 0) return PFZ_OK;
@@ -514,7 +514,13 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     // to-side slices: one per XCD when there are enough blocks (tuning knob PFZ_K3_SLICES)
     // (measured: slicing LOSES at 100k x 100k -- 7.4 ms -> 9.9 ms with 8 slices -- because every slice
     // restarts the top-n threshold and pays the row set-up again; it stays off by default)
-    int n_slices = env_int("PFZ_K3_SLICES", 1);
+    int n_slices = env_int("PFZ_K3_SLICES", 0);
+    if (n_slices <= 0) {
+        // auto: a handful of query rows (fit once / transform many, reference polyfuzz.py:234-240) cannot
+        // fill 256 CUs with one workgroup per row -- cut the to-side so that ~2 workgroups per CU exist
+        const int64_t want = (int64_t)ctx->prop.multiProcessorCount * 2;
+        n_slices = A->n_rows >= want ? 1 : (int)((want + A->n_rows - 1) / A->n_rows);
+    }
     n_slices = n_slices < 1 ? 1 : (n_slices > ix->n_blocks ? (ix->n_blocks > 0 ? ix->n_blocks : 1) : n_slices);
     uint64_t *part = nullptr;
     if (n_slices > 1) {

@@ -532,6 +532,17 @@ void pfz_topn_free(pfz_topn *t)
     delete t;
 }
 
+int pfz_topn_clear(pfz_ctx *ctx, pfz_topn *t)
+{
+    PFZ_REQUIRE(ctx && t, "pfz_topn_clear: NULL argument");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)t->n_rows * (size_t)t->ntop;
+    if (n == 0) return PFZ_OK;
+    PFZ_HIP(hipMemsetAsync(t->idx, 0xFF, n * sizeof(int32_t), ctx->stream));   // -1
+    PFZ_HIP(hipMemsetAsync(t->val, 0, n * sizeof(float), ctx->stream));
+    return PFZ_OK;
+}
+
 int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *out_val)
 {
     PFZ_REQUIRE(ctx && t, "pfz_topn_download: NULL argument");

@@ -18,7 +18,7 @@ from scipy.sparse import csr_matrix
 
 from .. import _lib
 from ._base import BaseMatcher
-from ._utils import topn_to_frame, _METHODS
+from ._utils import topn_to_frame, clip_top_n, _METHODS
 
 
 def _clean_string(string: str) -> str:
@@ -133,9 +133,7 @@ class TFIDF(BaseMatcher):
             raise ValueError(f"cosine_method must be one of {_METHODS}")
         ctx = _lib.Context.default()
         from_dev, to_dev = self._extract_tf_idf(from_list, to_list, re_train)
-        top_n = self.top_n
-        if to_list is not None and top_n > len(set(to_list)):     # _utils.py:54-56
-            top_n = len(set(to_list))
+        top_n = clip_top_n(self.top_n, to_list)                   # _utils.py:54-56
         self_match = to_list is None
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
         idx, val = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower,

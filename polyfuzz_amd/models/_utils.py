@@ -39,6 +39,19 @@ def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_lis
     return pd.DataFrame(data)
 
 
+def clip_top_n(top_n: int, to_list) -> int:
+    """reference _utils.py:54-56: top_n = min(top_n, len(set(to_list))) -- without hashing the
+    whole to-list on every call: stop as soon as top_n distinct strings have been seen."""
+    if to_list is None or top_n <= 1 and len(to_list) >= 1:
+        return top_n
+    seen = set()
+    for s in to_list:
+        seen.add(s)
+        if len(seen) >= top_n:
+            return top_n
+    return len(seen)
+
+
 def _to_device_csr(ctx, m):
     if issparse(m):
         return _lib.DeviceCSR.from_scipy(ctx, m)
@@ -60,9 +73,7 @@ def cosine_similarity(from_vector,
     """
     if method not in _METHODS:
         raise ValueError(f"method must be one of {_METHODS}, got {method!r}")
-    if to_list is not None:
-        if top_n > len(set(to_list)):          # _utils.py:54-56
-            top_n = len(set(to_list))
+    top_n = clip_top_n(top_n, to_list)
     self_match = to_list is None
     lower = float(min_similarity) if method in ("sparse", "hip") else 0.0
     ctx = _lib.Context.default()

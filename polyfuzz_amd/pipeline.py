@@ -29,7 +29,10 @@ def shard_bounds(n, world, rank):
 
 class TfidfMatchJob:
     def __init__(self, ctx, from_shard, to_list, top_n=1, min_similarity=0.0, n_gram_range=(3, 3),
-                 clean_string=True, remove_space_ngrams=True, comm=None, self_match=False, shard_offset=0):
+                 clean_string=True, remove_space_ngrams=True, comm=None, self_match=False, shard_offset=0,
+                 rows_per_rank=None):
+        """rows_per_rank: size of the largest shard when the ranks' shards differ (shard_bounds); the
+        per-rank result block is padded to it so that the all-gather moves equal blocks."""
         self.ctx = ctx
         self.comm = comm
         self.top_n = int(top_n)
@@ -42,10 +45,14 @@ class TfidfMatchJob:
         self.n_to = len(to_list)
         self.from_dev = _lib.DeviceStrings.upload(ctx, from_shard)
         self.to_dev = _lib.DeviceStrings.upload(ctx, to_list)
-        self.local = _lib.DeviceTopN.alloc(ctx, self.n_from, self.top_n)
+        self.rows_per_rank = self.n_from if rows_per_rank is None else int(rows_per_rank)
+        if self.rows_per_rank < self.n_from:
+            raise ValueError("rows_per_rank is smaller than this rank's shard")
+        self.local = _lib.DeviceTopN.alloc(ctx, self.rows_per_rank, self.top_n)
+        self.local.clear()                     # padding rows stay "no match"
         self.gathered = None
         if comm is not None and comm.world > 1:
-            self.gathered = _lib.DeviceTopN.alloc(ctx, self.n_from * comm.world, self.top_n)
+            self.gathered = _lib.DeviceTopN.alloc(ctx, self.rows_per_rank * comm.world, self.top_n)
         self.vec = self.from_csr = self.to_csr = self.index = None
 
     def step(self):
@@ -62,6 +69,13 @@ class TfidfMatchJob:
         if self.gathered is not None:
             self.comm.allgather_topn(self.local, self.gathered)
         return self.gathered if self.gathered is not None else self.local
+
+    @staticmethod
+    def unpad(idx, val, shard_sizes, rows_per_rank):
+        """Drop the padding rows of an all-gathered result: (idx, val) of shape
+        [world * rows_per_rank, top_n] -> [sum(shard_sizes), top_n]."""
+        keep = np.concatenate([np.arange(r * rows_per_rank, r * rows_per_rank + n) for r, n in enumerate(shard_sizes)])
+        return idx[keep], val[keep]
 
     def step_description(self):
         return ("fit vocabulary+idf on to+from (K1/K2), vectorise both lists, build the to-side inverted index, "

@@ -64,6 +64,31 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_clip_top_n_equals_reference_rule():
+    from polyfuzz_amd.models._utils import clip_top_n
+    for to_list in (["a", "b", "a"], ["x"], [], ["a"] * 5, list("abcdefg")):
+        for top_n in (1, 2, 3, 10):
+            assert clip_top_n(top_n, to_list) == min(top_n, len(set(to_list)))     # reference _utils.py:54-56
+    assert clip_top_n(7, None) == 7
+
+
+def test_unpad_gathered_shards():
+    from polyfuzz_amd.pipeline import TfidfMatchJob, shard_bounds
+    n, world, top_n = 11, 3, 2
+    sizes = [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
+    rpr = max(sizes)
+    idx = np.full((world * rpr, top_n), -1, np.int32)
+    val = np.zeros((world * rpr, top_n), np.float32)
+    row = 0
+    for r, sz in enumerate(sizes):
+        for i in range(sz):
+            idx[r * rpr + i] = row
+            val[r * rpr + i] = row / 10
+            row += 1
+    i2, v2 = TfidfMatchJob.unpad(idx, val, sizes, rpr)
+    assert i2.shape == (n, top_n) and (i2[:, 0] == np.arange(n)).all() and np.allclose(v2[:, 1], np.arange(n) / 10)
+
+
 def test_synthetic_names_are_deterministic_and_name_like():
     from polyfuzz_amd import synth
     a, b = synth.company_names(500, 7), synth.company_names(500, 7)
