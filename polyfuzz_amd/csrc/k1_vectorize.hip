@@ -51,13 +51,20 @@ __device__ inline uint32_t vocab_rank(const VocabView &v, uint64_t code)
 {
     const uint64_t g = code >> 8;
     const uint32_t wi = (uint32_t)(code >> 5) & 7u;
-    const uint32_t *words = v.bitmap + g * 8;
-    const uint32_t word = words[wi];
     const uint32_t bit = (uint32_t)code & 31u;
-    if (!((word >> bit) & 1u)) return kInvalid;
-    uint32_t r = (uint32_t)v.prefix[g] + __popc(word & ((1u << bit) - 1u));
-    for (uint32_t j = 0; j < wi; ++j) r += __popc(words[j]);
-    return r;
+    // the whole 256-bit group in two 16-byte loads (independent of each other and of the prefix load)
+    const uint4 *w4 = (const uint4 *)(v.bitmap + g * 8);
+    const uint4 lo = w4[0], hi = w4[1];
+    const uint32_t words[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t r = (uint32_t)v.prefix[g];
+    uint32_t present = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t m = j < wi ? 0xFFFFFFFFu : (j == wi ? ((1u << bit) - 1u) : 0u);
+        r += __popc(words[j] & m);
+        present |= j == wi ? (words[j] >> bit) & 1u : 0u;
+    }
+    return present ? r : kInvalid;
 }
 
 struct ExtractParams {
@@ -208,10 +215,32 @@ __global__ __launch_bounds__(256) void k_export_codes(const uint32_t *__restrict
 // ---------------------------------------------------------------------------
 // k_rows_short: one wave per string with <= 64 n-grams.
 // ---------------------------------------------------------------------------
+// Document-frequency counters.  A hot n-gram ('inc': 20 % of all names) would
+// serialise tens of thousands of atomics on ONE address, so every n-gram has
+// 2^shift counters selected by a salt (the row); k_df_reduce adds them up.
+struct DfSink {
+    int32_t *p;   // [vocab << shift], or NULL: do not count
+    int shift;
+    __device__ inline void add(uint32_t key, int64_t salt) const
+    {
+        if (p) atomicAdd(&p[((int64_t)key << shift) + (salt & ((1 << shift) - 1))], 1);
+    }
+};
+
+__global__ __launch_bounds__(256) void k_df_reduce(const int32_t *__restrict__ sharded, int64_t vocab, int shift,
+                                                    int32_t *__restrict__ df)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= vocab) return;
+    int32_t s = 0;
+    for (int j = 0; j < (1 << shift); ++j) s += sharded[(k << shift) + j];
+    df[k] = s;
+}
+
 __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ off, int64_t n, int32_t R,
                                                      VocabView V, uint64_t *__restrict__ slots,
                                                      const int32_t *__restrict__ row_cnt,
-                                                     int32_t *__restrict__ row_nnz, int32_t *__restrict__ df)
+                                                     int32_t *__restrict__ row_nnz, DfSink df)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -247,7 +276,7 @@ __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ 
         const uint64_t above = lane == 63 ? 0ull : (H >> (lane + 1));
         const int next = above ? lane + 1 + __builtin_ctzll(above) : nvalid;
         base[pos] = ((uint64_t)(uint32_t)(next - lane) << 32) | key;   // (.x = id, .y = tf) little-endian
-        if (df) atomicAdd(&df[key], 1);
+        df.add(key, row);
     }
     if (lane == 0) row_nnz[row] = __popcll(H);
 }
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ 
 // runtime-selected flat pointer is avoided on purpose).
 template <typename KEYS>
 __device__ inline void rows_long_body(KEYS keys, int cnt, const VocabView &V, uint64_t *base, int32_t *row_nnz_out,
-                                      int32_t *df, int *sh_heads, int *sh_valid)
+                                      DfSink df, int *sh_heads, int *sh_valid)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int npow2 = 128;
@@ -298,7 +327,7 @@ __device__ inline void rows_long_body(KEYS keys, int cnt, const VocabView &V, ui
             const uint64_t H = __ballot(head);
             if (head) {
                 out[nheads + __popcll(H & ((1ull << lane) - 1ull))] = make_uint2(key, (uint32_t)t);
-                if (df) atomicAdd(&df[key], 1);
+                df.add(key, blockIdx.x);
             }
             nheads += __popcll(H);
             nvalid += __popcll(__ballot(valid));
@@ -324,7 +353,7 @@ __device__ inline void rows_long_body(KEYS keys, int cnt, const VocabView &V, ui
 __global__ __launch_bounds__(256) void k_rows_long(const int64_t *__restrict__ off, int64_t n, int32_t R, VocabView V,
                                                     uint64_t *__restrict__ slots,
                                                     const int32_t *__restrict__ row_cnt,
-                                                    int32_t *__restrict__ row_nnz, int32_t *__restrict__ df,
+                                                    int32_t *__restrict__ row_nnz, DfSink df,
                                                     uint32_t *__restrict__ giant_scratch, int64_t giant_stride)
 {
     __shared__ uint32_t lds_keys[kLongMax];
@@ -421,13 +450,12 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     return PFZ_OK;
 }
 
-static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool count_df)
+static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df)
 {
     if (s->n == 0) return PFZ_OK;
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
     VocabView V{v->bitmap, v->prefix};
     int32_t *row_nnz = s->row_cnt + (s->n + 1);
-    int32_t *df = count_df ? v->df : nullptr;
     {
         ProfScope ps(ctx, "k2_rows_short");
         hipLaunchKernelGGL(k_rows_short, dim3(grid_for(s->n, 4)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, V,
@@ -685,7 +713,16 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
     }
     PFZ_TRY(pool_alloc(ctx, &v->df, (size_t)v->vocab * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &v->idf, (size_t)v->vocab * sizeof(double)));
-    PFZ_HIP(hipMemsetAsync(v->df, 0, (size_t)v->vocab * sizeof(int32_t), ctx->stream));
+    // sharded df counters: up to 32 per n-gram, at most 64 Mi counters in total
+    int df_shift = 5;
+    while (df_shift > 0 && (v->vocab << df_shift) > ((int64_t)64 << 20)) --df_shift;
+    int32_t *df_sh = nullptr;
+    PFZ_TRY(pool_alloc(ctx, &df_sh, (size_t)(v->vocab << df_shift) * sizeof(int32_t)));
+    struct ShGuard {
+        int32_t *p;
+        ~ShGuard() { pool_free(p); }
+    } sh_guard{df_sh};
+    PFZ_HIP(hipMemsetAsync(df_sh, 0, (size_t)(v->vocab << df_shift) * sizeof(int32_t), ctx->stream));
     v->n_docs = 0;
     int64_t local_docs = 0;
     for (int li = 0; li < 2; ++li) {
@@ -693,10 +730,11 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         if (!s) continue;
         // the replicated list (docs_a) is counted by rank 0 only
         const bool counts = (li == 1) || rank == 0 || world == 1;
-        PFZ_TRY(run_rows(ctx, v, s, counts));
+        PFZ_TRY(run_rows(ctx, v, s, DfSink{counts ? df_sh : nullptr, df_shift}));
         s->cache_gen = v->gen;
         if (counts) local_docs += s->n;
     }
+    hipLaunchKernelGGL(k_df_reduce, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, df_sh, v->vocab, df_shift, v->df);
     v->n_docs = local_docs;
     if (world > 1) {
         PFZ_TRY(comm_allreduce_sum_i32(comm, v->df, (size_t)v->vocab));
@@ -757,7 +795,7 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
     }
     if (s->cache_gen != v->gen) {
         PFZ_TRY(run_extract(ctx, v, s, false));
-        PFZ_TRY(run_rows(ctx, v, s, false));
+        PFZ_TRY(run_rows(ctx, v, s, DfSink{nullptr, 0}));
         s->cache_gen = v->gen;
     }
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;

@@ -229,12 +229,15 @@ __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, in
                                      int wave)
 {
     const int nch = (e - s + 63) >> 6;
-    int pin = nch;                                  // inclusive scan over the 64 lanes
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(pin, d, 64);
-        if (lane >= d) pin += o;
-    }
+    // inclusive scan over the 64 lanes with DPP adds (no LDS traffic, unlike __shfl_up/ds_bpermute):
+    // row_shr 1,2,4,8 inside each 16-lane row, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
+    int pin = nch;
+    pin += __builtin_amdgcn_update_dpp(0, pin, 0x111, 0xf, 0xf, false);
+    pin += __builtin_amdgcn_update_dpp(0, pin, 0x112, 0xf, 0xf, false);
+    pin += __builtin_amdgcn_update_dpp(0, pin, 0x114, 0xf, 0xf, false);
+    pin += __builtin_amdgcn_update_dpp(0, pin, 0x118, 0xf, 0xf, false);
+    pin += __builtin_amdgcn_update_dpp(0, pin, 0x142, 0xa, 0xf, false);
+    pin += __builtin_amdgcn_update_dpp(0, pin, 0x143, 0xc, 0xf, false);
     // entry index of chunk g of the lane's list = qbase + g*64 + lane
     const int qbase = s - (pin - nch) * 64;
     const int total = __builtin_amdgcn_readlane(pin, 63);
