@@ -47,7 +47,10 @@
 
 namespace pfz {
 
-constexpr int kCap = 256;        // candidate keys per wave (2 KiB LDS)
+// Candidate keys per wave are a template parameter CAP of the kernel: 128 (1 KiB of LDS) for
+// ntop <= 64, 256 for ntop <= 128 -- LDS per workgroup decides how many from-rows a CU works on
+// at once, and CAP = 128 instead of 256 alone took K3 from 6.1 to 5.3 ms.
+constexpr int kMergeCap = 256;   // candidate keys per wave in k3_merge_slices
 constexpr int kMaxTop = 128;
 constexpr int kSlots = 8;        // 64-entry posting chunks in flight per wave (12 measured slower)
 
@@ -136,6 +139,7 @@ struct TopState {
 };
 
 // Keep the ntop best of cand[0..cnt) sorted at cand[0..keep).
+template <int kCap>
 __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
 {
     wave_sync();
@@ -168,6 +172,7 @@ __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
 }
 
 // push the entries of one int4 (columns j0..j0+3) that beat the threshold
+template <int kCap>
 __device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0, int self_col, int ntop, int lane)
 {
     const int vv[4] = {v.x, v.y, v.z, v.w};
@@ -180,7 +185,7 @@ __device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0
             const int pos = st.cnt + __popcll(mk & ((1ull << lane) - 1ull));
             if (pred) cand[pos] = ((uint64_t)(uint32_t)vv[c] << 32) | (uint32_t)(~j);
             st.cnt += __popcll(mk);
-            if (st.cnt > kCap - 64) compact(cand, st, ntop, lane);
+            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane);
         }
     }
 }
@@ -194,7 +199,7 @@ __device__ inline void lds_barrier()
 
 // Read, clear and filter this wave's share of one block of accumulators: int4
 // slots [i_begin, i_begin + N4) of the block whose first column is col0.
-template <int N4>
+template <int N4, int kCap>
 __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int i_begin, int col0, int self_col,
                                    int ntop, int lane)
 {
@@ -208,8 +213,8 @@ __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int
         acc4[i1] = zero4;
         const int mx = max3i(max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y), max3i(v1.z, v1.w, v1.w));
         if (__ballot(mx > st.thr)) {
-            push4(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
-            push4(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane);
+            push4<kCap>(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
+            push4<kCap>(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane);
         }
     }
 }
@@ -269,7 +274,7 @@ __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, in
 
 
 // C to-rows per block, W waves per workgroup; the workgroup owns one from-row at a time.
-template <int C, int W>
+template <int C, int W, int kCap>
 __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
     const int32_t *__restrict__ a_indptr, const int32_t *__restrict__ a_idx, const float *__restrict__ a_val,
     int32_t n_a, const int32_t *__restrict__ tab, const int2 *__restrict__ post, int32_t nb, int32_t ntop,
@@ -339,13 +344,13 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
             }
             if (touched && ablate != 2) {
                 lds_barrier();     // every wave's updates of this block are in acc
-                sweep_block<N4>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane);
+                sweep_block<N4, kCap>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane);
                 lds_barrier();     // acc is zero again
             }
         }
 
         // merge the waves' candidates: wave 0 folds the others' top-n into its own
-        compact(cand, st, ntop, lane);
+        compact<kCap>(cand, st, ntop, lane);
         if (lane == 0) cnt_all[wave] = st.cnt;
         lds_barrier();
         if (wave == 0) {
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
                 const int cw = cnt_all[w];
                 for (int r = lane; r < cw; r += 64) cand[st.cnt + r] = cand_all[w][r];
                 st.cnt += cw;
-                compact(cand, st, ntop, lane);
+                compact<kCap>(cand, st, ntop, lane);
             }
             for (int r = lane; r < ntop; r += 64) {
                 const uint64_t key = r < st.cnt ? cand[r] : 0ull;
@@ -374,6 +379,7 @@ __global__ __launch_bounds__(256) void k3_merge_slices(const uint64_t *__restric
                                                        int32_t n_slices, int32_t ntop, float inv_scale,
                                                        int32_t *__restrict__ out_idx, float *__restrict__ out_val)
 {
+    constexpr int kCap = kMergeCap;
     __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][kCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
@@ -390,10 +396,10 @@ __global__ __launch_bounds__(256) void k3_merge_slices(const uint64_t *__restric
             const uint64_t mk = __ballot(key != 0ull);
             if (key) cand[st.cnt + __popcll(mk & ((1ull << lane) - 1ull))] = key;
             st.cnt += __popcll(mk);
-            if (st.cnt > kCap - 64) compact(cand, st, ntop, lane);
+            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane);
         }
     }
-    compact(cand, st, ntop, lane);
+    compact<kCap>(cand, st, ntop, lane);
     for (int r = lane; r < ntop; r += 64) {
         const uint64_t key = r < st.cnt ? cand[r] : 0ull;
         out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
@@ -420,7 +426,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     // tuning knob: to-rows per block.  Measured at 100k x 100k (tools/sweep_k3.sh): 2048 rows x 2 waves
     // is the best point -- larger blocks fill the 64-entry chunks better but cost occupancy (LDS).
     int block = env_int("PFZ_K3_BLOCK", 2048);
-    if (block != 2048 && block != 4096 && block != 8192) block = 2048;
+    if (block != 1024 && block != 2048 && block != 4096 && block != 8192) block = 2048;
     int c_shift = 0;
     while ((1 << c_shift) < block) ++c_shift;
     const int64_t nb = (B->n_rows + block - 1) / block;
@@ -533,33 +539,38 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     const int64_t items = A->n_rows * n_slices;
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 16 * 64 * 8;
     const unsigned grid = (unsigned)(items < max_grid ? items : max_grid / n_slices * n_slices);
-    const int waves = env_int("PFZ_K3_WAVES", 2);   // tuning knob: waves per workgroup (= per from-row)
+    const int waves = env_int("PFZ_K3_WAVES", 1);   // tuning knob: waves per workgroup (= per from-row)
+    const int cap = ntop <= 64 ? 128 : 256;         // candidate keys per wave
     const int variant = ix->block_cols * 100 + waves;
     const int ablate = env_int("PFZ_K3_ABLATE", 0);   // timing experiments only: 1 = no scatter, 2 = no sweep
     {
         ProfScope ps(ctx, "k3_cossim_topn");
-#define PFZ_K3_CASE(CC, WW)                                                                                        \
-    case CC * 100 + WW:                                                                                            \
-        hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, WW>), dim3(grid), dim3(WW * 64), 0, ctx->stream, A->indptr,  \
-                           A->indices, A->data, (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ntop, thr0,   \
-                           scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate, n_slices, part); \
+#define PFZ_K3_LAUNCH(CC, WW, CAP)                                                                                 \
+    hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, WW, CAP>), dim3(grid), dim3(WW * 64), 0, ctx->stream, A->indptr, \
+                       A->indices, A->data, (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ntop, thr0,       \
+                       scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate, n_slices, part)
+#define PFZ_K3_CASE(CC, WW)                            \
+    case CC * 100 + WW:                                \
+        if (cap == 128) PFZ_K3_LAUNCH(CC, WW, 128);    \
+        else PFZ_K3_LAUNCH(CC, WW, 256);               \
         break;
         switch (variant) {
+            PFZ_K3_CASE(1024, 1)
+            PFZ_K3_CASE(1024, 2)
             PFZ_K3_CASE(2048, 1)
             PFZ_K3_CASE(2048, 2)
             PFZ_K3_CASE(2048, 4)
             PFZ_K3_CASE(4096, 1)
             PFZ_K3_CASE(4096, 2)
             PFZ_K3_CASE(4096, 4)
-            PFZ_K3_CASE(4096, 8)
             PFZ_K3_CASE(8192, 2)
             PFZ_K3_CASE(8192, 4)
-            PFZ_K3_CASE(8192, 8)
         default:
             set_error("pfz_cossim_topn: no kernel for block size %d with %d waves", ix->block_cols, waves);
             return PFZ_ERR_INVALID;
         }
 #undef PFZ_K3_CASE
+#undef PFZ_K3_LAUNCH
     }
     if (n_slices > 1) {
         ProfScope ps(ctx, "k3_merge_slices");
