@@ -115,3 +115,52 @@ def test_cosine_similarity_operator_sparse_input(oracle_mod):
     df = cosine_similarity(A, B, fl, tl, min_similarity=0, top_n=5)
     assert list(df.columns) == ["From", "To", "Similarity", "To_2", "Similarity_2", "To_3", "Similarity_3"]
     assert df["To"].tolist() == ["apple", "apples", "apple", None, "mouse", None]
+
+
+def _frame_idx(df, to_list, top_n):
+    pos = {}
+    for i, s in enumerate(to_list):
+        pos.setdefault(s, i)
+    idx = np.full((len(df), top_n), -1, np.int64)
+    sim = np.zeros((len(df), top_n))
+    for r in range(top_n):
+        tc = "To" if r == 0 else f"To_{r + 1}"
+        sc = "Similarity" if r == 0 else f"Similarity_{r + 1}"
+        idx[:, r] = [(-1 if t is None else pos[t]) for t in df[tc].tolist()]
+        sim[:, r] = df[sc].to_numpy()
+    return idx, sim
+
+
+def test_company_self_match_frame_vs_reference(golden):
+    """TFIDF.match(list) -- the docs' own use case (self-match, diagonal excluded) -- vs the reference run."""
+    from polyfuzz_amd.models import TFIDF
+    sl = golden["company_self_list"]["from_list"]
+    df = TFIDF(cosine_method="sklearn", min_similarity=0, top_n=3).match(sl)
+    idx, sim = _frame_idx(df, sl, 3)
+    np.testing.assert_allclose(sim, golden["npz"]["self_ref_sim"], atol=1.01e-3)
+    canon = np.where(golden["npz"]["self_ref_sim"] < 0.001, -1, golden["npz"]["self_canon_idx"])
+    # duplicate strings in the list make To -> index ambiguous: compare through the strings
+    names = np.array(sl + [None], dtype=object)
+    same = (names[idx] == names[canon])
+    assert (~same).sum() <= 0.003 * same.size
+
+
+@pytest.mark.parametrize("clean", [True, False])
+def test_non_ascii_titles_vs_reference(golden, clean):
+    """Movie titles with Latin-1 and CJK / Hangul characters: clean_string=True goes through the host-side
+    Unicode-aware cleaning + 1-byte device path, clean_string=False through the UTF-32 device path with an
+    alphabet of > 255 symbols.  Goldens: the reference's TFIDF(cosine_method='sklearn')."""
+    from polyfuzz_amd.models import TFIDF
+    t = golden["titles_lists"]
+    fl, tl = t["from_list"], t["to_list"]
+    df = TFIDF(cosine_method="sklearn", min_similarity=0, top_n=2, clean_string=clean).match(fl, tl)
+    key = "titles_tfidf_clean" if clean else "titles_tfidf_raw"
+    idx, sim = _frame_idx(df, tl, 2)
+    np.testing.assert_allclose(sim, golden["npz"][key + "_sim"], atol=1.01e-3)
+    ref_idx = golden["npz"][key + "_idx"]
+    names = np.array(tl + [None], dtype=object)
+    diff = names[idx] != names[ref_idx]
+    # the reference's order among equal scores is undefined (flipped argsort): only tied ranks may differ
+    for i, r in zip(*np.nonzero(diff)):
+        row_sims = golden["npz"][key + "_sim"][i]
+        assert (np.abs(row_sims - row_sims[r]) < 1.5e-3).sum() >= 2 or row_sims[r] < 0.001, (i, r, df.iloc[i].tolist())
