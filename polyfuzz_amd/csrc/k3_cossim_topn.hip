@@ -243,8 +243,11 @@ __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, in
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x118, 0xf, 0xf, false);
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x142, 0xa, 0xf, false);
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x143, 0xc, 0xf, false);
-    // entry index of chunk g of the lane's list = qbase + g*64 + lane
-    const int qbase = s - (pin - nch) * 64;
+    // BYTE offset of entry (chunk g, lane) of the lane's list = qbase8 + g*512 + lane*8; everything is kept
+    // in bytes so that the per-chunk work is one scalar add, one v_add, one v_cmp and one v_cndmask
+    const int qbase8 = (s - (pin - nch) * 64) * 8;
+    const int e8 = e * 8;
+    const int lane8 = lane * 8;
     const int total = __builtin_amdgcn_readlane(pin, 63);
     const char *post_bytes = (const char *)post;
     for (int g0 = wave; g0 < total; g0 += W * kSlots) {
@@ -256,14 +259,14 @@ __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, in
             const int g = g0 + j * W;                                   // wave-uniform chunk number
             int src = __popcll(__ballot(pin <= g));                    // lane that owns chunk g
             src = src > 63 ? 63 : src;                                  // g >= total: lane 63's list, q >= its end
-            const int ee = __builtin_amdgcn_readlane(e, src);
-            const int q = __builtin_amdgcn_readlane(qbase, src) + g * 64 + lane;
+            const int ee8 = __builtin_amdgcn_readlane(e8, src);
+            const int q8 = (__builtin_amdgcn_readlane(qbase8, src) + g * 512) + lane8;
             pa[j] = readlane_f(as, src);
-            ok[j] = q < ee;
+            ok[j] = q8 < ee8;
             // unconditional load (idle lanes re-read entry 0): a branch around the load would make
             // the compiler wait for every load separately.  32-bit unsigned byte offset from the
             // uniform base -> SGPR-base addressing, no 64-bit address arithmetic per lane.
-            const uint32_t off = ok[j] ? (uint32_t)q * 8u : 0u;
+            const uint32_t off = ok[j] ? (uint32_t)q8 : 0u;
             pe[j] = *(const int2 *)(post_bytes + off);
         }
 #pragma unroll
@@ -431,8 +434,8 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     while ((1 << c_shift) < block) ++c_shift;
     const int64_t nb = (B->n_rows + block - 1) / block;
     const int64_t slots = B->n_cols * nb;
-    if (B->nnz >= ((int64_t)1 << 29)) {
-        set_error("pfz_index_build: %lld postings exceed the 4 GiB the kernel addresses with 32-bit offsets",
+    if (B->nnz >= ((int64_t)1 << 28)) {
+        set_error("pfz_index_build: %lld postings exceed the 2 GiB the kernel addresses with 32-bit byte offsets",
                   (long long)B->nnz);
         return PFZ_ERR_UNSUPPORTED;
     }
