@@ -111,3 +111,25 @@ def test_bad_arguments(ctx):
         _lib.cossim_topn_host(ctx, e3, e3, 4, 0, 0.0)
     with pytest.raises(NotImplementedError):
         _lib.cossim_topn_host(ctx, e3, e3, 4, 1000, 0.0)
+
+
+@pytest.mark.parametrize("fa,fb", [(7.5, 3.0), (1e-3, 2e-2), (300.0, 1e-4)])
+def test_unnormalised_rows_scale_safely(ctx, oracle_mod, fa, fb):
+    """The operator is also called on matrices that are NOT L2-normalised (reference _utils.py:74-82: the
+    sparse branch returns raw dot products).  K3 sizes its fixed-point scale from the largest row norms,
+    so scores keep ~2^-30 relative precision and cannot overflow."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(5)
+    a3 = random_csr(rng, 90, 120, 0.15)
+    b3 = random_csr(rng, 700, 120, 0.15)
+    sa = fa * (0.5 + rng.random(len(a3[2])))
+    sb = fb * (0.5 + rng.random(len(b3[2])))
+    a3 = (a3[0], a3[1], a3[2] * sa)
+    b3 = (b3[0], b3[1], b3[2] * sb)
+    idx, val = _lib.cossim_topn_host(ctx, a3, b3, 120, 6, 0.0)
+    e_idx, e_val = oracle_mod.cossim_topn((a3[0], a3[1], a3[2].astype(np.float32).astype(np.float64)),
+                                          (b3[0], b3[1], b3[2].astype(np.float32).astype(np.float64)), 120, 6, 0.0)
+    bound = fa * fb * 2.5
+    np.testing.assert_allclose(val, e_val, rtol=0, atol=1e-5 * bound)
+    assert (idx != e_idx).any(axis=1).mean() < 0.05
+    assert (val >= 0).all()
