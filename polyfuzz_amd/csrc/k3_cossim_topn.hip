@@ -55,137 +55,38 @@ constexpr int kMaxTop = 128;
 constexpr int kSlots = 8;        // 64-entry posting chunks in flight per wave (12 measured slower)
 
 // ---------------------------------------------------------------------------
-// inverted-index build (block size = 1 << c_shift to-rows)
+// inverted-index build (`block` to-rows per block)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_index_count(const int32_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices, int32_t n_rows,
-                                                      int32_t nb, int32_t c_shift, int32_t *__restrict__ tab1 /* tab + 1 */)
+                                                      int32_t nb, int32_t block, int32_t *__restrict__ tab1 /* tab + 1 */)
 {
     // one 16-lane group per to-row: rows have ~13 entries
     const int gid = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
     if (gid >= n_rows) return;
     const int p0 = indptr[gid], p1 = indptr[gid + 1];
-    const int b = gid >> c_shift;
+    const int b = gid / block;
     for (int p = p0 + sub; p < p1; p += 16) atomicAdd(&tab1[(int64_t)indices[p] * nb + b], 1);
 }
 
 __global__ __launch_bounds__(256) void k_index_fill(const int32_t *__restrict__ indptr,
                                                      const int32_t *__restrict__ indices,
                                                      const float *__restrict__ data, int32_t n_rows, int32_t nb,
-                                                     int32_t c_shift, int32_t *__restrict__ tab1,
-                                                     int2 *__restrict__ post, const int8_t *__restrict__ heavy_id,
-                                                     float *__restrict__ heavy_val, int32_t heavy_shift)
+                                                     int32_t block, int32_t *__restrict__ tab1,
+                                                     int2 *__restrict__ post)
 {
     const int gid = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
     if (gid >= n_rows) return;
     const int p0 = indptr[gid], p1 = indptr[gid + 1];
-    const int b = gid >> c_shift;
-    const int local = gid - (b << c_shift);
+    const int b = gid / block;
+    const int local = gid - b * block;
     for (int p = p0 + sub; p < p1; p += 16) {
         // the order inside one (k,b) list is irrelevant to the results (integer sums)
-        const int k = indices[p];
-        const float v = data[p];
-        int pos = atomicAdd(&tab1[(int64_t)k * nb + b], 1);
-        post[pos] = make_int2(local * 4, __float_as_int(v));   // .x = byte offset into acc
-        if (heavy_id) {   // heavy n-grams also go into the dense (to-row, slot) table (zeroed beforehand)
-            const int h = heavy_id[k];
-            if (h >= 0) heavy_val[((size_t)gid << heavy_shift) + h] = v;
-        }
+        int pos = atomicAdd(&tab1[(int64_t)indices[p] * nb + b], 1);
+        post[pos] = make_int2(local * 4, __float_as_int(data[p]));   // .x = byte offset into acc
     }
-}
-
-// ---------------------------------------------------------------------------
-// heavy n-grams: the (at most) H n-grams with the longest posting lists get a slot
-// 0..H-1, in roughly descending list length (exact inside a histogram bucket is not
-// needed: ANY choice of heavy set and slot order gives the same K3 results, the
-// choice only decides how much work the pruning saves).  Run between the offset
-// scan and the fill: tab1[i] = start(i), the list of n-gram k is tab1[k*nb .. (k+1)*nb).
-// ---------------------------------------------------------------------------
-constexpr int kHeavyBuckets = 1024;
-
-__device__ inline int heavy_bucket(const int32_t *__restrict__ tab1, int32_t k, int32_t n_cols, int32_t nb,
-                                   int32_t nnz, int32_t shift, int32_t min_len)
-{
-    const int s = tab1[(int64_t)k * nb];
-    const int e = k + 1 == n_cols ? nnz : tab1[(int64_t)(k + 1) * nb];
-    const int len = e - s;
-    if (len < min_len) return -1;
-    const int bk = len >> shift;
-    return bk < kHeavyBuckets ? bk : kHeavyBuckets - 1;
-}
-
-__global__ __launch_bounds__(256) void k_heavy_hist(const int32_t *__restrict__ tab1, int32_t n_cols, int32_t nb,
-                                                     int32_t nnz, int32_t shift, int32_t min_len,
-                                                     int32_t *__restrict__ hist)
-{
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_cols) return;
-    const int bk = heavy_bucket(tab1, k, n_cols, nb, nnz, shift, min_len);
-    if (bk >= 0) atomicAdd(&hist[bk], 1);
-}
-
-// base[b] = number of n-grams in longer buckets = first slot of bucket b   (one workgroup of 1024)
-__global__ __launch_bounds__(kHeavyBuckets) void k_heavy_bases(int32_t *__restrict__ hist /* [3][1024]: hist, base, cursor */)
-{
-    __shared__ int s[kHeavyBuckets];
-    const int t = threadIdx.x;
-    const int mine = hist[t];
-    s[t] = mine;
-    __syncthreads();
-    for (int d = 1; d < kHeavyBuckets; d <<= 1) {   // inclusive suffix sums
-        const int v = t + d < kHeavyBuckets ? s[t + d] : 0;
-        __syncthreads();
-        s[t] += v;
-        __syncthreads();
-    }
-    hist[kHeavyBuckets + t] = s[t] - mine;
-    hist[2 * kHeavyBuckets + t] = 0;
-}
-
-__global__ __launch_bounds__(256) void k_heavy_assign(const int32_t *__restrict__ tab1, int32_t n_cols, int32_t nb,
-                                                       int32_t nnz, int32_t shift, int32_t min_len, int32_t n_slots,
-                                                       int32_t *__restrict__ hist, int8_t *__restrict__ heavy_id)
-{
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_cols) return;
-    const int bk = heavy_bucket(tab1, k, n_cols, nb, nnz, shift, min_len);
-    int slot = -1;
-    if (bk >= 0 && hist[kHeavyBuckets + bk] < n_slots) {
-        slot = hist[kHeavyBuckets + bk] + atomicAdd(&hist[2 * kHeavyBuckets + bk], 1);
-        if (slot >= n_slots) slot = -1;
-    }
-    heavy_id[k] = (int8_t)slot;
-}
-
-// bmax[b] = max over the to-rows j of block b of || b_j restricted to the heavy slots ||, rounded up:
-// the factor of K3's Cauchy-Schwarz bound that depends on the to-side
-__global__ __launch_bounds__(256) void k_heavy_blockmax(const float *__restrict__ heavy_val, int32_t n_rows,
-                                                         int32_t c_shift, int32_t heavy_shift,
-                                                         float *__restrict__ bmax)
-{
-    __shared__ float red[256];
-    const int b = blockIdx.x;
-    const int lo = b << c_shift, hi = min(n_rows, (b + 1) << c_shift);
-    const int H = 1 << heavy_shift;
-    float mx = 0.f;
-    for (int j = lo + (int)threadIdx.x; j < hi; j += 256) {
-        const float4 *row = (const float4 *)(heavy_val + ((size_t)j << heavy_shift));
-        float ss = 0.f;
-        for (int q = 0; q < H / 4; ++q) {
-            const float4 v = row[q];
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        }
-        mx = fmaxf(mx, ss);
-    }
-    red[threadIdx.x] = mx;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + d]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) bmax[b] = sqrtf(red[0]) * 1.0001f;
 }
 
 // ---------------------------------------------------------------------------
@@ -242,9 +143,10 @@ template <int kCap>
 __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
 {
     wave_sync();
-    uint64_t e[kCap / 64];
+    constexpr int kPer = (kCap + 63) / 64;   // keys per lane
+    uint64_t e[kPer];
 #pragma unroll
-    for (int i = 0; i < kCap / 64; ++i) {
+    for (int i = 0; i < kPer; ++i) {
         int p = lane + 64 * i;
         e[i] = p < st.cnt ? cand[p] : 0ull;
     }
@@ -254,10 +156,10 @@ __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
     for (int r = 0; r < keep; ++r) {
         uint64_t m = e[0];
 #pragma unroll
-        for (int i = 1; i < kCap / 64; ++i) m = e[i] > m ? e[i] : m;
+        for (int i = 1; i < kPer; ++i) m = e[i] > m ? e[i] : m;
         best = wave_max_u64(m);
 #pragma unroll
-        for (int i = 0; i < kCap / 64; ++i)
+        for (int i = 0; i < kPer; ++i)
             if (e[i] == best) e[i] = 0ull;
         if (lane == 0) cand[r] = best;
     }
@@ -289,113 +191,6 @@ __device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0
     }
 }
 
-// ---------------------------------------------------------------------------
-// Pruning (MaxScore-style, exact).  A few n-grams ('inc', 'llc', ...) own most of
-// the postings.  The index keeps, for its H heaviest n-grams, a dense side table
-// heavy_val[to-row][slot].  While a from-row is walked, the heavy n-grams of the row
-// whose joint upper bound  ub = ||a_N|| * max||b||  (Cauchy-Schwarz over the deferred
-// set N, in fixed-point units, rounded up) is at most alpha * thr are DEFERRED: their
-// lists are not scattered.  A to-row can then still beat the threshold only if its
-// partial sum exceeds thr - ub; those few rows are parked in `pend` and completed 64
-// at a time from the side table with exactly the products the scatter would have
-// added (same fp32 multiply, same truncation; integer sums are order-free), so the
-// results are bit-identical to the unpruned kernel.  N is a prefix of the row's heavy
-// n-grams in slot order; it only grows as thr rises, and each parked entry carries the
-// last slot of the N it was produced under.
-// ---------------------------------------------------------------------------
-constexpr int kPendCap = 64;           // parked entries = one batch (LDS per workgroup decides occupancy)
-constexpr uint32_t kColMask = 0x1ffffffu;   // parked entry: partial<<32 | slot<<25 | to-row (< 2^25)
-
-struct PruneState {
-    int cnt;          // parked entries
-    int ub;           // upper bound of the deferred part (0: nothing deferred)
-    uint32_t tag;     // last deferred slot << 25
-    uint64_t dmask;   // lanes of the row whose n-gram is deferred in the current block
-    uint64_t umask;   // ... in any block so far (a superset of the N of every parked entry)
-    int n_parked, n_batches, n_pushed, n_bad;   // diagnostics (PFZ_K3_STATS)
-};
-
-struct HeavyRef {
-    const float *__restrict__ val;   // heavy_val
-    int shift;                       // slots per to-row = 1 << shift
-    int hid;                         // per lane: slot of the lane's n-gram, -1 = not heavy
-    float as;                        // per lane: row value * scale
-    int n_rows;                      // to-rows of the index
-    int ablate;                      // timing experiments only (PFZ_K3_ABLATE): 3 = no look-ups, 4 = lazy compaction
-};
-
-// complete the last (up to) 64 parked entries and push the ones that beat the threshold
-template <int kCap>
-__device__ inline void flush_batch(uint64_t *cand, const uint64_t *pend, TopState &st, PruneState &ps,
-                                   const HeavyRef &hr, int ntop, int lane)
-{
-    wave_sync();
-    const int take = ps.cnt < 64 ? ps.cnt : 64;
-    const int base = ps.cnt - take;
-    const bool valid = lane < take;
-    const uint64_t ent = valid ? pend[base + lane] : 0ull;
-    wave_sync();
-    ps.cnt = base;
-    int v = (int)(uint32_t)(ent >> 32);
-    const uint32_t lo = (uint32_t)ent;
-    int col = (int)(lo & kColMask);
-    ps.n_bad += __popcll(__ballot(valid && col >= hr.n_rows));
-    if (col >= hr.n_rows) col = 0;
-    const int hm = (int)(lo >> 25);
-    const float *hrow = hr.val + ((size_t)col << hr.shift);
-    uint64_t m = hr.ablate == 3 ? 0ull : ps.umask;
-    while (m) {
-        int ht[4];
-        float at[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = m ? __builtin_ctzll(m) : 0;
-            ht[u] = m ? __builtin_amdgcn_readlane(hr.hid, t) : 0;
-            at[u] = m ? readlane_f(hr.as, t) : 0.f;
-            m &= m - 1;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bv[u] = hrow[ht[u]];   // four look-ups in flight
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (ht[u] <= hm) v += (int)(at[u] * bv[u]);
-    }
-    const bool pred = valid && v > st.thr;
-    const uint64_t mk = __ballot(pred);
-    ps.n_batches += 1;
-    ps.n_pushed += __popcll(mk);
-    if (mk) {
-        const int pos = st.cnt + __popcll(mk & ((1ull << lane) - 1ull));
-        if (pred) cand[pos] = ((uint64_t)(uint32_t)v << 32) | (uint32_t)(~col);
-        st.cnt += __popcll(mk);
-        // a fresh threshold defers more: compact at once when that is cheap (small ntop)
-        if (st.cnt > (ntop <= 16 && hr.ablate != 4 ? ntop : kCap - 64)) compact<kCap>(cand, st, ntop, lane);
-    }
-}
-
-// park the entries of one int4 whose partial sum can still beat the threshold
-template <int kCap>
-__device__ inline void pend4(uint64_t *cand, uint64_t *pend, TopState &st, PruneState &ps, const HeavyRef &hr,
-                             const int4 &v, int j0, int self_col, int ntop, int lane)
-{
-    const int vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int j = j0 + c;
-        const bool pred = vv[c] > st.thr - ps.ub && j != self_col;
-        const uint64_t mk = __ballot(pred);
-        if (mk) {
-            const int n = __popcll(mk);
-            if (ps.cnt + n > kPendCap) flush_batch<kCap>(cand, pend, st, ps, hr, ntop, lane);   // make room
-            const int pos = ps.cnt + __popcll(mk & ((1ull << lane) - 1ull));
-            if (pred) pend[pos] = ((uint64_t)(uint32_t)vv[c] << 32) | ps.tag | (uint32_t)j;
-            ps.cnt += n;
-            ps.n_parked += n;
-            if (ps.cnt >= kPendCap) flush_batch<kCap>(cand, pend, st, ps, hr, ntop, lane);
-        }
-    }
-}
-
 // Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads()
 // would also drain vmcnt and expose the latency of the offset-table prefetch.
 __device__ inline void lds_barrier()
@@ -403,8 +198,8 @@ __device__ inline void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// The same hand-off between the W waves of a workgroup; a one-wave workgroup needs no
-// instruction at all (its LDS operations execute in program order).
+// The same hand-off between the W waves of a workgroup.  A one-wave workgroup needs no
+// instruction at all: its LDS operations execute in program order.
 template <int W>
 __device__ inline void wg_sync()
 {
@@ -414,10 +209,9 @@ __device__ inline void wg_sync()
 
 // Read, clear and filter this wave's share of one block of accumulators: int4
 // slots [i_begin, i_begin + N4) of the block whose first column is col0.
-// `ps`/`hr`/`pend` describe the deferred heavy n-grams (ps.dmask == 0: none, plain top-n filter).
 template <int N4, int kCap>
-__device__ inline void sweep_block(int4 *acc4, uint64_t *cand, uint64_t *pend, TopState &st, PruneState &ps,
-                                   const HeavyRef &hr, int i_begin, int col0, int self_col, int ntop, int lane)
+__device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int i_begin, int col0, int self_col,
+                                   int ntop, int lane)
 {
     const int4 zero4 = make_int4(0, 0, 0, 0);
     static_assert(N4 % 128 == 0, "a wave sweeps whole 128-slot steps");
@@ -428,14 +222,9 @@ __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, uint64_t *pend, T
         acc4[i0] = zero4;
         acc4[i1] = zero4;
         const int mx = max3i(max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y), max3i(v1.z, v1.w, v1.w));
-        if (__ballot(mx > st.thr - ps.ub)) {
-            if (ps.dmask) {
-                pend4<kCap>(cand, pend, st, ps, hr, v0, col0 + i0 * 4, self_col, ntop, lane);
-                pend4<kCap>(cand, pend, st, ps, hr, v1, col0 + i1 * 4, self_col, ntop, lane);
-            } else {
-                push4<kCap>(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
-                push4<kCap>(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane);
-            }
+        if (__ballot(mx > st.thr)) {
+            push4<kCap>(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
+            push4<kCap>(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane);
         }
     }
 }
@@ -504,16 +293,11 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
     int32_t n_a, const int32_t *__restrict__ tab, const int2 *__restrict__ post, int32_t nb, int32_t ntop,
     int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset,
     int32_t *__restrict__ out_idx, float *__restrict__ out_val, int32_t ablate, int32_t n_slices,
-    uint64_t *__restrict__ part_keys, const int8_t *__restrict__ heavy_id, const float *__restrict__ heavy_val,
-    int32_t heavy_shift, const float *__restrict__ heavy_bmax, float inv_alpha, int32_t n_b,
-    unsigned long long *__restrict__ stats)
+    uint64_t *__restrict__ part_keys)
 {
     __shared__ __attribute__((aligned(16))) int acc[C];
     __shared__ __attribute__((aligned(16))) uint64_t cand_all[W][kCap];
-    __shared__ __attribute__((aligned(16))) uint64_t pend[W == 1 ? kPendCap : 1];
     __shared__ int cnt_all[W];
-    // pruning needs one threshold per from-row: only the one-wave workgroup has that
-    const bool prune = W == 1 && heavy_id != nullptr;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tell the compiler it is wave-uniform
     uint64_t *cand = cand_all[wave];
@@ -544,85 +328,17 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
         float as0 = 0.f;
         const bool have0 = lane < nnz;
         const int32_t *trow = tab;
-        HeavyRef hr;
-        hr.val = heavy_val;
-        hr.shift = heavy_shift;
-        hr.hid = -1;
-        hr.ablate = ablate;
-        hr.n_rows = n_b;
         if (have0) {
-            const int k0 = a_idx[p0 + lane];
             as0 = a_val[p0 + lane] * scale;
-            trow = tab + (int64_t)k0 * nb;
+            trow = tab + (int64_t)a_idx[p0 + lane] * nb;
             cur0 = trow[b_lo];
             nxt0 = trow[b_lo + 1];
-            if (prune) hr.hid = heavy_id[k0];
-        }
-        hr.as = as0;
-
-        // per lane: ||a_N|| (times the scale, rounded up) for N = the row's heavy n-grams up to and
-        // including the lane's own slot; times the block's bound on ||b_j restricted to heavy slots||
-        // it bounds the joint contribution of N from above (Cauchy-Schwarz)
-        PruneState ps;
-        ps.cnt = 0;
-        ps.ub = 0;
-        ps.tag = 0u;
-        ps.dmask = 0ull;
-        ps.umask = 0ull;
-        ps.n_parked = ps.n_batches = ps.n_pushed = ps.n_bad = 0;
-        int st_scattered = 0, st_deferred = 0, st_swept = 0, st_dblocks = 0;   // diagnostics
-        float cumn_l = 3.0e38f, cumn_last = 0.f, hb_next = 0.f;
-        bool has_heavy = false;
-        if (prune) {
-            const uint64_t hmask = __ballot(hr.hid >= 0);
-            if (hmask) {
-                float cum2 = 0.f;
-                for (uint64_t m = hmask; m; m &= m - 1) {
-                    const int t = __builtin_ctzll(m);
-                    const int ht = __builtin_amdgcn_readlane(hr.hid, t);
-                    const float at = readlane_f(as0, t);
-                    if (ht <= hr.hid) cum2 += at * at;
-                }
-                if (hr.hid >= 0) cumn_l = sqrtf(cum2) * 1.0001f;
-                has_heavy = true;
-                hb_next = heavy_bmax[b_lo];
-            }
         }
 
         for (int b = b_lo; b < b_hi; ++b) {
-            bool deferred = false;
-            if (has_heavy) {
-                // which heavy n-grams of the row can be deferred in this block?  (a prefix in slot order)
-                const float hb = hb_next;
-                hb_next = heavy_bmax[b + 1 < nb ? b + 1 : b];
-                deferred = hr.hid >= 0 && (cumn_l * hb + 4.f) * inv_alpha <= (float)st.thr;
-                const uint64_t dm = __ballot(deferred);
-                if (dm != ps.dmask) {
-                    ps.dmask = dm;
-                    ps.umask |= dm;
-                    int hm = 0;
-                    cumn_last = 0.f;
-                    for (uint64_t m = dm; m; m &= m - 1) {
-                        const int t = __builtin_ctzll(m);
-                        const int h = __builtin_amdgcn_readlane(hr.hid, t);
-                        const float cn = readlane_f(cumn_l, t);
-                        hm = h > hm ? h : hm;
-                        cumn_last = cn > cumn_last ? cn : cumn_last;
-                    }
-                    ps.tag = (uint32_t)hm << 25;
-                }
-                ps.ub = dm ? (int)fminf(cumn_last * hb + 4.f, 2.0e9f) + 1 : 0;
-            }
-            const int s = cur0;
-            int e = have0 ? nxt0 : cur0;
+            const int s = cur0, e = have0 ? nxt0 : cur0;
             cur0 = e;
             if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];   // prefetch for block b+1 (tab has V*nb+2 slots)
-            if (stats) {
-                st_deferred += deferred ? e - s : 0;
-                st_scattered += deferred ? 0 : e - s;
-                st_dblocks += ps.dmask != 0ull;
-            }
-            if (deferred) e = s;                    // the list is not scattered
             bool touched = __ballot(e > s) != 0;    // identical in every wave of the workgroup
             if (touched && ablate != 1) scatter_block<W>(acc, post, s, e, as0, lane, wave);
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
@@ -641,32 +357,14 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
             }
             if (touched && ablate != 2) {
                 wg_sync<W>();      // every wave's updates of this block are in acc
-                sweep_block<N4, kCap>(acc4, cand, pend, st, ps, hr, wave * N4, b * C, self_col, ntop, lane);
+                sweep_block<N4, kCap>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane);
                 wg_sync<W>();      // acc is zero again
-                st_swept += 1;
-            }
-        }
-        while (ps.cnt > 0) flush_batch<kCap>(cand, pend, st, ps, hr, ntop, lane);   // complete what is still parked
-        if (stats && wave == 0) {
-            for (int d = 32; d >= 1; d >>= 1) {
-                st_scattered += __shfl_xor(st_scattered, d, 64);
-                st_deferred += __shfl_xor(st_deferred, d, 64);
-            }
-            if (lane == 0) {
-                atomicAdd(&stats[0], (unsigned long long)st_scattered);
-                atomicAdd(&stats[1], (unsigned long long)st_deferred);
-                atomicAdd(&stats[2], (unsigned long long)ps.n_parked);
-                atomicAdd(&stats[3], (unsigned long long)ps.n_batches);
-                atomicAdd(&stats[4], (unsigned long long)ps.n_pushed);
-                atomicAdd(&stats[5], (unsigned long long)st_swept);
-                atomicAdd(&stats[6], ((unsigned long long)ps.n_bad << 40) + (unsigned long long)st_dblocks);
-                atomicAdd(&stats[7], (unsigned long long)(b_hi - b_lo));
             }
         }
 
         // merge the waves' candidates: wave 0 folds the others' top-n into its own
         compact<kCap>(cand, st, ntop, lane);
-        if (lane == 0) cnt_all[wave] = st.cnt;
+        if (W > 1 && lane == 0) cnt_all[wave] = st.cnt;
         wg_sync<W>();
         if (wave == 0) {
             for (int w = 1; w < W; ++w) {
@@ -685,7 +383,7 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
                 }
             }
         }
-        wg_sync<W>();   // cand_all is reused by the next item
+        wg_sync<W>();    // cand_all is reused by the next item
     }
 }
 
@@ -741,9 +439,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     // tuning knob: to-rows per block.  Measured at 100k x 100k (tools/sweep_k3.sh): 2048 rows x 2 waves
     // is the best point -- larger blocks fill the 64-entry chunks better but cost occupancy (LDS).
     int block = env_int("PFZ_K3_BLOCK", 2048);
-    if (block != 1024 && block != 2048 && block != 4096 && block != 8192) block = 2048;
-    int c_shift = 0;
-    while ((1 << c_shift) < block) ++c_shift;
+    if (block != 1024 && block != 1536 && block != 2048 && block != 2560 && block != 4096 && block != 8192) block = 2048;
     const int64_t nb = (B->n_rows + block - 1) / block;
     const int64_t slots = B->n_cols * nb;
     if (B->nnz >= ((int64_t)1 << 28)) {
@@ -772,47 +468,15 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
         {
             ProfScope ps(ctx, "k_index_count");
             hipLaunchKernelGGL(k_index_count, dim3(grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
-                               (int32_t)B->n_rows, (int32_t)nb, c_shift, ix->tab + 1);
+                               (int32_t)B->n_rows, (int32_t)nb, block, ix->tab + 1);
         }
         // counts sit at tab[1 + i]; exclusive scan of tab[1..] -> tab[1+i] = start(i)
         PFZ_TRY(exclusive_scan_i32(ctx, ix->tab + 1, slots));
-        // heavy n-grams for K3's pruning (tuning knob PFZ_K3_HEAVY = slots per to-row, 0 = off); parked
-        // entries address to-rows with 25 bits
-        int heavy = env_int("PFZ_K3_HEAVY", 32);
-        if (heavy != 16 && heavy != 32 && heavy != 64) heavy = 0;
-        if (heavy > 0 && B->n_rows <= (int64_t)kColMask) {
-            while ((1 << ix->heavy_shift) < heavy) ++ix->heavy_shift;
-            int len_shift = 0;   // histogram bucket = list length >> len_shift
-            while ((B->n_rows >> len_shift) >= kHeavyBuckets) ++len_shift;
-            // a list must be worth a look-up: at least two postings per to-block on average
-            const int32_t min_len = (int32_t)(2 * nb > 16 ? 2 * nb : 16);
-            const size_t hv_bytes = ((size_t)B->n_rows << ix->heavy_shift) * sizeof(float);
-            PFZ_TRY(pool_alloc(ctx, &ix->heavy_id, (size_t)B->n_cols));
-            PFZ_TRY(pool_alloc(ctx, &ix->heavy_val, hv_bytes));
-            PFZ_TRY(pool_alloc(ctx, &ix->heavy_tmp, (size_t)3 * kHeavyBuckets * sizeof(int32_t)));
-            PFZ_TRY(pool_alloc(ctx, &ix->heavy_bmax, (size_t)nb * sizeof(float)));
-            PFZ_HIP(hipMemsetAsync(ix->heavy_tmp, 0, (size_t)3 * kHeavyBuckets * sizeof(int32_t), ctx->stream));
-            PFZ_HIP(hipMemsetAsync(ix->heavy_val, 0, hv_bytes, ctx->stream));
-            ProfScope ps(ctx, "k_heavy_select");
-            const unsigned vgrid = (unsigned)((B->n_cols + 255) / 256);
-            hipLaunchKernelGGL(k_heavy_hist, dim3(vgrid), dim3(256), 0, ctx->stream, ix->tab + 1, (int32_t)B->n_cols,
-                               (int32_t)nb, (int32_t)B->nnz, len_shift, min_len, ix->heavy_tmp);
-            hipLaunchKernelGGL(k_heavy_bases, dim3(1), dim3(kHeavyBuckets), 0, ctx->stream, ix->heavy_tmp);
-            hipLaunchKernelGGL(k_heavy_assign, dim3(vgrid), dim3(256), 0, ctx->stream, ix->tab + 1,
-                               (int32_t)B->n_cols, (int32_t)nb, (int32_t)B->nnz, len_shift, min_len, heavy,
-                               ix->heavy_tmp, ix->heavy_id);
-        }
         {
             ProfScope ps(ctx, "k_index_fill");
             // the fill advances tab[1+i] to end(i) = start(i+1); tab[0] = 0 = start(0)
             hipLaunchKernelGGL(k_index_fill, dim3(grid), dim3(256), 0, ctx->stream, B->indptr, B->indices, B->data,
-                               (int32_t)B->n_rows, (int32_t)nb, c_shift, ix->tab + 1, ix->post, ix->heavy_id,
-                               ix->heavy_val, ix->heavy_shift);
-        }
-        if (ix->heavy_id) {
-            ProfScope ps(ctx, "k_heavy_select");
-            hipLaunchKernelGGL(k_heavy_blockmax, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ix->heavy_val,
-                               (int32_t)B->n_rows, c_shift, ix->heavy_shift, ix->heavy_bmax);
+                               (int32_t)B->n_rows, (int32_t)nb, block, ix->tab + 1, ix->post);
         }
         PFZ_HIP(hipGetLastError());
     }
@@ -826,10 +490,6 @@ void pfz_index_free(pfz_index *ix)
     if (ix->ctx) (void)hipSetDevice(ix->ctx->device);
     if (ix->tab) pool_free(ix->tab);
     if (ix->post) pool_free(ix->post);
-    if (ix->heavy_id) pool_free(ix->heavy_id);
-    if (ix->heavy_val) pool_free(ix->heavy_val);
-    if (ix->heavy_tmp) pool_free(ix->heavy_tmp);
-    if (ix->heavy_bmax) pool_free(ix->heavy_bmax);
     delete ix;
 }
 
@@ -891,36 +551,31 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 16 * 64 * 8;
     const unsigned grid = (unsigned)(items < max_grid ? items : max_grid / n_slices * n_slices);
     const int waves = env_int("PFZ_K3_WAVES", 1);   // tuning knob: waves per workgroup (= per from-row)
-    const int cap = ntop <= 64 ? 128 : 256;         // candidate keys per wave
+    // candidate keys per wave: room for ntop kept keys + the 64 one sweep step can add.  LDS per
+    // workgroup decides how many from-rows a CU works on at once: 8 KiB of accumulators + 96 keys is
+    // 8960 B = 18 workgroups per CU, 128 keys 17, 256 keys 15
+    int cap = ntop <= 32 ? 96 : (ntop <= 64 ? 128 : 256);
+    { const int forced = env_int("PFZ_K3_CAP", 0); if (forced == 128 && ntop <= 64) cap = 128; }
     const int variant = ix->block_cols * 100 + waves;
     const int ablate = env_int("PFZ_K3_ABLATE", 0);   // timing experiments only: 1 = no scatter, 2 = no sweep
-    // pruning: defer heavy n-grams while their upper bound is <= alpha * threshold (PFZ_K3_ALPHA in
-    // percent, 0 = never defer).  alpha <= 1 keeps "partial sum > thr - ub" a positive test.
-    int alpha_pct = env_int("PFZ_K3_ALPHA", 75);
-    alpha_pct = alpha_pct < 0 ? 0 : (alpha_pct > 100 ? 100 : alpha_pct);
-    const int8_t *heavy_id = alpha_pct > 0 ? ix->heavy_id : nullptr;
-    const float inv_alpha = alpha_pct > 0 ? 100.f / (float)alpha_pct : 1.f;
-    unsigned long long *stats = nullptr;   // PFZ_K3_STATS=1: work counters of this launch on stderr (diagnostics)
-    if (env_int("PFZ_K3_STATS", 0)) {
-        PFZ_TRY(pool_alloc(ctx, &stats, 8 * sizeof(unsigned long long)));
-        PFZ_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    }
     {
         ProfScope ps(ctx, "k3_cossim_topn");
 #define PFZ_K3_LAUNCH(CC, WW, CAP)                                                                                 \
     hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, WW, CAP>), dim3(grid), dim3(WW * 64), 0, ctx->stream, A->indptr, \
                        A->indices, A->data, (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ntop, thr0,       \
-                       scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate, n_slices, part,    \
-                       heavy_id, ix->heavy_val, ix->heavy_shift, ix->heavy_bmax, inv_alpha, (int32_t)ix->n_rows, stats)
+                       scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate, n_slices, part)
 #define PFZ_K3_CASE(CC, WW)                            \
     case CC * 100 + WW:                                \
-        if (cap == 128) PFZ_K3_LAUNCH(CC, WW, 128);    \
+        if (cap == 96) PFZ_K3_LAUNCH(CC, WW, 96);      \
+        else if (cap == 128) PFZ_K3_LAUNCH(CC, WW, 128); \
         else PFZ_K3_LAUNCH(CC, WW, 256);               \
         break;
         switch (variant) {
             PFZ_K3_CASE(1024, 1)
             PFZ_K3_CASE(1024, 2)
+            PFZ_K3_CASE(1536, 1)
             PFZ_K3_CASE(2048, 1)
+            PFZ_K3_CASE(2560, 1)
             PFZ_K3_CASE(2048, 2)
             PFZ_K3_CASE(2048, 4)
             PFZ_K3_CASE(4096, 1)
@@ -941,16 +596,6 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
                            (int32_t)A->n_rows, n_slices, ntop, inv_scale, out->idx, out->val);
     }
     PFZ_HIP(hipGetLastError());
-    if (stats) {
-        unsigned long long h[8];
-        PFZ_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        PFZ_HIP(hipStreamSynchronize(ctx->stream));
-        pool_free(stats);
-        fprintf(stderr,
-                "[k3 stats] rows %lld: postings scattered %llu deferred %llu | parked %llu batches %llu pushed %llu | "
-                "blocks swept %llu of %llu, with deferral %llu\n",
-                (long long)A->n_rows, h[0], h[1], h[2], h[3], h[4], h[5], h[7], h[6]);
-    }
     return PFZ_OK;
 }
 

@@ -81,13 +81,6 @@ struct pfz_index {
     int32_t *tab = nullptr;  // [n_cols * n_blocks + 1]
     int2 *post = nullptr;    // [nnz]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
     float max_norm = 1.f;    // of the indexed matrix' rows
-    // heavy n-grams (the longest posting lists): K3 may defer them and complete the few to-rows that
-    // can still reach the top-n from the dense side table (k3_cossim_topn.hip, "pruning")
-    int32_t heavy_shift = 0;    // log2 of the heavy slots per to-row (0: no heavy table)
-    int8_t *heavy_id = nullptr; // [n_cols] slot of the n-gram, -1 = not heavy; slots in ~descending list length
-    float *heavy_val = nullptr; // [n_rows << heavy_shift] value of (to-row, heavy slot), 0 = absent
-    int32_t *heavy_tmp = nullptr;  // selection scratch (histogram, bases, cursors)
-    float *heavy_bmax = nullptr;   // [n_blocks] max over the block's to-rows of ||row restricted to heavy slots||
 };
 
 struct pfz_topn {
