@@ -69,13 +69,19 @@ __device__ inline uint32_t vocab_rank(const VocabView &v, uint64_t code)
 
 struct ExtractParams {
     int32_t lo, hi, clean, remove_space, w;
+    int32_t bitmap_words;   // words of the vocabulary bitmap (only read by the LDS-bitmap variant)
     int64_t alpha_len;
 };
+
+constexpr int kLdsBitmapWords = 8192;   // code spaces of up to 18 bits (cleaned 3-grams) fit a 32 KiB LDS bitmap
 
 // ---------------------------------------------------------------------------
 // k_extract: one thread per string.
 // ---------------------------------------------------------------------------
-template <int CW>
+// LB: the workgroup first marks its n-grams in an LDS copy of the bitmap and merges the non-zero
+// words into the global one at the end -- a probe of the global bitmap inside the per-character loop
+// is a dependent L2 round trip per n-gram, and the loop of the longest string is the kernel's runtime.
+template <int CW, bool LB>
 __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_v, const int64_t *__restrict__ off,
                                                   int64_t n, ExtractParams P, const uint32_t *__restrict__ alpha_map,
                                                   uint64_t *__restrict__ slots, int32_t *__restrict__ row_cnt,
@@ -86,6 +92,9 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
     // global memory costs one uncoalesced load per character), then walk from LDS.
     constexpr int kStageBytes = 24 * 1024;
     __shared__ uint32_t stage[kStageBytes / 4];
+    __shared__ uint32_t lbm[LB ? kLdsBitmapWords : 1];
+    if (LB)
+        for (int t = threadIdx.x; t < P.bitmap_words; t += 256) lbm[t] = 0u;
     const int64_t i0 = (int64_t)blockIdx.x * 256;
     const int64_t i_end = i0 + 256 < n ? i0 + 256 : n;
     const int64_t byte0 = off[i0] * CW, byte1 = off[i_end] * CW;
@@ -108,8 +117,8 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
     };
 
     const int64_t i = i0 + threadIdx.x;
-    if (i >= n) return;
-    const int64_t b = off[i], e = off[i + 1];
+    const bool live = i < n;
+    const int64_t b = live ? off[i] : 0, e = live ? off[i + 1] : 0;
     const int R = P.hi - P.lo + 1;
     uint64_t *out = slots + b * R;
     const int w = P.w;
@@ -128,9 +137,14 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
                 if (bitmap) {
                     // test before set: almost every n-gram occurrence finds its bit already there, and the
                     // hot words ('inc', 'llc', ...) would otherwise serialise thousands of atomics
-                    uint32_t *wp = &bitmap[code >> 5];
                     const uint32_t bit = 1u << ((uint32_t)code & 31u);
-                    if (!(*(volatile uint32_t *)wp & bit)) atomicOr(wp, bit);
+                    if (LB) {
+                        uint32_t *wp = &lbm[code >> 5];
+                        if (!(*(volatile uint32_t *)wp & bit)) atomicOr(wp, bit);
+                    } else {
+                        uint32_t *wp = &bitmap[code >> 5];
+                        if (!(*(volatile uint32_t *)wp & bit)) atomicOr(wp, bit);
+                    }
                 }
             }
         }
@@ -160,7 +174,14 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
             feed(m, m == 0u || (P.remove_space && c == ' '));
         }
     }
-    row_cnt[i] = cnt;
+    if (live) row_cnt[i] = cnt;
+    if (LB && bitmap) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < P.bitmap_words; t += 256) {
+            const uint32_t wv = lbm[t];
+            if (wv && (wv & ~bitmap[t])) atomicOr(&bitmap[t], wv);
+        }
+    }
 }
 
 template <int CW>
@@ -235,6 +256,53 @@ __global__ __launch_bounds__(256) void k_df_reduce(const int32_t *__restrict__ s
     int32_t s = 0;
     for (int j = 0; j < (1 << shift); ++j) s += sharded[(k << shift) + j];
     df[k] = s;
+}
+
+// Document frequencies WITHOUT global atomics, for vocabularies of up to 2 * kHistWords n-grams: one
+// workgroup per kHistRows strings counts the strings' distinct column ids (the (id, tf) pairs
+// k_rows_* left in the slots) in an LDS histogram, two 16-bit counters per word, and writes the
+// histogram out as one dense row of `partial`; k_df_hist_reduce adds the rows up.  (1.4 M device-scope
+// atomics, even spread over 32 counters per n-gram, were 70 % of the vectoriser's run time.)
+constexpr int kHistRows = 1024;   // <= 65 535, the range of a 16-bit counter; small enough for >= 1 workgroup per CU at 100k strings
+
+__global__ __launch_bounds__(1024) void k_df_hist(const int64_t *__restrict__ off, int64_t n, int32_t R,
+                                                   const uint64_t *__restrict__ slots,
+                                                   const int32_t *__restrict__ row_nnz, int32_t words,
+                                                   uint32_t *__restrict__ partial)
+{
+    __shared__ uint32_t h[kHistWords];
+    for (int t = threadIdx.x; t < words; t += 1024) h[t] = 0u;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * kHistRows;
+    const int64_t r1 = r0 + kHistRows < n ? r0 + kHistRows : n;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    for (int64_t row = r0 + grp; row < r1; row += 64) {
+        const int nn = row_nnz[row];
+        const uint2 *in = (const uint2 *)(slots + off[row] * R);
+        for (int t = sub; t < nn; t += 16) {
+            const uint32_t k = in[t].x;
+            atomicAdd(&h[k >> 1], 1u << ((k & 1u) * 16));
+        }
+    }
+    __syncthreads();
+    uint32_t *dst = partial + (int64_t)blockIdx.x * words;
+    for (int t = threadIdx.x; t < words; t += 1024) dst[t] = h[t];
+}
+
+__global__ __launch_bounds__(256) void k_df_hist_reduce(const uint32_t *__restrict__ partial, int32_t words,
+                                                         int32_t chunks, int64_t vocab, int32_t *__restrict__ df)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= words) return;
+    int32_t lo = 0, hi = 0;
+#pragma unroll 8
+    for (int c = 0; c < chunks; ++c) {   // (unrolled: eight independent loads in flight)
+        const uint32_t v = partial[(int64_t)c * words + w];
+        lo += (int32_t)(v & 0xffffu);
+        hi += (int32_t)(v >> 16);
+    }
+    df[2 * (int64_t)w] = lo;
+    if (2 * (int64_t)w + 1 < vocab) df[2 * (int64_t)w + 1] = hi;
 }
 
 __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ off, int64_t n, int32_t R,
@@ -380,25 +448,48 @@ __global__ __launch_bounds__(256) void k_idf(const int32_t *__restrict__ df, int
     idf[k] = log((n_docs + 1.0) / ((double)df[k] + 1.0)) + 1.0;
 }
 
-// one thread per string: tf*idf in float64, sequential sum of squares in index
-// order, sqrt, divide (sklearn inplace_csr_row_normalize_l2), round to fp32.
+// 16 lanes per string: tf*idf in float64, the sum of squares accumulated SEQUENTIALLY in index order
+// (every lane replays the same additions, so the result is bit-identical to sklearn's
+// inplace_csr_row_normalize_l2 loop), sqrt, divide, round to fp32.  The lanes fetch their (id, tf)
+// pair and idf in parallel; a thread per string walked them as ~14 dependent L2 round trips.
+__device__ inline double shfl_f64(double v, int src_lane)
+{
+    const int lo = __shfl(__double2loint(v), src_lane, 64), hi = __shfl(__double2hiint(v), src_lane, 64);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void k_finalize(const int64_t *__restrict__ off, int64_t n, int32_t R,
                                                    const uint64_t *__restrict__ slots,
                                                    const int32_t *__restrict__ indptr, const double *__restrict__ idf,
                                                    int32_t *__restrict__ indices, float *__restrict__ data)
 {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= n) return;
-    const uint2 *in = (const uint2 *)(slots + off[row] * R);
-    const int o = indptr[row], nn = indptr[row + 1] - o;
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    const int lane0 = (threadIdx.x & 63) & ~15;    // first lane of this row's group inside the wave
+    const bool live = row < n;
+    const uint2 *in = live ? (const uint2 *)(slots + off[row] * R) : nullptr;
+    const int o = live ? indptr[row] : 0, nn = live ? indptr[row + 1] - o : 0;
+    // rows of one wave may differ in length: every lane runs the longest row's trip count so that the
+    // shuffles stay convergent
+    int nn_max = nn;
+    for (int d = 16; d < 64; d <<= 1) nn_max = max(nn_max, __shfl_xor(nn_max, d, 64));
     double ss = 0.0;
-    for (int t = 0; t < nn; ++t) {
-        const uint2 e = in[t];
-        const double v = __dmul_rn((double)e.y, idf[e.x]);
-        ss = __dadd_rn(ss, __dmul_rn(v, v));
+    for (int c0 = 0; c0 < nn_max; c0 += 16) {          // pass 1: ss
+        const int t = c0 + sub;
+        double v = 0.0;
+        if (t < nn) {
+            const uint2 e = in[t];
+            v = __dmul_rn((double)e.y, idf[e.x]);
+        }
+        const double v2 = __dmul_rn(v, v);
+        const int m = min(16, nn_max - c0);
+        for (int j = 0; j < m; ++j) {
+            const double term = shfl_f64(v2, lane0 + j);
+            if (c0 + j < nn) ss = __dadd_rn(ss, term);
+        }
     }
     const double nrm = sqrt(ss);
-    for (int t = 0; t < nn; ++t) {
+    for (int t = sub; t < nn; t += 16) {                // pass 2: normalise and store
         const uint2 e = in[t];
         double v = __dmul_rn((double)e.y, idf[e.x]);
         if (ss != 0.0) v = v / nrm;
@@ -437,15 +528,22 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     }
     if (!s->row_cnt) PFZ_TRY(pool_alloc(ctx, &s->row_cnt, (size_t)(s->n + 1) * 2 * sizeof(int32_t)));
     if (s->n == 0) return PFZ_OK;
+    const int64_t bitmap_words = v->n_groups * 8;
     ExtractParams P{v->params.ngram_lo, v->params.ngram_hi, v->params.clean, v->params.remove_space_ngrams,
-                    v->bits_per_char, v->alpha_map_len};
+                    v->bits_per_char, (int32_t)(bitmap_words <= kLdsBitmapWords ? bitmap_words : 0), v->alpha_map_len};
+    const bool lds_bitmap = mark && bitmap_words <= kLdsBitmapWords;
     ProfScope ps(ctx, "k1_extract");
-    if (s->char_width == 1)
-        hipLaunchKernelGGL(k_extract<1>, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->chars, s->offsets, s->n, P,
-                           v->alpha_map, s->slots, s->row_cnt, mark ? v->bitmap : nullptr);
-    else
-        hipLaunchKernelGGL(k_extract<4>, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->chars, s->offsets, s->n, P,
-                           v->alpha_map, s->slots, s->row_cnt, mark ? v->bitmap : nullptr);
+#define PFZ_EXTRACT(CW, LB)                                                                                          \
+    hipLaunchKernelGGL((k_extract<CW, LB>), dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->chars, s->offsets,   \
+                       s->n, P, v->alpha_map, s->slots, s->row_cnt, mark ? v->bitmap : nullptr)
+    if (s->char_width == 1) {
+        if (lds_bitmap) PFZ_EXTRACT(1, true);
+        else PFZ_EXTRACT(1, false);
+    } else {
+        if (lds_bitmap) PFZ_EXTRACT(4, true);
+        else PFZ_EXTRACT(4, false);
+    }
+#undef PFZ_EXTRACT
     PFZ_HIP(hipGetLastError());
     return PFZ_OK;
 }
@@ -713,28 +811,50 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
     }
     PFZ_TRY(pool_alloc(ctx, &v->df, (size_t)v->vocab * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &v->idf, (size_t)v->vocab * sizeof(double)));
-    // sharded df counters: up to 32 per n-gram, at most 64 Mi counters in total
+    // document frequencies: LDS histograms per kHistRows strings when the vocabulary fits one
+    // (every realistic case), else sharded global counters -- up to 32 per n-gram, at most 64 Mi in total
+    const bool lds_hist = v->vocab <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST");   // env: tests
     int df_shift = 5;
     while (df_shift > 0 && (v->vocab << df_shift) > ((int64_t)64 << 20)) --df_shift;
-    int32_t *df_sh = nullptr;
-    PFZ_TRY(pool_alloc(ctx, &df_sh, (size_t)(v->vocab << df_shift) * sizeof(int32_t)));
+    const int32_t words = (int32_t)((v->vocab + 1) / 2);
+    int64_t chunks = 0;
+    for (int li = 0; li < 2; ++li)
+        if (lists[li] && ((li == 1) || rank == 0 || world == 1)) chunks += (lists[li]->n + kHistRows - 1) / kHistRows;
+    int32_t *df_sh = nullptr;   // sharded counters, or the partial histograms
+    const size_t df_sh_bytes = lds_hist ? (size_t)(chunks > 0 ? chunks : 1) * (size_t)words * sizeof(uint32_t)
+                                        : (size_t)(v->vocab << df_shift) * sizeof(int32_t);
+    PFZ_TRY(pool_alloc(ctx, &df_sh, df_sh_bytes));
     struct ShGuard {
         int32_t *p;
         ~ShGuard() { pool_free(p); }
     } sh_guard{df_sh};
-    PFZ_HIP(hipMemsetAsync(df_sh, 0, (size_t)(v->vocab << df_shift) * sizeof(int32_t), ctx->stream));
+    if (!lds_hist) PFZ_HIP(hipMemsetAsync(df_sh, 0, df_sh_bytes, ctx->stream));
     v->n_docs = 0;
-    int64_t local_docs = 0;
+    int64_t local_docs = 0, chunk0 = 0;
+    const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
     for (int li = 0; li < 2; ++li) {
         pfz_strings *s = lists[li];
         if (!s) continue;
         // the replicated list (docs_a) is counted by rank 0 only
         const bool counts = (li == 1) || rank == 0 || world == 1;
-        PFZ_TRY(run_rows(ctx, v, s, DfSink{counts ? df_sh : nullptr, df_shift}));
+        PFZ_TRY(run_rows(ctx, v, s, DfSink{counts && !lds_hist ? df_sh : nullptr, df_shift}));
         s->cache_gen = v->gen;
         if (counts) local_docs += s->n;
+        if (counts && lds_hist && s->n > 0) {
+            const int64_t nch = (s->n + kHistRows - 1) / kHistRows;
+            ProfScope ps(ctx, "k2_df_hist");
+            hipLaunchKernelGGL(k_df_hist, dim3((unsigned)nch), dim3(1024), 0, ctx->stream, s->offsets, s->n, R, s->slots,
+                               s->row_cnt + (s->n + 1), words, (uint32_t *)df_sh + chunk0 * words);
+            chunk0 += nch;
+        }
     }
-    hipLaunchKernelGGL(k_df_reduce, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, df_sh, v->vocab, df_shift, v->df);
+    if (lds_hist) {
+        ProfScope ps(ctx, "k2_df_hist");
+        hipLaunchKernelGGL(k_df_hist_reduce, dim3(grid_for(words)), dim3(256), 0, ctx->stream, (const uint32_t *)df_sh, words,
+                           (int32_t)chunks, v->vocab, v->df);
+    } else {
+        hipLaunchKernelGGL(k_df_reduce, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, df_sh, v->vocab, df_shift, v->df);
+    }
     v->n_docs = local_docs;
     if (world > 1) {
         PFZ_TRY(comm_allreduce_sum_i32(comm, v->df, (size_t)v->vocab));
@@ -819,7 +939,7 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
     PFZ_TRY(pool_alloc(ctx, &m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
     if (s->n > 0 && nnz > 0) {
         ProfScope ps(ctx, "k2_finalize");
-        hipLaunchKernelGGL(k_finalize, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
+        hipLaunchKernelGGL(k_finalize, dim3(grid_for(s->n, 16)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
                            m->indptr, v->idf, m->indices, m->data);
     }
     PFZ_HIP(hipGetLastError());

@@ -89,6 +89,64 @@ __global__ __launch_bounds__(256) void k_index_fill(const int32_t *__restrict__ 
     }
 }
 
+// The same two passes WITHOUT global atomics (device-scope atomics cost ~85 ns each in aggregate on
+// this part -- 1.3 M of them were 90 % of the index build): one workgroup per to-block keeps a
+// histogram of the block's n-grams in LDS, two 16-bit counters per word (a block has at most 8192
+// rows), for vocabularies of up to 2 * kHistWords n-grams.
+//   count: tab[k*nb + b] = number of rows of block b that contain k      (tab zeroed beforehand)
+//   fill : position inside the (k,b) list = value the LDS counter had before this row's increment
+__global__ __launch_bounds__(1024) void k_index_count_lds(const int32_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices, int32_t n_rows,
+                                                           int32_t nb, int32_t block, int32_t words,
+                                                           int32_t *__restrict__ tab)
+{
+    __shared__ uint32_t h[kHistWords];
+    for (int t = threadIdx.x; t < words; t += 1024) h[t] = 0u;
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int lo = b * block, hi = min(n_rows, lo + block);
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    for (int row = lo + grp; row < hi; row += 64) {
+        const int p0 = indptr[row], p1 = indptr[row + 1];
+        for (int p = p0 + sub; p < p1; p += 16) {
+            const int k = indices[p];
+            atomicAdd(&h[k >> 1], 1u << ((k & 1) * 16));
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < words; w += 1024) {
+        const uint32_t v = h[w];
+        if (v & 0xffffu) tab[(int64_t)(2 * w) * nb + b] = (int32_t)(v & 0xffffu);
+        if (v >> 16) tab[(int64_t)(2 * w + 1) * nb + b] = (int32_t)(v >> 16);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices,
+                                                          const float *__restrict__ data, int32_t n_rows, int32_t nb,
+                                                          int32_t block, int32_t words,
+                                                          const int32_t *__restrict__ tab /* starts */,
+                                                          int2 *__restrict__ post)
+{
+    __shared__ uint32_t h[kHistWords];
+    for (int t = threadIdx.x; t < words; t += 1024) h[t] = 0u;
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int lo = b * block, hi = min(n_rows, lo + block);
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    for (int row = lo + grp; row < hi; row += 64) {
+        const int p0 = indptr[row], p1 = indptr[row + 1];
+        for (int p = p0 + sub; p < p1; p += 16) {
+            const int k = indices[p];
+            const int sh = (k & 1) * 16;
+            const uint32_t old = atomicAdd(&h[k >> 1], 1u << sh);
+            // the order inside one (k,b) list is irrelevant to the results (integer sums)
+            const int pos = tab[(int64_t)k * nb + b] + (int)((old >> sh) & 0xffffu);
+            post[pos] = make_int2((row - lo) * 4, __float_as_int(data[p]));   // .x = byte offset into acc
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------
@@ -463,7 +521,24 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     PFZ_TRY(pool_alloc(ctx, &ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)(B->nnz > 0 ? B->nnz : 1) * sizeof(int2)));
     PFZ_HIP(hipMemsetAsync(ix->tab, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
-    if (B->n_rows > 0 && B->nnz > 0) {
+    // (PFZ_NO_LDS_HIST=1 forces the global-atomics path of huge vocabularies: tests)
+    if (B->n_rows > 0 && B->nnz > 0 && B->n_cols <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST")) {
+        // per-block LDS histograms, no global atomics
+        const int32_t words = (int32_t)((B->n_cols + 1) / 2);
+        {
+            ProfScope ps(ctx, "k_index_count");
+            hipLaunchKernelGGL(k_index_count_lds, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
+                               (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab);
+        }
+        PFZ_TRY(exclusive_scan_i32(ctx, ix->tab, slots));   // tab[i] = start(i), tab[slots] = nnz
+        {
+            ProfScope ps(ctx, "k_index_fill");
+            hipLaunchKernelGGL(k_index_fill_lds, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
+                               B->data, (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab, ix->post);
+        }
+        PFZ_HIP(hipGetLastError());
+    } else if (B->n_rows > 0 && B->nnz > 0) {
+        // huge vocabularies: global atomics
         const unsigned grid = (unsigned)((B->n_rows * 16 + 255) / 256);
         {
             ProfScope ps(ctx, "k_index_count");

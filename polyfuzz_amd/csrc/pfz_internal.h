@@ -36,6 +36,9 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     } while (0)
 
 constexpr int kWave = 64;
+// LDS histograms with two 16-bit counters per word (index build, document frequencies): 144 KiB of the
+// CU's 160 KiB, i.e. vocabularies of up to 73 728 n-grams; larger ones fall back to global atomics
+constexpr int kHistWords = 36864;
 constexpr int kEventSlots = 64;
 
 struct ProfEntry {

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 
-PROFILED_KERNELS = ("k1_extract", "k2_rows_short", "k2_rows_long", "k2_finalize", "k_index_count",
+PROFILED_KERNELS = ("k1_extract", "k2_rows_short", "k2_rows_long", "k2_df_hist", "k2_finalize", "k_index_count",
                     "k_index_fill", "k3_cossim_topn")
 
 
