@@ -89,7 +89,8 @@ _lock = threading.Lock()
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # POLYFUZZ_HIP_LIB: another build of the same sources (tuning experiments: tools/build_variant.sh)
+    return os.environ.get("POLYFUZZ_HIP_LIB") or _build.LIB_PATH
 
 
 def load():

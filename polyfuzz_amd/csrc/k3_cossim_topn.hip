@@ -52,7 +52,13 @@ namespace pfz {
 // at once, and CAP = 128 instead of 256 alone took K3 from 6.1 to 5.3 ms.
 constexpr int kMergeCap = 256;   // candidate keys per wave in k3_merge_slices
 constexpr int kMaxTop = 128;
-constexpr int kSlots = 8;        // 64-entry posting chunks in flight per wave (12 measured slower)
+#ifndef PFZ_K3_EXP
+#define PFZ_K3_EXP 0   // timing experiments (tools/build_variant.sh -DPFZ_K3_EXP=n); 0 = the product
+#endif
+#ifndef PFZ_K3_SLOTS
+#define PFZ_K3_SLOTS 16
+#endif
+constexpr int kSlots = PFZ_K3_SLOTS;   // 64-entry posting chunks in flight per wave, a multiple of 4 (measured: 8 4.64 ms, 16 4.43 ms)
 
 // ---------------------------------------------------------------------------
 // inverted-index build (`block` to-rows per block)
@@ -188,7 +194,52 @@ __device__ inline int max3i(int a, int b, int c)
 __device__ inline void acc_add(int *acc, int off, float as, int bbits)
 {
     const int v = (int)(as * __int_as_float(bbits));
+#if PFZ_K3_EXP == 5     // timing experiment: no LDS atomics (results are wrong)
+    if (v == 0x7fffffff) atomicAdd((int *)((char *)acc + off), v);
+#elif PFZ_K3_EXP == 7   // timing experiment: conflict-free LDS addresses (results are wrong)
+    atomicAdd((int *)((char *)acc + (((off >> 8) << 8) & 0x1f00) + (threadIdx.x & 63) * 4), v);
+#else
     atomicAdd((int *)((char *)acc + off), v);
+#endif
+}
+
+// Four chunk applications  acc[x] += trunc(as * b)  for the lanes of each chunk's mask, as one
+// straight-line sequence: per chunk  s_mov exec / v_mul / v_cvt / ds_add.  (The compiler's own
+// lowering of `if (ok) ...` is s_and_saveexec + s_cbranch_execz + ... + s_or per chunk, and every
+// instruction of a wave costs an issue turn.)  The accumulators sit at LDS address 0 (checked in the
+// kernel), so a posting's byte offset is its LDS address.
+__device__ inline void apply4(const uint64_t (&m)[4], const int2 (&pe)[4], const float (&pa)[4])
+{
+#if PFZ_K3_EXP == 5 || PFZ_K3_EXP == 7
+    for (int j = 0; j < 4; ++j)
+        if ((m[j] >> (threadIdx.x & 63)) & 1) acc_add((int *)nullptr + 0, pe[j].x, pa[j], pe[j].y);
+#else
+    int t0, t1, t2, t3;
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %4, exec\n\t"
+        "s_mov_b64 exec, %5\n\t"
+        "v_mul_f32_e32 %0, %9, %13\n\t"
+        "v_cvt_i32_f32_e32 %0, %0\n\t"
+        "ds_add_u32 %17, %0\n\t"
+        "s_mov_b64 exec, %6\n\t"
+        "v_mul_f32_e32 %1, %10, %14\n\t"
+        "v_cvt_i32_f32_e32 %1, %1\n\t"
+        "ds_add_u32 %18, %1\n\t"
+        "s_mov_b64 exec, %7\n\t"
+        "v_mul_f32_e32 %2, %11, %15\n\t"
+        "v_cvt_i32_f32_e32 %2, %2\n\t"
+        "ds_add_u32 %19, %2\n\t"
+        "s_mov_b64 exec, %8\n\t"
+        "v_mul_f32_e32 %3, %12, %16\n\t"
+        "v_cvt_i32_f32_e32 %3, %3\n\t"
+        "ds_add_u32 %20, %3\n\t"
+        "s_mov_b64 exec, %4"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(saved)
+        : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(pa[0]), "s"(pa[1]), "s"(pa[2]), "s"(pa[3]),
+          "v"(pe[0].y), "v"(pe[1].y), "v"(pe[2].y), "v"(pe[3].y), "v"(pe[0].x), "v"(pe[1].x), "v"(pe[2].x), "v"(pe[3].x)
+        : "memory");
+#endif
 }
 
 struct TopState {
@@ -269,9 +320,8 @@ __device__ inline void wg_sync()
 // slots [i_begin, i_begin + N4) of the block whose first column is col0.
 template <int N4, int kCap>
 __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int i_begin, int col0, int self_col,
-                                   int ntop, int lane)
+                                   int ntop, int lane, const int4 &zero4)
 {
-    const int4 zero4 = make_int4(0, 0, 0, 0);
     static_assert(N4 % 128 == 0, "a wave sweeps whole 128-slot steps");
 #pragma unroll 2
     for (int t = 0; t < N4 / 128; ++t) {
@@ -299,7 +349,7 @@ __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int
 // wave, regardless of list boundaries.
 template <int W>
 __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, int s, int e, float as, int lane,
-                                     int wave)
+                                     int wave, bool acc_at_lds0)
 {
     const int nch = (e - s + 63) >> 6;
     // inclusive scan over the 64 lanes with DPP adds (no LDS traffic, unlike __shfl_up/ds_bpermute):
@@ -318,28 +368,59 @@ __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, in
     const int lane8 = lane * 8;
     const int total = __builtin_amdgcn_readlane(pin, 63);
     const char *post_bytes = (const char *)post;
+    // The kernel is bound by VALU issue (a wave64 instruction occupies its SIMD for four cycles), so the
+    // per-chunk instruction count is what matters: the uniform part of the address is added on the
+    // scalar unit (inline asm: the compiler would otherwise carry it in a VGPR), and the second half of
+    // a round is skipped when the block has no chunks left for it.
+    constexpr int kGroup = 4, kGroups = kSlots / kGroup;
     for (int g0 = wave; g0 < total; g0 += W * kSlots) {
         int2 pe[kSlots];
         float pa[kSlots];
-        bool ok[kSlots];
-#pragma unroll
-        for (int j = 0; j < kSlots; ++j) {
+        uint64_t okm[kSlots];
+        auto issue = [&](int j) {
             const int g = g0 + j * W;                                   // wave-uniform chunk number
             int src = __popcll(__ballot(pin <= g));                    // lane that owns chunk g
             src = src > 63 ? 63 : src;                                  // g >= total: lane 63's list, q >= its end
             const int ee8 = __builtin_amdgcn_readlane(e8, src);
-            const int q8 = (__builtin_amdgcn_readlane(qbase8, src) + g * 512) + lane8;
+            int sbase;
+            asm("s_add_i32 %0, %1, %2" : "=s"(sbase) : "s"(__builtin_amdgcn_readlane(qbase8, src)), "s"(g * 512) : "scc");
+            const int q8 = sbase + lane8;
             pa[j] = readlane_f(as, src);
-            ok[j] = q8 < ee8;
+            const bool okj = q8 < ee8;
+            okm[j] = __ballot(okj);
             // unconditional load (idle lanes re-read entry 0): a branch around the load would make
             // the compiler wait for every load separately.  32-bit unsigned byte offset from the
             // uniform base -> SGPR-base addressing, no 64-bit address arithmetic per lane.
-            const uint32_t off = ok[j] ? (uint32_t)q8 : 0u;
+            const uint32_t off = okj ? (uint32_t)q8 : 0u;
+#if PFZ_K3_EXP == 6     // timing experiment: no posting loads (results are wrong)
+            pe[j] = make_int2((int)((off * 2654435761u) >> 19) & 8188, 0x3c000000);
+#else
             pe[j] = *(const int2 *)(post_bytes + off);
+#endif
+        };
+        // groups of four chunk loads; a group is skipped (wave-uniformly) when the block has no chunk for it
+#pragma unroll
+        for (int q = 0; q < kGroups; ++q) {
+            if (q == 0 || g0 + W * kGroup * q < total) {
+#pragma unroll
+                for (int j = q * kGroup; j < (q + 1) * kGroup; ++j) issue(j);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j)
-            if (ok[j]) acc_add(acc, pe[j].x, pa[j], pe[j].y);
+        for (int q = 0; q < kGroups; ++q) {
+            if (q == 0 || g0 + W * kGroup * q < total) {
+                if (acc_at_lds0) {
+                    const uint64_t m4[4] = {okm[q * 4], okm[q * 4 + 1], okm[q * 4 + 2], okm[q * 4 + 3]};
+                    const int2 p4[4] = {pe[q * 4], pe[q * 4 + 1], pe[q * 4 + 2], pe[q * 4 + 3]};
+                    const float a4[4] = {pa[q * 4], pa[q * 4 + 1], pa[q * 4 + 2], pa[q * 4 + 3]};
+                    apply4(m4, p4, a4);
+                } else {
+#pragma unroll
+                    for (int j = q * kGroup; j < (q + 1) * kGroup; ++j)
+                        if ((okm[j] >> lane) & 1) acc_add(acc, pe[j].x, pa[j], pe[j].y);
+                }
+            }
+        }
     }
 }
 
@@ -353,14 +434,27 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
     int32_t *__restrict__ out_idx, float *__restrict__ out_val, int32_t ablate, int32_t n_slices,
     uint64_t *__restrict__ part_keys)
 {
-    __shared__ __attribute__((aligned(16))) int acc[C];
-    __shared__ __attribute__((aligned(16))) uint64_t cand_all[W][kCap];
-    __shared__ int cnt_all[W];
+    // accumulators first: when they land at LDS address 0 (they do when this struct is the kernel's only
+    // LDS object, i.e. for W == 1) a posting's byte offset IS its LDS address and apply4() can be used
+    __shared__ __attribute__((aligned(16))) struct {
+        int acc[C];
+        uint64_t cand_all[W][kCap];
+    } sm;
+    __shared__ int cnt_all[W];   // only referenced (and therefore only allocated) when W > 1
+    int *const acc = sm.acc;
+    uint64_t (*const cand_all)[kCap] = sm.cand_all;
+    constexpr bool acc_at_lds0 = W == 1;
+    if (acc_at_lds0 && (uint32_t)(uintptr_t)sm.acc != 0u) __builtin_trap();   // layout assumption of apply4()
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tell the compiler it is wave-uniform
     uint64_t *cand = cand_all[wave];
     int4 *acc4 = (int4 *)acc;
     constexpr int N4 = C / 4 / W;   // int4 slots swept by one wave
+    // four zero registers for the whole kernel: as an asm result the compiler cannot re-materialise them
+    // (it rebuilt them with 5 instructions in every sweep step)
+    int4 zero4;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
+                 : "=v"(zero4.x), "=v"(zero4.y), "=v"(zero4.z), "=v"(zero4.w));
     for (int t = threadIdx.x; t < C / 4; t += W * 64) acc4[t] = make_int4(0, 0, 0, 0);
     lds_barrier();
 
@@ -398,7 +492,7 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
             cur0 = e;
             if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];   // prefetch for block b+1 (tab has V*nb+2 slots)
             bool touched = __ballot(e > s) != 0;    // identical in every wave of the workgroup
-            if (touched && ablate != 1) scatter_block<W>(acc, post, s, e, as0, lane, wave);
+            if (touched && ablate != 1) scatter_block<W>(acc, post, s, e, as0, lane, wave, acc_at_lds0);
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
                 int s2 = 0, e2 = 0;
                 float as2 = 0.f;
@@ -410,12 +504,14 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
                 }
                 if (__ballot(e2 > s2)) {
                     touched = true;
-                    scatter_block<W>(acc, post, s2, e2, as2, lane, wave);
+                    // (plain C++ apply here: in this rarely taken loop the compiler keeps the chunk masks in
+                    // VGPR pairs, which apply4()'s scalar operands cannot take)
+                    scatter_block<W>(acc, post, s2, e2, as2, lane, wave, false);
                 }
             }
             if (touched && ablate != 2) {
                 wg_sync<W>();      // every wave's updates of this block are in acc
-                sweep_block<N4, kCap>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane);
+                sweep_block<N4, kCap>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane, zero4);
                 wg_sync<W>();      // acc is zero again
             }
         }
