@@ -326,7 +326,7 @@ def pack_strings(strings):
 
     1-byte code units (Latin-1) when every code point is <= 0xFF, UTF-32 otherwise."""
     n = len(strings)
-    lens = np.fromiter((len(s) for s in strings), np.int64, n)
+    lens = np.fromiter(map(len, strings), np.int64, n)
     off = np.zeros(n + 1, np.int64)
     np.cumsum(lens, out=off[1:])
     joined = "".join(strings)

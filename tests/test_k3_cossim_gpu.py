@@ -104,6 +104,22 @@ def test_empty_and_degenerate(ctx, oracle_mod):
     np.testing.assert_array_equal(idx, exp_idx)
 
 
+def test_index_build_paths_agree(ctx, oracle_mod, monkeypatch):
+    """The LDS-histogram index build and the global-atomic one kept for huge vocabularies
+    (PFZ_NO_LDS_HIST) lead to bit-identical K3 results (integer sums do not depend on the order of the
+    postings inside a list), with to-rows spread over several to-blocks."""
+    rng = np.random.default_rng(11)
+    a3 = random_csr(rng, 300, 501, 0.03)
+    b3 = random_csr(rng, 7001, 501, 0.03)
+    idx, val = _run(ctx, a3, b3, 501, 8, 0.05)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, 501, 8, 0.05)
+    assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, 501)
+    monkeypatch.setenv("PFZ_NO_LDS_HIST", "1")
+    idx2, val2 = _run(ctx, a3, b3, 501, 8, 0.05)
+    np.testing.assert_array_equal(idx2, idx)
+    np.testing.assert_array_equal(val2, val)
+
+
 def test_bad_arguments(ctx):
     from polyfuzz_amd import _lib, PfzError
     e3 = (np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))

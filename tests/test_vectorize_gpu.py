@@ -57,6 +57,26 @@ def test_company_c2(ctx, oracle_mod, golden):
     assert min(exact_a, exact_b) > 0.999   # fp32(float64 value) bit-for-bit on (nearly) every entry
 
 
+def test_document_frequencies_both_counting_paths(ctx, oracle_mod, golden, monkeypatch):
+    """df over 20k strings (several LDS-histogram workgroups) equals the oracle's, and the global-atomic
+    kernels kept for vocabularies beyond the LDS histogram (forced by PFZ_NO_LDS_HIST) give the same
+    vectoriser and the same matrices bit for bit."""
+    fl = golden["company_c2_lists"]["from_list"]
+    tl = golden["company_c2_lists"]["to_list"]
+    o = oracle_mod.TfidfOracle().fit(tl + fl)
+    vec, (a, b) = _device_vectorize(ctx, fl, tl, 3, 3, True)
+    _, idf, df = vec.export()
+    np.testing.assert_array_equal(df, o.df)
+    np.testing.assert_allclose(idf, o.idf, rtol=1e-15)
+    monkeypatch.setenv("PFZ_NO_LDS_HIST", "1")
+    vec2, (a2, b2) = _device_vectorize(ctx, fl, tl, 3, 3, True)
+    _, idf2, df2 = vec2.export()
+    np.testing.assert_array_equal(df2, df)
+    np.testing.assert_array_equal(idf2, idf)
+    for x, y in zip(a + b, a2 + b2):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_self_fit_and_messy_strings(ctx, oracle_mod):
     docs = ["  Hello,   World!! ", "A\tB  C\nD", "", "   ", "a", "ab", "abc", "ABC abc AbC", "x" * 70 + " " + "yz" * 40,
             "1st & 2nd St.", "trailing   ", "Ünited été", "a  b", "..."]
