@@ -177,9 +177,12 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
     if (live) row_cnt[i] = cnt;
     if (LB && bitmap) {
         __syncthreads();
+        // the global words are fetched unconditionally (coalesced, independent loads): a load behind
+        // `if (wv)` made every non-zero word a dependent L2 round trip
+#pragma unroll 8
         for (int t = threadIdx.x; t < P.bitmap_words; t += 256) {
-            const uint32_t wv = lbm[t];
-            if (wv && (wv & ~bitmap[t])) atomicOr(&bitmap[t], wv);
+            const uint32_t wv = lbm[t], gv = bitmap[t];
+            if (wv & ~gv) atomicOr(&bitmap[t], wv);
         }
     }
 }
@@ -425,16 +428,30 @@ __global__ __launch_bounds__(256) void k_rows_long(const int64_t *__restrict__ o
                                                     uint32_t *__restrict__ giant_scratch, int64_t giant_stride)
 {
     __shared__ uint32_t lds_keys[kLongMax];
-    __shared__ int sh_heads, sh_valid;
-    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
-        const int cnt = row_cnt[row];
-        if (cnt <= 64) continue;
-        uint64_t *base = slots + off[row] * R;
-        if (cnt <= kLongMax)
-            rows_long_body(&lds_keys[0], cnt, V, base, row_nnz + row, df, &sh_heads, &sh_valid);
-        else
-            rows_long_body(giant_scratch + (int64_t)blockIdx.x * giant_stride, cnt, V, base, row_nnz + row, df,
-                           &sh_heads, &sh_valid);
+    __shared__ int sh_heads, sh_valid, n_long;
+    __shared__ int long_rows[256];
+    // tiles of 256 strings: the threads look at one string each (a workgroup walking the strings one by
+    // one spent its time on ~50 dependent loads that almost always said "short"), then the workgroup
+    // handles the tile's long strings one after the other
+    const int64_t n_tiles = (n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x == 0) n_long = 0;
+        __syncthreads();
+        const int64_t mine = tile * 256 + threadIdx.x;
+        if (mine < n && row_cnt[mine] > 64) long_rows[atomicAdd(&n_long, 1)] = (int)threadIdx.x;
+        __syncthreads();
+        const int m = n_long;
+        for (int i = 0; i < m; ++i) {
+            const int64_t row = tile * 256 + long_rows[i];
+            const int cnt = row_cnt[row];
+            uint64_t *base = slots + off[row] * R;
+            if (cnt <= kLongMax)
+                rows_long_body(&lds_keys[0], cnt, V, base, row_nnz + row, df, &sh_heads, &sh_valid);
+            else
+                rows_long_body(giant_scratch + (int64_t)blockIdx.x * giant_stride, cnt, V, base, row_nnz + row, df,
+                               &sh_heads, &sh_valid);
+            __syncthreads();
+        }
         __syncthreads();
     }
 }
@@ -561,11 +578,12 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df)
     }
     if (s->max_len * R > 64) {
         const int64_t max_cnt = s->max_len * R;
-        unsigned grid = (unsigned)std::min<int64_t>(s->n, 2048);
+        const int64_t n_tiles = (s->n + 255) / 256;
+        unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 2048);
         uint32_t *giant = nullptr;
         int64_t stride = 0;
         if (max_cnt > kLongMax) {
-            grid = (unsigned)std::min<int64_t>(s->n, 64);
+            grid = (unsigned)std::min<int64_t>(n_tiles, 64);
             stride = 128;
             while (stride < max_cnt) stride <<= 1;
             PFZ_TRY(ensure_scratch(ctx, (size_t)grid * (size_t)stride * sizeof(uint32_t)));

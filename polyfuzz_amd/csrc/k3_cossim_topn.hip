@@ -52,6 +52,7 @@ namespace pfz {
 // at once, and CAP = 128 instead of 256 alone took K3 from 6.1 to 5.3 ms.
 constexpr int kMergeCap = 256;   // candidate keys per wave in k3_merge_slices
 constexpr int kMaxTop = 128;
+constexpr int kWarmMaxTop = 8;    // threshold warm start (one wave-max round per rank) up to this top_n
 #ifndef PFZ_K3_EXP
 #define PFZ_K3_EXP 0   // timing experiments (tools/build_variant.sh -DPFZ_K3_EXP=n); 0 = the product
 #endif
@@ -316,6 +317,36 @@ __device__ inline void wg_sync()
     else lds_barrier();
 }
 
+// Warm start of the threshold from the first block a from-row touches.  With the threshold still at the
+// lower bound every non-zero sum of that block would be pushed (and compacted away again).  The k-th
+// largest of the 64 lanes' own maxima is a lower bound of the k-th largest sum of the block (each lane
+// maximum is a different to-row), so it can serve as the threshold before the block is filtered.
+// Equal maxima are counted once, which only lowers the bound; `k` is ntop, plus one when the self-match
+// column is excluded (it may be one of the maxima).
+template <int N4>
+__device__ inline int warm_threshold(const int4 *acc4, int i_begin, int k, int lane)
+{
+    int lm = 0;
+#pragma unroll
+    for (int t = 0; t < N4 / 128; ++t) {
+        const int4 v0 = acc4[i_begin + t * 128 + lane], v1 = acc4[i_begin + t * 128 + lane + 64];
+        lm = max3i(lm, max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y));
+        lm = max3i(lm, v1.z, v1.w);
+    }
+    int best = 0;
+    for (int r = 0; r < k; ++r) {
+        best = lm;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(best, d, 64);
+            best = o > best ? o : best;
+        }
+        if (best == 0) break;          // fewer than k positive sums
+        if (lm == best) lm = 0;
+    }
+    return best - 1;                   // the filter accepts sum > threshold
+}
+
 // Read, clear and filter this wave's share of one block of accumulators: int4
 // slots [i_begin, i_begin + N4) of the block whose first column is col0.
 template <int N4, int kCap>
@@ -487,6 +518,7 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
             nxt0 = trow[b_lo + 1];
         }
 
+        bool warmed = ablate == 3;   // (3: timing experiment without the threshold warm start)
         for (int b = b_lo; b < b_hi; ++b) {
             const int s = cur0, e = have0 ? nxt0 : cur0;
             cur0 = e;
@@ -511,6 +543,13 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
             }
             if (touched && ablate != 2) {
                 wg_sync<W>();      // every wave's updates of this block are in acc
+                if (!warmed) {
+                    warmed = true;
+                    if (ntop <= kWarmMaxTop) {
+                        const int t = warm_threshold<N4>(acc4, wave * N4, ntop + (self_col >= 0 ? 1 : 0), lane);
+                        st.thr = t > st.thr ? t : st.thr;
+                    }
+                }
                 sweep_block<N4, kCap>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane, zero4);
                 wg_sync<W>();      // acc is zero again
             }
