@@ -278,13 +278,41 @@ __global__ __launch_bounds__(1024) void k_df_hist(const int64_t *__restrict__ of
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * kHistRows;
     const int64_t r1 = r0 + kHistRows < n ? r0 + kHistRows : n;
+    // a 16-lane group takes 16 consecutive strings at a time: the lanes fetch the 16 strings' lengths
+    // and slot addresses in parallel, then the first 16 entries of all 16 strings are loaded back to back
+    // (a group walking its strings one by one paid three dependent L2 round trips per string)
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    for (int64_t row = r0 + grp; row < r1; row += 64) {
-        const int nn = row_nnz[row];
-        const uint2 *in = (const uint2 *)(slots + off[row] * R);
-        for (int t = sub; t < nn; t += 16) {
-            const uint32_t k = in[t].x;
-            atomicAdd(&h[k >> 1], 1u << ((k & 1u) * 16));
+    const int lane0 = (threadIdx.x & 63) & ~15;
+    for (int64_t rb = r0 + grp * 16; rb < r1; rb += 64 * 16) {   // (uniform trip count per wave: r1 - r0 <= 1024)
+        const int64_t mine = rb + sub;
+        int nn = 0;
+        int64_t so = 0;
+        if (mine < r1) {
+            nn = row_nnz[mine];
+            so = off[mine] * R;
+        }
+        uint32_t kk[16];
+        int nni[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            nni[i] = __shfl(nn, lane0 + i, 64);
+            const int64_t soi = ((int64_t)__shfl((int)(so >> 32), lane0 + i, 64) << 32) |
+                                (uint32_t)__shfl((int)(uint32_t)so, lane0 + i, 64);
+            kk[i] = sub < nni[i] ? ((const uint2 *)(slots + soi))[sub].x : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (sub < nni[i]) atomicAdd(&h[kk[i] >> 1], 1u << ((kk[i] & 1u) * 16));
+        for (int i = 0; i < 16; ++i) {                            // strings with more than 16 distinct n-grams
+            const int n_i = __shfl(nn, lane0 + i, 64);
+            if (n_i <= 16) continue;
+            const int64_t soi = ((int64_t)__shfl((int)(so >> 32), lane0 + i, 64) << 32) |
+                                (uint32_t)__shfl((int)(uint32_t)so, lane0 + i, 64);
+            const uint2 *in = (const uint2 *)(slots + soi);
+            for (int t = sub + 16; t < n_i; t += 16) {
+                const uint32_t k = in[t].x;
+                atomicAdd(&h[k >> 1], 1u << ((k & 1u) * 16));
+            }
         }
     }
     __syncthreads();

@@ -112,12 +112,33 @@ __global__ __launch_bounds__(1024) void k_index_count_lds(const int32_t *__restr
     __syncthreads();
     const int b = blockIdx.x;
     const int lo = b * block, hi = min(n_rows, lo + block);
+    // a 16-lane group takes 16 consecutive to-rows at a time: row bounds fetched in parallel by the lanes,
+    // then the first 16 entries of all 16 rows loaded back to back (no dependent round trip per row)
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    for (int row = lo + grp; row < hi; row += 64) {
-        const int p0 = indptr[row], p1 = indptr[row + 1];
-        for (int p = p0 + sub; p < p1; p += 16) {
-            const int k = indices[p];
-            atomicAdd(&h[k >> 1], 1u << ((k & 1) * 16));
+    const int lane0 = (threadIdx.x & 63) & ~15;
+    for (int rb = lo + grp * 16; rb < hi; rb += 64 * 16) {
+        const int mine = rb + sub;
+        int q0 = 0, q1 = 0;
+        if (mine < hi) {
+            q0 = indptr[mine];
+            q1 = indptr[mine + 1];
+        }
+        int kk[16], p0i[16], p1i[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            p0i[i] = __shfl(q0, lane0 + i, 64);
+            p1i[i] = __shfl(q1, lane0 + i, 64);
+            kk[i] = p0i[i] + sub < p1i[i] ? indices[p0i[i] + sub] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (p0i[i] + sub < p1i[i]) atomicAdd(&h[kk[i] >> 1], 1u << ((kk[i] & 1) * 16));
+        for (int i = 0; i < 16; ++i) {            // rows with more than 16 entries
+            const int a = __shfl(q0, lane0 + i, 64), e = __shfl(q1, lane0 + i, 64);
+            for (int p = a + 16 + sub; p < e; p += 16) {
+                const int k = indices[p];
+                atomicAdd(&h[k >> 1], 1u << ((k & 1) * 16));
+            }
         }
     }
     __syncthreads();
@@ -141,15 +162,42 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
     const int b = blockIdx.x;
     const int lo = b * block, hi = min(n_rows, lo + block);
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    for (int row = lo + grp; row < hi; row += 64) {
-        const int p0 = indptr[row], p1 = indptr[row + 1];
-        for (int p = p0 + sub; p < p1; p += 16) {
-            const int k = indices[p];
-            const int sh = (k & 1) * 16;
-            const uint32_t old = atomicAdd(&h[k >> 1], 1u << sh);
-            // the order inside one (k,b) list is irrelevant to the results (integer sums)
-            const int pos = tab[(int64_t)k * nb + b] + (int)((old >> sh) & 0xffffu);
-            post[pos] = make_int2((row - lo) * 4, __float_as_int(data[p]));   // .x = byte offset into acc
+    const int lane0 = (threadIdx.x & 63) & ~15;
+    // one posting: its list position = start(k,b) + the value the LDS counter had before this row
+    // (the order inside one (k,b) list is irrelevant to the results: integer sums)
+    auto place = [&](int k, float v, int row, int start) {
+        const int sh = (k & 1) * 16;
+        const uint32_t old = atomicAdd(&h[k >> 1], 1u << sh);
+        post[start + (int)((old >> sh) & 0xffffu)] = make_int2((row - lo) * 4, __float_as_int(v));   // .x = byte offset into acc
+    };
+    for (int rb = lo + grp * 16; rb < hi; rb += 64 * 16) {   // 16 consecutive rows per group, as in the count kernel
+        const int mine = rb + sub;
+        int q0 = 0, q1 = 0;
+        if (mine < hi) {
+            q0 = indptr[mine];
+            q1 = indptr[mine + 1];
+        }
+        int kk[16], st[16];
+        float vv[16];
+        bool ok[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int a = __shfl(q0, lane0 + i, 64), e = __shfl(q1, lane0 + i, 64);
+            ok[i] = a + sub < e;
+            kk[i] = ok[i] ? indices[a + sub] : 0;
+            vv[i] = ok[i] ? data[a + sub] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = ok[i] ? tab[(int64_t)kk[i] * nb + b] : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (ok[i]) place(kk[i], vv[i], rb + i, st[i]);
+        for (int i = 0; i < 16; ++i) {            // rows with more than 16 entries
+            const int a = __shfl(q0, lane0 + i, 64), e = __shfl(q1, lane0 + i, 64);
+            for (int p = a + 16 + sub; p < e; p += 16) {
+                const int k = indices[p];
+                place(k, data[p], rb + i, tab[(int64_t)k * nb + b]);
+            }
         }
     }
 }

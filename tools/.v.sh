@@ -1,2 +1,2 @@
-timeout 300 python -m pytest tests/test_vectorize_gpu.py tests/test_matchers_gpu.py tests/test_fullsize_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -3
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -3
 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kernel_ms_per_step'], d['ms_per_step'])"
