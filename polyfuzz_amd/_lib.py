@@ -348,12 +348,17 @@ class DeviceStrings(_Handle):
 
     @classmethod
     def upload(cls, ctx, strings):
-        chars, off, width = pack_strings(strings)
+        return cls.upload_packed(ctx, *pack_strings(strings))
+
+    @classmethod
+    def upload_packed(cls, ctx, chars, off, width):
+        """Upload the result of pack_strings()."""
+        n = len(off) - 1
         h = c_vp()
-        check(ctx.lib.pfz_strings_upload(ctx.h, _ptr(chars) if len(chars) else None, _ptr(off), len(strings), width,
+        check(ctx.lib.pfz_strings_upload(ctx.h, _ptr(chars) if len(chars) else None, _ptr(off), n, width,
                                          ctypes.byref(h)))
         s = cls(ctx, h)
-        s.n = len(strings)
+        s.n = n
         s.char_width = width
         return s
 

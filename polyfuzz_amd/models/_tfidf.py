@@ -29,14 +29,6 @@ def _clean_string(string: str) -> str:
     return string
 
 
-def _is_latin1(strings) -> bool:
-    try:
-        "".join(strings).encode("latin-1")
-        return True
-    except UnicodeEncodeError:
-        return False
-
-
 class HipTfidfVectorizer:
     """What `TFIDF.vectorizer` holds after a fit: the device-resident vocabulary +
     idf, with the read-only parts of sklearn's TfidfVectorizer surface
@@ -148,10 +140,12 @@ class TFIDF(BaseMatcher):
 
     def _upload(self, strings):
         ctx = _lib.Context.default()
-        if self.clean_string and not _is_latin1(strings):
-            # cleaning is idempotent, so the device's clean pass leaves these untouched
-            strings = [_clean_string(s) for s in strings]
-        return _lib.DeviceStrings.upload(ctx, strings)
+        packed = _lib.pack_strings(strings)
+        if self.clean_string and packed[2] != 1:
+            # code points > 0xFF: clean on the host (str.lower() can map into ASCII); cleaning is idempotent,
+            # so the device's clean pass leaves these untouched
+            packed = _lib.pack_strings([_clean_string(s) for s in strings])
+        return _lib.DeviceStrings.upload_packed(ctx, *packed)
 
     def _extract_tf_idf(self, from_list, to_list=None, re_train=True):
         """ reference _tfidf.py:102-118: fit on to_list + from_list (or from_list alone), keep the
