@@ -446,6 +446,7 @@ __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, in
     const int e8 = e * 8;
     const int lane8 = lane * 8;
     const int total = __builtin_amdgcn_readlane(pin, 63);
+    const int pin_cmp = lane == 63 ? 0x7fffffff : pin;
     const char *post_bytes = (const char *)post;
     // The kernel is bound by VALU issue (a wave64 instruction occupies its SIMD for four cycles), so the
     // per-chunk instruction count is what matters: the uniform part of the address is added on the
@@ -458,8 +459,10 @@ __device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, in
         uint64_t okm[kSlots];
         auto issue = [&](int j) {
             const int g = g0 + j * W;                                   // wave-uniform chunk number
-            int src = __popcll(__ballot(pin <= g));                    // lane that owns chunk g
-            src = src > 63 ? 63 : src;                                  // g >= total: lane 63's list, q >= its end
+            // lane that owns chunk g = number of lanes whose prefix is <= g.  Lane 63 never counts (its
+            // prefix is replaced by INT_MAX), so the result is a valid lane without a clamp; for
+            // g >= total it is lane 63, whose list ends before chunk g: all lanes idle
+            const int src = __popcll(__ballot(pin_cmp <= g));
             const int ee8 = __builtin_amdgcn_readlane(e8, src);
             int sbase;
             asm("s_add_i32 %0, %1, %2" : "=s"(sbase) : "s"(__builtin_amdgcn_readlane(qbase8, src)), "s"(g * 512) : "scc");
