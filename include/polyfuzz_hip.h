@@ -199,6 +199,14 @@ int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_fr
                                const float *to_vec, int64_t n_to, int64_t dim,
                                int32_t ntop, float lower_bound, int32_t exclude_diag,
                                int32_t *out_idx, float *out_val);
+/* The same without the normalisation: raw dot products.  This is what the reference's
+ * "sparse" back-end computes on dense input (_utils.py:74-82: the ndarrays are wrapped in
+ * csr_matrix and multiplied as they are); Embeddings._embed hands it unit-norm rows
+ * (_embeddings.py:136-145), user-supplied embeddings need not be. */
+int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
+                            const float *to_vec, int64_t n_to, int64_t dim,
+                            int32_t ntop, float lower_bound, int32_t exclude_diag,
+                            int32_t *out_idx, float *out_val);
 
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) ----------------------
  * The from-side is row-sharded, the to-side replicated; the only exchange is

@@ -5,13 +5,18 @@ float64 restatement of the dense branch of the reference's cosine_similarity ope
 (polyfuzz/models/_utils.py:94-102 -> sklearn.metrics.pairwise.cosine_similarity,
 sklearn/metrics/pairwise.py:1683+: normalize(X) . normalize(Y)^T with zero rows left
 at zero), followed by the canonical top-n (score desc, column asc), scores > lower_bound.
+normalize=False: the raw dot products the "sparse" branch forms from dense input
+(_utils.py:74-82: csr_matrix(ndarray) @ csr_matrix(ndarray).T; sparse_dot_topn is not
+installable here, so this variant is anchored on the call site, not on a reference run).
 """
 import numpy as np
 
 
-def dense_cossim(a, b):
+def dense_cossim(a, b, normalize=True):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
+    if not normalize:
+        return a @ b.T
     na = np.sqrt((a * a).sum(1))
     nb = np.sqrt((b * b).sum(1))
     na[na == 0] = 1.0
@@ -19,8 +24,8 @@ def dense_cossim(a, b):
     return (a / na[:, None]) @ (b / nb[:, None]).T
 
 
-def dense_cossim_topn(a, b, ntop, lower_bound=0.0, exclude_diag=False):
-    d = dense_cossim(a, b)
+def dense_cossim_topn(a, b, ntop, lower_bound=0.0, exclude_diag=False, normalize=True):
+    d = dense_cossim(a, b, normalize)
     if exclude_diag:
         np.fill_diagonal(d, -np.inf)
     n, m = d.shape

@@ -75,6 +75,8 @@ SIGNATURES = {
     "pfz_indel_matrix_host": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "pfz_dense_cossim_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                   c_vp, c_vp]),
+    "pfz_dense_dot_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
+                                               c_vp, c_vp]),
     "pfz_comm_unique_id": (ctypes.c_int, [c_vp]),
     "pfz_comm_init": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_vp)]),
     "pfz_comm_destroy": (None, [c_vp]),
@@ -434,15 +436,17 @@ def indel_matrix(ctx, from_dev, to_dev, begin=0, end=None):
     return out
 
 
-def dense_cossim_topn_host(ctx, from_vec, to_vec, ntop, lower_bound, exclude_diag=False):
+def dense_cossim_topn_host(ctx, from_vec, to_vec, ntop, lower_bound, exclude_diag=False, normalize=True):
+    """normalize=False: raw dot products (the reference's "sparse" back-end on dense input)."""
     a = np.ascontiguousarray(from_vec, np.float32)
     b = np.ascontiguousarray(to_vec, np.float32)
     if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
         raise ValueError(f"dense cosine needs two 2-D arrays with equal width, got {a.shape} and {b.shape}")
     idx = np.empty((a.shape[0], ntop), np.int32)
     val = np.empty((a.shape[0], ntop), np.float32)
-    check(ctx.lib.pfz_dense_cossim_topn_host(ctx.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], int(ntop),
-                                             float(lower_bound), int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
+    fn = ctx.lib.pfz_dense_cossim_topn_host if normalize else ctx.lib.pfz_dense_dot_topn_host
+    check(fn(ctx.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], int(ntop), float(lower_bound),
+             int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
     return idx, val
 
 

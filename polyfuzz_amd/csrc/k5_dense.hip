@@ -33,12 +33,17 @@ constexpr int kBK = 32;      // k-depth staged per step
 constexpr int kLd = kBK + 1; // LDS leading dimension
 constexpr int kCap5 = 256;
 
+// normalize == 0: raw dot products are wanted, every scale factor is 1
 __global__ __launch_bounds__(256) void k5_inv_norms(const float *__restrict__ x, int64_t n, int64_t d,
-                                                     float *__restrict__ inv)
+                                                     float *__restrict__ inv, int32_t normalize)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
+    if (!normalize) {
+        if (lane == 0) inv[row] = 1.f;
+        return;
+    }
     const float *p = x + row * d;
     double ss = 0.0;
     for (int64_t k = lane; k < d; k += 64) ss += (double)p[k] * (double)p[k];
@@ -225,9 +230,9 @@ using namespace pfz;
 
 extern "C" {
 
-int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,
-                               int64_t dim, int32_t ntop, float lower_bound, int32_t exclude_diag, int32_t *out_idx,
-                               float *out_val)
+static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,
+                           int64_t dim, int32_t ntop, float lower_bound, int32_t exclude_diag, int32_t normalize,
+                           int32_t *out_idx, float *out_val)
 {
     PFZ_REQUIRE(ctx && out_idx && out_val, "pfz_dense_cossim_topn_host: NULL argument");
     PFZ_REQUIRE(n_from >= 0 && n_to >= 0 && dim >= 1, "pfz_dense_cossim_topn_host: bad shape");
@@ -264,9 +269,9 @@ int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_fr
     PFZ_TRY(pool_alloc(ctx, &dIb.p, (size_t)(n_to > 0 ? n_to : 1) * sizeof(float)));
     PFZ_TRY(pool_alloc(ctx, &dOi.p, (size_t)n_from * ntop * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &dOv.p, (size_t)n_from * ntop * sizeof(float)));
-    hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_from + 3) / 4)), dim3(256), 0, ctx->stream, A, n_from, dim, (float *)dIa.p);
+    hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_from + 3) / 4)), dim3(256), 0, ctx->stream, A, n_from, dim, (float *)dIa.p, normalize);
     if (n_to > 0)
-        hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_to + 3) / 4)), dim3(256), 0, ctx->stream, B, n_to, dim, (float *)dIb.p);
+        hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_to + 3) / 4)), dim3(256), 0, ctx->stream, B, n_to, dim, (float *)dIb.p, normalize);
 
     const int64_t ld = ((n_to + 255) / 256) * 256;                      // whole float4 x 64-lane steps
     int64_t panel = ld > 0 ? ((int64_t)8 << 30) / (ld * 4) : n_from;     // <= 8 GiB of scores
@@ -292,6 +297,20 @@ int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_fr
     PFZ_HIP(hipMemcpyAsync(out_val, dOv.p, (size_t)n_from * ntop * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PFZ_HIP(hipStreamSynchronize(ctx->stream));
     return PFZ_OK;
+}
+
+int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,
+                               int64_t dim, int32_t ntop, float lower_bound, int32_t exclude_diag, int32_t *out_idx,
+                               float *out_val)
+{
+    return dense_topn_host(ctx, from_vec, n_from, to_vec, n_to, dim, ntop, lower_bound, exclude_diag, 1, out_idx, out_val);
+}
+
+int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,
+                            int64_t dim, int32_t ntop, float lower_bound, int32_t exclude_diag, int32_t *out_idx,
+                            float *out_val)
+{
+    return dense_topn_host(ctx, from_vec, n_from, to_vec, n_to, dim, ntop, lower_bound, exclude_diag, 0, out_idx, out_val);
 }
 
 }  // extern "C"

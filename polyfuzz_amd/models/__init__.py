@@ -2,5 +2,6 @@ from ._base import BaseMatcher
 from ._utils import cosine_similarity
 from ._tfidf import TFIDF
 from ._distance import EditDistance
+from ._embeddings import Embeddings
 
-__all__ = ["BaseMatcher", "cosine_similarity", "TFIDF", "EditDistance"]
+__all__ = ["BaseMatcher", "cosine_similarity", "TFIDF", "EditDistance", "Embeddings"]

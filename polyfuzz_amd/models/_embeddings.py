@@ -1,0 +1,87 @@
+"""Embeddings -- the reference's embedding matcher (polyfuzz/models/_embeddings.py:15-145) on the MI355X
+engine, for the part of it that is on the hot path: cosine top-n over ready-made embedding matrices
+(SURVEY.md §8 row A12).
+
+The reference embeds the strings with Flair/word-embedding models that have to be downloaded; those
+models are out of scope.  What is mirrored here is the matcher: `match(from_list, to_list,
+embeddings_from=..., embeddings_to=..., re_train=...)` with the reference's argument meaning, the stored
+`embeddings_to` for `re_train=False`, and the similarity operator on dense input.  An `embedding_method`
+may be any callable `list[str] -> ndarray[n, d]` (the rows are L2-normalised like _embeddings.py:145);
+without one, the embeddings must be passed in.
+"""
+from typing import Callable, List, Optional
+
+import numpy as np
+import pandas as pd
+
+from ._base import BaseMatcher
+from ._utils import cosine_similarity
+
+
+class Embeddings(BaseMatcher):
+    """
+    Match two lists of strings by the cosine similarity of their embeddings
+
+    Arguments (reference _embeddings.py:60-65):
+        embedding_method: callable mapping a list of strings to an ndarray of row vectors, or None when
+                          the embeddings are always supplied to `match`
+        min_similarity: The minimum similarity between strings, otherwise return 0 similarity
+        top_n: The number of best matches you want returned
+        cosine_method: "sparse" (raw dot product of the vectors as given, honours `min_similarity`),
+                       "sklearn" / "knn" (true cosine, ignore `min_similarity`) -- the reference's
+                       semantics, _utils.py:59-102 -- or "hip" (true cosine, honours `min_similarity`)
+        model_id: The name of the particular instance, used when comparing models
+    """
+    def __init__(self,
+                 embedding_method: Optional[Callable[[List[str]], np.ndarray]] = None,
+                 min_similarity: float = 0.75,
+                 top_n: int = 1,
+                 cosine_method: str = "sparse",
+                 model_id: str = None):
+        super().__init__(model_id)
+        self.type = "Embeddings"
+        if embedding_method is not None and not callable(embedding_method):
+            raise TypeError("polyfuzz_amd.Embeddings: embedding_method must be a callable list[str] -> ndarray "
+                            "(Flair embedding objects are not supported: their models need downloads)")
+        self.embedding_method = embedding_method
+        self.min_similarity = min_similarity
+        self.top_n = top_n
+        self.cosine_method = cosine_method
+        self.embeddings_to = None
+
+    def match(self,
+              from_list: List[str],
+              to_list: List[str] = None,
+              embeddings_from: np.ndarray = None,
+              embeddings_to: np.ndarray = None,
+              re_train: bool = True) -> pd.DataFrame:
+        """ Matches the two lists of strings to each other and returns the best mapping
+        (reference _embeddings.py:87-135) """
+        if not isinstance(embeddings_from, np.ndarray):
+            embeddings_from = self._embed(from_list)
+        if not isinstance(embeddings_to, np.ndarray):
+            if not re_train:
+                embeddings_to = self.embeddings_to
+                if embeddings_to is None:
+                    raise ValueError("This Embeddings instance holds no to-side embeddings yet: "
+                                     "call match(..., re_train=True) first")
+            elif to_list is None:
+                embeddings_to = self._embed(from_list) if self.embedding_method is not None else embeddings_from
+            else:
+                embeddings_to = self._embed(to_list)
+        matches = cosine_similarity(embeddings_from, embeddings_to, from_list, to_list, self.min_similarity,
+                                    top_n=self.top_n, method=self.cosine_method)
+        self.embeddings_to = embeddings_to
+        return matches
+
+    def _embed(self, strings: List[str]) -> np.ndarray:
+        """ Embed with the user's callable and L2-normalise the rows (reference _embeddings.py:136-145) """
+        if self.embedding_method is None:
+            raise ValueError("polyfuzz_amd.Embeddings was created without an embedding_method: pass "
+                             "embeddings_from / embeddings_to to match()")
+        vec = np.asarray(self.embedding_method(list(strings)), dtype=np.float64)
+        if vec.ndim != 2 or vec.shape[0] != len(strings):
+            raise ValueError(f"embedding_method returned shape {vec.shape} for {len(strings)} strings")
+        norms = np.sqrt((vec * vec).sum(axis=1, keepdims=True))
+        norms[norms == 0.0] = 1.0
+        return vec / norms

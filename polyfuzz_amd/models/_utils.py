@@ -83,8 +83,10 @@ def cosine_similarity(from_vector,
     ctx = _lib.Context.default()
 
     if isinstance(from_vector, np.ndarray) or isinstance(to_vector, np.ndarray):
+        # "sparse" multiplies the arrays as they are (reference _utils.py:74-82: csr_matrix(ndarray), no
+        # normalisation); "sklearn"/"knn"/"hip" are true cosines (_utils.py:59-70,94-95)
         idx, val = _lib.dense_cossim_topn_host(ctx, np.asarray(from_vector), np.asarray(to_vector), max(top_n, 1),
-                                               lower, self_match)
+                                               lower, self_match, normalize=method != "sparse")
     else:
         a = _to_device_csr(ctx, from_vector)
         b = a if to_vector is from_vector else _to_device_csr(ctx, to_vector)

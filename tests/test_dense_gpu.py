@@ -49,6 +49,72 @@ def test_self_match_and_lower_bound(ctx, oracle_mod):
     assert (idx[:, 0] != np.arange(400)).all() and (idx[:10, 0] == np.arange(100, 110)).all()
 
 
+def test_raw_dot_products_of_unnormalised_vectors(ctx, oracle_mod):
+    """pfz_dense_dot_topn_host: what the reference's "sparse" back-end forms from dense input
+    (_utils.py:74-82) -- no normalisation, so the ranking follows the dot product, not the cosine."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(21)
+    a = (rng.standard_normal((150, 70)) * rng.uniform(0.2, 3.0, (150, 1))).astype(np.float32)
+    b = (rng.standard_normal((900, 70)) * rng.uniform(0.2, 3.0, (900, 1))).astype(np.float32)
+    idx, val = _lib.dense_cossim_topn_host(ctx, a, b, 6, 0.5, normalize=False)
+    e_idx, e_val = oracle_mod.dense_cossim_topn(a, b, 6, 0.5, normalize=False)
+    dots = oracle_mod.dense_cossim(a, b, normalize=False)
+    np.testing.assert_allclose(val, e_val, rtol=2e-6, atol=2e-5)
+    bad = np.nonzero((idx != e_idx).any(axis=1))[0]
+    for i in bad:                                    # only fp32-level near-ties may swap
+        for r in range(idx.shape[1]):
+            if idx[i, r] != e_idx[i, r]:
+                s_got = dots[i, idx[i, r]] if idx[i, r] >= 0 else 0.0
+                assert abs(s_got - e_val[i, r]) < 1e-4 * max(1.0, abs(e_val[i, r]))
+    assert len(bad) <= 3
+    c_idx, _ = _lib.dense_cossim_topn_host(ctx, a, b, 6, 0.0)
+    assert (c_idx[:, 0] != idx[:, 0]).any()           # cosine and dot product rank differently here
+
+
+def test_embeddings_matcher(ctx, golden_dense):
+    """polyfuzz_amd.models.Embeddings with ready-made vectors: the reference's frames for its own
+    fixtures, `re_train=False` reuse of the stored to-side, a callable embedding_method, loud errors."""
+    from polyfuzz_amd.models import Embeddings
+    g, cases = golden_dense
+    fv, tv = g["from_vec"], g["to_vec"]
+    fl, tl = cases["from_list"], cases["to_list"]
+    case = next(c for c in cases["cases"] if c["top_n"] == 2 and not c["self"])
+    m = Embeddings(min_similarity=0.0, top_n=2, cosine_method="sklearn")
+    df = m.match(fl, tl, embeddings_from=fv, embeddings_to=tv)
+    assert m.type == "Embeddings" and m.embeddings_to is tv
+    for c in df.columns:
+        if "Similarity" in c:
+            np.testing.assert_allclose(np.array(df[c].tolist(), float), np.array(case["df"][c], float), atol=1.01e-3)
+        else:
+            assert df[c].tolist() == case["df"][c], c
+    df2 = m.match(fl, tl, embeddings_from=fv, re_train=False)       # stored to-side
+    assert df2.equals(df)
+    # unit-norm rows: the "sparse" back-end (raw dot) gives the same frame as the cosine ones
+    df3 = Embeddings(min_similarity=0.0, top_n=2, cosine_method="sparse").match(
+        fl, tl, embeddings_from=fv, embeddings_to=tv)
+    assert df3["To"].tolist() == df["To"].tolist()
+    np.testing.assert_allclose(df3["Similarity"].to_numpy(), df["Similarity"].to_numpy(), atol=1.01e-3)
+    # a callable embedding method (bag of characters) and the self-match form
+    def bag(strings):
+        out = np.zeros((len(strings), 26))
+        for i, s in enumerate(strings):
+            for ch in s:
+                if "a" <= ch <= "z":
+                    out[i, ord(ch) - 97] += 1
+        return out
+    me = Embeddings(bag, min_similarity=0.0, cosine_method="hip")
+    d = me.match(["apple", "apples", "house"], ["mouse", "appel"])
+    assert d["To"].tolist() == ["appel", "appel", "mouse"]
+    ds = me.match(["apple", "apples", "house"])
+    assert ds["To"].tolist() == ["apples", "apple", "apples"]
+    with pytest.raises(ValueError, match="embedding_method"):
+        Embeddings().match(["a"], ["b"])
+    with pytest.raises(ValueError, match="no to-side"):
+        Embeddings(bag).match(["a"], ["b"], re_train=False)
+    with pytest.raises(TypeError):
+        Embeddings(embedding_method=[object()])
+
+
 def test_reference_embedding_fixtures(golden_dense):
     """cosine_similarity operator on the reference's unit-norm 300-d fixtures == the reference's own frames."""
     from polyfuzz_amd.models import cosine_similarity
