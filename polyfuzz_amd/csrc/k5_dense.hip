@@ -141,6 +141,102 @@ __global__ __launch_bounds__(256) void k5_gemm_panel(const float *__restrict__ A
     }
 }
 
+// The same tile program for d % 32 == 0 (embedding widths: 128 ... 768 ... 4096), software-pipelined:
+// the next k-step's operands travel from HBM/L2 into registers while the MFMAs of the current one run
+// out of LDS, and two LDS buffers leave one barrier per k-step (87 -> 110 TFLOP/s at 50k x 50k x 768).
+// Rows beyond the matrix edge are clamped to the last row (their products are discarded by the store),
+// so the loop has no edge tests.  (Tried and dropped: a leading dimension of 36 with b128 LDS accesses
+// and k split by lane half -- 73 TFLOP/s, the fragment reads conflict.)
+__global__ __launch_bounds__(256) void k5_gemm_panel_pipe(const float *__restrict__ A, const float *__restrict__ B,
+                                                           const float *__restrict__ inv_a,
+                                                           const float *__restrict__ inv_b, int64_t a0, int64_t a1,
+                                                           int64_t n_b, int64_t d, float *__restrict__ S, int64_t ld)
+{
+    __shared__ float As[2][kTile * kLd];
+    __shared__ float Bs[2][kTile * kLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = a0 + (int64_t)blockIdx.y * kTile;
+    const int64_t col0 = (int64_t)blockIdx.x * kTile;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = tid >> 3;          // 0..31
+    const int lk = (tid & 7) * 4;     // 0,4,..,28
+    const float *pa[4], *pb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t ga = min(row0 + lr + p * 32, a1 - 1), gb = min(col0 + lr + p * 32, n_b - 1);
+        pa[p] = A + ga * d + lk;
+        pb[p] = B + gb * d + lk;
+    }
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ra[p] = *(const float4 *)pa[p];
+        rb[p] = *(const float4 *)pb[p];
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float *da = As[buf] + (lr + p * 32) * kLd + lk, *db = Bs[buf] + (lr + p * 32) * kLd + lk;
+            da[0] = ra[p].x; da[1] = ra[p].y; da[2] = ra[p].z; da[3] = ra[p].w;
+            db[0] = rb[p].x; db[1] = rb[p].y; db[2] = rb[p].z; db[3] = rb[p].w;
+        }
+    };
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k0 = 0; k0 < d; k0 += kBK) {
+        const bool more = k0 + kBK < d;
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ra[p] = *(const float4 *)(pa[p] + k0 + kBK);
+                rb[p] = *(const float4 *)(pb[p] + k0 + kBK);
+            }
+        }
+        const float *as = As[cur], *bs = Bs[cur];
+#pragma unroll 4
+        for (int kk = 0; kk < kBK; kk += 2) {
+            const int kq = kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = as[(wm + i * 32 + (lane & 31)) * kLd + kq];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = bs[(wn + j * 32 + (lane & 31)) * kLd + kq];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t col = col0 + wn + j * 32 + (lane & 31);
+        const float sb = col < n_b ? inv_b[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a1 && col < ld) S[(row - a0) * ld + col] = acc[i][j][r] * inv_a[row] * sb;
+            }
+        }
+    }
+}
+
 __device__ inline uint64_t wave_max_u64_5(uint64_t v)
 {
 #pragma unroll
@@ -282,8 +378,13 @@ static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, 
         if (ld > 0) {
             ProfScope ps(ctx, "k5_gemm_panel");
             dim3 grid((unsigned)(ld / kTile), (unsigned)((a1 - a0 + kTile - 1) / kTile));
-            hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, A, B, (const float *)dIa.p,
-                               (const float *)dIb.p, a0, a1, n_to, dim, (float *)dS.p, ld);
+            // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
+            if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE"))
+                hipLaunchKernelGGL(k5_gemm_panel_pipe, grid, dim3(256), 0, ctx->stream, A, B, (const float *)dIa.p,
+                                   (const float *)dIb.p, a0, a1, n_to, dim, (float *)dS.p, ld);
+            else
+                hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, A, B, (const float *)dIa.p,
+                                   (const float *)dIb.p, a0, a1, n_to, dim, (float *)dS.p, ld);
         }
         {
             ProfScope ps(ctx, "k5_row_topn");
