@@ -81,7 +81,9 @@ constexpr int kLdsBitmapWords = 8192;   // code spaces of up to 18 bits (cleaned
 // LB: the workgroup first marks its n-grams in an LDS copy of the bitmap and merges the non-zero
 // words into the global one at the end -- a probe of the global bitmap inside the per-character loop
 // is a dependent L2 round trip per n-gram, and the loop of the longest string is the kernel's runtime.
-template <int CW, bool LB>
+// CODE: uint32_t when the n-gram codes fit 32 bits (cleaned text up to 5-grams): half the ALU work of the
+// per-character loop, which is what this kernel's run time consists of.
+template <int CW, bool LB, typename CODE>
 __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_v, const int64_t *__restrict__ off,
                                                   int64_t n, ExtractParams P, const uint32_t *__restrict__ alpha_map,
                                                   uint64_t *__restrict__ slots, int32_t *__restrict__ row_cnt,
@@ -122,17 +124,18 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
     const int R = P.hi - P.lo + 1;
     uint64_t *out = slots + b * R;
     const int w = P.w;
-    const uint64_t full_mask = (1ull << (P.hi * w)) - 1ull;
-    uint64_t win = 0;
+    constexpr int kBits = (int)sizeof(CODE) * 8;
+    const CODE full_mask = (CODE)((CODE)~(CODE)0 >> (kBits - P.hi * w));   // low hi*w bits (1 <= hi*w <= kBits)
+    CODE win = 0;
     int run = 0, cnt = 0;
     bool pending_space = false, any = false;
 
     auto feed = [&](uint32_t m, bool breaks) {
-        win = ((win << w) | m) & full_mask;
+        win = (CODE)(((win << w) | (CODE)m) & full_mask);
         run = breaks ? 0 : (run < P.hi ? run + 1 : P.hi);
         for (int nn = P.lo; nn <= P.hi; ++nn) {
             if (run >= nn) {
-                const uint64_t code = (win & ((1ull << (nn * w)) - 1ull)) << ((P.hi - nn) * w);
+                const CODE code = (CODE)((win & (CODE)((CODE)~(CODE)0 >> (kBits - nn * w))) << ((P.hi - nn) * w));
                 out[cnt++] = code;
                 if (bitmap) {
                     // test before set: almost every n-gram occurrence finds its bit already there, and the
@@ -579,8 +582,16 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     const bool lds_bitmap = mark && bitmap_words <= kLdsBitmapWords;
     ProfScope ps(ctx, "k1_extract");
 #define PFZ_EXTRACT(CW, LB)                                                                                          \
-    hipLaunchKernelGGL((k_extract<CW, LB>), dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->chars, s->offsets,   \
-                       s->n, P, v->alpha_map, s->slots, s->row_cnt, mark ? v->bitmap : nullptr)
+    do {                                                                                                             \
+        if (v->code_bits <= 32)                                                                                      \
+            hipLaunchKernelGGL((k_extract<CW, LB, uint32_t>), dim3(grid_for(s->n)), dim3(256), 0, ctx->stream,       \
+                               s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,                    \
+                               mark ? v->bitmap : nullptr);                                                          \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_extract<CW, LB, uint64_t>), dim3(grid_for(s->n)), dim3(256), 0, ctx->stream,       \
+                               s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,                    \
+                               mark ? v->bitmap : nullptr);                                                          \
+    } while (0)
     if (s->char_width == 1) {
         if (lds_bitmap) PFZ_EXTRACT(1, true);
         else PFZ_EXTRACT(1, false);
