@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 namespace pfz {
 
@@ -108,15 +109,6 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
         for (int t = threadIdx.x; t < words; t += 256) stage[t] = src[t];
     }
     __syncthreads();
-    // (two explicit address spaces; a pointer selected at run time between LDS and global
-    // would become a flat pointer)
-    auto fetch = [&](int64_t p) -> uint32_t {
-        if (staged) {
-            const int o = (int)(p * CW - base4);
-            return CW == 1 ? (uint32_t)((const uint8_t *)stage)[o] : stage[o >> 2];
-        }
-        return CW == 1 ? (uint32_t)((const uint8_t *)chars_v)[p] : ((const uint32_t *)chars_v)[p];
-    };
 
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < n;
@@ -139,22 +131,35 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
                 out[cnt++] = code;
                 if (bitmap) {
                     // test before set: almost every n-gram occurrence finds its bit already there, and the
-                    // hot words ('inc', 'llc', ...) would otherwise serialise thousands of atomics
+                    // hot words ('inc', 'llc', ...) would otherwise serialise thousands of atomics.  The probe
+                    // is a RELAXED ATOMIC load: a `volatile` one made the compiler drain vmcnt -- i.e. wait for
+                    // the global store of the code just emitted -- before every probe (0.6 us per n-gram).
                     const uint32_t bit = 1u << ((uint32_t)code & 31u);
                     if (LB) {
                         uint32_t *wp = &lbm[code >> 5];
-                        if (!(*(volatile uint32_t *)wp & bit)) atomicOr(wp, bit);
+                        if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit)) atomicOr(wp, bit);
                     } else {
                         uint32_t *wp = &bitmap[code >> 5];
-                        if (!(*(volatile uint32_t *)wp & bit)) atomicOr(wp, bit);
+                        if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
                     }
                 }
             }
         }
     };
 
+    // The walk is instantiated once per address space of the characters.  (A fetch helper with an
+    // `if (staged)` inside was compiled to ONE flat load, and a flat load waits for vmcnt as well as
+    // lgkmcnt: every character waited for the global stores of the codes emitted before it.)
+    auto walk = [&](auto staged_tag) {
+    constexpr bool kStaged = decltype(staged_tag)::value;
     for (int64_t p = b; p < e; ++p) {
-        uint32_t c = fetch(p);
+        uint32_t c;
+        if constexpr (kStaged) {
+            const int o = (int)(p * CW - base4);
+            c = CW == 1 ? (uint32_t)((const uint8_t *)stage)[o] : stage[o >> 2];
+        } else {
+            c = CW == 1 ? (uint32_t)((const uint8_t *)chars_v)[p] : ((const uint32_t *)chars_v)[p];
+        }
         if (P.clean) {
             // reference _tfidf.py:142-146 on code points <= 0xFF: lower(), keep
             // [a-z0-9 ], collapse runs of ' ', strip
@@ -177,6 +182,9 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
             feed(m, m == 0u || (P.remove_space && c == ' '));
         }
     }
+    };
+    if (staged) walk(std::true_type{});
+    else walk(std::false_type{});
     if (live) row_cnt[i] = cnt;
     if (LB && bitmap) {
         __syncthreads();
