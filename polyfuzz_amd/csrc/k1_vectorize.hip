@@ -731,7 +731,7 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
         return PFZ_ERR_UNSUPPORTED;
     }
     PFZ_HIP(hipSetDevice(ctx->device));
-    pfz_strings *s = new pfz_strings();
+    Owner<pfz_strings, pfz_strings_free> s(new pfz_strings());
     s->ctx = ctx;
     s->n = n;
     s->n_units = n_units;
@@ -745,7 +745,7 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
         PFZ_HIP(hipMemcpyAsync(s->chars, chars, (size_t)n_units * (size_t)char_width, hipMemcpyHostToDevice, ctx->stream));
     PFZ_HIP(hipMemcpyAsync(s->offsets, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PFZ_HIP(hipStreamSynchronize(ctx->stream));
-    *out = s;
+    *out = s.release();
     return PFZ_OK;
 }
 
@@ -984,7 +984,7 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
         s->cache_gen = v->gen;
     }
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
-    pfz_csr *m = new pfz_csr();
+    Owner<pfz_csr, pfz_csr_free> m(new pfz_csr());
     m->ctx = ctx;
     m->n_rows = s->n;
     m->n_cols = v->vocab;
@@ -1008,7 +1008,7 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
                            m->indptr, v->idf, m->indices, m->data);
     }
     PFZ_HIP(hipGetLastError());
-    *out = m;
+    *out = m.release();
     return PFZ_OK;
 }
 

@@ -696,7 +696,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
                   (long long)B->n_cols, (long long)nb);
         return PFZ_ERR_UNSUPPORTED;
     }
-    pfz_index *ix = new pfz_index();
+    Owner<pfz_index, pfz_index_free> ix(new pfz_index());
     ix->ctx = ctx;
     ix->n_rows = B->n_rows;
     ix->n_cols = B->n_cols;
@@ -741,7 +741,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
         }
         PFZ_HIP(hipGetLastError());
     }
-    *out = ix;
+    *out = ix.release();
     return PFZ_OK;
 }
 

@@ -431,7 +431,7 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
     }
     PFZ_REQUIRE(nnz == 0 || (indices && data), "pfz_csr_upload: NULL indices/data");
     PFZ_HIP(hipSetDevice(ctx->device));
-    pfz_csr *m = new pfz_csr();
+    Owner<pfz_csr, pfz_csr_free> m(new pfz_csr());
     m->ctx = ctx;
     m->n_rows = n_rows;
     m->n_cols = n_cols;
@@ -442,7 +442,6 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
             double ss = 0.0;
             for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) ss += (double)data[p] * (double)data[p];
             if (!(ss == ss) || ss > 1e60) {
-                delete m;
                 set_error("pfz_csr_upload: row %lld has a non-finite or huge norm", (long long)i);
                 return PFZ_ERR_INVALID;
             }
@@ -453,7 +452,6 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
     std::vector<int32_t> ip32((size_t)n_rows + 1);
     for (int64_t i = 0; i <= n_rows; ++i) {
         if (i > 0 && indptr[i] < indptr[i - 1]) {
-            delete m;
             set_error("pfz_csr_upload: indptr not monotone at row %lld", (long long)i);
             return PFZ_ERR_INVALID;
         }
@@ -468,7 +466,7 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
         PFZ_HIP(hipMemcpyAsync(m->data, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
     PFZ_HIP(hipStreamSynchronize(ctx->stream));  // ip32 is a temporary
-    *out = m;
+    *out = m.release();
     return PFZ_OK;
 }
 
@@ -512,14 +510,14 @@ int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out)
 {
     PFZ_REQUIRE(ctx && out && n_rows >= 0 && ntop >= 1, "pfz_topn_alloc: bad args");
     PFZ_HIP(hipSetDevice(ctx->device));
-    pfz_topn *t = new pfz_topn();
+    Owner<pfz_topn, pfz_topn_free> t(new pfz_topn());
     t->ctx = ctx;
     t->n_rows = n_rows;
     t->ntop = ntop;
     size_t n = (size_t)(n_rows > 0 ? n_rows : 1) * (size_t)ntop;
     PFZ_TRY(pool_alloc(ctx, &t->idx, n * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &t->val, n * sizeof(float)));
-    *out = t;
+    *out = t.release();
     return PFZ_OK;
 }
 

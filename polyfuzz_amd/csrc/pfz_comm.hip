@@ -88,9 +88,10 @@ int pfz_comm_init(pfz_ctx *ctx, const uint8_t id128[128], int32_t rank, int32_t 
         delete c;
         return rccl_fail(r, "ncclCommInitRank", __LINE__);
     }
+    Owner<pfz_comm, pfz_comm_destroy> guard(c);
     PFZ_TRY(pool_alloc(ctx, &c->flag, sizeof(int32_t)));
     PFZ_HIP(hipMemsetAsync(c->flag, 0, sizeof(int32_t), ctx->stream));
-    *out = c;
+    *out = guard.release();
     return PFZ_OK;
 }
 

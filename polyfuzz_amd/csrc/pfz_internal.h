@@ -134,6 +134,18 @@ struct pfz_tfidf {
 
 namespace pfz {
 
+// Owns a half-built object until the entry point succeeds: an error return (PFZ_TRY / PFZ_HIP /
+// PFZ_REQUIRE) releases it through its own free function instead of leaking the device buffers.
+template <typename T, void (*Free)(T *)> struct Owner {
+    T *p;
+    explicit Owner(T *q) : p(q) {}
+    ~Owner() { if (p) Free(p); }
+    Owner(const Owner &) = delete;
+    Owner &operator=(const Owner &) = delete;
+    T *operator->() const { return p; }
+    T *release() { T *q = p; p = nullptr; return q; }
+};
+
 int ensure_scratch(pfz_ctx *ctx, size_t bytes);
 // profile helpers: bracket a launch when ctx->prof is on
 struct ProfScope {
