@@ -120,6 +120,27 @@ def test_index_build_paths_agree(ctx, oracle_mod, monkeypatch):
     np.testing.assert_array_equal(val2, val)
 
 
+@pytest.mark.parametrize("knobs", [
+    {"PFZ_K3_WAVES": "2"}, {"PFZ_K3_WAVES": "4", "PFZ_K3_BLOCK": "4096"}, {"PFZ_K3_BLOCK": "1024"},
+    {"PFZ_K3_BLOCK": "1536"}, {"PFZ_K3_BLOCK": "8192", "PFZ_K3_WAVES": "2"}, {"PFZ_K3_CAP": "128"},
+    {"PFZ_K3_SLICES": "3"}, {"PFZ_K3_SLICES": "7", "PFZ_K3_WAVES": "2"},
+])
+def test_tuning_knobs_do_not_change_results(ctx, oracle_mod, monkeypatch, knobs):
+    """Every launch shape the tuning knobs can select (waves per row, to-block size, candidate buffer,
+    to-side slices) gives the default shape's results bit for bit -- and the oracle's."""
+    rng = np.random.default_rng(17)
+    a3 = random_csr(rng, 260, 400, 0.04)
+    b3 = random_csr(rng, 20000, 400, 0.04)
+    ref_idx, ref_val = _run(ctx, a3, b3, 400, 6, 0.1)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, 400, 6, 0.1)
+    assert_topn_parity(ref_idx, ref_val, exp_idx, exp_val, oracle_mod, a3, b3, 400)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    idx, val = _run(ctx, a3, b3, 400, 6, 0.1)
+    np.testing.assert_array_equal(idx, ref_idx)
+    np.testing.assert_array_equal(val, ref_val)
+
+
 def test_bad_arguments(ctx):
     from polyfuzz_amd import _lib, PfzError
     e3 = (np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
