@@ -33,8 +33,27 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+PACK_SRC = os.path.join(_HERE, "csrc_host", "_pack.c")
+PACK_PATH = os.path.join(_HERE, "_pack.so")
+
+
+def build_host_helpers(force=False, verbose=False):
+    """Compile the CPython helper polyfuzz_amd/_pack.so (string packing for the upload).  It is glue, not
+    compute: when it is missing `_lib.pack_strings` uses its pure-Python twin."""
+    if not force and os.path.exists(PACK_PATH) and os.path.getmtime(PACK_PATH) >= os.path.getmtime(PACK_SRC):
+        return PACK_PATH
+    import sysconfig
+    cmd = ["gcc", "-O2", "-shared", "-fPIC", "-I", sysconfig.get_paths()["include"], PACK_SRC, "-o", PACK_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=REPO)
+    os.replace(PACK_PATH + ".tmp", PACK_PATH)
+    return PACK_PATH
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source of the package into polyfuzz_amd/libpolyfuzz_hip.so."""
+    """Compile every HIP source of the package into polyfuzz_amd/libpolyfuzz_hip.so (and the host helper)."""
+    build_host_helpers(force, verbose)
     if not force and not is_stale():
         return LIB_PATH
     rocm_lib = "/opt/rocm/lib"

@@ -323,10 +323,23 @@ def cossim_topn_host(ctx, from_csr3, to_csr3, n_cols, ntop, lower_bound, exclude
 
 # ---- strings / vectoriser -------------------------------------------------------
 
+try:  # CPython helper built by _build.build_host_helpers(); same result as the Python code below
+    from . import _pack
+except ImportError:  # pragma: no cover - not built
+    _pack = None
+
+
 def pack_strings(strings):
     """list[str] -> (code units ndarray, offsets int64[n+1], char_width).
 
     1-byte code units (Latin-1) when every code point is <= 0xFF, UTF-32 otherwise."""
+    if _pack is not None and isinstance(strings, (list, tuple)):
+        raw, off, width = _pack.pack(strings)
+        return np.frombuffer(raw, np.uint8 if width == 1 else np.uint32), np.frombuffer(off, np.int64), width
+    return _pack_strings_py(strings)
+
+
+def _pack_strings_py(strings):
     n = len(strings)
     lens = np.fromiter(map(len, strings), np.int64, n)
     off = np.zeros(n + 1, np.int64)

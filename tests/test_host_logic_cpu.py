@@ -14,6 +14,27 @@ def test_pack_strings_widths():
     assert len(chars) == 0 and off.tolist() == [0]
 
 
+def test_c_packer_equals_python_packer():
+    """polyfuzz_amd/_pack.so (CPython helper) and its pure-Python twin give identical buffers."""
+    from polyfuzz_amd import _lib
+    if _lib._pack is None:
+        pytest.skip("_pack.so not built")
+    rng = np.random.default_rng(4)
+    pools = ["abc XYZ-09 ", "a\u00f1\u00e9\u00fc ", "\u65e5\u672c\u8a9e ab", "x\U0001f600y", "a\ud800b"]   # latin-1, wide, astral, lone surrogate
+    for pool in pools:
+        chars = np.array(list(pool), dtype=object)
+        strings = ["".join(rng.choice(chars, size=int(rng.integers(0, 12))).tolist()) for _ in range(300)] + ["", pool]
+        a = _lib.pack_strings(strings)
+        b = _lib._pack_strings_py(strings)
+        assert a[2] == b[2]
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    assert _lib.pack_strings([])[1].tolist() == [0]
+    assert _lib.pack_strings(("ab", "c"))[1].tolist() == [0, 2, 3]        # tuples too
+    with pytest.raises(TypeError):
+        _lib.pack_strings(["ok", 3])
+
+
 def test_topn_to_frame_contract():
     """reference _utils.py:104-125: column order, 3-dp rounding, < 0.001 -> 0.0 / None, -1 -> None."""
     from polyfuzz_amd.models._utils import topn_to_frame

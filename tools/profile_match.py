@@ -13,3 +13,9 @@ t0 = time.perf_counter(); m.match(fl, tl); print("match wall %.1f ms" % ((time.p
 pr = cProfile.Profile(); pr.enable(); df = m.match(fl, tl); pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:6000])
 print(df.head(3))
+from polyfuzz_amd import _lib, pipeline
+ctx = _lib.Context.default()
+ctx.sync(); ctx.prof_enable(True); ctx.prof_reset()
+t0 = time.perf_counter(); m.match(fl, tl); ctx.sync(); dt = time.perf_counter() - t0
+print("kernels (ms):", {k: round(ctx.prof_get(k)[0], 3) for k in pipeline.PROFILED_KERNELS}, "wall %.1f ms" % (dt * 1e3))
+ctx.prof_enable(False)
