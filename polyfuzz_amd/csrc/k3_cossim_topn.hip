@@ -52,6 +52,7 @@ namespace pfz {
 // at once, and CAP = 128 instead of 256 alone took K3 from 6.1 to 5.3 ms.
 constexpr int kMergeCap = 256;   // candidate keys per wave in k3_merge_slices
 constexpr int kMaxTop = 128;
+constexpr int kSelectMinTop = 16;  // above this top_n, intermediate compactions select instead of sorting
 constexpr int kWarmMaxTop = 8;    // threshold warm start (one wave-max round per rank) up to this top_n
 #ifndef PFZ_K3_EXP
 #define PFZ_K3_EXP 0   // timing experiments (tools/build_variant.sh -DPFZ_K3_EXP=n); 0 = the product
@@ -298,7 +299,7 @@ struct TopState {
 
 // Keep the ntop best of cand[0..cnt) sorted at cand[0..keep).
 template <int kCap>
-__device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
+__device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane, bool sorted = true)
 {
     wave_sync();
     constexpr int kPer = (kCap + 63) / 64;   // keys per lane
@@ -309,6 +310,34 @@ __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane)
         e[i] = p < st.cnt ? cand[p] : 0ull;
     }
     wave_sync();
+    if (!sorted && ntop > kSelectMinTop) {
+        // Large top_n, order not needed yet: one wave-max round per kept key (ntop x ~45 instructions) is
+        // replaced by a selection -- the ntop-th largest key T is built bit by bit from the top (64 steps
+        // of "are there still >= ntop keys >= T | bit ?"), then the keys >= T are written out, unsorted.
+        // The keys are distinct (they contain the column), so exactly ntop survive.
+        if (st.cnt <= ntop) return;          // nothing to drop, the threshold cannot move
+        uint64_t T = 0ull;
+        for (int bit = 62; bit >= 0; --bit) {   // sums are < 2^31: bit 63 is never set
+            const uint64_t c = T | (1ull << bit);
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) n += __popcll(__ballot(e[i] >= c));
+            T = n >= ntop ? c : T;
+        }
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const bool keep_it = e[i] >= T;
+            const uint64_t mk = __ballot(keep_it);
+            if (keep_it) cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = e[i];
+            base += __popcll(mk);
+        }
+        st.cnt = base;                         // == ntop
+        const int t = (int)(uint32_t)(T >> 32) - 1;
+        st.thr = t > st.thr ? t : st.thr;
+        wave_sync();
+        return;
+    }
     const int keep = st.cnt < ntop ? st.cnt : ntop;
     uint64_t best = 0;
     for (int r = 0; r < keep; ++r) {
@@ -344,7 +373,7 @@ __device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0
             const int pos = st.cnt + __popcll(mk & ((1ull << lane) - 1ull));
             if (pred) cand[pos] = ((uint64_t)(uint32_t)vv[c] << 32) | (uint32_t)(~j);
             st.cnt += __popcll(mk);
-            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane);
+            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane, false);
         }
     }
 }
@@ -653,7 +682,7 @@ __global__ __launch_bounds__(256) void k3_merge_slices(const uint64_t *__restric
             const uint64_t mk = __ballot(key != 0ull);
             if (key) cand[st.cnt + __popcll(mk & ((1ull << lane) - 1ull))] = key;
             st.cnt += __popcll(mk);
-            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane);
+            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane, false);
         }
     }
     compact<kCap>(cand, st, ntop, lane);
