@@ -264,13 +264,40 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
     int cnt = 0;
     float thr = lower_bound;
 
-    auto compact = [&]() {
+    // sorted == false (intermediate compactions) and a large top_n: select the ntop-th largest key bit by bit
+    // (64 ballot steps) instead of one wave-max round per kept key -- the same scheme as K3's compact()
+    auto compact = [&](bool sorted) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint64_t e[kCap5 / 64];
 #pragma unroll
         for (int i = 0; i < kCap5 / 64; ++i) e[i] = lane + 64 * i < cnt ? cand[lane + 64 * i] : 0ull;
         __builtin_amdgcn_wave_barrier();
+        if (!sorted && ntop > 16) {
+            if (cnt <= ntop) return;
+            uint64_t T = 0ull;
+            for (int bit = 62; bit >= 0; --bit) {   // positive floats: bit 63 is never set
+                const uint64_t c = T | (1ull << bit);
+                int n = 0;
+#pragma unroll
+                for (int i = 0; i < kCap5 / 64; ++i) n += __popcll(__ballot(e[i] >= c));
+                T = n >= ntop ? c : T;
+            }
+            int base = 0;
+#pragma unroll
+            for (int i = 0; i < kCap5 / 64; ++i) {
+                const bool keep_it = e[i] >= T;
+                const uint64_t mk = __ballot(keep_it);
+                if (keep_it) cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = e[i];
+                base += __popcll(mk);
+            }
+            cnt = base;
+            const float t = __uint_as_float((uint32_t)(T >> 32) - 1u);
+            thr = t > thr ? t : thr;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         const int keep = cnt < ntop ? cnt : ntop;
         uint64_t best = 0;
         for (int r = 0; r < keep; ++r) {
@@ -308,11 +335,11 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
                 const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
                 if (pred) cand[pos] = ((uint64_t)__float_as_uint(vv[q]) << 32) | (uint32_t)(~(uint32_t)j);
                 cnt += __popcll(mk);
-                if (cnt > kCap5 - 64) compact();
+                if (cnt > kCap5 - 64) compact(false);
             }
         }
     }
-    compact();
+    compact(true);
     for (int r = lane; r < ntop; r += 64) {
         const uint64_t key = r < cnt ? cand[r] : 0ull;
         out_idx[row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
