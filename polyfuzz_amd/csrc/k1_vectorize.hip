@@ -38,6 +38,7 @@ namespace pfz {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 constexpr int kLongMax = 4096;     // n-grams per string sorted in LDS by k_rows_long
+constexpr int kLongTile = 16;      // strings per scheduling tile of k_rows_long
 constexpr int kMaxCodeBits = 36;
 
 static std::atomic<uint64_t> g_gen{1};
@@ -468,20 +469,21 @@ __global__ __launch_bounds__(256) void k_rows_long(const int64_t *__restrict__ o
 {
     __shared__ uint32_t lds_keys[kLongMax];
     __shared__ int sh_heads, sh_valid, n_long;
-    __shared__ int long_rows[256];
-    // tiles of 256 strings: the threads look at one string each (a workgroup walking the strings one by
-    // one spent its time on ~50 dependent loads that almost always said "short"), then the workgroup
-    // handles the tile's long strings one after the other
-    const int64_t n_tiles = (n + 255) / 256;
+    __shared__ int long_rows[kLongTile];
+    // tiles of kLongTile strings: the threads look at one string each (a workgroup walking the strings one
+    // by one spent its time on dependent loads that almost always said "short"), then the workgroup handles
+    // the tile's long strings one after the other.  Small tiles: a list of long documents must still
+    // spread over all workgroups.
+    const int64_t n_tiles = (n + kLongTile - 1) / kLongTile;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (threadIdx.x == 0) n_long = 0;
         __syncthreads();
-        const int64_t mine = tile * 256 + threadIdx.x;
-        if (mine < n && row_cnt[mine] > 64) long_rows[atomicAdd(&n_long, 1)] = (int)threadIdx.x;
+        const int64_t mine = tile * kLongTile + threadIdx.x;
+        if ((int)threadIdx.x < kLongTile && mine < n && row_cnt[mine] > 64) long_rows[atomicAdd(&n_long, 1)] = (int)threadIdx.x;
         __syncthreads();
         const int m = n_long;
         for (int i = 0; i < m; ++i) {
-            const int64_t row = tile * 256 + long_rows[i];
+            const int64_t row = tile * kLongTile + long_rows[i];
             const int cnt = row_cnt[row];
             uint64_t *base = slots + off[row] * R;
             if (cnt <= kLongMax)
@@ -625,7 +627,7 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df)
     }
     if (s->max_len * R > 64) {
         const int64_t max_cnt = s->max_len * R;
-        const int64_t n_tiles = (s->n + 255) / 256;
+        const int64_t n_tiles = (s->n + kLongTile - 1) / kLongTile;
         unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 2048);
         uint32_t *giant = nullptr;
         int64_t stride = 0;
