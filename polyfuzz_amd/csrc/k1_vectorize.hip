@@ -12,14 +12,16 @@
 // Device representation
 //   n-gram code : the n characters, each mapped to a small rank (1..S, 0 = pad)
 //                 of w bits, packed big-endian and left-aligned into
-//                 ngram_hi*w <= 36 bits.  Numeric order of codes == Python's
+//                 ngram_hi*w <= 64 bits.  Numeric order of codes == Python's
 //                 lexicographic order of the n-gram strings (shorter prefix
 //                 first), so "rank of the code among the distinct codes" is
 //                 exactly sklearn's column id.
-//   vocabulary  : presence bitmap over the code space (2^code_bits bits; 32 KiB
-//                 for cleaned 3-grams, HBM-sized for long n-grams) + an int32
+//   vocabulary  : up to 32-bit codes: presence bitmap over the code space (32 KiB
+//                 for cleaned 3-grams, 512 MiB at 32 bits) + an int32
 //                 rank prefix per 256-bit group: column id = prefix[g] +
 //                 popcount of the lower bits -- no sort, no hash, no search.
+//                 Wider codes (up to 64 bits): the distinct codes as a sorted array
+//                 (gather + rocPRIM radix sort + unique), column id by binary search.
 //   per string  : a slot range of len*R uint64 in HBM (R = number of n values),
 //                 holding first the codes, then in place the sorted distinct
 //                 (column id, tf) pairs.
@@ -39,18 +41,30 @@ namespace pfz {
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 constexpr int kLongMax = 4096;     // n-grams per string sorted in LDS by k_rows_long
 constexpr int kLongTile = 16;      // strings per scheduling tile of k_rows_long
-constexpr int kMaxCodeBits = 36;
+constexpr int kMaxCodeBits = 64;     // n-gram codes are uint64
+constexpr int kBitmapMaxBits = 32;   // presence bitmap (512 MiB at 32 bits) up to here, sorted code array beyond
 
 static std::atomic<uint64_t> g_gen{1};
 
 struct VocabView {
     const uint32_t *bitmap;
     const int32_t *prefix;
+    const uint64_t *vcodes;   // sorted-vocabulary mode (codes wider than kBitmapMaxBits bits): the distinct codes,
+    int64_t vocab;            // ascending; column id = position, found by binary search
 };
 
 // column id of a code, or kInvalid when the code is not in the vocabulary
 __device__ inline uint32_t vocab_rank(const VocabView &v, uint64_t code)
 {
+    if (v.vcodes) {
+        int64_t lo = 0, hi = v.vocab;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (v.vcodes[mid] < code) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo < v.vocab && v.vcodes[lo] == code ? (uint32_t)lo : kInvalid;
+    }
     const uint64_t g = code >> 8;
     const uint32_t wi = (uint32_t)(code >> 5) & 7u;
     const uint32_t bit = (uint32_t)code & 31u;
@@ -227,6 +241,36 @@ __global__ __launch_bounds__(256) void k_set_bits(const uint64_t *__restrict__ c
     if (i >= n) return;
     const uint64_t code = codes[i];
     atomicOr(&bitmap[code >> 5], 1u << ((uint32_t)code & 31u));
+}
+
+// ---- sorted-vocabulary mode: gather every emitted code, sort, keep the distinct ones ----------------
+// 16 lanes per string: copy the string's row_cnt codes from its slot range to dst[code_off[i] ...]
+__global__ __launch_bounds__(256) void k_gather_codes(const int64_t *__restrict__ off, int64_t n, int32_t R,
+                                                       const uint64_t *__restrict__ slots,
+                                                       const int32_t *__restrict__ code_off,
+                                                       uint64_t *__restrict__ dst)
+{
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (row >= n) return;
+    const int o = code_off[row], cnt = code_off[row + 1] - o;
+    const uint64_t *src = slots + off[row] * R;
+    for (int t = sub; t < cnt; t += 16) dst[o + t] = src[t];
+}
+
+__global__ __launch_bounds__(256) void k_flag_heads(const uint64_t *__restrict__ sorted, int64_t n,
+                                                     int32_t *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = i == 0 || sorted[i] != sorted[i - 1];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_heads(const uint64_t *__restrict__ sorted, int64_t n,
+                                                        const int32_t *__restrict__ pos /* exclusive scan of flags */,
+                                                        uint64_t *__restrict__ vcodes)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && (i == 0 || sorted[i] != sorted[i - 1])) vcodes[pos[i]] = sorted[i];
 }
 
 // codes of the vocabulary in column order
@@ -618,7 +662,7 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df)
 {
     if (s->n == 0) return PFZ_OK;
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
-    VocabView V{v->bitmap, v->prefix};
+    VocabView V{v->bitmap, v->prefix, v->vcodes, v->vocab};
     int32_t *row_nnz = s->row_cnt + (s->n + 1);
     {
         ProfScope ps(ctx, "k2_rows_short");
@@ -658,6 +702,58 @@ static int build_prefix(pfz_ctx *ctx, pfz_tfidf *v)
     return PFZ_OK;
 }
 
+// Sorted-vocabulary mode (codes wider than kBitmapMaxBits): gather the codes k_extract left in the slot
+// ranges of the fitted lists, radix-sort them, keep the distinct ones.  v->vcodes / v->vocab on return.
+static int build_sorted_vocab(pfz_ctx *ctx, pfz_tfidf *v, pfz_strings *const lists[2])
+{
+    const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
+    struct Tmp {
+        void *p = nullptr;
+        ~Tmp() { if (p) pool_free(p); }
+    } code_off[2], gathered, sorted, flags;
+    int64_t base[2] = {0, 0}, total = 0;
+    for (int li = 0; li < 2; ++li) {
+        pfz_strings *s = lists[li];
+        if (!s || s->n == 0) continue;
+        PFZ_TRY(pool_alloc(ctx, &code_off[li].p, (size_t)(s->n + 1) * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, s->row_cnt, s->n, (int32_t *)code_off[li].p);
+        PFZ_TRY(exclusive_scan_i32(ctx, (int32_t *)code_off[li].p, s->n));
+        int32_t t = 0;
+        PFZ_HIP(hipMemcpyAsync(&t, (int32_t *)code_off[li].p + s->n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        base[li] = total;
+        total += t;
+    }
+    v->vocab = 0;
+    if (total == 0) return PFZ_OK;
+    if (total >= ((int64_t)1 << 31) - 2) {
+        set_error("pfz_tfidf_fit: %lld n-gram occurrences exceed the int32 layout of the sorted-vocabulary path", (long long)total);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    PFZ_TRY(pool_alloc(ctx, &gathered.p, (size_t)total * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &sorted.p, (size_t)total * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &flags.p, (size_t)(total + 1) * sizeof(int32_t)));
+    for (int li = 0; li < 2; ++li) {
+        pfz_strings *s = lists[li];
+        if (!s || s->n == 0) continue;
+        hipLaunchKernelGGL(k_gather_codes, dim3(grid_for(s->n, 16)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
+                           (const int32_t *)code_off[li].p, (uint64_t *)gathered.p + base[li]);
+    }
+    PFZ_TRY(sort_codes_u64(ctx, (const uint64_t *)gathered.p, (uint64_t *)sorted.p, total, v->code_bits));
+    hipLaunchKernelGGL(k_flag_heads, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const uint64_t *)sorted.p, total,
+                       (int32_t *)flags.p);
+    PFZ_TRY(exclusive_scan_i32(ctx, (int32_t *)flags.p, total));
+    int32_t n_distinct = 0;
+    PFZ_HIP(hipMemcpyAsync(&n_distinct, (int32_t *)flags.p + total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    PFZ_TRY(pool_alloc(ctx, &v->vcodes, (size_t)n_distinct * sizeof(uint64_t)));
+    hipLaunchKernelGGL(k_scatter_heads, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const uint64_t *)sorted.p, total,
+                       (const int32_t *)flags.p, v->vcodes);
+    PFZ_HIP(hipGetLastError());
+    v->vocab = n_distinct;
+    return PFZ_OK;
+}
+
 static int alloc_vocab_space(pfz_ctx *ctx, pfz_tfidf *v)
 {
     const int64_t n_bits = std::max<int64_t>((int64_t)1 << v->code_bits, 256);
@@ -684,7 +780,7 @@ static int set_alphabet(pfz_ctx *ctx, pfz_tfidf *v, const std::vector<uint32_t> 
     v->code_bits = v->bits_per_char * v->params.ngram_hi;
     if (v->code_bits > kMaxCodeBits) {
         set_error("pfz_tfidf: n_gram_range upper bound %d with an alphabet of %llu symbols needs %d-bit n-gram codes; "
-                  "this build supports up to %d bits (e.g. cleaned strings up to 6-grams, 255 symbols up to 4-grams)",
+                  "this build supports up to %d bits (e.g. cleaned strings up to 10-grams, 255 symbols up to 8-grams)",
                   v->params.ngram_hi, (unsigned long long)S, v->code_bits, kMaxCodeBits);
         return PFZ_ERR_UNSUPPORTED;
     }
@@ -769,6 +865,7 @@ void pfz_tfidf_free(pfz_tfidf *v)
     if (v->alpha_map) pool_free(v->alpha_map);
     if (v->bitmap) pool_free(v->bitmap);
     if (v->prefix) pool_free(v->prefix);
+    if (v->vcodes) pool_free(v->vcodes);
     if (v->df) pool_free(v->df);
     if (v->idf) pool_free(v->idf);
     delete v;
@@ -855,9 +952,20 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         }
         PFZ_TRY(set_alphabet(ctx, v, cps));
     }
-    PFZ_TRY(alloc_vocab_space(ctx, v));
-    for (pfz_strings *s : lists)
-        if (s) PFZ_TRY(run_extract(ctx, v, s, true));
+    const bool sorted_vocab = v->code_bits > kBitmapMaxBits;
+    if (sorted_vocab && world > 1) {
+        set_error("pfz_tfidf_fit_sharded: %d-bit n-gram codes use the sorted-vocabulary path, which is single-GPU", v->code_bits);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    if (sorted_vocab) {
+        for (pfz_strings *s : lists)
+            if (s) PFZ_TRY(run_extract(ctx, v, s, false));
+        PFZ_TRY(build_sorted_vocab(ctx, v, lists));
+    } else {
+        PFZ_TRY(alloc_vocab_space(ctx, v));
+        for (pfz_strings *s : lists)
+            if (s) PFZ_TRY(run_extract(ctx, v, s, true));
+    }
     if (world > 1) {   // vocabulary = union of the ranks' n-gram sets
         const int64_t n_words = v->n_groups * 8;
         if (v->code_bits > 30) {
@@ -870,7 +978,7 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         const unsigned grid = (unsigned)std::min<int64_t>((n_words + 255) / 256, 4096);
         hipLaunchKernelGGL(k_or_reduce, dim3(grid), dim3(256), 0, ctx->stream, gathered, n_words, world, v->bitmap);
     }
-    PFZ_TRY(build_prefix(ctx, v));
+    if (!sorted_vocab) PFZ_TRY(build_prefix(ctx, v));
     if (v->vocab == 0) {
         // sklearn text.py:1282-1285
         set_error("empty vocabulary; perhaps the documents only contain stop words");
@@ -1026,15 +1134,19 @@ int pfz_tfidf_export(pfz_ctx *ctx, const pfz_tfidf *v, uint32_t *ngrams, double 
         for (size_t i = 0; i < h.size(); ++i) df[i] = h[i];
     }
     if (ngrams && v->vocab > 0) {
-        uint64_t *d_codes = nullptr;
-        PFZ_TRY(pool_alloc(ctx, &d_codes, (size_t)v->vocab * sizeof(uint64_t)));
-        hipLaunchKernelGGL(k_export_codes, dim3(grid_for(v->n_groups)), dim3(256), 0, ctx->stream, v->bitmap, v->prefix,
-                           v->n_groups, d_codes);
         std::vector<uint64_t> codes((size_t)v->vocab);
-        hipError_t e = hipMemcpyAsync(codes.data(), d_codes, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        pool_free(d_codes);
-        PFZ_HIP(e);
+        if (v->vcodes) {
+            PFZ_HIP(hipMemcpy(codes.data(), v->vcodes, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        } else {
+            uint64_t *d_codes = nullptr;
+            PFZ_TRY(pool_alloc(ctx, &d_codes, (size_t)v->vocab * sizeof(uint64_t)));
+            hipLaunchKernelGGL(k_export_codes, dim3(grid_for(v->n_groups)), dim3(256), 0, ctx->stream, v->bitmap, v->prefix,
+                               v->n_groups, d_codes);
+            hipError_t e = hipMemcpyAsync(codes.data(), d_codes, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            pool_free(d_codes);
+            PFZ_HIP(e);
+        }
         const int hi = v->params.ngram_hi, w = v->bits_per_char;
         const uint64_t cmask = (1ull << w) - 1ull;
         for (size_t i = 0; i < codes.size(); ++i)
@@ -1100,17 +1212,24 @@ int pfz_tfidf_import(pfz_ctx *ctx, const pfz_tfidf_params *params, int64_t vocab
         PFZ_REQUIRE(i == 0 || code > codes[(size_t)i - 1], "pfz_tfidf_import: vocabulary not in sorted order at %lld", (long long)i);
         codes[(size_t)i] = code;
     }
-    PFZ_TRY(alloc_vocab_space(ctx, v));
-    uint64_t *d_codes = nullptr;
-    PFZ_TRY(pool_alloc(ctx, &d_codes, (size_t)vocab * sizeof(uint64_t)));
-    hipError_t e = hipMemcpyAsync(d_codes, codes.data(), (size_t)vocab * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_set_bits, dim3(grid_for(vocab)), dim3(256), 0, ctx->stream, d_codes, vocab, v->bitmap);
-        e = hipStreamSynchronize(ctx->stream);
+    if (v->code_bits > kBitmapMaxBits) {     // sorted-vocabulary mode: the (ascending) codes ARE the vocabulary
+        PFZ_TRY(pool_alloc(ctx, &v->vcodes, (size_t)vocab * sizeof(uint64_t)));
+        PFZ_HIP(hipMemcpyAsync(v->vcodes, codes.data(), (size_t)vocab * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        v->vocab = vocab;
+    } else {
+        PFZ_TRY(alloc_vocab_space(ctx, v));
+        uint64_t *d_codes = nullptr;
+        PFZ_TRY(pool_alloc(ctx, &d_codes, (size_t)vocab * sizeof(uint64_t)));
+        hipError_t e = hipMemcpyAsync(d_codes, codes.data(), (size_t)vocab * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_set_bits, dim3(grid_for(vocab)), dim3(256), 0, ctx->stream, d_codes, vocab, v->bitmap);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        pool_free(d_codes);
+        PFZ_HIP(e);
+        PFZ_TRY(build_prefix(ctx, v));
     }
-    pool_free(d_codes);
-    PFZ_HIP(e);
-    PFZ_TRY(build_prefix(ctx, v));
     PFZ_REQUIRE(v->vocab == vocab, "pfz_tfidf_import: %lld distinct n-grams, expected %lld", (long long)v->vocab, (long long)vocab);
     PFZ_TRY(pool_alloc(ctx, &v->df, (size_t)vocab * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &v->idf, (size_t)vocab * sizeof(double)));

@@ -128,6 +128,8 @@ struct pfz_tfidf {
     int32_t *prefix = nullptr;       // device [n_groups + 1]
     int64_t n_groups = 0;
     int64_t vocab = 0, n_docs = 0;
+    // codes wider than kBitmapMaxBits: the vocabulary is the sorted array of distinct codes instead
+    uint64_t *vcodes = nullptr;      // device [vocab], ascending; NULL in bitmap mode
     int32_t *df = nullptr;           // device [vocab]
     double *idf = nullptr;           // device [vocab]
 };
@@ -178,5 +180,8 @@ int comm_allreduce_sum_i64(pfz_comm *c, int64_t *buf, size_t n);
 // exclusive scan of n int32 counters in place, total written to in[n]
 // (array must have n+1 slots).  Enqueues on ctx->stream.
 int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n);
+
+// radix sort of n-gram codes on bits [0, end_bit) (sort_u64.hip, rocPRIM); uses ctx->scratch
+int sort_codes_u64(pfz_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, int end_bit);
 
 }  // namespace pfz

@@ -77,6 +77,37 @@ def test_document_frequencies_both_counting_paths(ctx, oracle_mod, golden, monke
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("rng,clean", [((3, 7), True), ((6, 10), True), ((2, 6), False), ((4, 4), False)])
+def test_wide_ngram_codes_use_the_sorted_vocabulary(ctx, oracle_mod, golden, rng, clean):
+    """n-gram codes wider than the presence bitmap addresses (> 32 bits: long n-grams, big alphabets) go
+    through the sorted-vocabulary path (radix sort + unique, binary-search ranks).  Same contract: the
+    oracle's vocabulary order, df, idf and matrices; export -> import round trip."""
+    from polyfuzz_amd import _lib
+    fl = golden["company_c2_lists"]["from_list"][:1500]
+    tl = golden["company_c2_lists"]["to_list"][:2000]
+    if not clean:       # a large alphabet: 6 bits x 6 = 36 bits, and with the wide characters 9+ bits x 4
+        t = golden["titles_lists"]
+        fl = fl[:700] + t["from_list"][:700] + ["\u65e5\u672c\u8a9e\u30c6\u30b9\u30c8 \u6771\u4eac", "\u00fcber stra\u00dfe"]
+        tl = tl[:900] + t["to_list"][:900] + ["\u6771\u4eac\u30c6\u30b9\u30c8", "stra\u00dfe"]
+        extra = "".join(chr(0x400 + i) for i in range(600))          # pad the alphabet past 511 symbols
+        tl = tl + [extra[i:i + 40] for i in range(0, 600, 40)]
+    vec, (a, b) = _device_vectorize(ctx, fl, tl, rng[0], rng[1], clean)
+    assert vec.info()["code_bits"] > 32
+    o = oracle_mod.TfidfOracle(n_gram_range=rng, clean=clean).fit(tl + fl)
+    _check_csr(a, o.transform(fl), len(o.vocabulary))
+    _check_csr(b, o.transform(tl), len(o.vocabulary))
+    ngrams, idf, df = vec.export()
+    names = ["".join(chr(c) for c in row if c) for row in ngrams.tolist()]
+    assert names == o.vocabulary
+    np.testing.assert_array_equal(df, o.df)
+    np.testing.assert_allclose(idf, o.idf, rtol=1e-15)
+    params = _lib.TfidfParams(rng[0], rng[1], int(clean), 1)
+    vec2 = _lib.DeviceTfidf.from_state(ctx, params, ngrams, idf, vec.info()["n_docs"])
+    got2 = vec2.transform(_lib.DeviceStrings.upload(ctx, fl)).download()
+    for x, y in zip(a, got2):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_self_fit_and_messy_strings(ctx, oracle_mod):
     docs = ["  Hello,   World!! ", "A\tB  C\nD", "", "   ", "a", "ab", "abc", "ABC abc AbC", "x" * 70 + " " + "yz" * 40,
             "1st & 2nd St.", "trailing   ", "Ünited été", "a  b", "..."]
@@ -122,6 +153,6 @@ def test_errors(ctx):
     with pytest.raises(ValueError, match="empty vocabulary"):
         _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 3, 1, 1), s, None)
     with pytest.raises(NotImplementedError):
-        _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 7, 1, 1), s, None)
+        _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 11, 1, 1), s, None)     # 66-bit codes: more than a uint64
     with pytest.raises(_lib.PfzError):
         _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 2, 1, 1), s, None)
