@@ -826,9 +826,11 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     // restarts the top-n threshold and pays the row set-up again; it stays off by default)
     int n_slices = env_int("PFZ_K3_SLICES", 0);
     if (n_slices <= 0) {
-        // auto: a handful of query rows (fit once / transform many, reference polyfuzz.py:234-240) cannot
-        // fill 256 CUs with one workgroup per row -- cut the to-side so that ~2 workgroups per CU exist
-        const int64_t want = (int64_t)ctx->prop.multiProcessorCount * 2;
+        // auto: a small query batch (fit once / transform many, reference polyfuzz.py:234-240) cannot fill
+        // 256 CUs x 18 resident workgroups with one workgroup per row -- cut the to-side until ~24 work items
+        // per CU exist (measured: 1000 x 300k rows 1.07 -> 0.24 ms, 600 x 1M 2.9 -> 0.5 ms, 3000 x 100k
+        // 0.36 -> 0.22 ms; a single query 1.0 ms; the 100k-row benchmark is unaffected)
+        const int64_t want = (int64_t)ctx->prop.multiProcessorCount * 24;
         n_slices = A->n_rows >= want ? 1 : (int)((want + A->n_rows - 1) / A->n_rows);
     }
     n_slices = n_slices < 1 ? 1 : (n_slices > ix->n_blocks ? (ix->n_blocks > 0 ? ix->n_blocks : 1) : n_slices);
