@@ -24,9 +24,6 @@ def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_lis
     columns From, To, Similarity[, To_2, Similarity_2 ...]; scores rounded to 3
     decimals (_utils.py:70,102,143); Similarity < 0.001 -> 0.0 and To -> None."""
     n = len(from_list)
-    to_arr = np.empty(len(to_list) + 1, dtype=object)
-    to_arr[:len(to_list)] = to_list
-    to_arr[len(to_list)] = None
     from_arr = np.empty(n, dtype=object)
     from_arr[:] = from_list
     # all ranks at once; the frame is built from ready-made columns without a consolidating copy
@@ -36,9 +33,23 @@ def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_lis
     none = (sim < 0.001) | (j < 0)
     sim[none] = 0.0
     j = np.where(none, len(to_list), j)
+    if n * top_n * 8 < len(to_list):
+        # a few queries against a long to-list (fit once / transform many): pick the names one by one
+        # instead of turning the whole to-list into an object array first (1 ms per 100k names)
+        def names(col):
+            out = np.empty(n, dtype=object)
+            out[:] = [to_list[k] if k < len(to_list) else None for k in col.tolist()]
+            return out
+    else:
+        to_arr = np.empty(len(to_list) + 1, dtype=object)
+        to_arr[:len(to_list)] = to_list
+        to_arr[len(to_list)] = None
+
+        def names(col):
+            return to_arr[col]
     data = {"From": from_arr}
     for r in range(top_n):
-        data["To" if r == 0 else f"To_{r + 1}"] = to_arr[j[:, r]]
+        data["To" if r == 0 else f"To_{r + 1}"] = names(j[:, r])
         data["Similarity" if r == 0 else f"Similarity_{r + 1}"] = sim[:, r].copy()
     return pd.DataFrame(data, copy=False)
 
