@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--top-n", type=int, default=TOP_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--latency", action="store_true",
+                    help="also measure the top-1 single-query latency (adds many tiny K3 launches: keep it out of "
+                         "runs whose rocprofv3 kernel averages are compared with roofline.avg_launch_ms)")
     return ap.parse_args()
 
 
@@ -250,7 +253,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             idx, val = result.download()
             out["cpu_baseline"], out["parity_check"] = cpu_baseline_and_check(job, idx, val, args.cpu_seconds)
-        if world == 1:
+        if world == 1 and args.latency:
             out["latency"] = top1_latency(from_list, to_list)
     barrier()
     if dist is not None:
