@@ -228,13 +228,28 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, c
     // alphabet: rank (1..S) of every distinct code point of both lists
     std::vector<uint32_t> cps;
     {
-        std::vector<uint8_t> seen(0x110000 / 8 + 1, 0);
-        for (const pfz_strings *s : {F, T})
-            for (int64_t p = 0; p < s->n_units; ++p) {
-                const uint32_t c = unit_at(s, p);
-                if (c < 0x110000u) seen[c >> 3] |= (uint8_t)(1u << (c & 7));
+        // (typed loops over the host mirror and a scan that stops at the largest code point seen: the generic
+        // per-unit accessor + a walk over all 1.1 M code points cost 2-15 ms per call)
+        const bool any_wide = F->char_width != 1 || T->char_width != 1;
+        std::vector<uint8_t> seen(any_wide ? 0x110000 / 8 + 1 : 32, 0);
+        uint32_t max_cp = 0;
+        for (const pfz_strings *s : {F, T}) {
+            if (s->char_width == 1) {
+                const uint8_t *u = s->h_chars.data();
+                for (int64_t p = 0; p < s->n_units; ++p) seen[u[p] >> 3] |= (uint8_t)(1u << (u[p] & 7));
+                if (s->n_units > 0 && max_cp < 255) max_cp = 255;
+            } else {
+                const uint32_t *u = (const uint32_t *)s->h_chars.data();
+                for (int64_t p = 0; p < s->n_units; ++p) {
+                    const uint32_t c = u[p];
+                    if (c < 0x110000u) {
+                        seen[c >> 3] |= (uint8_t)(1u << (c & 7));
+                        max_cp = c > max_cp ? c : max_cp;
+                    }
+                }
             }
-        for (uint32_t c = 0; c < 0x110000u; ++c)
+        }
+        for (uint32_t c = 0; c <= max_cp; ++c)
             if (seen[c >> 3] & (1u << (c & 7))) cps.push_back(c);
     }
     const int S = (int)cps.size();
@@ -256,7 +271,12 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, c
 
     // from side: symbol arrays + word classes by length
     std::vector<uint16_t> a_ids((size_t)F->n_units);
-    for (int64_t p = 0; p < F->n_units; ++p) a_ids[(size_t)p] = sym_fast(unit_at(F, p));
+    if (F->char_width == 1 && !lut.empty()) {
+        const uint8_t *u = F->h_chars.data();
+        for (int64_t p = 0; p < F->n_units; ++p) a_ids[(size_t)p] = lut[u[p]];
+    } else {
+        for (int64_t p = 0; p < F->n_units; ++p) a_ids[(size_t)p] = sym_fast(unit_at(F, p));
+    }
     static const int kClassMax[7] = {32, 64, 128, 256, 512, 1024, INT_MAX};
     std::vector<int32_t> cls[7];
     for (int64_t i = begin; i < end; ++i) {
@@ -301,8 +321,13 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, c
             const int32_t j = order[(size_t)(g * 64 + l)];
             const int64_t b0 = T->h_off[(size_t)j], len = T->h_off[(size_t)j + 1] - b0;
             uint32_t *dst = packed.data() + g_off[(size_t)g] + l;
-            for (int64_t t = 0; t < len; ++t)
-                dst[(t / per) * 64] |= (uint32_t)sym_fast(unit_at(T, b0 + t)) << ((t % per) * idb);
+            if (T->char_width == 1 && !lut.empty()) {
+                const uint8_t *u = T->h_chars.data() + b0;
+                for (int64_t t = 0; t < len; ++t) dst[(t / per) * 64] |= (uint32_t)lut[u[t]] << ((t % per) * idb);
+            } else {
+                for (int64_t t = 0; t < len; ++t)
+                    dst[(t / per) * 64] |= (uint32_t)sym_fast(unit_at(T, b0 + t)) << ((t % per) * idb);
+            }
         }
 
     DevBuf d_a, d_aoff, d_packed, d_goff, d_gsteps, d_blen, d_borig, d_skip, d_oidx, d_oscore, d_matrix, d_rows[6];
