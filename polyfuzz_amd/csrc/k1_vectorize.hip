@@ -21,7 +21,7 @@
 //                 rank prefix per 256-bit group: column id = prefix[g] +
 //                 popcount of the lower bits -- no sort, no hash, no search.
 //                 Wider codes (up to 64 bits): the distinct codes as a sorted array
-//                 (gather + rocPRIM radix sort + unique), column id by binary search.
+//                 (gather + bitonic sort + unique), column id by binary search.
 //   per string  : a slot range of len*R uint64 in HBM (R = number of n values),
 //                 holding first the codes, then in place the sorted distinct
 //                 (column id, tf) pairs.
@@ -722,7 +722,7 @@ static int build_prefix(pfz_ctx *ctx, pfz_tfidf *v)
 }
 
 // Sorted-vocabulary mode (codes wider than kBitmapMaxBits): gather the codes k_extract left in the slot
-// ranges of the fitted lists, radix-sort them, keep the distinct ones.  v->vcodes / v->vocab on return.
+// ranges of the fitted lists, sort them, keep the distinct ones.  v->vcodes / v->vocab on return.
 static int build_sorted_vocab(pfz_ctx *ctx, pfz_tfidf *v, pfz_strings *const lists[2])
 {
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
@@ -750,7 +750,7 @@ static int build_sorted_vocab(pfz_ctx *ctx, pfz_tfidf *v, pfz_strings *const lis
         return PFZ_ERR_UNSUPPORTED;
     }
     PFZ_TRY(pool_alloc(ctx, &gathered.p, (size_t)total * sizeof(uint64_t)));
-    PFZ_TRY(pool_alloc(ctx, &sorted.p, (size_t)total * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &sorted.p, (size_t)sort_codes_capacity(total) * sizeof(uint64_t)));
     PFZ_TRY(pool_alloc(ctx, &flags.p, (size_t)(total + 1) * sizeof(int32_t)));
     for (int li = 0; li < 2; ++li) {
         pfz_strings *s = lists[li];
@@ -758,7 +758,7 @@ static int build_sorted_vocab(pfz_ctx *ctx, pfz_tfidf *v, pfz_strings *const lis
         hipLaunchKernelGGL(k_gather_codes, dim3(grid_for(s->n, 16)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
                            (const int32_t *)code_off[li].p, (uint64_t *)gathered.p + base[li]);
     }
-    PFZ_TRY(sort_codes_u64(ctx, (const uint64_t *)gathered.p, (uint64_t *)sorted.p, total, v->code_bits));
+    PFZ_TRY(sort_codes_u64(ctx, (const uint64_t *)gathered.p, (uint64_t *)sorted.p, total));
     hipLaunchKernelGGL(k_flag_heads, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const uint64_t *)sorted.p, total,
                        (int32_t *)flags.p);
     PFZ_TRY(exclusive_scan_i32(ctx, (int32_t *)flags.p, total));

@@ -181,7 +181,9 @@ int comm_allreduce_sum_i64(pfz_comm *c, int64_t *buf, size_t n);
 // (array must have n+1 slots).  Enqueues on ctx->stream.
 int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n);
 
-// radix sort of n-gram codes on bits [0, end_bit) (sort_u64.hip, rocPRIM); uses ctx->scratch
-int sort_codes_u64(pfz_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, int end_bit);
+// ascending sort of n-gram codes (sort_u64.hip: bitonic network, LDS tiles + streaming passes);
+// `out` must hold sort_codes_capacity(n) keys
+int64_t sort_codes_capacity(int64_t n);
+int sort_codes_u64(pfz_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n);
 
 }  // namespace pfz
