@@ -22,6 +22,14 @@ def test_readme_matrix_known_answers(ctx):
     np.testing.assert_array_equal(idx, [0, 1, 0, 0, 2, 0])       # first maximum wins (rows 3 and 5 tie)
 
 
+def test_published_rapidfuzz_values(ctx):
+    """The values rapidfuzz itself publishes for fuzz.ratio / Indel (README and API docs), on the device."""
+    m, _ = _matrix(ctx, ["this is a test", "lewenstein", "", "abc"], ["this is a test!", "levenshtein", ""])
+    assert m[0, 0] == 96.55172413793103
+    assert abs(m[1, 1] - 85.71428571428572) < 1e-12
+    assert m[2, 2] == 100.0 and m[3, 2] == 0.0 and m[2, 0] == 0.0
+
+
 def test_titles_bit_exact_vs_oracle(ctx, oracle_mod, golden):
     t = golden["titles_lists"]
     fl, tl = t["from_list"], t["to_list"]
