@@ -7,7 +7,9 @@
  *   (_distance.py:4,32), np.argmax (FIRST maximum) and np.max.
  *
  * rapidfuzz (setup.py:20, rapidfuzz>=0.13.1, C++, un-vendored and NOT
- * installed in this image -> PARITY UNPINNED for the scorer itself) publishes
+ * installed in this image -> PARITY UNPINNED for the scorer itself against an
+ * executable reference; anchored on the values rapidfuzz publishes, see
+ * tests/test_oracle_cpu.py::test_indel_ratio_published_known_answers) publishes
  * fuzz.ratio as the normalised Indel similarity * 100:
  *     dist      = |a| + |b| - 2 * LCS(a, b)          (insert/delete only)
  *     norm_dist = (|a|+|b| == 0) ? 0.0 : dist / (|a|+|b|)      (float64)
