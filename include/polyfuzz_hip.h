@@ -108,12 +108,14 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
 
 /* For every from-row i: the ntop largest cosine scores C[i][j] = sum_k
  * A[i][k] * B[j][k] with C[i][j] > lower_bound (strict, as sparse_dot_topn),
- * ordered by (score desc, j asc).  Accumulation is fp32, per (i,j) in
- * ascending k.  exclude_diag != 0 drops j == i + diag_offset (self-match,
+ * ordered by (score desc, j asc).  Every product is computed in fp32, scaled by
+ * 2^30 / (norm bound) and truncated to int32; the sums are int32 (order-
+ * independent, bit-reproducible; |error| ~ 3e-8).  exclude_diag != 0 drops j == i + diag_offset (self-match,
  * _utils.py:84-87; diag_offset = global index of from-row 0 when the from
  * side is a row shard).  lower_bound < 0 is treated as 0 (non-positive scores
  * are "no match" in the reference's output contract, _utils.py:122-123).
- * 1 <= ntop <= 128.  `out` may have MORE rows than the from-matrix (a padded
+ * Limits: 1 <= ntop <= 128 (PFZ_ERR_UNSUPPORTED beyond); fewer than 2^28
+ * postings in the to-side; n_cols equal on both sides.  `out` may have MORE rows than the from-matrix (a padded
  * shard buffer for the equal-sized all-gather): the extra rows are not touched.
  * Enqueues on the context stream. */
 int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,

@@ -28,7 +28,7 @@
 // Kernels: k_extract (thread per string: clean + window + emit + mark bitmap),
 // k_group_popc (+ scan), k_rows_short (wave per string: 64-lane bitonic sort,
 // ballot run-lengths, df atomics), k_rows_long (workgroup per long string),
-// k_idf, k_finalize (thread per string: fp64 tf*idf, sequential L2 norm, CSR).
+// k_idf, k_finalize (16 lanes per string: fp64 tf*idf, sum of squares replayed in index order, CSR).
 // All of it is HBM-streaming work over a few MB; none of it is MFMA-shaped.
 #include "pfz_internal.h"
 

@@ -834,6 +834,12 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
         n_slices = A->n_rows >= want ? 1 : (int)((want + A->n_rows - 1) / A->n_rows);
     }
     n_slices = n_slices < 1 ? 1 : (n_slices > ix->n_blocks ? (ix->n_blocks > 0 ? ix->n_blocks : 1) : n_slices);
+    if (ix->n_blocks > 0) {
+        // no empty trailing slice (nb = 9, 8 slices -> 2 blocks per slice -> only 5 slices have blocks): an empty
+        // slice would still read its offset-table entries, past the end of the table for the last n-gram
+        const int per_slice = (ix->n_blocks + n_slices - 1) / n_slices;
+        n_slices = (ix->n_blocks + per_slice - 1) / per_slice;
+    }
     uint64_t *part = nullptr;
     if (n_slices > 1) {
         PFZ_TRY(ensure_scratch(ctx, (size_t)A->n_rows * (size_t)n_slices * (size_t)ntop * sizeof(uint64_t)));

@@ -436,19 +436,6 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
     m->n_rows = n_rows;
     m->n_cols = n_cols;
     m->nnz = nnz;
-    {   // largest row norm (the caller's matrix need not be normalised, reference _utils.py:74-82)
-        double mx = 0.0;
-        for (int64_t i = 0; i < n_rows; ++i) {
-            double ss = 0.0;
-            for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) ss += (double)data[p] * (double)data[p];
-            if (!(ss == ss) || ss > 1e60) {
-                set_error("pfz_csr_upload: row %lld has a non-finite or huge norm", (long long)i);
-                return PFZ_ERR_INVALID;
-            }
-            if (ss > mx) mx = ss;
-        }
-        m->max_norm = (float)(sqrt(mx) * 1.000001);
-    }
     std::vector<int32_t> ip32((size_t)n_rows + 1);
     for (int64_t i = 0; i <= n_rows; ++i) {
         if (i > 0 && indptr[i] < indptr[i - 1]) {
@@ -456,6 +443,27 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
             return PFZ_ERR_INVALID;
         }
         ip32[(size_t)i] = (int32_t)indptr[i];
+    }
+    {   // largest row norm (the caller's matrix need not be normalised, reference _utils.py:74-82) and the
+        // column range: K3 indexes its offset table with these ids, scipy does not guarantee them
+        double mx = 0.0;
+        for (int64_t i = 0; i < n_rows; ++i) {
+            double ss = 0.0;
+            for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) {
+                if (indices[p] < 0 || indices[p] >= n_cols) {
+                    set_error("pfz_csr_upload: row %lld has column index %d outside [0, %lld)", (long long)i,
+                              indices[p], (long long)n_cols);
+                    return PFZ_ERR_INVALID;
+                }
+                ss += (double)data[p] * (double)data[p];
+            }
+            if (!(ss == ss) || ss > 1e60) {
+                set_error("pfz_csr_upload: row %lld has a non-finite or huge norm", (long long)i);
+                return PFZ_ERR_INVALID;
+            }
+            if (ss > mx) mx = ss;
+        }
+        m->max_norm = (float)(sqrt(mx) * 1.000001);
     }
     PFZ_TRY(pool_alloc(ctx, &m->indptr, (size_t)(n_rows + 1) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));

@@ -67,6 +67,15 @@ def clip_top_n(top_n: int, to_list) -> int:
     return len(seen)
 
 
+def _l2_rows(m):
+    """rows / ||row||_2 (zero rows stay zero), float64 -- host preparation of caller-supplied matrices"""
+    m = m.tocsr().astype(np.float64)
+    norms = np.sqrt(np.asarray(m.multiply(m).sum(axis=1)).ravel())
+    norms[norms == 0.0] = 1.0
+    from scipy.sparse import diags
+    return (diags(1.0 / norms) @ m).tocsr()
+
+
 def _to_device_csr(ctx, m):
     if issparse(m):
         return _lib.DeviceCSR.from_scipy(ctx, m)
@@ -93,12 +102,25 @@ def cosine_similarity(from_vector,
     lower = float(min_similarity) if method in ("sparse", "hip") else 0.0
     ctx = _lib.Context.default()
 
-    if isinstance(from_vector, np.ndarray) or isinstance(to_vector, np.ndarray):
+    if isinstance(from_vector, np.ndarray) != isinstance(to_vector, np.ndarray):
+        # one dense, one sparse operand: the reference turns the ndarray into a csr_matrix (_utils.py:74-77)
+        from scipy.sparse import csr_matrix
+        if isinstance(from_vector, np.ndarray):
+            from_vector = csr_matrix(from_vector)
+        else:
+            to_vector = csr_matrix(to_vector)
+    if isinstance(from_vector, np.ndarray):
         # "sparse" multiplies the arrays as they are (reference _utils.py:74-82: csr_matrix(ndarray), no
         # normalisation); "sklearn"/"knn"/"hip" are true cosines (_utils.py:59-70,94-95)
         idx, val = _lib.dense_cossim_topn_host(ctx, np.asarray(from_vector), np.asarray(to_vector), max(top_n, 1),
                                                lower, self_match, normalize=method != "sparse")
     else:
+        if method in ("sklearn", "knn"):
+            # true cosines whatever the caller's row norms are (sklearn pairwise.py normalises both operands;
+            # a no-op for TF-IDF rows).  "sparse" multiplies the matrices as they are (_utils.py:82)
+            same = to_vector is from_vector
+            from_vector = _l2_rows(from_vector)
+            to_vector = from_vector if same else _l2_rows(to_vector)
         a = _to_device_csr(ctx, from_vector)
         b = a if to_vector is from_vector else _to_device_csr(ctx, to_vector)
         index = _lib.DeviceIndex.build(ctx, b)

@@ -31,7 +31,9 @@ class TfidfMatchJob:
     def __init__(self, ctx, from_shard, to_list, top_n=1, min_similarity=0.0, n_gram_range=(3, 3),
                  clean_string=True, remove_space_ngrams=True, comm=None, self_match=False, shard_offset=0,
                  rows_per_rank=None):
-        """rows_per_rank: size of the largest shard when the ranks' shards differ (shard_bounds); the
+        """self_match: the from-rows are rows [shard_offset, shard_offset + len(from_shard)) of to_list (the whole
+        list, replicated); to_list=None = the from-list is the whole list (single GPU).
+        rows_per_rank: size of the largest shard when the ranks' shards differ (shard_bounds); the
         per-rank result block is padded to it so that the all-gather moves equal blocks."""
         self.ctx = ctx
         self.comm = comm
@@ -42,9 +44,14 @@ class TfidfMatchJob:
         self.params = _lib.TfidfParams(int(n_gram_range[0]), int(n_gram_range[1]), int(bool(clean_string)),
                                        int(bool(remove_space_ngrams)))
         self.n_from = len(from_shard)
-        self.n_to = len(to_list)
         self.from_dev = _lib.DeviceStrings.upload(ctx, from_shard)
-        self.to_dev = _lib.DeviceStrings.upload(ctx, to_list)
+        if to_list is None:                    # single-list self-match: the list is its own to-side
+            if not self.self_match or self.shard_offset != 0:
+                raise ValueError("to_list=None means a whole-list self-match (self_match=True, shard_offset=0)")
+            self.n_to, self.to_dev = self.n_from, self.from_dev
+        else:
+            self.n_to = len(to_list)
+            self.to_dev = _lib.DeviceStrings.upload(ctx, to_list)
         self.rows_per_rank = self.n_from if rows_per_rank is None else int(rows_per_rank)
         if self.rows_per_rank < self.n_from:
             raise ValueError("rows_per_rank is smaller than this rank's shard")
@@ -57,13 +64,21 @@ class TfidfMatchJob:
 
     def step(self):
         ctx = self.ctx
-        if self.comm is not None and self.comm.world > 1:
+        sharded = self.comm is not None and self.comm.world > 1
+        if self.self_match:
+            # reference _tfidf.py:113-116: a self-match fits on the list ALONE (n_docs = len(list)); the
+            # replicated list is the whole list on every rank, so the fit needs no exchange
+            self.vec = _lib.DeviceTfidf.fit(ctx, self.params, self.to_dev, None)
+        elif sharded:
             self.vec = _lib.tfidf_fit_sharded(ctx, self.comm, self.params, self.to_dev, self.from_dev)
         else:
             self.vec = _lib.DeviceTfidf.fit(ctx, self.params, self.to_dev, self.from_dev)
         self.to_csr = self.vec.transform(self.to_dev)
         self.index = _lib.DeviceIndex.build(ctx, self.to_csr)
-        self.from_csr = self.vec.transform(self.from_dev)
+        if self.self_match and not sharded and self.n_from == self.n_to and self.shard_offset == 0:
+            self.from_csr = self.to_csr            # the same rows: vectorise once (reference _tfidf.py:114-116)
+        else:
+            self.from_csr = self.vec.transform(self.from_dev)
         _lib.cossim_topn(ctx, self.index, self.from_csr, self.top_n, self.min_similarity,
                          exclude_diag=self.self_match, diag_offset=self.shard_offset, out=self.local)
         if self.gathered is not None:
@@ -78,8 +93,11 @@ class TfidfMatchJob:
         return idx[keep], val[keep]
 
     def step_description(self):
-        return ("fit vocabulary+idf on to+from (K1/K2), vectorise both lists, build the to-side inverted index, "
-                "fused cosine top-n (K3)" + ("; all-gather of the per-shard results (RCCL)" if self.gathered else ""))
+        what = ("fit vocabulary+idf on the list (K1/K2), vectorise it, build the inverted index, fused cosine top-n "
+                "with the diagonal excluded (K3)" if self.self_match else
+                "fit vocabulary+idf on to+from (K1/K2), vectorise both lists, build the to-side inverted index, "
+                "fused cosine top-n (K3)")
+        return what + ("; all-gather of the per-shard results (RCCL)" if self.gathered else "")
 
     # ---- host-side accounting (never inside the timed region) ---------------------
     def host_matrices(self):

@@ -56,4 +56,6 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(root, f), encoding="utf-8").read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
-                assert "sklearn" not in src or f == "_utils.py" or "sklearn\"" in src or True
+                # the product never calls scikit-learn either (the name appears only in comments/docstrings
+                # and as the reference's back-end name "sklearn")
+                assert not re.search(r"^\s*(import|from)\s+sklearn\b", src, flags=re.M), f

@@ -29,8 +29,6 @@ def test_readme_cases_match_reference_frames(golden):
         kw = dict(case["kwargs"])
         if "n_gram_range" in kw:
             kw["n_gram_range"] = tuple(kw["n_gram_range"])
-            if kw["n_gram_range"][1] > 5 and not kw.get("clean_string", True):
-                continue            # 6-grams of uncleaned text exceed the 36-bit code space (loud error, tested elsewhere)
         m = TFIDF(cosine_method="sklearn", **kw)      # goldens were made with the reference's sklearn back-end
         df = m.match(fl) if case["self"] else m.match(fl, tl)
         _cmp_frame(df, case["df"])
