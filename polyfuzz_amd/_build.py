@@ -38,12 +38,12 @@ PACK_PATH = os.path.join(_HERE, "_pack.so")
 
 
 def build_host_helpers(force=False, verbose=False):
-    """Compile the CPython helper polyfuzz_amd/_pack.so (string packing for the upload).  It is glue, not
-    compute: when it is missing `_lib.pack_strings` uses its pure-Python twin."""
+    """Compile the CPython helper polyfuzz_amd/_pack.so (string packing for the upload, object-column gathers
+    of the result frame).  It is glue, not compute: when it is missing the pure-Python twins run."""
     if not force and os.path.exists(PACK_PATH) and os.path.getmtime(PACK_PATH) >= os.path.getmtime(PACK_SRC):
         return PACK_PATH
     import sysconfig
-    cmd = ["gcc", "-O2", "-shared", "-fPIC", "-I", sysconfig.get_paths()["include"], PACK_SRC, "-o", PACK_PATH + ".tmp"]
+    cmd = ["gcc", "-O3", "-msse4.1", "-shared", "-fPIC", "-I", sysconfig.get_paths()["include"], PACK_SRC, "-lm", "-lpthread", "-o", PACK_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=REPO)

@@ -10,6 +10,7 @@
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
+#include <math.h>
 
 static PyObject *pack(PyObject *self, PyObject *arg)
 {
@@ -66,8 +67,146 @@ static PyObject *pack(PyObject *self, PyObject *arg)
     return out;
 }
 
+/* fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads)
+ *
+ * The (To_r, Similarity_r) column pairs of the result frame (reference polyfuzz/models/_utils.py:104-125),
+ * r = 0..top_n-1, from the engine's int32 idx[n][top_n] / fp32 val[n][top_n] result arrays:
+ *   sim_r[i] = round(float64(val[i][r]), 3)            -- numpy's round: rint(x * 1000) / 1000
+ *   if sim_r[i] < 0.001 or idx[i][r] is not a row of `names`:  sim_r[i] = 0.0, obj_r[i] = None
+ *   else                                                        obj_r[i] = names[idx[i][r]]
+ * obj_addrs / sim_addrs: tuples of the data addresses of top_n FRESH numpy object arrays (every slot NULL
+ * or None, as np.empty(n, object) leaves them) and top_n float64 arrays, n elements each.
+ *
+ * The gathers are random reads of PyObject headers -- one cache miss per name -- so the loop prefetches a
+ * few rows ahead, and above ~64k entries the (column, row-chunk) tasks are spread over n_threads pthreads.
+ * The workers make no Python API call: they bump reference counts with atomic adds and store into disjoint
+ * slots, while the calling thread keeps the GIL and waits, so no other reference-count update can race.
+ */
+#include <pthread.h>
+
+typedef struct {
+    PyObject **items;
+    Py_ssize_t n_names, n, top_n;
+    const int32_t *idx;
+    const float *val;
+    PyObject ***obj;
+    double **sim;
+    Py_ssize_t chunk, n_chunks;
+    long next_task;   /* atomic */
+} fill_job;
+
+static void fill_range(const fill_job *job, Py_ssize_t r, Py_ssize_t lo, Py_ssize_t hi, int atomic)
+{
+    enum { AHEAD = 12 };
+    const Py_ssize_t stride = job->top_n;
+    const int32_t *idx = job->idx + r;
+    const float *val = job->val + r;
+    PyObject **obj = job->obj[r];
+    double *sim = job->sim[r];
+    PyObject **items = job->items;
+    const Py_ssize_t n_names = job->n_names;
+    for (Py_ssize_t i = lo; i < hi; ++i) {
+        if (i + AHEAD < hi) {
+            const int32_t jn = idx[(i + AHEAD) * stride];
+            if (jn >= 0 && jn < n_names) __builtin_prefetch(items[jn], 1, 1);
+        }
+        const int32_t j = idx[i * stride];
+        double s = rint((double)val[i * stride] * 1000.0) / 1000.0;
+        PyObject *o = Py_None;
+        if (s < 0.001 || j < 0 || j >= n_names) s = 0.0;
+        else o = items[j];
+        sim[i] = s;
+        if (atomic) __atomic_fetch_add(&o->ob_refcnt, 1, __ATOMIC_RELAXED);
+        else Py_INCREF(o);
+        obj[i] = o;
+    }
+}
+
+static void *fill_worker(void *arg)
+{
+    fill_job *job = (fill_job *)arg;
+    const long n_tasks = (long)(job->n_chunks * job->top_n);
+    for (;;) {
+        const long t = __atomic_fetch_add(&job->next_task, 1, __ATOMIC_RELAXED);
+        if (t >= n_tasks) break;
+        const Py_ssize_t r = t / job->n_chunks, c = t % job->n_chunks;
+        const Py_ssize_t lo = c * job->chunk, hi = lo + job->chunk < job->n ? lo + job->chunk : job->n;
+        fill_range(job, r, lo, hi, 1);
+    }
+    return NULL;
+}
+
+static PyObject *fill_columns(PyObject *self, PyObject *args)
+{
+    (void)self;
+    PyObject *names, *obj_addrs, *sim_addrs;
+    unsigned long long idx_addr, val_addr;
+    Py_ssize_t n, top_n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "OKKnnO!O!i", &names, &idx_addr, &val_addr, &n, &top_n, &PyTuple_Type, &obj_addrs,
+                          &PyTuple_Type, &sim_addrs, &n_threads))
+        return NULL;
+    if (n < 0 || top_n < 1 || top_n > 1024 || PyTuple_GET_SIZE(obj_addrs) != top_n || PyTuple_GET_SIZE(sim_addrs) != top_n) {
+        PyErr_SetString(PyExc_ValueError, "fill_columns(): need top_n object and top_n float64 column addresses");
+        return NULL;
+    }
+    PyObject *seq = PySequence_Fast(names, "fill_columns() expects a sequence of names");
+    if (!seq) return NULL;
+    PyObject **obj[1024];
+    double *sim[1024];
+    Py_ssize_t old_none = 0;
+    for (Py_ssize_t r = 0; r < top_n; ++r) {
+        obj[r] = (PyObject **)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(obj_addrs, r));
+        sim[r] = (double *)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(sim_addrs, r));
+        if (PyErr_Occurred()) {
+            Py_DECREF(seq);
+            return NULL;
+        }
+        for (Py_ssize_t i = 0; i < n; ++i) {
+            if (obj[r][i] == Py_None) ++old_none;     /* np.empty(n, object) holds n references to None */
+            else if (obj[r][i] != NULL) {
+                Py_DECREF(seq);
+                PyErr_SetString(PyExc_ValueError, "fill_columns(): the object columns must be fresh np.empty arrays");
+                return NULL;
+            }
+        }
+    }
+    fill_job job;
+    job.items = PySequence_Fast_ITEMS(seq);
+    job.n_names = PySequence_Fast_GET_SIZE(seq);
+    job.n = n;
+    job.top_n = top_n;
+    job.idx = (const int32_t *)(uintptr_t)idx_addr;
+    job.val = (const float *)(uintptr_t)val_addr;
+    job.obj = obj;
+    job.sim = sim;
+    job.chunk = 8192;
+    job.n_chunks = (n + job.chunk - 1) / job.chunk;
+    job.next_task = 0;
+    const long n_tasks = (long)(job.n_chunks * top_n);
+    if (n_threads > 16) n_threads = 16;
+    if (n_threads > n_tasks) n_threads = (int)n_tasks;
+    int started = 0;
+    pthread_t th[16];
+    if (n * top_n >= 65536 && n_threads > 1) {
+        for (; started < n_threads - 1; ++started)
+            if (pthread_create(&th[started], NULL, fill_worker, &job) != 0) break;
+    }
+    if (started > 0) {
+        fill_worker(&job);                     /* the calling thread works too (atomic adds, like the others) */
+        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    } else {
+        for (Py_ssize_t r = 0; r < top_n; ++r) fill_range(&job, r, 0, n, 0);
+    }
+    Py_None->ob_refcnt -= old_none;            /* the references the overwritten slots held (None stays alive) */
+    Py_DECREF(seq);
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     {"pack", pack, METH_O, "pack(list[str]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)"},
+    {"fill_columns", fill_columns, METH_VARARGS,
+     "fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads): the (To, Similarity) column pairs"},
     {NULL, NULL, 0, NULL},
 };
 

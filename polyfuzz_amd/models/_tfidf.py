@@ -10,6 +10,7 @@ resident in HBM between `match(..., re_train=False)` calls (reference
 polyfuzz.py:234-240, "production" path).
 """
 import re
+import time
 from typing import List, Tuple
 
 import numpy as np
@@ -18,7 +19,7 @@ from scipy.sparse import csr_matrix
 
 from .. import _lib
 from ._base import BaseMatcher
-from ._utils import topn_to_frame, clip_top_n, _METHODS
+from ._utils import topn_to_frame, object_column, clip_top_n, _METHODS
 
 
 def _clean_string(string: str) -> str:
@@ -106,6 +107,7 @@ class TFIDF(BaseMatcher):
         self._dev_index = None      # _lib.DeviceIndex of the to-side
         self._vectorizer = None
         self._host_state = None     # picklable copy (see __getstate__)
+        self.last_timings = None
 
     # ---- reference attributes ------------------------------------------------
     @property
@@ -128,14 +130,24 @@ class TFIDF(BaseMatcher):
         if self.cosine_method not in _METHODS:
             raise ValueError(f"cosine_method must be one of {_METHODS}")
         ctx = _lib.Context.default()
+        t0 = time.perf_counter()
         from_dev, to_dev = self._extract_tf_idf(from_list, to_list, re_train)
         top_n = clip_top_n(self.top_n, to_list)                   # _utils.py:54-56
         self_match = to_list is None
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
-        idx, val = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower,
-                                    exclude_diag=self_match).download()
-        names = list(from_list) if self_match else to_list
-        return topn_to_frame(idx, val, from_list, names, top_n)
+        res = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=self_match)
+        t1 = time.perf_counter()
+        from_col = object_column(from_list)        # host work while the device runs K3
+        t2 = time.perf_counter()
+        idx, val = res.download()
+        t3 = time.perf_counter()
+        frame = topn_to_frame(idx, val, from_list, from_list if self_match else to_list, top_n, from_col=from_col)
+        t4 = time.perf_counter()
+        # where the wall time of the last match went (ms): pack + upload + enqueue of K1/K2/index/K3, the From
+        # column (overlapped with the device), waiting for the device + D2H, the remaining frame columns
+        self.last_timings = {"upload_and_enqueue": (t1 - t0) * 1e3, "from_column": (t2 - t1) * 1e3,
+                             "wait_and_download": (t3 - t2) * 1e3, "frame": (t4 - t3) * 1e3}
+        return frame
 
     # ---- internals ---------------------------------------------------------------
     def _params(self):

@@ -7,6 +7,7 @@ dense ndarray input) -- they differ only in what the reference makes them differ
 in: "sparse" honours `min_similarity` (strict >), "sklearn"/"knn" ignore it
 (_utils.py:62-68,95 vs :82).  There is no CPU path.
 """
+import os
 from typing import List
 
 import numpy as np
@@ -16,40 +17,67 @@ from scipy.sparse import issparse
 from .. import _lib
 
 _METHODS = ("sparse", "sklearn", "knn", "hip")
+# host threads that gather the To columns of a large result frame (memory-latency bound; _pack.fill_columns).
+# PFZ_FRAME_THREADS overrides; small hosts stay serial (thread start-up costs more than it saves there)
+def _fill_threads():
+    env = os.environ.get("PFZ_FRAME_THREADS")
+    if env:
+        return max(1, int(env))
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return 4 if cpus >= 16 else 1
+
+
+_FILL_THREADS = _fill_threads()
+
+
+def object_column(strings) -> np.ndarray:
+    """list[str] -> 1-D object ndarray (the From column; built while the GPU is still busy)."""
+    arr = np.empty(len(strings), dtype=object)
+    arr[:] = strings
+    return arr
 
 
 def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_list: List[str],
-                  top_n: int) -> pd.DataFrame:
+                  top_n: int, from_col: np.ndarray = None) -> pd.DataFrame:
     """(idx, score) arrays -> the reference's DataFrame (_utils.py:104-125):
     columns From, To, Similarity[, To_2, Similarity_2 ...]; scores rounded to 3
-    decimals (_utils.py:70,102,143); Similarity < 0.001 -> 0.0 and To -> None."""
+    decimals (_utils.py:70,102,143); Similarity < 0.001 -> 0.0 and To -> None.
+
+    Every (To_r, Similarity_r) pair is filled by one pass of the CPython helper
+    (_pack.fill_columns: rounding, the <0.001 rule and the prefetched gather of the
+    names); without the helper the numpy twin below builds the same frame."""
     n = len(from_list)
-    from_arr = np.empty(n, dtype=object)
-    from_arr[:] = from_list
-    # all ranks at once; the frame is built from ready-made columns without a consolidating copy
-    # (100k x top-5: 56 -> 19 ms, same frame)
+    if _lib._pack is None or not isinstance(to_list, (list, tuple)):
+        return _topn_to_frame_numpy(idx, val, from_list, to_list, top_n)
+    idx = np.ascontiguousarray(idx, np.int32).reshape(n, top_n)
+    val = np.ascontiguousarray(val, np.float32).reshape(n, top_n)
+    data = {"From": object_column(from_list) if from_col is None else from_col}
+    names = [np.empty(n, dtype=object) for _ in range(top_n)]
+    sims = [np.empty(n, np.float64) for _ in range(top_n)]
+    if n and top_n:
+        _lib._pack.fill_columns(to_list, idx.ctypes.data, val.ctypes.data, n, top_n,
+                                tuple(a.ctypes.data for a in names), tuple(a.ctypes.data for a in sims), _FILL_THREADS)
+    for r in range(top_n):
+        data["To" if r == 0 else f"To_{r + 1}"] = names[r]
+        data["Similarity" if r == 0 else f"Similarity_{r + 1}"] = sims[r]
+    return pd.DataFrame(data, copy=False)
+
+
+def _topn_to_frame_numpy(idx, val, from_list, to_list, top_n) -> pd.DataFrame:
+    """numpy twin of topn_to_frame (fallback when _pack.so is not built; the tests compare the two)."""
+    n = len(from_list)
+    from_arr = object_column(from_list)
     sim = np.round(np.asarray(val, np.float64).reshape(n, top_n), 3)
     j = np.asarray(idx, np.int64).reshape(n, top_n)
-    none = (sim < 0.001) | (j < 0)
+    none = (sim < 0.001) | (j < 0) | (j >= len(to_list))
     sim[none] = 0.0
     j = np.where(none, len(to_list), j)
-    if n * top_n * 8 < len(to_list):
-        # a few queries against a long to-list (fit once / transform many): pick the names one by one
-        # instead of turning the whole to-list into an object array first (1 ms per 100k names)
-        def names(col):
-            out = np.empty(n, dtype=object)
-            out[:] = [to_list[k] if k < len(to_list) else None for k in col.tolist()]
-            return out
-    else:
-        to_arr = np.empty(len(to_list) + 1, dtype=object)
-        to_arr[:len(to_list)] = to_list
-        to_arr[len(to_list)] = None
-
-        def names(col):
-            return to_arr[col]
+    to_arr = np.empty(len(to_list) + 1, dtype=object)
+    to_arr[:len(to_list)] = to_list
+    to_arr[len(to_list)] = None
     data = {"From": from_arr}
     for r in range(top_n):
-        data["To" if r == 0 else f"To_{r + 1}"] = names(j[:, r])
+        data["To" if r == 0 else f"To_{r + 1}"] = to_arr[j[:, r]]
         data["Similarity" if r == 0 else f"Similarity_{r + 1}"] = sim[:, r].copy()
     return pd.DataFrame(data, copy=False)
 

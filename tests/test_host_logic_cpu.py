@@ -115,3 +115,45 @@ def test_synthetic_names_are_deterministic_and_name_like():
     a, b = synth.company_names(500, 7), synth.company_names(500, 7)
     assert a == b and a != synth.company_names(500, 8)
     assert 15 < np.mean([len(s) for s in a]) < 35
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_frame_helper_equals_numpy_twin(threads, monkeypatch):
+    """_pack.fill_columns (C, optionally threaded with atomic reference counts) builds exactly the frame of
+    the numpy twin -- np.round(., 3), the < 0.001 rule at the rounding boundary, -1 / out-of-range rows --
+    and leaves every reference count balanced."""
+    import sys
+    from polyfuzz_amd import _lib
+    from polyfuzz_amd.models import _utils
+    if _lib._pack is None:
+        pytest.skip("_pack.so not built")
+    monkeypatch.setattr(_utils, "_FILL_THREADS", threads)
+    rng = np.random.default_rng(11)
+    to_list = [f"name {i} é" for i in range(5000)]
+    for n, top_n in ((0, 1), (7, 3), (30000, 5)):
+        from_list = [f"q{i}" for i in range(n)]
+        idx = rng.integers(-1, len(to_list) + 2, (n, top_n)).astype(np.int32)
+        val = rng.random((n, top_n)).astype(np.float32)
+        val[rng.random((n, top_n)) < 0.2] *= np.float32(0.0015)              # around the 0.001 / 0.0005 boundaries
+        if n:
+            val[0, 0], val[1 % n, 0] = np.float32(0.0005), np.float32(0.00049999)
+        a = _utils.topn_to_frame(idx, val, from_list, to_list, top_n)
+        b = _utils._topn_to_frame_numpy(idx, val, from_list, to_list, top_n)
+        assert list(a.columns) == list(b.columns) and a.dtypes.tolist() == b.dtypes.tolist()
+        for c in a.columns:
+            if c.startswith("Similarity"):
+                np.testing.assert_array_equal(a[c].to_numpy(), b[c].to_numpy())
+            else:
+                assert a[c].tolist() == b[c].tolist(), c
+
+    def held(i):          # references a frame holds on to_list[i] while alive / after it is gone
+        before = sys.getrefcount(to_list[i])
+        frame = _utils.topn_to_frame(idx, val, from_list, to_list, top_n)
+        during = sys.getrefcount(to_list[i])
+        del frame
+        return during - before, sys.getrefcount(to_list[i]) - before
+    during, after = held(17)
+    assert after == 0 and during == int(((idx == 17) & (np.round(val.astype(np.float64), 3) >= 0.001)).sum())
+    # the few-queries-against-a-long-list path takes the list as it is (no object-array copy of it)
+    df = _utils.topn_to_frame(np.array([[4999]], np.int32), np.array([[0.5]], np.float32), ["q"], to_list, 1)
+    assert df["To"].tolist() == [to_list[4999]]

@@ -162,3 +162,38 @@ def test_non_ascii_titles_vs_reference(golden, clean):
     for i, r in zip(*np.nonzero(diff)):
         row_sims = golden["npz"][key + "_sim"][i]
         assert (np.abs(row_sims - row_sims[r]) < 1.5e-3).sum() >= 2 or row_sims[r] < 0.001, (i, r, df.iloc[i].tolist())
+
+
+def test_knn_backend_name_vs_reference_frames(golden):
+    """cosine_method="knn" (reference _utils.py:59-70) is an alias of the HIP op that ignores min_similarity:
+    same frames as the reference's sklearn back-end produced (the reference's knn and sklearn branches agree
+    on these lists)."""
+    from polyfuzz_amd.models import TFIDF
+    rc = golden["readme_cases"]
+    fl, tl = rc["from_list"], rc["to_list"]
+    for case in rc["cases"][:6]:
+        kw = dict(case["kwargs"])
+        kw["min_similarity"] = 0.99            # must be ignored by "knn"
+        m = TFIDF(cosine_method="knn", **kw)
+        df = m.match(fl) if case["self"] else m.match(fl, tl)
+        _cmp_frame(df, case["df"])
+
+
+def test_self_match_job_equals_matcher_and_oracle(ctx, oracle_mod, golden):
+    """pipeline.TfidfMatchJob(self_match=True): the fit runs on the list ALONE (reference _tfidf.py:113-116;
+    n_docs = len(list), not twice that), single-list and row-shard forms give the oracle's result."""
+    from polyfuzz_amd import pipeline
+    sl = golden["company_self_list"]["from_list"]
+    n = len(sl)
+    a3, _, n_col = __import__("tests.helpers", fromlist=["x"]).vectorize_pair(oracle_mod, sl, None)
+    e_idx, e_val = oracle_mod.cossim_topn(a3, a3, n_col, 3, 0.0, exclude_diag=True)
+    job = pipeline.TfidfMatchJob(ctx, sl, None, top_n=3, min_similarity=0.0, self_match=True)
+    idx, val = job.step().download()
+    assert job.vec.info()["n_docs"] == n
+    assert np.abs(val - e_val).max() <= 1e-5 and (idx != e_idx).any(axis=1).sum() <= 2
+    # a row shard of the same job: rows [b, e) against the whole list, diagonal at the shard offset
+    b, e = pipeline.shard_bounds(n, 3, 1)
+    shard = pipeline.TfidfMatchJob(ctx, sl[b:e], sl, top_n=3, min_similarity=0.0, self_match=True, shard_offset=b)
+    s_idx, s_val = shard.step().download()
+    np.testing.assert_array_equal(s_idx, idx[b:e])
+    np.testing.assert_array_equal(s_val, val[b:e])
