@@ -858,10 +858,8 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
     if (n_units > 0) s->h_chars.assign((const uint8_t *)chars, (const uint8_t *)chars + (size_t)n_units * (size_t)char_width);
     PFZ_TRY(pool_alloc(ctx, &s->chars, (size_t)(n_units > 0 ? n_units : 1) * (size_t)char_width + 16));
     PFZ_TRY(pool_alloc(ctx, &s->offsets, (size_t)(n + 1) * sizeof(int64_t)));
-    if (n_units > 0)
-        PFZ_HIP(hipMemcpyAsync(s->chars, chars, (size_t)n_units * (size_t)char_width, hipMemcpyHostToDevice, ctx->stream));
-    PFZ_HIP(hipMemcpyAsync(s->offsets, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_units > 0) PFZ_TRY(copy_h2d(ctx, s->chars, chars, (size_t)n_units * (size_t)char_width));
+    PFZ_TRY(copy_h2d(ctx, s->offsets, offsets, (size_t)(n + 1) * sizeof(int64_t)));
     *out = s.release();
     return PFZ_OK;
 }

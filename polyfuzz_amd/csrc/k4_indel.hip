@@ -188,7 +188,8 @@ struct DevBuf {
     template <typename T> int upload(const std::vector<T> &v, hipStream_t st)
     {
         PFZ_TRY(alloc(v.size() * sizeof(T)));
-        if (!v.empty()) PFZ_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        (void)st;
+        if (!v.empty()) PFZ_TRY(copy_h2d(ctx, p, v.data(), v.size() * sizeof(T)));   // ctx->stream; v may be freed on return
         return PFZ_OK;
     }
 };
@@ -381,10 +382,9 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, c
         default: PFZ_TRY((launch_class<uint64_t, 16>(ctx, A, idb, grid))); break;
         }
     }
-    if (out_idx) PFZ_HIP(hipMemcpyAsync(out_idx, d_oidx.p, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (out_score) PFZ_HIP(hipMemcpyAsync(out_score, d_oscore.p, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (out_matrix)
-        PFZ_HIP(hipMemcpyAsync(out_matrix, d_matrix.p, (size_t)n_rows * (size_t)n_to * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_idx) PFZ_TRY(copy_d2h(ctx, out_idx, d_oidx.p, (size_t)n_rows * sizeof(int32_t)));
+    if (out_score) PFZ_TRY(copy_d2h(ctx, out_score, d_oscore.p, (size_t)n_rows * sizeof(double)));
+    if (out_matrix) PFZ_TRY(copy_d2h(ctx, out_matrix, d_matrix.p, (size_t)n_rows * (size_t)n_to * sizeof(double)));
     PFZ_HIP(hipStreamSynchronize(ctx->stream));
     return PFZ_OK;
 }

@@ -382,10 +382,10 @@ static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, 
     const size_t a_bytes = (size_t)n_from * (size_t)dim * sizeof(float);
     const size_t b_bytes = (size_t)(n_to > 0 ? n_to : 1) * (size_t)dim * sizeof(float);
     PFZ_TRY(pool_alloc(ctx, &dA.p, a_bytes));
-    PFZ_HIP(hipMemcpyAsync(dA.p, from_vec, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+    PFZ_TRY(copy_h2d(ctx, dA.p, from_vec, a_bytes));
     if (!same) {
         PFZ_TRY(pool_alloc(ctx, &dB.p, b_bytes));
-        if (n_to > 0) PFZ_HIP(hipMemcpyAsync(dB.p, to_vec, (size_t)n_to * (size_t)dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if (n_to > 0) PFZ_TRY(copy_h2d(ctx, dB.p, to_vec, (size_t)n_to * (size_t)dim * sizeof(float)));
     }
     const float *A = (const float *)dA.p, *B = same ? A : (const float *)dB.p;
     PFZ_TRY(pool_alloc(ctx, &dIa.p, (size_t)n_from * sizeof(float)));
@@ -421,8 +421,8 @@ static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, 
         }
     }
     PFZ_HIP(hipGetLastError());
-    PFZ_HIP(hipMemcpyAsync(out_idx, dOi.p, (size_t)n_from * ntop * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PFZ_HIP(hipMemcpyAsync(out_val, dOv.p, (size_t)n_from * ntop * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PFZ_TRY(copy_d2h(ctx, out_idx, dOi.p, (size_t)n_from * ntop * sizeof(int32_t)));
+    PFZ_TRY(copy_d2h(ctx, out_val, dOv.p, (size_t)n_from * ntop * sizeof(float)));
     PFZ_HIP(hipStreamSynchronize(ctx->stream));
     return PFZ_OK;
 }

@@ -45,6 +45,67 @@ int ensure_scratch(pfz_ctx *ctx, size_t bytes)
     return PFZ_OK;
 }
 
+// ---- staged host <-> device copies ----------------------------------------------
+constexpr size_t kStageBytes = (size_t)64 << 20;    // pinned once per context
+constexpr size_t kStageDirect = (size_t)256 << 20;  // larger one-off buffers (dense matrices) go to the runtime as they are
+
+static int stage_take(pfz_ctx *ctx, size_t bytes, char **out)
+{
+    if (!ctx->stage) {
+        PFZ_HIP(hipHostMalloc((void **)&ctx->stage, kStageBytes, hipHostMallocDefault));
+        ctx->stage_bytes = kStageBytes;
+        ctx->stage_off = 0;
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (ctx->stage_off + need > ctx->stage_bytes) {   // wrap: everything staged so far must have left the buffer
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->stage_off = 0;
+    }
+    *out = ctx->stage + ctx->stage_off;
+    ctx->stage_off += need;
+    return PFZ_OK;
+}
+
+int copy_h2d(pfz_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return PFZ_OK;
+    if (bytes > kStageDirect) {
+        PFZ_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        return PFZ_OK;
+    }
+    for (size_t done = 0; done < bytes;) {
+        const size_t part = bytes - done < kStageBytes ? bytes - done : kStageBytes;
+        char *st = nullptr;
+        PFZ_TRY(stage_take(ctx, part, &st));
+        memcpy(st, (const char *)src_host + done, part);
+        PFZ_HIP(hipMemcpyAsync((char *)dst_dev + done, st, part, hipMemcpyHostToDevice, ctx->stream));
+        done += part;
+    }
+    return PFZ_OK;
+}
+
+int copy_d2h(pfz_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0) return PFZ_OK;
+    if (bytes > kStageDirect) {
+        PFZ_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        return PFZ_OK;
+    }
+    for (size_t done = 0; done < bytes;) {
+        const size_t part = bytes - done < kStageBytes ? bytes - done : kStageBytes;
+        char *st = nullptr;
+        PFZ_TRY(stage_take(ctx, part, &st));
+        PFZ_HIP(hipMemcpyAsync(st, (const char *)src_dev + done, part, hipMemcpyDeviceToHost, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy((char *)dst_host + done, st, part);
+        ctx->stage_off = 0;                           // the stream is idle: the whole buffer is free again
+        done += part;
+    }
+    return PFZ_OK;
+}
+
 // ---- caching allocator -------------------------------------------------------
 static std::mutex g_pool_mu;
 static std::unordered_map<void *, std::pair<pfz_ctx *, size_t>> g_pool_owner;  // live block -> (ctx, class size)
@@ -334,6 +395,7 @@ void pfz_ctx_destroy(pfz_ctx *ctx)
     for (int i = 0; i < kEventSlots; ++i)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     (void)pool_release(ctx);
     {   // blocks still owned by live handles of this context: free them, the handles become inert
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -468,12 +530,11 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
     PFZ_TRY(pool_alloc(ctx, &m->indptr, (size_t)(n_rows + 1) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
-    PFZ_HIP(hipMemcpyAsync(m->indptr, ip32.data(), (size_t)(n_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PFZ_TRY(copy_h2d(ctx, m->indptr, ip32.data(), (size_t)(n_rows + 1) * sizeof(int32_t)));
     if (nnz > 0) {
-        PFZ_HIP(hipMemcpyAsync(m->indices, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        PFZ_HIP(hipMemcpyAsync(m->data, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        PFZ_TRY(copy_h2d(ctx, m->indices, indices, (size_t)nnz * sizeof(int32_t)));
+        PFZ_TRY(copy_h2d(ctx, m->data, data, (size_t)nnz * sizeof(float)));
     }
-    PFZ_HIP(hipStreamSynchronize(ctx->stream));  // ip32 is a temporary
     *out = m.release();
     return PFZ_OK;
 }
@@ -494,11 +555,11 @@ int pfz_csr_download(pfz_ctx *ctx, const pfz_csr *m, int64_t *indptr, int32_t *i
     PFZ_HIP(hipStreamSynchronize(ctx->stream));
     if (indptr) {
         std::vector<int32_t> ip32((size_t)m->n_rows + 1);
-        PFZ_HIP(hipMemcpy(ip32.data(), m->indptr, ip32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        PFZ_TRY(copy_d2h(ctx, ip32.data(), m->indptr, ip32.size() * sizeof(int32_t)));
         for (size_t i = 0; i < ip32.size(); ++i) indptr[i] = ip32[i];
     }
-    if (indices && m->nnz > 0) PFZ_HIP(hipMemcpy(indices, m->indices, (size_t)m->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (data && m->nnz > 0) PFZ_HIP(hipMemcpy(data, m->data, (size_t)m->nnz * sizeof(float), hipMemcpyDeviceToHost));
+    if (indices && m->nnz > 0) PFZ_TRY(copy_d2h(ctx, indices, m->indices, (size_t)m->nnz * sizeof(int32_t)));
+    if (data && m->nnz > 0) PFZ_TRY(copy_d2h(ctx, data, m->data, (size_t)m->nnz * sizeof(float)));
     return PFZ_OK;
 }
 
@@ -556,8 +617,8 @@ int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *
     PFZ_HIP(hipStreamSynchronize(ctx->stream));
     size_t n = (size_t)t->n_rows * (size_t)t->ntop;
     if (n == 0) return PFZ_OK;
-    if (out_idx) PFZ_HIP(hipMemcpy(out_idx, t->idx, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (out_val) PFZ_HIP(hipMemcpy(out_val, t->val, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_idx) PFZ_TRY(copy_d2h(ctx, out_idx, t->idx, n * sizeof(int32_t)));
+    if (out_val) PFZ_TRY(copy_d2h(ctx, out_val, t->val, n * sizeof(float)));
     return PFZ_OK;
 }
 

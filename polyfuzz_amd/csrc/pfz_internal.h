@@ -60,6 +60,9 @@ struct pfz_ctx {
     // reusable scratch (grown on demand, never inside a timed region after warm-up)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // pinned staging buffer of the host <-> device copies (copy_h2d / copy_d2h)
+    char *stage = nullptr;
+    size_t stage_bytes = 0, stage_off = 0;
     // caching allocator state: size class -> free blocks
     std::map<size_t, std::vector<void *>> pool_free_lists;
     size_t pool_cached_bytes = 0, pool_live_bytes = 0;
@@ -149,6 +152,13 @@ template <typename T, void (*Free)(T *)> struct Owner {
 };
 
 int ensure_scratch(pfz_ctx *ctx, size_t bytes);
+// Host <-> device copies of caller-owned (pageable) buffers through the context's pinned staging buffer.
+// Handing a pageable pointer to hipMemcpy makes the runtime register those pages with the GPU driver; when
+// the caller later frees the buffer (a numpy array, a Python bytes object) the unmap evicts and restores the
+// process' GPU queues -- measured here as +20..30 ms on every second TFIDF.match() call.  Both enqueue on
+// ctx->stream; copy_d2h blocks until the data is in `dst`, copy_h2d returns once `src` may be reused.
+int copy_h2d(pfz_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int copy_d2h(pfz_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 // profile helpers: bracket a launch when ctx->prof is on
 struct ProfScope {
     pfz_ctx *ctx;
