@@ -96,6 +96,9 @@ void pfz_index_free(pfz_index *ix);
 /* bytes of postings + offset table (for the bench's byte accounting) */
 int pfz_index_info(const pfz_index *ix, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
                    int64_t *block_cols, int64_t *n_blocks, int64_t *table_bytes);
+/* the index stores every (n-gram, to-block) posting list padded to whole pieces of `piece_postings`
+ * (16) postings = one 128-byte line each: number of pieces (index bytes = 128 * (n_pieces + 1)) */
+int pfz_index_pieces(const pfz_index *ix, int64_t *n_pieces, int64_t *piece_postings);
 
 int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out);
 void pfz_topn_free(pfz_topn *t);
@@ -114,8 +117,8 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
  * _utils.py:84-87; diag_offset = global index of from-row 0 when the from
  * side is a row shard).  lower_bound < 0 is treated as 0 (non-positive scores
  * are "no match" in the reference's output contract, _utils.py:122-123).
- * Limits: 1 <= ntop <= 128 (PFZ_ERR_UNSUPPORTED beyond); fewer than 2^28
- * postings in the to-side; n_cols equal on both sides.  `out` may have MORE rows than the from-matrix (a padded
+ * Limits: 1 <= ntop <= 128 (PFZ_ERR_UNSUPPORTED beyond); fewer than 2^25
+ * 16-posting index pieces (4 GiB) in the to-side; n_cols equal on both sides.  `out` may have MORE rows than the from-matrix (a padded
  * shard buffer for the equal-sized all-gather): the extra rows are not touched.
  * Enqueues on the context stream. */
 int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "pfz_index_build": (ctypes.c_int, [c_vp, c_vp, P(c_vp)]),
     "pfz_index_free": (None, [c_vp]),
     "pfz_index_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
+    "pfz_index_pieces": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
     "pfz_topn_alloc": (ctypes.c_int, [c_vp, c_i64, c_i32, P(c_vp)]),
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
@@ -264,7 +265,11 @@ class DeviceIndex(_Handle):
         v = [c_i64() for _ in range(6)]
         check(self.ctx.lib.pfz_index_info(self.h, *[ctypes.byref(x) for x in v]))
         keys = ("n_rows", "n_cols", "nnz", "block_cols", "n_blocks", "table_bytes")
-        return dict(zip(keys, (x.value for x in v)))
+        out = dict(zip(keys, (x.value for x in v)))
+        npc, per = c_i64(), c_i64()
+        check(self.ctx.lib.pfz_index_pieces(self.h, ctypes.byref(npc), ctypes.byref(per)))
+        out.update(n_pieces=npc.value, piece_postings=per.value)
+        return out
 
 
 class DeviceTopN(_Handle):

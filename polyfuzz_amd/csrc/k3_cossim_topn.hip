@@ -7,67 +7,71 @@
 // Data layout in HBM
 //   from side : CSR (indptr int32, indices int32 sorted, data fp32)
 //   to side   : inverted index.  The to-rows are cut into blocks of C rows
-//               (C = 2048 / 4096 / 8192); for n-gram id k and block b the
-//               postings (byte offset of the to-row's accumulator, fp32 value)
-//               are post[tab[k*nb+b] .. tab[k*nb+b+1]).  tab is one int32 array
-//               of V*nb+1 offsets, so a from-row walks block b of all its
-//               n-grams by streaming along one table row per n-gram.
+//               (C = 1024 / 2048 / 4096); the postings of n-gram id k in block b
+//               -- (byte offset of the to-row's accumulator, fp32 value) pairs --
+//               form list (k,b).  Every list is PADDED to a multiple of 16
+//               postings with zero-valued entries, so the index is an array of
+//               16-posting PIECES, each exactly one aligned 128-byte line:
+//               piece p is post[16p .. 16p+16), list (k,b) is pieces
+//               tab[k*nb+b] .. tab[k*nb+b+1).  tab is one int32 array of V*nb+1
+//               piece offsets, so a from-row walks block b of all its n-grams by
+//               streaming along one table row per n-gram.  Piece tab[V*nb] is an
+//               all-zero dummy.
 //
 // Arithmetic: fixed point.  Every product a*b is computed in fp32, scaled by
 // S = 2^30 / (norm bound) and truncated to int32; the accumulators are int32 and
 // are updated with ds_add_u32.  Integer addition is associative, so the sum does
 // not depend on the order in which postings arrive: results are bit-reproducible,
 // exact ties (duplicate to-strings) stay exact ties, and the kernel is free to
-// process postings in whatever order fills the lanes best.  |sum/S - exact| is
-// below 13 * 2^-30 + fp32 product rounding (~3e-8), far inside the 1e-5 budget.
+// process postings in whatever order fills the lanes best -- and a padding entry
+// (value 0) adds nothing.  |sum/S - exact| is below 13 * 2^-30 + fp32 product
+// rounding (~3e-8), far inside the 1e-5 budget.
 // (Measured on MI355X, tools/ubench/lds_atomic.hip: ds_add_u32 6.6 lanes/clk/CU,
 // plain LDS read+fadd+write 3.6, ds_add_f32 0.31 -- the float atomic is unusable.)
 //
-// Kernel (one workgroup of W waves == one from-row at a time; the hardware
+// Kernel (one one-wave workgroup == one from-row at a time; the hardware
 // dispatcher load-balances the very skewed rows)
 //   for each to-block b:
-//     scatter: lane l owns n-gram l of the row and its (k,b) posting range; the
-//       ranges are cut into 64-entry chunks, numbered across all lists, and dealt
-//       round-robin to the W waves of the workgroup, kSlots chunk loads in flight
-//       per wave (see scatter_block).
+//     scatter: lane l owns n-gram l of the row and its (k,b) list; the lists'
+//       pieces are numbered across all lists (DPP prefix sum) and dealt to the
+//       four 16-lane quarters of the wave, 64 pieces per round: a round finds the
+//       owner list of each of its 64 pieces once (LDS markers + DPP max-scan,
+//       three ds_bpermute), then every step is v_add_dpp / global_load_dwordx2 /
+//       v_mul_dpp / v_cvt / ds_add_u32 with the quarter's piece descriptor
+//       broadcast by DPP row_newbcast -- no scalar work, no exec masking, one
+//       full 128-byte line per quarter (see scatter_pieces).
 //     sweep: lanes read acc as int4 pairs, write zeros back, and test the max of
 //       8 sums against the running threshold (v_max3_i32); survivors go to a
-//       per-wave candidate buffer as 64-bit keys sum<<32 | ~col, so an unsigned
-//       max is "score desc, col asc".  When the buffer fills the wave keeps its
-//       ntop best (rounds of wave-max) and raises the threshold to the ntop-th sum.
+//       candidate buffer as 64-bit keys sum<<32 | ~col, so an unsigned max is
+//       "score desc, col asc".  When the buffer fills the wave keeps its ntop best
+//       (rounds of wave-max) and raises the threshold to the ntop-th sum.
 //   The final compaction leaves the sorted top-n; lanes write (idx, sum/S).
 //
-// Roofline: bound by LDS atomics + sweep and by instruction issue; HBM traffic is
-// ~1/3 of the algorithmic bytes (8 B per multiply-add + 8 B per from-nnz + 8 B
-// per result) because the index (tens of MB) lives in L2 / Infinity Cache.
+// Roofline: bound by LDS (atomics + sweep) and instruction issue; the index
+// (tens of MB) is served by L2 / Infinity Cache, not HBM.
 #include "pfz_internal.h"
 
 #include <math.h>
 #include <stdlib.h>
+#include <utility>
 
 namespace pfz {
 
-// Candidate keys per wave are a template parameter CAP of the kernel: 128 (1 KiB of LDS) for
-// ntop <= 64, 256 for ntop <= 128 -- LDS per workgroup decides how many from-rows a CU works on
-// at once, and CAP = 128 instead of 256 alone took K3 from 6.1 to 5.3 ms.
 constexpr int kMergeCap = 256;   // candidate keys per wave in k3_merge_slices
 constexpr int kMaxTop = 128;
 constexpr int kSelectMinTop = 16;  // above this top_n, intermediate compactions select instead of sorting
 constexpr int kWarmMaxTop = 8;    // threshold warm start (one wave-max round per rank) up to this top_n
-#ifndef PFZ_K3_EXP
-#define PFZ_K3_EXP 0   // timing experiments (tools/build_variant.sh -DPFZ_K3_EXP=n); 0 = the product
-#endif
-#ifndef PFZ_K3_SLOTS
-#define PFZ_K3_SLOTS 16
-#endif
-constexpr int kSlots = PFZ_K3_SLOTS;   // 64-entry posting chunks in flight per wave, a multiple of 4 (measured: 8 4.64 ms, 16 4.43 ms)
+constexpr int kPiece = 16;        // postings per piece (one 128-byte line, one 16-lane DPP row)
 
 // ---------------------------------------------------------------------------
 // inverted-index build (`block` to-rows per block)
+//   cnt[k*nb + b]  = postings of list (k,b)                 (count kernels)
+//   tab[k*nb + b]  = pieces of the list -> exclusive scan -> first piece
+//   pad, then fill: post[16 * tab[k*nb+b] + position inside the list]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_index_count(const int32_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices, int32_t n_rows,
-                                                      int32_t nb, int32_t block, int32_t *__restrict__ tab1 /* tab + 1 */)
+                                                      int32_t nb, int32_t block, int32_t *__restrict__ cnt)
 {
     // one 16-lane group per to-row: rows have ~13 entries
     const int gid = (blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -75,14 +79,15 @@ __global__ __launch_bounds__(256) void k_index_count(const int32_t *__restrict__
     if (gid >= n_rows) return;
     const int p0 = indptr[gid], p1 = indptr[gid + 1];
     const int b = gid / block;
-    for (int p = p0 + sub; p < p1; p += 16) atomicAdd(&tab1[(int64_t)indices[p] * nb + b], 1);
+    for (int p = p0 + sub; p < p1; p += 16) atomicAdd(&cnt[(int64_t)indices[p] * nb + b], 1);
 }
 
+// (global-atomics path of huge vocabularies) position inside the list = what is left of the count
 __global__ __launch_bounds__(256) void k_index_fill(const int32_t *__restrict__ indptr,
                                                      const int32_t *__restrict__ indices,
                                                      const float *__restrict__ data, int32_t n_rows, int32_t nb,
-                                                     int32_t block, int32_t *__restrict__ tab1,
-                                                     int2 *__restrict__ post)
+                                                     int32_t block, int32_t *__restrict__ cnt,
+                                                     const int32_t *__restrict__ tab, int2 *__restrict__ post)
 {
     const int gid = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
@@ -92,21 +97,46 @@ __global__ __launch_bounds__(256) void k_index_fill(const int32_t *__restrict__ 
     const int local = gid - b * block;
     for (int p = p0 + sub; p < p1; p += 16) {
         // the order inside one (k,b) list is irrelevant to the results (integer sums)
-        int pos = atomicAdd(&tab1[(int64_t)indices[p] * nb + b], 1);
-        post[pos] = make_int2(local * 4, __float_as_int(data[p]));   // .x = byte offset into acc
+        const int64_t slot = (int64_t)indices[p] * nb + b;
+        const int pos = atomicSub(&cnt[slot], 1) - 1;
+        post[(int64_t)tab[slot] * kPiece + pos] = make_int2(local * 4, __float_as_int(data[p]));   // .x = byte offset into acc
     }
 }
 
-// The same two passes WITHOUT global atomics (device-scope atomics cost ~85 ns each in aggregate on
+// pieces per list (before the scan)
+__global__ __launch_bounds__(256) void k_index_pieces(const int32_t *__restrict__ cnt, int64_t slots,
+                                                       int32_t *__restrict__ tab)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < slots) tab[i] = (cnt[i] + kPiece - 1) / kPiece;
+}
+
+// Padding entries of every list (positions count .. 16*pieces) and the dummy piece at n_pieces: value 0
+// -- they add nothing -- at accumulator offsets spread over 64 cells, so the padding lanes of one
+// ds_add_u32 do not pile up on one LDS address.
+__global__ __launch_bounds__(256) void k_index_pad(const int32_t *__restrict__ cnt, const int32_t *__restrict__ tab,
+                                                    int64_t slots, int32_t n_pieces, int2 *__restrict__ post)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < kPiece) post[(int64_t)n_pieces * kPiece + i] = make_int2((int)i * 4, 0);
+    if (i >= slots) return;
+    const int c = cnt[i];
+    if ((c & (kPiece - 1)) == 0) return;
+    const int64_t base = (int64_t)tab[i] * kPiece;
+    const int end = (c + kPiece - 1) & ~(kPiece - 1);
+    for (int p = c; p < end; ++p) post[base + p] = make_int2(((((int)i & 3) << 4) | (p & 15)) * 4, 0);
+}
+
+// The count / fill passes WITHOUT global atomics (device-scope atomics cost ~85 ns each in aggregate on
 // this part -- 1.3 M of them were 90 % of the index build): one workgroup per to-block keeps a
 // histogram of the block's n-grams in LDS, two 16-bit counters per word (a block has at most 8192
 // rows), for vocabularies of up to 2 * kHistWords n-grams.
-//   count: tab[k*nb + b] = number of rows of block b that contain k      (tab zeroed beforehand)
+//   count: cnt[k*nb + b] = number of rows of block b that contain k      (cnt zeroed beforehand)
 //   fill : position inside the (k,b) list = value the LDS counter had before this row's increment
 __global__ __launch_bounds__(1024) void k_index_count_lds(const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices, int32_t n_rows,
                                                            int32_t nb, int32_t block, int32_t words,
-                                                           int32_t *__restrict__ tab)
+                                                           int32_t *__restrict__ cnt)
 {
     __shared__ uint32_t h[kHistWords];
     for (int t = threadIdx.x; t < words; t += 1024) h[t] = 0u;
@@ -145,8 +175,8 @@ __global__ __launch_bounds__(1024) void k_index_count_lds(const int32_t *__restr
     __syncthreads();
     for (int w = threadIdx.x; w < words; w += 1024) {
         const uint32_t v = h[w];
-        if (v & 0xffffu) tab[(int64_t)(2 * w) * nb + b] = (int32_t)(v & 0xffffu);
-        if (v >> 16) tab[(int64_t)(2 * w + 1) * nb + b] = (int32_t)(v >> 16);
+        if (v & 0xffffu) cnt[(int64_t)(2 * w) * nb + b] = (int32_t)(v & 0xffffu);
+        if (v >> 16) cnt[(int64_t)(2 * w + 1) * nb + b] = (int32_t)(v >> 16);
     }
 }
 
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
                                                           const int32_t *__restrict__ indices,
                                                           const float *__restrict__ data, int32_t n_rows, int32_t nb,
                                                           int32_t block, int32_t words,
-                                                          const int32_t *__restrict__ tab /* starts */,
+                                                          const int32_t *__restrict__ tab /* first pieces */,
                                                           int2 *__restrict__ post)
 {
     __shared__ uint32_t h[kHistWords];
@@ -164,12 +194,12 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
     const int lo = b * block, hi = min(n_rows, lo + block);
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int lane0 = (threadIdx.x & 63) & ~15;
-    // one posting: its list position = start(k,b) + the value the LDS counter had before this row
+    // one posting: its list position = the value the LDS counter had before this row
     // (the order inside one (k,b) list is irrelevant to the results: integer sums)
     auto place = [&](int k, float v, int row, int start) {
         const int sh = (k & 1) * 16;
         const uint32_t old = atomicAdd(&h[k >> 1], 1u << sh);
-        post[start + (int)((old >> sh) & 0xffffu)] = make_int2((row - lo) * 4, __float_as_int(v));   // .x = byte offset into acc
+        post[(int64_t)start * kPiece + (int)((old >> sh) & 0xffffu)] = make_int2((row - lo) * 4, __float_as_int(v));   // .x = byte offset into acc
     };
     for (int rb = lo + grp * 16; rb < hi; rb += 64 * 16) {   // 16 consecutive rows per group, as in the count kernel
         const int mine = rb + sub;
@@ -238,58 +268,6 @@ __device__ inline int max3i(int a, int b, int c)
     int r;
     asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
-}
-
-// acc += trunc(as * b) at byte offset off
-__device__ inline void acc_add(int *acc, int off, float as, int bbits)
-{
-    const int v = (int)(as * __int_as_float(bbits));
-#if PFZ_K3_EXP == 5     // timing experiment: no LDS atomics (results are wrong)
-    if (v == 0x7fffffff) atomicAdd((int *)((char *)acc + off), v);
-#elif PFZ_K3_EXP == 7   // timing experiment: conflict-free LDS addresses (results are wrong)
-    atomicAdd((int *)((char *)acc + (((off >> 8) << 8) & 0x1f00) + (threadIdx.x & 63) * 4), v);
-#else
-    atomicAdd((int *)((char *)acc + off), v);
-#endif
-}
-
-// Four chunk applications  acc[x] += trunc(as * b)  for the lanes of each chunk's mask, as one
-// straight-line sequence: per chunk  s_mov exec / v_mul / v_cvt / ds_add.  (The compiler's own
-// lowering of `if (ok) ...` is s_and_saveexec + s_cbranch_execz + ... + s_or per chunk, and every
-// instruction of a wave costs an issue turn.)  The accumulators sit at LDS address 0 (checked in the
-// kernel), so a posting's byte offset is its LDS address.
-__device__ inline void apply4(const uint64_t (&m)[4], const int2 (&pe)[4], const float (&pa)[4])
-{
-#if PFZ_K3_EXP == 5 || PFZ_K3_EXP == 7
-    for (int j = 0; j < 4; ++j)
-        if ((m[j] >> (threadIdx.x & 63)) & 1) acc_add((int *)nullptr + 0, pe[j].x, pa[j], pe[j].y);
-#else
-    int t0, t1, t2, t3;
-    uint64_t saved;
-    asm volatile(
-        "s_mov_b64 %4, exec\n\t"
-        "s_mov_b64 exec, %5\n\t"
-        "v_mul_f32_e32 %0, %9, %13\n\t"
-        "v_cvt_i32_f32_e32 %0, %0\n\t"
-        "ds_add_u32 %17, %0\n\t"
-        "s_mov_b64 exec, %6\n\t"
-        "v_mul_f32_e32 %1, %10, %14\n\t"
-        "v_cvt_i32_f32_e32 %1, %1\n\t"
-        "ds_add_u32 %18, %1\n\t"
-        "s_mov_b64 exec, %7\n\t"
-        "v_mul_f32_e32 %2, %11, %15\n\t"
-        "v_cvt_i32_f32_e32 %2, %2\n\t"
-        "ds_add_u32 %19, %2\n\t"
-        "s_mov_b64 exec, %8\n\t"
-        "v_mul_f32_e32 %3, %12, %16\n\t"
-        "v_cvt_i32_f32_e32 %3, %3\n\t"
-        "ds_add_u32 %20, %3\n\t"
-        "s_mov_b64 exec, %4"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(saved)
-        : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(pa[0]), "s"(pa[1]), "s"(pa[2]), "s"(pa[3]),
-          "v"(pe[0].y), "v"(pe[1].y), "v"(pe[2].y), "v"(pe[3].y), "v"(pe[0].x), "v"(pe[1].x), "v"(pe[2].x), "v"(pe[3].x)
-        : "memory");
-#endif
 }
 
 struct TopState {
@@ -378,22 +356,6 @@ __device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0
     }
 }
 
-// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads()
-// would also drain vmcnt and expose the latency of the offset-table prefetch.
-__device__ inline void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// The same hand-off between the W waves of a workgroup.  A one-wave workgroup needs no
-// instruction at all: its LDS operations execute in program order.
-template <int W>
-__device__ inline void wg_sync()
-{
-    if (W == 1) wave_sync();
-    else lds_barrier();
-}
-
 // Warm start of the threshold from the first block a from-row touches.  With the threshold still at the
 // lower bound every non-zero sum of that block would be pushed (and compacted away again).  The k-th
 // largest of the 64 lanes' own maxima is a lower bound of the k-th largest sum of the block (each lane
@@ -445,134 +407,139 @@ __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int
     }
 }
 
-// Scatter this wave's share of the (k,b) posting lists of up to 64 n-grams of one
-// from-row into the workgroup's accumulators.
-//   s, e : per lane, the lane's posting range in this block (e == s: nothing)
-//   as   : per lane, the row's value for the lane's n-gram times the fixed-point scale
-// The lists are cut into 64-entry chunks and the chunks numbered g = 0..T-1 across
-// all lists (inclusive prefix `pin` of the per-lane chunk counts).  Because the sums
-// are integers the order is free, so chunk g simply belongs to wave g % W, and a
-// wave finds the list of ANY chunk number in O(1): owner lane = number of lanes
-// whose prefix is <= g (one v_cmp + s_bcnt1).  kSlots chunk loads are in flight per
-// wave, regardless of list boundaries.
-template <int W>
-__device__ inline void scatter_block(int *acc, const int2 *__restrict__ post, int s, int e, float as, int lane,
-                                     int wave, bool acc_at_lds0)
+// ---------------------------------------------------------------------------
+// scatter
+// ---------------------------------------------------------------------------
+// NS steps of one round.  Lane L = 16q + s holds in (addr_t, as_t) the descriptor of the piece quarter q
+// processes in step s: byte offset of the piece in the index and the from-row's scaled value for the
+// piece's n-gram.  A step broadcasts lane s of every 16-lane row to the row (DPP row_newbcast, folded
+// into the add / the multiply), so quarter q's 16 lanes read the 16 postings of their piece -- one aligned
+// 128-byte line -- and apply them: acc[x] += trunc(as * b).  All loads of the round are issued before the
+// first is consumed.  The accumulators sit at LDS address 0 (checked in the kernel), so a posting's byte
+// offset is its LDS address and the add below folds to nothing.
+template <int S> __device__ inline int row_bcast_i(int v)
 {
-    const int nch = (e - s + 63) >> 6;
-    // inclusive scan over the 64 lanes with DPP adds (no LDS traffic, unlike __shfl_up/ds_bpermute):
-    // row_shr 1,2,4,8 inside each 16-lane row, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
-    int pin = nch;
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xf, 0xf, false);   // DPP row_newbcast:S
+}
+
+template <int... S>
+__device__ inline void run_steps_seq(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8,
+                                     std::integer_sequence<int, S...>)
+{
+    const int2 pe[sizeof...(S)] = {*(const int2 *)(post_bytes + (uint32_t)(row_bcast_i<S>(addr_t) + sub8))...};
+    (atomicAdd((int *)((char *)acc + pe[S].x),                               // ds_add_u32, no return
+               (int)(__int_as_float(row_bcast_i<S>(__float_as_int(as_t))) * __int_as_float(pe[S].y))), ...);
+}
+
+template <int NS>
+__device__ inline void run_steps(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8)
+{
+    run_steps_seq(acc, post_bytes, addr_t, as_t, sub8, std::make_integer_sequence<int, NS>{});
+}
+
+__device__ inline int dpp_max_scan(int m)
+{
+    // inclusive prefix maximum over the 64 lanes (values >= 0): row_shr 1,2,4,8 inside each 16-lane row,
+    // then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
+    return m;
+}
+
+// Scatter the (k,b) lists of up to 64 n-grams of one from-row into the accumulators.
+//   np, st : per lane, number of pieces and first piece of the lane's list in this block (np == 0: nothing)
+//   as     : per lane, the row's value for the lane's n-gram times the fixed-point scale
+//   mark   : 64 ints of LDS scratch (the unused tail of the candidate buffer)
+// The pieces of all lists are numbered P = 0..T-1 (prefix sum of np) and taken 64 per round; in a round
+// quarter q of the wave processes pieces 4s + q, s = 0.., so the four quarters stay busy to the last step
+// whatever T is.  Owner search, once per round: every list that overlaps the round's window writes its lane
+// number at the window position of its first piece, a prefix maximum spreads it over the list's pieces.
+__device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_bytes, int *mark, int np, int st, float as,
+                                      int lane, int src4, int sub8, int dummy_addr)
+{
+    // inclusive scan over the 64 lanes with DPP adds (no LDS traffic, unlike __shfl_up/ds_bpermute)
+    int pin = np;
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x111, 0xf, 0xf, false);
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x112, 0xf, 0xf, false);
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x114, 0xf, 0xf, false);
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x118, 0xf, 0xf, false);
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x142, 0xa, 0xf, false);
     pin += __builtin_amdgcn_update_dpp(0, pin, 0x143, 0xc, 0xf, false);
-    // BYTE offset of entry (chunk g, lane) of the lane's list = qbase8 + g*512 + lane*8; everything is kept
-    // in bytes so that the per-chunk work is one scalar add, one v_add, one v_cmp and one v_cndmask
-    const int qbase8 = (s - (pin - nch) * 64) * 8;
-    const int e8 = e * 8;
-    const int lane8 = lane * 8;
     const int total = __builtin_amdgcn_readlane(pin, 63);
-    const int pin_cmp = lane == 63 ? 0x7fffffff : pin;
-    const char *post_bytes = (const char *)post;
-    // The kernel is bound by VALU issue (a wave64 instruction occupies its SIMD for four cycles), so the
-    // per-chunk instruction count is what matters: the uniform part of the address is added on the
-    // scalar unit (inline asm: the compiler would otherwise carry it in a VGPR), and the second half of
-    // a round is skipped when the block has no chunks left for it.
-    constexpr int kGroup = 4, kGroups = kSlots / kGroup;
-    for (int g0 = wave; g0 < total; g0 += W * kSlots) {
-        int2 pe[kSlots];
-        float pa[kSlots];
-        uint64_t okm[kSlots];
-        auto issue = [&](int j) {
-            const int g = g0 + j * W;                                   // wave-uniform chunk number
-            // lane that owns chunk g = number of lanes whose prefix is <= g.  Lane 63 never counts (its
-            // prefix is replaced by INT_MAX), so the result is a valid lane without a clamp; for
-            // g >= total it is lane 63, whose list ends before chunk g: all lanes idle
-            const int src = __popcll(__ballot(pin_cmp <= g));
-            const int ee8 = __builtin_amdgcn_readlane(e8, src);
-            int sbase;
-            asm("s_add_i32 %0, %1, %2" : "=s"(sbase) : "s"(__builtin_amdgcn_readlane(qbase8, src)), "s"(g * 512) : "scc");
-            const int q8 = sbase + lane8;
-            pa[j] = readlane_f(as, src);
-            const bool okj = q8 < ee8;
-            okm[j] = __ballot(okj);
-            // unconditional load (idle lanes re-read entry 0): a branch around the load would make
-            // the compiler wait for every load separately.  32-bit unsigned byte offset from the
-            // uniform base -> SGPR-base addressing, no 64-bit address arithmetic per lane.
-            const uint32_t off = okj ? (uint32_t)q8 : 0u;
-#if PFZ_K3_EXP == 6     // timing experiment: no posting loads (results are wrong)
-            pe[j] = make_int2((int)((off * 2654435761u) >> 19) & 8188, 0x3c000000);
-#else
-            pe[j] = *(const int2 *)(post_bytes + off);
-#endif
-        };
-        // groups of four chunk loads; a group is skipped (wave-uniformly) when the block has no chunk for it
-#pragma unroll
-        for (int q = 0; q < kGroups; ++q) {
-            if (q == 0 || g0 + W * kGroup * q < total) {
-#pragma unroll
-                for (int j = q * kGroup; j < (q + 1) * kGroup; ++j) issue(j);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < kGroups; ++q) {
-            if (q == 0 || g0 + W * kGroup * q < total) {
-                if (acc_at_lds0) {
-                    const uint64_t m4[4] = {okm[q * 4], okm[q * 4 + 1], okm[q * 4 + 2], okm[q * 4 + 3]};
-                    const int2 p4[4] = {pe[q * 4], pe[q * 4 + 1], pe[q * 4 + 2], pe[q * 4 + 3]};
-                    const float a4[4] = {pa[q * 4], pa[q * 4 + 1], pa[q * 4 + 2], pa[q * 4 + 3]};
-                    apply4(m4, p4, a4);
-                } else {
-#pragma unroll
-                    for (int j = q * kGroup; j < (q + 1) * kGroup; ++j)
-                        if ((okm[j] >> lane) & 1) acc_add(acc, pe[j].x, pa[j], pe[j].y);
-                }
-            }
+    const int excl = pin - np;
+    const int base = st - excl;            // piece P of this list is index piece base + P
+    const int pt = 4 * (lane & 15) + (lane >> 4);   // window position of the piece this lane processes
+    for (int r0 = 0; r0 < total; r0 += 64) {
+        const int rel = excl - r0;
+        mark[lane] = 0;
+        if (np > 0 && rel < 64 && rel + np > 0) mark[rel > 0 ? rel : 0] = lane + 1;
+        wave_sync();
+        const int owner1 = dpp_max_scan(mark[lane]);                         // owner lane + 1 of window position `lane`
+        const int o4 = __builtin_amdgcn_ds_bpermute(src4, owner1) * 4 - 4;   // ... of window position pt, as a bpermute index
+        const int b_o = __builtin_amdgcn_ds_bpermute(o4, base);
+        const float as_t = __int_as_float(__builtin_amdgcn_ds_bpermute(o4, __float_as_int(as)));
+        const int P = r0 + pt;
+        const int addr_t = P < total ? (int)((uint32_t)(b_o + P) << 7) : dummy_addr;
+        wave_sync();                                                         // mark[] is rewritten by the next round
+        const int left = total - r0;
+        const int ng = left >= 64 ? 8 : (left + 7) >> 3;                     // groups of two steps (8 pieces)
+        switch (ng) {
+        case 1: run_steps<2>(acc, post_bytes, addr_t, as_t, sub8); break;
+        case 2: run_steps<4>(acc, post_bytes, addr_t, as_t, sub8); break;
+        case 3: run_steps<6>(acc, post_bytes, addr_t, as_t, sub8); break;
+        case 4: run_steps<8>(acc, post_bytes, addr_t, as_t, sub8); break;
+        case 5: run_steps<10>(acc, post_bytes, addr_t, as_t, sub8); break;
+        case 6: run_steps<12>(acc, post_bytes, addr_t, as_t, sub8); break;
+        case 7: run_steps<14>(acc, post_bytes, addr_t, as_t, sub8); break;
+        default: run_steps<16>(acc, post_bytes, addr_t, as_t, sub8); break;
         }
     }
 }
 
 
-// C to-rows per block, W waves per workgroup; the workgroup owns one from-row at a time.
-template <int C, int W, int kCap>
-__global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
+// C to-rows per block; the (one-wave) workgroup owns one from-row at a time.
+template <int C, int kCap>
+__global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
     const int32_t *__restrict__ a_indptr, const int32_t *__restrict__ a_idx, const float *__restrict__ a_val,
-    int32_t n_a, const int32_t *__restrict__ tab, const int2 *__restrict__ post, int32_t nb, int32_t ntop,
-    int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset,
+    int32_t n_a, const int32_t *__restrict__ tab, const int2 *__restrict__ post, int32_t nb, int32_t n_pieces,
+    int32_t ntop, int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset,
     int32_t *__restrict__ out_idx, float *__restrict__ out_val, int32_t ablate, int32_t n_slices,
     uint64_t *__restrict__ part_keys)
 {
-    // accumulators first: when they land at LDS address 0 (they do when this struct is the kernel's only
-    // LDS object, i.e. for W == 1) a posting's byte offset IS its LDS address and apply4() can be used
+    // accumulators first: this struct is the kernel's only LDS object, so they land at LDS address 0 and a
+    // posting's byte offset IS its LDS address (run_steps)
     __shared__ __attribute__((aligned(16))) struct {
         int acc[C];
-        uint64_t cand_all[W][kCap];
+        uint64_t cand[kCap];
     } sm;
-    __shared__ int cnt_all[W];   // only referenced (and therefore only allocated) when W > 1
+    static_assert(kCap >= 64 + 32, "the last 32 keys of the candidate buffer double as the scatter's marker scratch");
     int *const acc = sm.acc;
-    uint64_t (*const cand_all)[kCap] = sm.cand_all;
-    constexpr bool acc_at_lds0 = W == 1;
-    if (acc_at_lds0 && (uint32_t)(uintptr_t)sm.acc != 0u) __builtin_trap();   // layout assumption of apply4()
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tell the compiler it is wave-uniform
-    uint64_t *cand = cand_all[wave];
+    uint64_t *const cand = sm.cand;
+    // push4() compacts as soon as more than kCap - 64 keys are buffered, so while a block is scattered the
+    // last 64 keys (512 B) are free: 64 marker ints live in the last 256 B
+    int *const mark = (int *)(sm.cand + kCap) - 64;
+    if ((uint32_t)(uintptr_t)sm.acc != 0u) __builtin_trap();   // layout assumption of run_steps()
+    const int lane = threadIdx.x;
     int4 *acc4 = (int4 *)acc;
-    constexpr int N4 = C / 4 / W;   // int4 slots swept by one wave
+    constexpr int N4 = C / 4;   // int4 slots swept by the wave
     // four zero registers for the whole kernel: as an asm result the compiler cannot re-materialise them
     // (it rebuilt them with 5 instructions in every sweep step)
     int4 zero4;
     asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
                  : "=v"(zero4.x), "=v"(zero4.y), "=v"(zero4.z), "=v"(zero4.w));
-    for (int t = threadIdx.x; t < C / 4; t += W * 64) acc4[t] = make_int4(0, 0, 0, 0);
-    lds_barrier();
+    for (int t = lane; t < C / 4; t += 64) acc4[t] = make_int4(0, 0, 0, 0);
+    wave_sync();
+    const char *post_bytes = (const char *)post;
+    const int src4 = (4 * (lane & 15) + (lane >> 4)) * 4;   // bpermute index of the window position this lane processes
+    const int sub8 = (lane & 15) * 8;                       // byte offset of this lane's posting inside its piece
+    const int dummy_addr = n_pieces << 7;                   // the all-zero piece
 
     // Work item = (from-row, to-slice).  The to-blocks are cut into n_slices contiguous
-    // ranges and item i works on slice i % n_slices: workgroups are dispatched round-robin
-    // over the 8 XCDs (observed, not relied on for correctness), so each XCD's L2 keeps
-    // seeing the same eighth of the inverted index instead of thrashing through all of it.
+    // ranges and item i works on slice i % n_slices (small query batches: fill the chip).
     const int per_slice = (nb + n_slices - 1) / n_slices;
     for (int item = blockIdx.x; item < n_a * n_slices; item += gridDim.x) {
         const int row = item / n_slices, slice = item - row * n_slices;
@@ -581,7 +548,7 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
         const int nnz = p1 - p0;
         const int64_t self_col64 = (int64_t)row + diag_offset;
         const int self_col = (exclude_diag && self_col64 >= 0 && self_col64 < 0x7fffffff) ? (int)self_col64 : -1;
-        TopState st;   // per wave: the best of the columns this wave sweeps
+        TopState st;
         st.cnt = 0;
         st.thr = thr0;
 
@@ -603,8 +570,8 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
             const int s = cur0, e = have0 ? nxt0 : cur0;
             cur0 = e;
             if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];   // prefetch for block b+1 (tab has V*nb+2 slots)
-            bool touched = __ballot(e > s) != 0;    // identical in every wave of the workgroup
-            if (touched && ablate != 1) scatter_block<W>(acc, post, s, e, as0, lane, wave, acc_at_lds0);
+            bool touched = __ballot(e > s) != 0;
+            if (touched && ablate != 1) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
                 int s2 = 0, e2 = 0;
                 float as2 = 0.f;
@@ -616,47 +583,34 @@ __global__ __launch_bounds__(W * 64) void k3_cossim_topn_kernel(
                 }
                 if (__ballot(e2 > s2)) {
                     touched = true;
-                    // (plain C++ apply here: in this rarely taken loop the compiler keeps the chunk masks in
-                    // VGPR pairs, which apply4()'s scalar operands cannot take)
-                    scatter_block<W>(acc, post, s2, e2, as2, lane, wave, false);
+                    scatter_pieces(acc, post_bytes, mark, e2 - s2, s2, as2, lane, src4, sub8, dummy_addr);
                 }
             }
             if (touched && ablate != 2) {
-                wg_sync<W>();      // every wave's updates of this block are in acc
+                wave_sync();      // the wave's LDS operations execute in order: the block's updates are in acc
                 if (!warmed) {
                     warmed = true;
                     if (ntop <= kWarmMaxTop) {
-                        const int t = warm_threshold<N4>(acc4, wave * N4, ntop + (self_col >= 0 ? 1 : 0), lane);
+                        const int t = warm_threshold<N4>(acc4, 0, ntop + (self_col >= 0 ? 1 : 0), lane);
                         st.thr = t > st.thr ? t : st.thr;
                     }
                 }
-                sweep_block<N4, kCap>(acc4, cand, st, wave * N4, b * C, self_col, ntop, lane, zero4);
-                wg_sync<W>();      // acc is zero again
+                sweep_block<N4, kCap>(acc4, cand, st, 0, b * C, self_col, ntop, lane, zero4);
+                wave_sync();      // acc is zero again
             }
         }
 
-        // merge the waves' candidates: wave 0 folds the others' top-n into its own
         compact<kCap>(cand, st, ntop, lane);
-        if (W > 1 && lane == 0) cnt_all[wave] = st.cnt;
-        wg_sync<W>();
-        if (wave == 0) {
-            for (int w = 1; w < W; ++w) {
-                const int cw = cnt_all[w];
-                for (int r = lane; r < cw; r += 64) cand[st.cnt + r] = cand_all[w][r];
-                st.cnt += cw;
-                compact<kCap>(cand, st, ntop, lane);
-            }
-            for (int r = lane; r < ntop; r += 64) {
-                const uint64_t key = r < st.cnt ? cand[r] : 0ull;
-                if (n_slices > 1) {   // partial result of this slice; k3_merge_slices finishes the row
-                    part_keys[((int64_t)row * n_slices + slice) * ntop + r] = key;
-                } else {
-                    out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
-                    out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * inv_scale : 0.f;
-                }
+        for (int r = lane; r < ntop; r += 64) {
+            const uint64_t key = r < st.cnt ? cand[r] : 0ull;
+            if (n_slices > 1) {   // partial result of this slice; k3_merge_slices finishes the row
+                part_keys[((int64_t)row * n_slices + slice) * ntop + r] = key;
+            } else {
+                out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
+                out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * inv_scale : 0.f;
             }
         }
-        wg_sync<W>();    // cand_all is reused by the next item
+        wave_sync();    // cand is reused by the next item
     }
 }
 
@@ -709,17 +663,11 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
 {
     PFZ_REQUIRE(ctx && B && out, "pfz_index_build: NULL argument");
     PFZ_HIP(hipSetDevice(ctx->device));
-    // tuning knob: to-rows per block.  Measured at 100k x 100k (tools/sweep_k3.sh): 2048 rows x 2 waves
-    // is the best point -- larger blocks fill the 64-entry chunks better but cost occupancy (LDS).
+    // tuning knob: to-rows per block (tools/sweep_k3.sh)
     int block = env_int("PFZ_K3_BLOCK", 2048);
-    if (block != 1024 && block != 1536 && block != 2048 && block != 2560 && block != 4096 && block != 8192) block = 2048;
+    if (block != 1024 && block != 1536 && block != 2048 && block != 4096) block = 2048;
     const int64_t nb = (B->n_rows + block - 1) / block;
     const int64_t slots = B->n_cols * nb;
-    if (B->nnz >= ((int64_t)1 << 28)) {
-        set_error("pfz_index_build: %lld postings exceed the 2 GiB the kernel addresses with 32-bit byte offsets",
-                  (long long)B->nnz);
-        return PFZ_ERR_UNSUPPORTED;
-    }
     if (slots >= ((int64_t)1 << 31) - 2) {
         set_error("pfz_index_build: vocabulary %lld x %lld to-blocks exceeds the int32 offset table",
                   (long long)B->n_cols, (long long)nb);
@@ -733,43 +681,57 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     ix->block_cols = block;
     ix->n_blocks = (int32_t)nb;
     ix->max_norm = B->max_norm;
+    struct Tmp {
+        int32_t *p = nullptr;
+        ~Tmp() { if (p) pool_free(p); }
+    } cnt;
     PFZ_TRY(pool_alloc(ctx, &ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
-    PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)(B->nnz > 0 ? B->nnz : 1) * sizeof(int2)));
+    PFZ_TRY(pool_alloc(ctx, &cnt.p, (size_t)(slots + 2) * sizeof(int32_t)));
     PFZ_HIP(hipMemsetAsync(ix->tab, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
-    // (PFZ_NO_LDS_HIST=1 forces the global-atomics path of huge vocabularies: tests)
-    if (B->n_rows > 0 && B->nnz > 0 && B->n_cols <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST")) {
-        // per-block LDS histograms, no global atomics
-        const int32_t words = (int32_t)((B->n_cols + 1) / 2);
+    PFZ_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
+    const bool any = B->n_rows > 0 && B->nnz > 0;
+    // per-block LDS histograms when the vocabulary fits (PFZ_NO_LDS_HIST=1 forces the global-atomics
+    // path of huge vocabularies: tests)
+    const bool lds_hist = B->n_cols <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST");
+    const int32_t words = (int32_t)((B->n_cols + 1) / 2);
+    const unsigned row_grid = (unsigned)((B->n_rows * 16 + 255) / 256);
+    const unsigned slot_grid = (unsigned)((slots + kPiece + 255) / 256);
+    int32_t n_pieces = 0;
+    if (any) {
         {
             ProfScope ps(ctx, "k_index_count");
-            hipLaunchKernelGGL(k_index_count_lds, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
-                               (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab);
+            if (lds_hist)
+                hipLaunchKernelGGL(k_index_count_lds, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
+                                   (int32_t)B->n_rows, (int32_t)nb, block, words, cnt.p);
+            else
+                hipLaunchKernelGGL(k_index_count, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
+                                   (int32_t)B->n_rows, (int32_t)nb, block, cnt.p);
+            hipLaunchKernelGGL(k_index_pieces, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, slots, ix->tab);
         }
-        PFZ_TRY(exclusive_scan_i32(ctx, ix->tab, slots));   // tab[i] = start(i), tab[slots] = nnz
-        {
-            ProfScope ps(ctx, "k_index_fill");
+        PFZ_TRY(exclusive_scan_i32(ctx, ix->tab, slots));   // tab[i] = first piece of list i, tab[slots] = pieces
+        PFZ_HIP(hipMemcpyAsync(&n_pieces, ix->tab + slots, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (n_pieces >= (1 << 25) - 1) {
+        set_error("pfz_index_build: %d index pieces (%lld postings padded to 16 per list and block) exceed the 4 GiB "
+                  "the kernel addresses with 32-bit byte offsets", n_pieces, (long long)B->nnz);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    ix->n_pieces = n_pieces;
+    PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)(n_pieces + 1) * kPiece * sizeof(int2)));
+    {
+        ProfScope ps(ctx, "k_index_fill");
+        // (before the fill: the global-atomics fill counts cnt down)
+        hipLaunchKernelGGL(k_index_pad, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, ix->tab, any ? slots : 0, n_pieces,
+                           ix->post);
+        if (any && lds_hist)
             hipLaunchKernelGGL(k_index_fill_lds, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
                                B->data, (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab, ix->post);
-        }
-        PFZ_HIP(hipGetLastError());
-    } else if (B->n_rows > 0 && B->nnz > 0) {
-        // huge vocabularies: global atomics
-        const unsigned grid = (unsigned)((B->n_rows * 16 + 255) / 256);
-        {
-            ProfScope ps(ctx, "k_index_count");
-            hipLaunchKernelGGL(k_index_count, dim3(grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
-                               (int32_t)B->n_rows, (int32_t)nb, block, ix->tab + 1);
-        }
-        // counts sit at tab[1 + i]; exclusive scan of tab[1..] -> tab[1+i] = start(i)
-        PFZ_TRY(exclusive_scan_i32(ctx, ix->tab + 1, slots));
-        {
-            ProfScope ps(ctx, "k_index_fill");
-            // the fill advances tab[1+i] to end(i) = start(i+1); tab[0] = 0 = start(0)
-            hipLaunchKernelGGL(k_index_fill, dim3(grid), dim3(256), 0, ctx->stream, B->indptr, B->indices, B->data,
-                               (int32_t)B->n_rows, (int32_t)nb, block, ix->tab + 1, ix->post);
-        }
-        PFZ_HIP(hipGetLastError());
+        else if (any)
+            hipLaunchKernelGGL(k_index_fill, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices, B->data,
+                               (int32_t)B->n_rows, (int32_t)nb, block, cnt.p, ix->tab, ix->post);
     }
+    PFZ_HIP(hipGetLastError());
     *out = ix.release();
     return PFZ_OK;
 }
@@ -793,6 +755,14 @@ int pfz_index_info(const pfz_index *ix, int64_t *n_rows, int64_t *n_cols, int64_
     if (block_cols) *block_cols = ix->block_cols;
     if (n_blocks) *n_blocks = ix->n_blocks;
     if (table_bytes) *table_bytes = (ix->n_cols * ix->n_blocks + 2) * (int64_t)sizeof(int32_t);
+    return PFZ_OK;
+}
+
+int pfz_index_pieces(const pfz_index *ix, int64_t *n_pieces, int64_t *piece_postings)
+{
+    PFZ_REQUIRE(ix, "pfz_index_pieces: NULL index");
+    if (n_pieces) *n_pieces = ix->n_pieces;
+    if (piece_postings) *piece_postings = kPiece;
     return PFZ_OK;
 }
 
@@ -821,9 +791,8 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     const float scale = (float)ldexp(1.0, k), inv_scale = (float)ldexp(1.0, -k);
     const double thr_d = floor((double)lower_bound * (double)scale);
     const int32_t thr0 = thr_d >= 2147483000.0 ? 2147483000 : (int32_t)thr_d;
-    // to-side slices: one per XCD when there are enough blocks (tuning knob PFZ_K3_SLICES)
-    // (measured: slicing LOSES at 100k x 100k -- 7.4 ms -> 9.9 ms with 8 slices -- because every slice
-    // restarts the top-n threshold and pays the row set-up again; it stays off by default)
+    // to-side slices (tuning knob PFZ_K3_SLICES).  Slicing LOSES on a full job -- every slice restarts the
+    // top-n threshold and pays the row set-up again -- and stays off there
     int n_slices = env_int("PFZ_K3_SLICES", 0);
     if (n_slices <= 0) {
         // auto: a small query batch (fit once / transform many, reference polyfuzz.py:234-240) cannot fill
@@ -848,41 +817,30 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     const int64_t items = A->n_rows * n_slices;
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 16 * 64 * 8;
     const unsigned grid = (unsigned)(items < max_grid ? items : max_grid / n_slices * n_slices);
-    const int waves = env_int("PFZ_K3_WAVES", 1);   // tuning knob: waves per workgroup (= per from-row)
-    // candidate keys per wave: room for ntop kept keys + the 64 one sweep step can add.  LDS per
-    // workgroup decides how many from-rows a CU works on at once: 8 KiB of accumulators + 96 keys is
-    // 8960 B = 18 workgroups per CU, 128 keys 17, 256 keys 15
-    int cap = ntop <= 32 ? 96 : (ntop <= 64 ? 128 : 256);
-    { const int forced = env_int("PFZ_K3_CAP", 0); if (forced == 128 && ntop <= 64) cap = 128; }
-    const int variant = ix->block_cols * 100 + waves;
+    // candidate keys: room for ntop kept keys + the 64 one sweep step can add.  LDS per workgroup decides how
+    // many from-rows a CU works on at once: 8 KiB of accumulators + 96 keys is 8960 B = 18 workgroups per CU
+    const int cap = ntop <= 32 ? 96 : (ntop <= 64 ? 128 : 256);
     const int ablate = env_int("PFZ_K3_ABLATE", 0);   // timing experiments only: 1 = no scatter, 2 = no sweep
     {
         ProfScope ps(ctx, "k3_cossim_topn");
-#define PFZ_K3_LAUNCH(CC, WW, CAP)                                                                                 \
-    hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, WW, CAP>), dim3(grid), dim3(WW * 64), 0, ctx->stream, A->indptr, \
-                       A->indices, A->data, (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ntop, thr0,       \
-                       scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate, n_slices, part)
-#define PFZ_K3_CASE(CC, WW)                            \
-    case CC * 100 + WW:                                \
-        if (cap == 96) PFZ_K3_LAUNCH(CC, WW, 96);      \
-        else if (cap == 128) PFZ_K3_LAUNCH(CC, WW, 128); \
-        else PFZ_K3_LAUNCH(CC, WW, 256);               \
+#define PFZ_K3_LAUNCH(CC, CAP)                                                                                  \
+    hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, CAP>), dim3(grid), dim3(64), 0, ctx->stream, A->indptr,       \
+                       A->indices, A->data, (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ix->n_pieces,  \
+                       ntop, thr0, scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate,     \
+                       n_slices, part)
+#define PFZ_K3_CASE(CC)                              \
+    case CC:                                         \
+        if (cap == 96) PFZ_K3_LAUNCH(CC, 96);        \
+        else if (cap == 128) PFZ_K3_LAUNCH(CC, 128); \
+        else PFZ_K3_LAUNCH(CC, 256);                 \
         break;
-        switch (variant) {
-            PFZ_K3_CASE(1024, 1)
-            PFZ_K3_CASE(1024, 2)
-            PFZ_K3_CASE(1536, 1)
-            PFZ_K3_CASE(2048, 1)
-            PFZ_K3_CASE(2560, 1)
-            PFZ_K3_CASE(2048, 2)
-            PFZ_K3_CASE(2048, 4)
-            PFZ_K3_CASE(4096, 1)
-            PFZ_K3_CASE(4096, 2)
-            PFZ_K3_CASE(4096, 4)
-            PFZ_K3_CASE(8192, 2)
-            PFZ_K3_CASE(8192, 4)
+        switch (ix->block_cols) {
+            PFZ_K3_CASE(1024)
+            PFZ_K3_CASE(1536)
+            PFZ_K3_CASE(2048)
+            PFZ_K3_CASE(4096)
         default:
-            set_error("pfz_cossim_topn: no kernel for block size %d with %d waves", ix->block_cols, waves);
+            set_error("pfz_cossim_topn: no kernel for block size %d", ix->block_cols);
             return PFZ_ERR_INVALID;
         }
 #undef PFZ_K3_CASE

@@ -78,14 +78,16 @@ struct pfz_csr {
 };
 
 // Inverted index of the to-side: for n-gram id k and to-row block b (block =
-// block_cols consecutive to-rows) the postings (local_row, value) live at
-// post[tab[k * n_blocks + b] .. tab[k * n_blocks + b + 1]).
+// block_cols consecutive to-rows) the postings (local_row, value), padded with
+// zero-valued entries to whole 16-posting pieces, are pieces
+// tab[k * n_blocks + b] .. tab[k * n_blocks + b + 1) of post; piece n_pieces is all zero.
 struct pfz_index {
     pfz_ctx *ctx = nullptr;
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     int32_t block_cols = 0, n_blocks = 0;
-    int32_t *tab = nullptr;  // [n_cols * n_blocks + 1]
-    int2 *post = nullptr;    // [nnz]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
+    int32_t n_pieces = 0;
+    int32_t *tab = nullptr;  // [n_cols * n_blocks + 2] first piece of every list
+    int2 *post = nullptr;    // [(n_pieces + 1) * 16]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
     float max_norm = 1.f;    // of the indexed matrix' rows
 };
 

@@ -121,13 +121,12 @@ def test_index_build_paths_agree(ctx, oracle_mod, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"PFZ_K3_WAVES": "2"}, {"PFZ_K3_WAVES": "4", "PFZ_K3_BLOCK": "4096"}, {"PFZ_K3_BLOCK": "1024"},
-    {"PFZ_K3_BLOCK": "1536"}, {"PFZ_K3_BLOCK": "8192", "PFZ_K3_WAVES": "2"}, {"PFZ_K3_CAP": "128"},
-    {"PFZ_K3_SLICES": "3"}, {"PFZ_K3_SLICES": "7", "PFZ_K3_WAVES": "2"},
+    {"PFZ_K3_BLOCK": "4096"}, {"PFZ_K3_BLOCK": "1024"}, {"PFZ_K3_BLOCK": "1536"},
+    {"PFZ_K3_SLICES": "3"}, {"PFZ_K3_SLICES": "7", "PFZ_K3_BLOCK": "1024"},
 ])
 def test_tuning_knobs_do_not_change_results(ctx, oracle_mod, monkeypatch, knobs):
-    """Every launch shape the tuning knobs can select (waves per row, to-block size, candidate buffer,
-    to-side slices) gives the default shape's results bit for bit -- and the oracle's."""
+    """Every launch shape the tuning knobs can select (to-block size, to-side slices) gives the default
+    shape's results bit for bit -- and the oracle's."""
     rng = np.random.default_rng(17)
     a3 = random_csr(rng, 260, 400, 0.04)
     b3 = random_csr(rng, 20000, 400, 0.04)
@@ -170,3 +169,45 @@ def test_unnormalised_rows_scale_safely(ctx, oracle_mod, fa, fb):
     np.testing.assert_allclose(val, e_val, rtol=0, atol=1e-5 * bound)
     assert (idx != e_idx).any(axis=1).mean() < 0.05
     assert (val >= 0).all()
+
+
+def test_padded_index_layout(ctx):
+    """The inverted index stores every (n-gram, to-block) list padded to whole 16-posting pieces: the piece
+    count is what the list lengths say, whichever build path made it."""
+    import os
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(23)
+    b3 = random_csr(rng, 5000, 300, 0.05)
+    for env in (None, "1"):
+        if env:
+            os.environ["PFZ_NO_LDS_HIST"] = env
+        try:
+            m = _lib.DeviceCSR.upload(ctx, b3[0], b3[1], b3[2].astype(np.float32), 300)
+            info = _lib.DeviceIndex.build(ctx, m).info()
+        finally:
+            os.environ.pop("PFZ_NO_LDS_HIST", None)
+        blk = info["block_cols"]
+        rows = np.repeat(np.arange(5000), np.diff(b3[0]))
+        cnt = np.bincount(b3[1].astype(np.int64) * info["n_blocks"] + rows // blk, minlength=300 * info["n_blocks"])
+        assert info["piece_postings"] == 16 and info["n_pieces"] == int(((cnt + 15) // 16).sum())
+
+
+@pytest.mark.parametrize("shape", ["many_lists", "long_lists", "more_than_64_ngrams"])
+def test_scatter_round_shapes(ctx, oracle_mod, shape):
+    """The scatter deals the pieces of a from-row's lists 64 per round, 4 per step: rows whose blocks need
+    several rounds (> 64 pieces), lists of hundreds of postings (one n-gram shared by most to-rows), and
+    from-rows with more than 64 n-grams (second pass over the lanes) against the oracle."""
+    rng = np.random.default_rng({"many_lists": 1, "long_lists": 2, "more_than_64_ngrams": 3}[shape])
+    n_col = 200
+    if shape == "many_lists":
+        a3 = random_csr(rng, 50, n_col, 0.3)            # ~60 n-grams per from-row
+        b3 = random_csr(rng, 9000, n_col, 0.1)          # every list ~200 postings per block: ~13 pieces x 60 lists
+    elif shape == "long_lists":
+        a3 = random_csr(rng, 40, n_col, 0.04)
+        b3 = random_csr(rng, 6000, n_col, 0.6)          # lists of ~1200 postings per block
+    else:
+        a3 = random_csr(rng, 30, n_col, 0.75)           # ~150 n-grams per from-row
+        b3 = random_csr(rng, 3000, n_col, 0.08)
+    idx, val = _run(ctx, a3, b3, n_col, 7, 0.0)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col, 7, 0.0)
+    assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, n_col)
