@@ -213,7 +213,7 @@ int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
                             int32_t ntop, float lower_bound, int32_t exclude_diag,
                             int32_t *out_idx, float *out_val);
 
-/* ---- multi-GPU (one process per GPU; RCCL over xGMI) ----------------------
+/* ---- multi-GPU (one process per GPU: RCCL over xGMI; or one process, many contexts) ------
  * The from-side is row-sharded, the to-side replicated; the only exchange is
  * the all-gather of per-shard results.  Bootstrap: rank 0 calls
  * pfz_comm_unique_id, the 128-byte id is broadcast by the host launcher
@@ -221,6 +221,14 @@ int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
 int pfz_comm_unique_id(uint8_t id128[128]);
 int pfz_comm_init(pfz_ctx *ctx, const uint8_t id128[128], int32_t rank, int32_t world, pfz_comm **out);
 void pfz_comm_destroy(pfz_comm *c);
+/* The same communicator interface inside ONE process: `world` contexts -- on different GPUs or on the
+ * same one -- each driven by its own host thread.  A collective is a host rendezvous of the ranks plus
+ * event waits and device-to-device copies on every rank's stream (no RCCL).  Every rank must make the
+ * same sequence of collective calls, from different threads.  The group outlives its communicators. */
+typedef struct pfz_comm_group pfz_comm_group;
+int pfz_comm_group_create(int32_t world, pfz_comm_group **out);
+void pfz_comm_group_destroy(pfz_comm_group *g);
+int pfz_comm_init_local(pfz_ctx *ctx, pfz_comm_group *g, int32_t rank, pfz_comm **out);
 /* all-gather equal-sized shards of top-n results: `local` holds rows
  * [rank*rows_per_rank, (rank+1)*rows_per_rank); `global` has world *
  * rows_per_rank rows.  Enqueues on the context stream. */

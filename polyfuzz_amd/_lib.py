@@ -81,6 +81,9 @@ SIGNATURES = {
     "pfz_comm_unique_id": (ctypes.c_int, [c_vp]),
     "pfz_comm_init": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_vp)]),
     "pfz_comm_destroy": (None, [c_vp]),
+    "pfz_comm_group_create": (ctypes.c_int, [c_i32, P(c_vp)]),
+    "pfz_comm_group_destroy": (None, [c_vp]),
+    "pfz_comm_init_local": (ctypes.c_int, [c_vp, c_vp, c_i32, P(c_vp)]),
     "pfz_comm_allgather_topn": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "pfz_comm_barrier": (ctypes.c_int, [c_vp]),
     "pfz_comm_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
@@ -470,6 +473,19 @@ def dense_cossim_topn_host(ctx, from_vec, to_vec, ntop, lower_bound, exclude_dia
 
 # ---- multi-GPU (one process per GPU, RCCL) -------------------------------------------
 
+class _LocalGroup:
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                load().pfz_comm_group_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class Comm(_Handle):
     """RCCL communicator bound to a Context.  Bootstrap: rank 0 creates the 128-byte
     unique id, the launcher broadcasts it (torch.distributed / MPI / file)."""
@@ -489,6 +505,24 @@ class Comm(_Handle):
         c = cls(ctx, h)
         c.rank, c.world = int(rank), int(world)
         return c
+
+    @classmethod
+    def local_group(cls, contexts):
+        """One communicator per context, all in THIS process (contexts on different GPUs or on the same one):
+        host rendezvous + device-to-device copies instead of RCCL.  Each rank must be driven by its own host
+        thread (the collectives block until every rank has arrived)."""
+        world = len(contexts)
+        g = c_vp()
+        check(load().pfz_comm_group_create(world, ctypes.byref(g)))
+        group = _LocalGroup(g)
+        comms = []
+        for rank, ctx in enumerate(contexts):
+            h = c_vp()
+            check(ctx.lib.pfz_comm_init_local(ctx.h, g, rank, ctypes.byref(h)))
+            c = cls(ctx, h)
+            c.rank, c.world, c._group = rank, world, group     # keeps the group alive
+            comms.append(c)
+        return comms
 
     @classmethod
     def from_torch_distributed(cls, ctx, dist):

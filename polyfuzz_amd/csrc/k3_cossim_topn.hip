@@ -55,6 +55,10 @@
 #include <stdlib.h>
 #include <utility>
 
+#ifndef PFZ_K3_EXP
+#define PFZ_K3_EXP 0   // timing experiments (tools/build_variant.sh -DPFZ_K3_EXP=n, results wrong on purpose); 0 = the product
+#endif
+
 namespace pfz {
 
 constexpr int kMergeCap = 256;   // candidate keys per wave in k3_merge_slices
@@ -386,19 +390,21 @@ __device__ inline int warm_threshold(const int4 *acc4, int i_begin, int k, int l
     return best - 1;                   // the filter accepts sum > threshold
 }
 
-// Read, clear and filter this wave's share of one block of accumulators: int4
-// slots [i_begin, i_begin + N4) of the block whose first column is col0.
+// Read, clear and filter one block of accumulators: int4 slots [0, N4) of the block whose first column is
+// col0.  (The accumulators start at LDS address 0.)
 template <int N4, int kCap>
-__device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int i_begin, int col0, int self_col,
-                                   int ntop, int lane, const int4 &zero4)
+__device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int col0, int self_col, int ntop, int lane,
+                                   int zero)
 {
     static_assert(N4 % 128 == 0, "a wave sweeps whole 128-slot steps");
 #pragma unroll 2
     for (int t = 0; t < N4 / 128; ++t) {
-        const int i0 = i_begin + t * 128 + lane, i1 = i0 + 64;
+        const int i0 = t * 128 + lane, i1 = i0 + 64;
         const int4 v0 = acc4[i0], v1 = acc4[i1];
-        acc4[i0] = zero4;
-        acc4[i1] = zero4;
+        // (clearing with eight ds_write_addtid_b32 per step instead -- 2 LDS cycles per 256 B against 13 per
+        // KiB -- measured 6 % SLOWER: the sweep is bound by its instruction stream, not by LDS cycles)
+        acc4[i0] = make_int4(zero, zero, zero, zero);
+        acc4[i1] = make_int4(zero, zero, zero, zero);
         const int mx = max3i(max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y), max3i(v1.z, v1.w, v1.w));
         if (__ballot(mx > st.thr)) {
             push4<kCap>(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
@@ -422,13 +428,35 @@ template <int S> __device__ inline int row_bcast_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xf, 0xf, false);   // DPP row_newbcast:S
 }
 
+template <int S>
+__device__ inline int2 load_piece_entry(const char *__restrict__ post_bytes, int addr_t, int sub8)
+{
+    const uint32_t a = (uint32_t)(row_bcast_i<S>(addr_t) + sub8);
+#if PFZ_K3_EXP == 2      // no posting loads
+    return make_int2((int)((a * 2654435761u) >> 19) & 8188, 0x3c000000);
+#else
+    return *(const int2 *)(post_bytes + a);
+#endif
+}
+
+template <int S> __device__ inline void apply_entry(int *acc, const int2 &pe, float as_t)
+{
+    const int v = (int)(__int_as_float(row_bcast_i<S>(__float_as_int(as_t))) * __int_as_float(pe.y));
+#if PFZ_K3_EXP == 1      // no LDS atomics
+    if (v == 0x7fffffff) atomicAdd((int *)((char *)acc + pe.x), v);
+#elif PFZ_K3_EXP == 3    // conflict-free LDS addresses
+    atomicAdd((int *)((char *)acc + ((pe.x & 0x1f00) | (threadIdx.x * 4))), v);
+#else
+    atomicAdd((int *)((char *)acc + pe.x), v);                               // ds_add_u32, no return
+#endif
+}
+
 template <int... S>
 __device__ inline void run_steps_seq(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8,
                                      std::integer_sequence<int, S...>)
 {
-    const int2 pe[sizeof...(S)] = {*(const int2 *)(post_bytes + (uint32_t)(row_bcast_i<S>(addr_t) + sub8))...};
-    (atomicAdd((int *)((char *)acc + pe[S].x),                               // ds_add_u32, no return
-               (int)(__int_as_float(row_bcast_i<S>(__float_as_int(as_t))) * __int_as_float(pe[S].y))), ...);
+    const int2 pe[sizeof...(S)] = {load_piece_entry<S>(post_bytes, addr_t, sub8)...};
+    (apply_entry<S>(acc, pe[S], as_t), ...);
 }
 
 template <int NS>
@@ -474,6 +502,10 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
     const int base = st - excl;            // piece P of this list is index piece base + P
     const int pt = 4 * (lane & 15) + (lane >> 4);   // window position of the piece this lane processes
     for (int r0 = 0; r0 < total; r0 += 64) {
+#if PFZ_K3_EXP == 4      // no owner search: every lane takes a piece of its own list
+        const int addr_t = np > 0 ? (int)((uint32_t)(st + ((r0 + pt) % np)) << 7) : dummy_addr;
+        const float as_t = as;
+#else
         const int rel = excl - r0;
         mark[lane] = 0;
         if (np > 0 && rel < 64 && rel + np > 0) mark[rel > 0 ? rel : 0] = lane + 1;
@@ -485,6 +517,7 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
         const int P = r0 + pt;
         const int addr_t = P < total ? (int)((uint32_t)(b_o + P) << 7) : dummy_addr;
         wave_sync();                                                         // mark[] is rewritten by the next round
+#endif
         const int left = total - r0;
         const int ng = left >= 64 ? 8 : (left + 7) >> 3;                     // groups of two steps (8 pieces)
         switch (ng) {
@@ -526,11 +559,9 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
     const int lane = threadIdx.x;
     int4 *acc4 = (int4 *)acc;
     constexpr int N4 = C / 4;   // int4 slots swept by the wave
-    // four zero registers for the whole kernel: as an asm result the compiler cannot re-materialise them
-    // (it rebuilt them with 5 instructions in every sweep step)
-    int4 zero4;
-    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
-                 : "=v"(zero4.x), "=v"(zero4.y), "=v"(zero4.z), "=v"(zero4.w));
+    // a zero register for the whole kernel: as an asm result the compiler cannot re-materialise it
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
     for (int t = lane; t < C / 4; t += 64) acc4[t] = make_int4(0, 0, 0, 0);
     wave_sync();
     const char *post_bytes = (const char *)post;
@@ -595,7 +626,7 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
                         st.thr = t > st.thr ? t : st.thr;
                     }
                 }
-                sweep_block<N4, kCap>(acc4, cand, st, 0, b * C, self_col, ntop, lane, zero4);
+                sweep_block<N4, kCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero);
                 wave_sync();      // acc is zero again
             }
         }

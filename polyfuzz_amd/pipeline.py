@@ -6,11 +6,19 @@ building the DataFrame (reference polyfuzz/models/_tfidf.py:93-98 ->
 _utils.py:54-102): fit the vocabulary/idf on to + from, vectorise both lists,
 build the to-side inverted index, run the fused cosine top-n.
 
-Multi-GPU (one process per GPU): the from-list is row-sharded (each rank holds
-its shard), the to-list is replicated.  The fit is exact: vocabulary bitmaps are
-all-gathered and document frequencies all-reduced over RCCL, so every rank ends
-with the vectoriser a single-GPU fit on the concatenated lists would produce;
-the per-shard top-n blocks are all-gathered into the full result on every rank.
+Multi-GPU (one process per GPU, or one process driving several contexts): the
+from-list is row-sharded (each rank holds its shard), the to-list is replicated.
+The fit is exact: vocabulary bitmaps are all-gathered and document frequencies
+all-reduced, so every rank ends with the vectoriser a single-GPU fit on the
+concatenated lists would produce; the per-shard top-n blocks -- padded to the
+largest shard so that the all-gather moves equal blocks -- are all-gathered into
+the full result on every rank.
+
+The job talks to the device through an *engine* object (`HipEngine`, the C ABI
+of include/polyfuzz_hip.h).  The seam exists so that the shard logic of this
+file -- which rank fits on what, padding, diagonal offsets, the order of the
+exchanges -- can be driven at world_size 2 on a CPU-only box by a test double
+(tests/cpu_engine.py: oracle arithmetic + gloo); the product has one engine.
 """
 import numpy as np
 
@@ -27,15 +35,49 @@ def shard_bounds(n, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+class HipEngine:
+    """The device operations a match job is made of, on libpolyfuzz_hip.so."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def upload_strings(self, strings):
+        return _lib.DeviceStrings.upload(self.ctx, strings)
+
+    def fit(self, params, docs_a, docs_b):
+        return _lib.DeviceTfidf.fit(self.ctx, params, docs_a, docs_b)
+
+    def fit_sharded(self, comm, params, replicated, local_shard):
+        return _lib.tfidf_fit_sharded(self.ctx, comm, params, replicated, local_shard)
+
+    def transform(self, vec, docs):
+        return vec.transform(docs)
+
+    def build_index(self, to_csr):
+        return _lib.DeviceIndex.build(self.ctx, to_csr)
+
+    def alloc_topn(self, n_rows, ntop):
+        return _lib.DeviceTopN.alloc(self.ctx, n_rows, ntop)
+
+    def cossim_topn(self, index, from_csr, ntop, lower_bound, exclude_diag, diag_offset, out):
+        return _lib.cossim_topn(self.ctx, index, from_csr, ntop, lower_bound, exclude_diag=exclude_diag,
+                                diag_offset=diag_offset, out=out)
+
+    def allgather_topn(self, comm, local, out):
+        return comm.allgather_topn(local, out)
+
+
 class TfidfMatchJob:
     def __init__(self, ctx, from_shard, to_list, top_n=1, min_similarity=0.0, n_gram_range=(3, 3),
                  clean_string=True, remove_space_ngrams=True, comm=None, self_match=False, shard_offset=0,
-                 rows_per_rank=None):
+                 rows_per_rank=None, engine=None):
         """self_match: the from-rows are rows [shard_offset, shard_offset + len(from_shard)) of to_list (the whole
         list, replicated); to_list=None = the from-list is the whole list (single GPU).
         rows_per_rank: size of the largest shard when the ranks' shards differ (shard_bounds); the
-        per-rank result block is padded to it so that the all-gather moves equal blocks."""
+        per-rank result block is padded to it so that the all-gather moves equal blocks.
+        comm: an object with .rank / .world (polyfuzz_amd.Comm)."""
         self.ctx = ctx
+        self.eng = engine if engine is not None else HipEngine(ctx)
         self.comm = comm
         self.top_n = int(top_n)
         self.min_similarity = float(min_similarity)
@@ -44,45 +86,45 @@ class TfidfMatchJob:
         self.params = _lib.TfidfParams(int(n_gram_range[0]), int(n_gram_range[1]), int(bool(clean_string)),
                                        int(bool(remove_space_ngrams)))
         self.n_from = len(from_shard)
-        self.from_dev = _lib.DeviceStrings.upload(ctx, from_shard)
+        self.from_dev = self.eng.upload_strings(from_shard)
         if to_list is None:                    # single-list self-match: the list is its own to-side
             if not self.self_match or self.shard_offset != 0:
                 raise ValueError("to_list=None means a whole-list self-match (self_match=True, shard_offset=0)")
             self.n_to, self.to_dev = self.n_from, self.from_dev
         else:
             self.n_to = len(to_list)
-            self.to_dev = _lib.DeviceStrings.upload(ctx, to_list)
+            self.to_dev = self.eng.upload_strings(to_list)
         self.rows_per_rank = self.n_from if rows_per_rank is None else int(rows_per_rank)
         if self.rows_per_rank < self.n_from:
             raise ValueError("rows_per_rank is smaller than this rank's shard")
-        self.local = _lib.DeviceTopN.alloc(ctx, self.rows_per_rank, self.top_n)
+        self.local = self.eng.alloc_topn(self.rows_per_rank, self.top_n)
         self.local.clear()                     # padding rows stay "no match"
         self.gathered = None
         if comm is not None and comm.world > 1:
-            self.gathered = _lib.DeviceTopN.alloc(ctx, self.rows_per_rank * comm.world, self.top_n)
+            self.gathered = self.eng.alloc_topn(self.rows_per_rank * comm.world, self.top_n)
         self.vec = self.from_csr = self.to_csr = self.index = None
 
     def step(self):
-        ctx = self.ctx
+        eng = self.eng
         sharded = self.comm is not None and self.comm.world > 1
         if self.self_match:
             # reference _tfidf.py:113-116: a self-match fits on the list ALONE (n_docs = len(list)); the
             # replicated list is the whole list on every rank, so the fit needs no exchange
-            self.vec = _lib.DeviceTfidf.fit(ctx, self.params, self.to_dev, None)
+            self.vec = eng.fit(self.params, self.to_dev, None)
         elif sharded:
-            self.vec = _lib.tfidf_fit_sharded(ctx, self.comm, self.params, self.to_dev, self.from_dev)
+            self.vec = eng.fit_sharded(self.comm, self.params, self.to_dev, self.from_dev)
         else:
-            self.vec = _lib.DeviceTfidf.fit(ctx, self.params, self.to_dev, self.from_dev)
-        self.to_csr = self.vec.transform(self.to_dev)
-        self.index = _lib.DeviceIndex.build(ctx, self.to_csr)
+            self.vec = eng.fit(self.params, self.to_dev, self.from_dev)
+        self.to_csr = eng.transform(self.vec, self.to_dev)
+        self.index = eng.build_index(self.to_csr)
         if self.self_match and not sharded and self.n_from == self.n_to and self.shard_offset == 0:
             self.from_csr = self.to_csr            # the same rows: vectorise once (reference _tfidf.py:114-116)
         else:
-            self.from_csr = self.vec.transform(self.from_dev)
-        _lib.cossim_topn(ctx, self.index, self.from_csr, self.top_n, self.min_similarity,
-                         exclude_diag=self.self_match, diag_offset=self.shard_offset, out=self.local)
+            self.from_csr = eng.transform(self.vec, self.from_dev)
+        eng.cossim_topn(self.index, self.from_csr, self.top_n, self.min_similarity, self.self_match, self.shard_offset,
+                        self.local)
         if self.gathered is not None:
-            self.comm.allgather_topn(self.local, self.gathered)
+            eng.allgather_topn(self.comm, self.local, self.gathered)
         return self.gathered if self.gathered is not None else self.local
 
     @staticmethod
@@ -97,7 +139,7 @@ class TfidfMatchJob:
                 "with the diagonal excluded (K3)" if self.self_match else
                 "fit vocabulary+idf on to+from (K1/K2), vectorise both lists, build the to-side inverted index, "
                 "fused cosine top-n (K3)")
-        return what + ("; all-gather of the per-shard results (RCCL)" if self.gathered else "")
+        return what + ("; all-gather of the per-shard results" if self.gathered else "")
 
     # ---- host-side accounting (never inside the timed region) ---------------------
     def host_matrices(self):
@@ -112,3 +154,29 @@ class TfidfMatchJob:
         df_to = np.bincount(ti, minlength=n_cols).astype(np.float64)
         return {"vocab": int(n_cols), "nnz_from": int(fp[-1]), "nnz_to": int(tp[-1]),
                 "madds": float((df_from * df_to).sum())}
+
+
+def run_sharded_job(ctxs, comms, from_list, to_list, **job_kw):
+    """One process, several contexts: run the row-sharded job with one host thread per rank and return
+    (idx, val) of the full from-list (the ranks' all-gathered, un-padded result; identical on every rank).
+    `comms` = polyfuzz_amd.Comm.local_group(ctxs).  self_match=True in job_kw: `to_list` is the whole list and
+    `from_list` must be the same list (every rank matches its row shard of it)."""
+    import concurrent.futures as cf
+    world = len(ctxs)
+    n = len(from_list)
+    bounds = [shard_bounds(n, world, r) for r in range(world)]
+    sizes = [e - b for b, e in bounds]
+    rpr = max(sizes)
+    self_match = bool(job_kw.get("self_match", False))
+
+    def rank_fn(r):
+        b, e = bounds[r]
+        job = TfidfMatchJob(ctxs[r], from_list[b:e], to_list, comm=comms[r], rows_per_rank=rpr,
+                            shard_offset=b if self_match else 0, **job_kw)
+        out = job.step()
+        idx, val = out.download()
+        return TfidfMatchJob.unpad(idx, val, sizes, rpr), job
+
+    with cf.ThreadPoolExecutor(world) as ex:
+        futs = [ex.submit(rank_fn, r) for r in range(world)]
+        return [f.result(timeout=300) for f in futs]

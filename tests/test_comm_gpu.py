@@ -36,3 +36,44 @@ def test_world1_comm_and_sharded_fit(ctx, oracle_mod):
     assert np.abs(val - e_val).max() <= 1e-5
     assert (idx != e_idx).any(axis=1).sum() <= 1
     comm.free()
+
+
+@pytest.mark.parametrize("clean", [True, False])
+def test_world2_local_transport_sharded_job(oracle_mod, clean):
+    """The sharded library code at world = 2 on ONE device: two contexts, one host thread per rank, the "local"
+    transport (host rendezvous + device-to-device copies) behind the same seams RCCL sits behind.
+    pfz_tfidf_fit_sharded (bitmap all-gather + OR, df / n_docs all-reduce; with clean=False also the alphabet
+    all-gather) + pfz_comm_allgather_topn + TfidfMatchJob(rows_per_rank, unpad) with uneven shards
+    (301 = 151 + 150) give the single-context result bit for bit, which is the oracle's."""
+    import polyfuzz_amd
+    from polyfuzz_amd import _lib, pipeline, synth
+    fl, tl = synth.company_names(301, 11), synth.company_names(257, 12)
+    if not clean:
+        fl = [s.title() + (" é" if i % 7 == 0 else "") for i, s in enumerate(fl)]   # rank-dependent alphabets
+    ctxs = [polyfuzz_amd.Context(0), polyfuzz_amd.Context(0)]
+    comms = _lib.Comm.local_group(ctxs)
+    res = pipeline.run_sharded_job(ctxs, comms, fl, tl, top_n=4, min_similarity=0.0, clean_string=clean)
+    single = pipeline.TfidfMatchJob(ctxs[0], fl, tl, top_n=4, min_similarity=0.0, clean_string=clean)
+    s_idx, s_val = single.step().download()
+    for (idx, val), job in res:                       # every rank holds the whole, un-padded result
+        np.testing.assert_array_equal(idx, s_idx)
+        np.testing.assert_array_equal(val, s_val)
+        np.testing.assert_array_equal(job.vec.export()[1], single.vec.export()[1])      # idf
+        assert job.vec.info() == single.vec.info()
+    a3, b3, n_col = single.host_matrices()
+    e_idx, e_val = oracle_mod.cossim_topn(a3, b3, n_col, 4, 0.0)
+    assert np.abs(s_val - e_val).max() <= 1e-5 and (s_idx != e_idx).any(axis=1).sum() <= 1
+
+    # row-sharded self-match: fit on the replicated list alone, diagonal at the shard offset
+    res = pipeline.run_sharded_job(ctxs, comms, fl, fl, top_n=3, min_similarity=0.0, clean_string=clean, self_match=True)
+    whole = pipeline.TfidfMatchJob(ctxs[1], fl, None, top_n=3, min_similarity=0.0, clean_string=clean, self_match=True)
+    w_idx, w_val = whole.step().download()
+    for (idx, val), job in res:
+        np.testing.assert_array_equal(idx, w_idx)
+        np.testing.assert_array_equal(val, w_val)
+        assert job.vec.info()["n_docs"] == len(fl)
+    for c in comms:
+        c.barrier_is_local = True
+    del res
+    for c in comms:
+        c.free()
