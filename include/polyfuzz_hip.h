@@ -213,6 +213,15 @@ int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
                             int32_t ntop, float lower_bound, int32_t exclude_diag,
                             int32_t *out_idx, float *out_val);
 
+/* ---- K6: reductions on the hot path's output --------------------------------
+ * precision_recall_curve (reference polyfuzz/metrics.py:12-53): for every threshold p_k
+ * (ascending, n_thresholds <= 4096) count_ge[k] = #{i : sim[i] >= p_k} and sum_ge[k] = the sum of
+ * those similarities (recall = count / n, average precision = sum / count on the host).  NaN
+ * similarities are never >= a threshold.  Sums are accumulated in 64-bit fixed point (bit-
+ * reproducible; absolute error of a mean below 1e-13 for similarities in [0, 100]).  Blocks. */
+int pfz_pr_curve_host(pfz_ctx *ctx, const double *sim, int64_t n, const double *thresholds,
+                      int32_t n_thresholds, int64_t *count_ge, double *sum_ge);
+
 /* ---- multi-GPU (one process per GPU: RCCL over xGMI; or one process, many contexts) ------
  * The from-side is row-sharded, the to-side replicated; the only exchange is
  * the all-gather of per-shard results.  Bootstrap: rank 0 calls

@@ -78,6 +78,7 @@ SIGNATURES = {
                                                   c_vp, c_vp]),
     "pfz_dense_dot_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                c_vp, c_vp]),
+    "pfz_pr_curve_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "pfz_comm_unique_id": (ctypes.c_int, [c_vp]),
     "pfz_comm_init": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_vp)]),
     "pfz_comm_destroy": (None, [c_vp]),
@@ -469,6 +470,17 @@ def dense_cossim_topn_host(ctx, from_vec, to_vec, ntop, lower_bound, exclude_dia
     check(fn(ctx.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], int(ntop), float(lower_bound),
              int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
     return idx, val
+
+
+def pr_curve(ctx, sims, thresholds):
+    """K6: (count of sims >= p_k int64[k], sum of those sims float64[k]) for ascending thresholds p_k."""
+    sims = np.ascontiguousarray(sims, np.float64)
+    thresholds = np.ascontiguousarray(thresholds, np.float64)
+    count = np.empty(len(thresholds), np.int64)
+    ssum = np.empty(len(thresholds), np.float64)
+    check(ctx.lib.pfz_pr_curve_host(ctx.h, _ptr(sims) if len(sims) else None, len(sims), _ptr(thresholds),
+                                    len(thresholds), _ptr(count), _ptr(ssum)))
+    return count, ssum
 
 
 # ---- multi-GPU (one process per GPU, RCCL) -------------------------------------------

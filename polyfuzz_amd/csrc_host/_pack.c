@@ -203,7 +203,69 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
     Py_RETURN_NONE;
 }
 
+/* linkage(from_ids, to_ids, n_strings) -> (cluster: bytes int32[n_strings], order: bytes int32[n_mapped])
+ *
+ * The order-dependent greedy assignment of reference polyfuzz/linkage.py:28-45 on integer string ids
+ * (the rows of `matches` that passed the similarity filter, in frame order):
+ *     if not mapping.get(From):            # unmapped -- or mapped to cluster 0, which is falsy
+ *         if not mapping.get(To):  mapping[To] = mapping[From] = cluster_id; cluster_id += 1
+ *         else:                    mapping[From] = mapping[To]
+ * cluster[x] = final cluster id of string x (-1: never mapped); order = the string ids in the order they
+ * first entered the mapping (Python dict insertion order, which the reference's `clusters` lists and
+ * `cluster_name_map` representatives follow).  from_ids / to_ids: int32 buffers of equal length.
+ */
+static PyObject *linkage(PyObject *self, PyObject *args)
+{
+    (void)self;
+    Py_buffer fb, tb;
+    Py_ssize_t n_strings;
+    if (!PyArg_ParseTuple(args, "y*y*n", &fb, &tb, &n_strings)) return NULL;
+    PyObject *out = NULL, *cl = NULL, *od = NULL;
+    const Py_ssize_t m = fb.len / (Py_ssize_t)sizeof(int32_t);
+    if (fb.len != tb.len || fb.len % (Py_ssize_t)sizeof(int32_t) || n_strings < 0) {
+        PyErr_SetString(PyExc_ValueError, "linkage(): from_ids and to_ids must be int32 buffers of equal length");
+        goto done;
+    }
+    cl = PyBytes_FromStringAndSize(NULL, n_strings * (Py_ssize_t)sizeof(int32_t));
+    od = PyBytes_FromStringAndSize(NULL, n_strings * (Py_ssize_t)sizeof(int32_t));
+    if (!cl || !od) goto done;
+    {
+        const int32_t *f = (const int32_t *)fb.buf, *t = (const int32_t *)tb.buf;
+        int32_t *map = (int32_t *)PyBytes_AS_STRING(cl), *order = (int32_t *)PyBytes_AS_STRING(od);
+        Py_ssize_t n_order = 0;
+        int32_t next = 0;
+        for (Py_ssize_t i = 0; i < n_strings; ++i) map[i] = -1;
+        for (Py_ssize_t r = 0; r < m; ++r) {
+            const int32_t a = f[r], b = t[r];
+            if (a < 0 || a >= n_strings || b < 0 || b >= n_strings) {
+                PyErr_SetString(PyExc_ValueError, "linkage(): string id out of range");
+                goto done;
+            }
+            if (map[a] > 0) continue;                       /* From already mapped (0 is falsy) */
+            if (map[b] <= 0) {                              /* To unmapped too: a new cluster */
+                if (map[b] < 0) order[n_order++] = b;
+                map[b] = next;
+                if (map[a] < 0) order[n_order++] = a;       /* (a == b: already entered) */
+                map[a] = next;
+                ++next;
+            } else {
+                if (map[a] < 0) order[n_order++] = a;
+                map[a] = map[b];
+            }
+        }
+        if (_PyBytes_Resize(&od, n_order * (Py_ssize_t)sizeof(int32_t)) < 0) goto done;
+    }
+    out = Py_BuildValue("(OO)", cl, od);
+done:
+    Py_XDECREF(cl);
+    Py_XDECREF(od);
+    PyBuffer_Release(&fb);
+    PyBuffer_Release(&tb);
+    return out;
+}
+
 static PyMethodDef methods[] = {
+    {"linkage", linkage, METH_VARARGS, "linkage(from_ids, to_ids, n_strings) -> (cluster int32[n], order int32[k]) as bytes"},
     {"pack", pack, METH_O, "pack(list[str]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)"},
     {"fill_columns", fill_columns, METH_VARARGS,
      "fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads): the (To, Similarity) column pairs"},

@@ -72,8 +72,6 @@ def test_world2_local_transport_sharded_job(oracle_mod, clean):
         np.testing.assert_array_equal(idx, w_idx)
         np.testing.assert_array_equal(val, w_val)
         assert job.vec.info()["n_docs"] == len(fl)
-    for c in comms:
-        c.barrier_is_local = True
     del res
     for c in comms:
         c.free()
