@@ -106,6 +106,8 @@ void pfz_topn_free(pfz_topn *t);
 int pfz_topn_clear(pfz_ctx *ctx, pfz_topn *t);
 /* blocks; out_idx / out_val are [n_rows * ntop] row-major host buffers */
 int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *out_val);
+/* fill a result buffer from host arrays [n_rows * ntop] (results computed elsewhere, e.g. another rank's block) */
+int pfz_topn_upload(pfz_ctx *ctx, pfz_topn *t, const int32_t *idx, const float *val);
 /* raw device pointers (for an RCCL all-gather issued by the caller) */
 int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int64_t *n_rows, int32_t *ntop);
 
@@ -221,6 +223,17 @@ int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
  * reproducible; absolute error of a mean below 1e-13 for similarities in [0, 100]).  Blocks. */
 int pfz_pr_curve_host(pfz_ctx *ctx, const double *sim, int64_t n, const double *thresholds,
                       int32_t n_thresholds, int64_t *count_ge, double *sum_ge);
+/* single_linkage (reference polyfuzz/linkage.py:5-53) of a self-match TOP-1 result, as
+ * PolyFuzz._create_groups builds it (polyfuzz.py:468-475: model.match(strings) on unique strings):
+ * row i = (From i, To = result idx[i][0], Similarity = round(score, 3)), rows with Similarity >
+ * min_similarity (>= 0) walked in order with the reference's greedy, order-dependent rule -- cluster 0
+ * is falsy, so the first cluster's members are re-assigned when met again.  out_cluster[i] = cluster
+ * id of string i (-1: in no cluster); out_key[i] = position key of string i in the reference's dicts
+ * (ascending key = insertion order; -1 where out_cluster is -1); out_info3 (may be NULL) = {first kept
+ * row or -1, fixpoint rounds, clusters founded}.  `result` may hold more than one rank per row; only
+ * rank 0 is read.  Blocks. */
+int pfz_linkage_top1(pfz_ctx *ctx, const pfz_topn *result, double min_similarity,
+                     int32_t *out_cluster, int32_t *out_key, int32_t *out_info3);
 
 /* ---- multi-GPU (one process per GPU: RCCL over xGMI; or one process, many contexts) ------
  * The from-side is row-sharded, the to-side replicated; the only exchange is

@@ -60,6 +60,7 @@ SIGNATURES = {
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pfz_topn_clear": (ctypes.c_int, [c_vp, c_vp]),
+    "pfz_topn_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pfz_topn_device_ptrs": (ctypes.c_int, [c_vp, P(c_vp), P(c_vp), P(c_i64), P(c_i32)]),
     "pfz_cossim_topn": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_f32, c_i32, c_i64, c_vp]),
     "pfz_cossim_topn_host": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -79,6 +80,7 @@ SIGNATURES = {
     "pfz_dense_dot_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                c_vp, c_vp]),
     "pfz_pr_curve_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
+    "pfz_linkage_top1": (ctypes.c_int, [c_vp, c_vp, c_f64, c_vp, c_vp, c_vp]),
     "pfz_comm_unique_id": (ctypes.c_int, [c_vp]),
     "pfz_comm_init": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_vp)]),
     "pfz_comm_destroy": (None, [c_vp]),
@@ -296,6 +298,16 @@ class DeviceTopN(_Handle):
     def clear(self):
         check(self.ctx.lib.pfz_topn_clear(self.ctx.h, self.h))
 
+    @classmethod
+    def from_host(cls, ctx, idx, val):
+        idx = np.ascontiguousarray(idx, np.int32)
+        val = np.ascontiguousarray(val, np.float32)
+        if idx.ndim == 1:
+            idx, val = idx[:, None], val[:, None]
+        t = cls.alloc(ctx, idx.shape[0], idx.shape[1])
+        check(ctx.lib.pfz_topn_upload(ctx.h, t.h, _ptr(idx), _ptr(val)))
+        return t
+
     def device_ptrs(self):
         pi, pv = c_vp(), c_vp()
         check(self.ctx.lib.pfz_topn_device_ptrs(self.h, ctypes.byref(pi), ctypes.byref(pv), None, None))
@@ -481,6 +493,15 @@ def pr_curve(ctx, sims, thresholds):
     check(ctx.lib.pfz_pr_curve_host(ctx.h, _ptr(sims) if len(sims) else None, len(sims), _ptr(thresholds),
                                     len(thresholds), _ptr(count), _ptr(ssum)))
     return count, ssum
+
+
+def linkage_top1(ctx, result, min_similarity):
+    """K6: (cluster int32[n], key int32[n], info) of the reference's single_linkage on a self-match top-1 result."""
+    cluster = np.empty(result.n_rows, np.int32)
+    key = np.empty(result.n_rows, np.int32)
+    info = np.zeros(3, np.int32)
+    check(ctx.lib.pfz_linkage_top1(ctx.h, result.h, float(min_similarity), _ptr(cluster), _ptr(key), _ptr(info)))
+    return cluster, key, {"first_row": int(info[0]), "rounds": int(info[1]), "clusters": int(info[2])}
 
 
 # ---- multi-GPU (one process per GPU, RCCL) -------------------------------------------

@@ -622,6 +622,16 @@ int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *
     return PFZ_OK;
 }
 
+int pfz_topn_upload(pfz_ctx *ctx, pfz_topn *t, const int32_t *idx, const float *val)
+{
+    PFZ_REQUIRE(ctx && t && idx && val, "pfz_topn_upload: NULL argument");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)t->n_rows * (size_t)t->ntop;
+    PFZ_TRY(copy_h2d(ctx, t->idx, idx, n * sizeof(int32_t)));
+    PFZ_TRY(copy_h2d(ctx, t->val, val, n * sizeof(float)));
+    return PFZ_OK;
+}
+
 int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int64_t *n_rows, int32_t *ntop)
 {
     PFZ_REQUIRE(t, "pfz_topn_device_ptrs: NULL argument");

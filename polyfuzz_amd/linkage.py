@@ -93,3 +93,34 @@ def single_linkage(matches: pd.DataFrame,
         strings.append(None)
     cluster, order = greedy_assign(codes[:m], codes[m:], len(strings))
     return dicts_from_assignment(strings, cluster, order)
+
+
+def group_top1(result, strings: List[str], min_similarity: float):
+    """The three dicts of `single_linkage(model.match(strings), min_similarity)` straight from the device-resident
+    self-match result of `strings` (a _lib.DeviceTopN; only rank 0 is read): K6's parallel re-statement of the
+    greedy walk, no frame in between.  `strings` must be unique (as in PolyFuzz._create_groups, polyfuzz.py:468-471)
+    and min_similarity >= 0; otherwise build the frame and call single_linkage."""
+    cluster, key, _ = _lib.linkage_top1(result.ctx, result, min_similarity)
+    mapped = np.nonzero(cluster >= 0)[0]
+    order = mapped[np.argsort(key[mapped], kind="stable")].astype(np.int32)
+    return dicts_from_assignment(strings, cluster, order)
+
+
+def create_groups(matches: pd.DataFrame, model=None, link_min_similarity: float = 0.75, group_all_strings: bool = False):
+    """What `PolyFuzz.group` does per model (reference polyfuzz.py:331-373,459-484): self-match the unique To
+    (or From) strings with `model` (default TFIDF(n_gram_range=(3, 3), min_similarity=link_min_similarity)),
+    single-linkage them, and add the `Group` column.  Returns (matches with Group, clusters, cluster_mapping).
+    With a polyfuzz_amd TFIDF model the self-match result never leaves the device before the linkage."""
+    from .models import TFIDF
+    if model is None:
+        model = TFIDF(n_gram_range=(3, 3), min_similarity=link_min_similarity)
+    col = matches.From if group_all_strings else matches.To
+    strings = list(col.dropna().unique())
+    if isinstance(model, TFIDF) and link_min_similarity >= 0 and len(strings) > 1:
+        result = model.match_device(strings)                       # top-1 self-match, diagonal excluded
+        clusters, cluster_id_map, cluster_name_map = group_top1(result, strings, link_min_similarity)
+    else:
+        clusters, cluster_id_map, cluster_name_map = single_linkage(model.match(strings), link_min_similarity)
+    df = matches.copy()
+    df["Group"] = df["To"].map(cluster_name_map).fillna(df["To"])
+    return df, clusters, cluster_id_map

@@ -149,6 +149,17 @@ class TFIDF(BaseMatcher):
                              "wait_and_download": (t3 - t2) * 1e3, "frame": (t4 - t3) * 1e3}
         return frame
 
+    def match_device(self, from_list: List[str], to_list: List[str] = None, re_train: bool = True):
+        """The match of `match()` left on the device: a _lib.DeviceTopN of (index into the to-list, fp32 cosine)
+        per from-string and rank -- for consumers that reduce it further there (polyfuzz_amd.linkage.group_top1)."""
+        if self.cosine_method not in _METHODS:
+            raise ValueError(f"cosine_method must be one of {_METHODS}")
+        ctx = _lib.Context.default()
+        from_dev, _ = self._extract_tf_idf(from_list, to_list, re_train)
+        top_n = clip_top_n(self.top_n, to_list)
+        lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
+        return _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=to_list is None)
+
     # ---- internals ---------------------------------------------------------------
     def _params(self):
         lo, hi = int(self.n_gram_range[0]), int(self.n_gram_range[1])
