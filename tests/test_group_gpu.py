@@ -36,7 +36,7 @@ def test_precision_recall_curve_vs_reference(gg, ctx):
             assert np.array_equal(np.isnan(got), np.isnan(exp))
             np.testing.assert_allclose(got[~np.isnan(exp)], exp[~np.isnan(exp)], rtol=0, atol=AP_TOL * max(1.0, df.Similarity.max()))
             n += 1
-    assert n >= 25
+    assert n >= 20
     with pytest.raises(ZeroDivisionError):
         precision_recall_curve(pd.DataFrame({"From": [], "To": [], "Similarity": []}))
 
