@@ -196,6 +196,14 @@ int pfz_indel_argmax(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_st
  * row-major host buffer (test / small-input entry point).  Blocks. */
 int pfz_indel_matrix_host(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
                           int64_t from_begin, int64_t from_end, double *out_matrix);
+/* K4's preparation of a to-list -- alphabet (distinct code points of the to-list), to-strings sorted by
+ * length into groups of 64, symbols packed per group on the device -- depends on the to-list alone: it is
+ * built on the first pfz_indel_* call that uses the handle as the to-side and cached on it, so matching
+ * further from-lists against the same pfz_strings (reference PolyFuzz.transform, polyfuzz.py:234-240)
+ * costs no preparation.  This entry builds the plan if needed and reports it: alphabet size, groups,
+ * and sum over to-strings of their padded length (x n_from x ceil(|from| / word) = the kernel's word-steps). */
+int pfz_indel_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_symbols, int64_t *n_groups,
+                        int64_t *char_steps);
 
 /* ---- K5: dense cosine top-n -----------------------------------------------
  * Replaces cosine_similarity on dense embedding matrices

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pfz_tfidf_transform": (ctypes.c_int, [c_vp, c_vp, c_vp, P(c_vp)]),
     "pfz_indel_argmax": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "pfz_indel_matrix_host": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "pfz_indel_plan_info": (ctypes.c_int, [c_vp, c_vp, P(c_i64), P(c_i64), P(c_i64)]),
     "pfz_dense_cossim_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                   c_vp, c_vp]),
     "pfz_dense_dot_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
@@ -461,6 +462,13 @@ def indel_argmax(ctx, from_dev, to_dev, skip_idx=None, begin=0, end=None):
     check(ctx.lib.pfz_indel_argmax(ctx.h, from_dev.h, to_dev.h, _ptr(skip_idx), int(begin), int(end),
                                    _ptr(idx), _ptr(score)))
     return idx, score
+
+
+def indel_plan_info(ctx, to_dev):
+    """Build (once) and describe K4's cached to-side plan of a DeviceStrings handle."""
+    v = [c_i64() for _ in range(3)]
+    check(ctx.lib.pfz_indel_plan_info(ctx.h, to_dev.h, *[ctypes.byref(x) for x in v]))
+    return {"n_symbols": v[0].value, "n_groups": v[1].value, "char_steps": v[2].value}
 
 
 def indel_matrix(ctx, from_dev, to_dev, begin=0, end=None):

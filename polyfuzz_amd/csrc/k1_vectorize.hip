@@ -855,7 +855,6 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
     s->char_width = char_width;
     s->max_len = max_len;
     s->h_off.assign(offsets, offsets + n + 1);
-    if (n_units > 0) s->h_chars.assign((const uint8_t *)chars, (const uint8_t *)chars + (size_t)n_units * (size_t)char_width);
     PFZ_TRY(pool_alloc(ctx, &s->chars, (size_t)(n_units > 0 ? n_units : 1) * (size_t)char_width + 16));
     PFZ_TRY(pool_alloc(ctx, &s->offsets, (size_t)(n + 1) * sizeof(int64_t)));
     if (n_units > 0) PFZ_TRY(copy_h2d(ctx, s->chars, chars, (size_t)n_units * (size_t)char_width));
@@ -871,6 +870,7 @@ void pfz_strings_free(pfz_strings *s)
     if (s->chars) pool_free(s->chars);
     if (s->offsets) pool_free(s->offsets);
     if (s->slots) pool_free(s->slots);
+    if (s->indel_plan) pfz_indel_plan_free(s->indel_plan);
     if (s->row_cnt) pool_free(s->row_cnt);
     delete s;
 }

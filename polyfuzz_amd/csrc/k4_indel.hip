@@ -15,8 +15,9 @@
 // Mapping to CDNA4
 //   workgroup (4 waves) = one from-string at a time: its PM table lives in LDS
 //     (one word per alphabet symbol; symbols are ranks of the distinct code
-//     points of both lists, so any Unicode input works), built with ds_or and
-//     cleared by re-visiting the from-string's own characters.
+//     points of the TO-list, so any Unicode input works -- a from-character the
+//     to-list never uses is never looked up and gets no entry), built with ds_or
+//     and cleared by re-visiting the from-string's own characters.
 //   lane = one to-string.  To-strings are sorted by length and stored in groups
 //     of 64 as [t/4][lane] dwords of 4 packed symbols (2 for >255 symbols), so a
 //     wave reads 256 contiguous bytes per step and lanes of a group finish
@@ -25,6 +26,9 @@
 //     characters, 1..16 64-bit words beyond) so V stays in registers.
 //   arg-max: per lane (score desc, original index asc) in float64 with the exact
 //     reference formula, then wave shuffles + one LDS step per from-string.
+// The to-side "plan" -- alphabet, length-sorted groups, packed symbols -- depends on
+// the to-list alone; it is built once per to-list (packing on the device) and cached
+// on its pfz_strings handle, so a repeated to-list costs no preparation at all.
 // Roofline: integer VALU + LDS lookups; HBM traffic is the to-strings once per
 // from-string out of L2 (0.3 MB) -- not HBM-bound.
 #include "pfz_internal.h"
@@ -59,8 +63,11 @@ __device__ inline int popc_word(uint32_t v) { return __popc(v); }
 __device__ inline int popc_word(uint64_t v) { return __popcll(v); }
 
 struct IndelArgs {
-    const uint16_t *a_ids;     // from-strings as symbol ranks
+    const void *a_chars;       // from-strings: code units of a_width bytes
+    int32_t a_width;
     const int64_t *a_off;      // [n_from + 1]
+    const uint16_t *lut;       // code unit -> symbol rank (0 = not in the to-list's alphabet), lut_len entries
+    uint32_t lut_len;
     const int32_t *rows;       // from-rows of this word class
     int32_t n_rows;
     const uint32_t *b_packed;  // to-strings, groups of 64, [t/PER][lane]
@@ -94,9 +101,16 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
 
     for (int r = blockIdx.x; r < A.n_rows; r += gridDim.x) {
         const int row = A.rows[r];
-        const uint16_t *a = A.a_ids + A.a_off[row];
-        const int m = (int)(A.a_off[row + 1] - A.a_off[row]);
-        for (int p = tid; p < m; p += 256) lds_or(&pm[(int)a[p] * W + p / WB], (WORD)1 << (p % WB));
+        const int64_t a0 = A.a_off[row];
+        const int m = (int)(A.a_off[row + 1] - a0);
+        auto a_sym = [&](int p) -> int {
+            const uint32_t c = A.a_width == 1 ? (uint32_t)((const uint8_t *)A.a_chars)[a0 + p] : ((const uint32_t *)A.a_chars)[a0 + p];
+            return c < A.lut_len ? (int)A.lut[c] : 0;
+        };
+        for (int p = tid; p < m; p += 256) {
+            const int sy = a_sym(p);
+            if (sy) lds_or(&pm[sy * W + p / WB], (WORD)1 << (p % WB));
+        }
         __syncthreads();
 
         const int skip = A.skip_idx ? A.skip_idx[row] : -1;
@@ -163,36 +177,188 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
         }
         // clear the PM entries of this from-string
         for (int p = tid; p < m; p += 256) {
+            const int sy = a_sym(p);
 #pragma unroll
-            for (int w = 0; w < W; ++w) pm[(int)a[p] * W + w] = 0;
+            for (int w = 0; w < W; ++w) pm[sy * W + w] = 0;       // (symbol 0 = padding: its entry is zero anyway)
         }
         __syncthreads();
     }
 }
 
-// ---- host side ---------------------------------------------------------------
+// ---- to-side plan (cached on the to-list's handle) -----------------------------
 
-static inline uint32_t unit_at(const pfz_strings *s, int64_t p)
+// distinct code units of a list: LDS bitmap for code points < 65536, global atomics beyond
+template <int CW>
+__global__ __launch_bounds__(256) void k4_mark_alphabet(const void *__restrict__ chars, int64_t n_units, uint32_t *__restrict__ present)
 {
-    if (s->char_width == 1) return s->h_chars[(size_t)p];
-    uint32_t v;
-    memcpy(&v, &s->h_chars[(size_t)p * 4], 4);
-    return v;
+    __shared__ uint32_t bm[2048];
+    for (int t = threadIdx.x; t < 2048; t += 256) bm[t] = 0u;
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_units; p += (int64_t)gridDim.x * 256) {
+        const uint32_t c = CW == 1 ? (uint32_t)((const uint8_t *)chars)[p] : ((const uint32_t *)chars)[p];
+        if (c < 65536u) {
+            if (!((bm[c >> 5] >> (c & 31)) & 1u)) atomicOr(&bm[c >> 5], 1u << (c & 31));
+        } else if (c < 0x110000u) {
+            atomicOr(&present[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2048; t += 256)
+        if (bm[t]) atomicOr(&present[t], bm[t]);
 }
 
-struct DevBuf {
+// slot (group g, lane l) = to-string order[g*64 + l]: its symbols as [t/PER][lane] dwords
+template <int CW, int IDB>
+__global__ __launch_bounds__(256) void k4_pack(const void *__restrict__ chars, const int64_t *__restrict__ off,
+                                                const int32_t *__restrict__ b_orig, const int64_t *__restrict__ g_off,
+                                                const int32_t *__restrict__ g_steps, int64_t n_slots,
+                                                const uint16_t *__restrict__ lut, uint32_t lut_len, uint32_t *__restrict__ packed)
+{
+    constexpr int PER = 32 / IDB;
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int64_t g = slot >> 6;
+    const int lane = (int)(slot & 63);
+    const int steps = g_steps[g];
+    uint32_t *dst = packed + g_off[g] + lane;
+    const int32_t j = b_orig[slot];
+    const int64_t b0 = j >= 0 ? off[j] : 0;
+    const int len = j >= 0 ? (int)(off[j + 1] - b0) : 0;
+    for (int t = 0; t < steps; ++t) {
+        uint32_t pk = 0u;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int pos = t * PER + q;
+            if (pos < len) {
+                const uint32_t c = CW == 1 ? (uint32_t)((const uint8_t *)chars)[b0 + pos] : ((const uint32_t *)chars)[b0 + pos];
+                pk |= (uint32_t)(c < lut_len ? lut[c] : 0) << (q * IDB);
+            }
+        }
+        dst[(int64_t)t * 64] = pk;
+    }
+}
+
+}  // namespace pfz
+
+struct pfz_indel_plan {
     pfz_ctx *ctx = nullptr;
-    void *p = nullptr;
-    ~DevBuf() { if (p) pool_free(p); }
-    int alloc(size_t bytes) { return pool_alloc(ctx, &p, bytes > 0 ? bytes : 16); }
-    template <typename T> int upload(const std::vector<T> &v, hipStream_t st)
+    int32_t n_sym = 0, idb = 8;          // alphabet size, bits per packed symbol
+    uint32_t lut_len = 0;
+    uint16_t *lut = nullptr;             // device [lut_len]
+    uint32_t *packed = nullptr;          // device
+    int64_t *g_off = nullptr;
+    int32_t *g_steps = nullptr, *b_len = nullptr, *b_orig = nullptr;
+    int64_t n_groups = 0;
+    int64_t char_steps = 0;              // sum over to-strings of their (padded) steps * 64 / per: the bench's work count
+    ~pfz_indel_plan()
     {
-        PFZ_TRY(alloc(v.size() * sizeof(T)));
-        (void)st;
-        if (!v.empty()) PFZ_TRY(copy_h2d(ctx, p, v.data(), v.size() * sizeof(T)));   // ctx->stream; v may be freed on return
-        return PFZ_OK;
+        for (void *p : {(void *)lut, (void *)packed, (void *)g_off, (void *)g_steps, (void *)b_len, (void *)b_orig})
+            if (p) pfz::pool_free(p);
     }
 };
+
+void pfz_indel_plan_free(pfz_indel_plan *p) { delete p; }
+
+namespace pfz {
+
+template <typename T> static int up(pfz_ctx *ctx, T **dst, const std::vector<T> &v)
+{
+    PFZ_TRY(pool_alloc(ctx, dst, (v.empty() ? 1 : v.size()) * sizeof(T)));
+    if (!v.empty()) PFZ_TRY(copy_h2d(ctx, *dst, v.data(), v.size() * sizeof(T)));
+    return PFZ_OK;
+}
+
+static int build_plan(pfz_ctx *ctx, const pfz_strings *T, pfz_indel_plan **out)
+{
+    Owner<pfz_indel_plan, pfz_indel_plan_free> pl(new pfz_indel_plan());
+    pl->ctx = ctx;
+    // alphabet of the to-list: presence bitmap on the device, ranks on the host
+    const size_t words = 0x110000 / 32;
+    uint32_t *present = nullptr;
+    PFZ_TRY(pool_alloc(ctx, &present, words * sizeof(uint32_t)));
+    struct Free {
+        void *p;
+        ~Free() { pool_free(p); }
+    } free_present{present};
+    const size_t used_words = T->char_width == 1 ? 8 : words;
+    PFZ_HIP(hipMemsetAsync(present, 0, used_words * sizeof(uint32_t), ctx->stream));
+    if (T->n_units > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>((T->n_units + 255) / 256, 2048);
+        if (T->char_width == 1)
+            hipLaunchKernelGGL(k4_mark_alphabet<1>, dim3(grid), dim3(256), 0, ctx->stream, T->chars, T->n_units, present);
+        else
+            hipLaunchKernelGGL(k4_mark_alphabet<4>, dim3(grid), dim3(256), 0, ctx->stream, T->chars, T->n_units, present);
+    }
+    std::vector<uint32_t> h(used_words);
+    PFZ_TRY(copy_d2h(ctx, h.data(), present, used_words * sizeof(uint32_t)));
+    std::vector<uint16_t> lut;
+    int32_t S = 0;
+    for (size_t wi = used_words; wi-- > 0;)
+        if (h[wi]) {
+            lut.assign((wi + 1) * 32, 0);
+            break;
+        }
+    for (size_t wi = 0; wi * 32 < lut.size(); ++wi) {
+        uint32_t word = h[wi];
+        while (word) {
+            const int bit = __builtin_ctz(word);
+            word &= word - 1;
+            if (S >= 65535) {
+                set_error("pfz_indel: more than 65535 distinct code points in the to-list exceed the 16-bit symbol space");
+                return PFZ_ERR_UNSUPPORTED;
+            }
+            lut[wi * 32 + (size_t)bit] = (uint16_t)(++S);
+        }
+    }
+    pl->n_sym = S;
+    pl->idb = S <= 255 ? 8 : 16;
+    pl->lut_len = (uint32_t)lut.size();
+    PFZ_TRY(up(ctx, &pl->lut, lut));
+    // groups of 64 to-strings of similar length: counting sort by length on the host (O(n) ints), packing on the device
+    const int per = 32 / pl->idb;
+    const int64_t n_to = T->n;
+    std::vector<int64_t> start((size_t)T->max_len + 2, 0);
+    for (int64_t j = 0; j < n_to; ++j) start[(size_t)(T->h_off[(size_t)j + 1] - T->h_off[(size_t)j]) + 1]++;
+    for (size_t l = 1; l < start.size(); ++l) start[l] += start[l - 1];
+    const int64_t n_groups = (n_to + 63) / 64;
+    std::vector<int32_t> b_len((size_t)n_groups * 64, 0), b_orig((size_t)n_groups * 64, -1), g_steps((size_t)n_groups);
+    std::vector<int64_t> g_off((size_t)n_groups);
+    for (int64_t j = 0; j < n_to; ++j) {      // ascending j inside one length: a stable sort
+        const int64_t len = T->h_off[(size_t)j + 1] - T->h_off[(size_t)j];
+        const int64_t pos = start[(size_t)len]++;
+        b_len[(size_t)pos] = (int32_t)len;
+        b_orig[(size_t)pos] = (int32_t)j;
+    }
+    int64_t total_dw = 0;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t last = std::min<int64_t>(n_to, (g + 1) * 64) - 1;     // sorted: the group's longest string
+        g_off[(size_t)g] = total_dw;
+        g_steps[(size_t)g] = (int32_t)((b_len[(size_t)last] + per - 1) / per);
+        total_dw += (int64_t)g_steps[(size_t)g] * 64;
+    }
+    pl->n_groups = n_groups;
+    pl->char_steps = total_dw * per;
+    PFZ_TRY(up(ctx, &pl->g_off, g_off));
+    PFZ_TRY(up(ctx, &pl->g_steps, g_steps));
+    PFZ_TRY(up(ctx, &pl->b_len, b_len));
+    PFZ_TRY(up(ctx, &pl->b_orig, b_orig));
+    PFZ_TRY(pool_alloc(ctx, &pl->packed, (size_t)(total_dw > 0 ? total_dw : 1) * sizeof(uint32_t)));
+    if (n_groups > 0) {
+        ProfScope ps(ctx, "k4_pack");
+        const unsigned grid = (unsigned)((n_groups * 64 + 255) / 256);
+#define PFZ_K4_PACK(CW, IDB)                                                                                        \
+    hipLaunchKernelGGL((k4_pack<CW, IDB>), dim3(grid), dim3(256), 0, ctx->stream, T->chars, T->offsets, pl->b_orig, \
+                       pl->g_off, pl->g_steps, n_groups * 64, pl->lut, pl->lut_len, pl->packed)
+        if (T->char_width == 1 && pl->idb == 8) PFZ_K4_PACK(1, 8);
+        else if (T->char_width == 1) PFZ_K4_PACK(1, 16);
+        else if (pl->idb == 8) PFZ_K4_PACK(4, 8);
+        else PFZ_K4_PACK(4, 16);
+#undef PFZ_K4_PACK
+        PFZ_HIP(hipGetLastError());
+    }
+    *out = pl.release();
+    return PFZ_OK;
+}
 
 template <typename WORD, int W>
 static int launch_class(pfz_ctx *ctx, const IndelArgs &A, int idb, unsigned grid)
@@ -212,72 +378,31 @@ static int launch_class(pfz_ctx *ctx, const IndelArgs &A, int idb, unsigned grid
     return PFZ_OK;
 }
 
-static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, const int32_t *skip_idx, int64_t begin,
+struct DevBuf {
+    pfz_ctx *ctx = nullptr;
+    void *p = nullptr;
+    ~DevBuf() { if (p) pool_free(p); }
+    int alloc(size_t bytes) { return pool_alloc(ctx, &p, bytes > 0 ? bytes : 16); }
+};
+
+static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c, const int32_t *skip_idx, int64_t begin,
                      int64_t end, int32_t *out_idx, double *out_score, double *out_matrix)
 {
-    PFZ_REQUIRE(ctx && F && T, "pfz_indel: NULL argument");
+    PFZ_REQUIRE(ctx && F && T_c, "pfz_indel: NULL argument");
     PFZ_REQUIRE(begin >= 0 && begin <= end && end <= F->n, "pfz_indel: row range [%lld,%lld) outside [0,%lld)",
                 (long long)begin, (long long)end, (long long)F->n);
     const int64_t n_rows = end - begin;
     if (n_rows == 0) return PFZ_OK;
     PFZ_HIP(hipSetDevice(ctx->device));
-    if (T->n >= INT_MAX - 64 || F->n >= INT_MAX) {
+    if (T_c->n >= INT_MAX - 64 || F->n >= INT_MAX) {
         set_error("pfz_indel: list too long");
         return PFZ_ERR_UNSUPPORTED;
     }
+    pfz_strings *T = const_cast<pfz_strings *>(T_c);    // the plan cache lives inside the (otherwise read-only) to-list
+    if (!T->indel_plan) PFZ_TRY(build_plan(ctx, T, &T->indel_plan));
+    const pfz_indel_plan *pl = T->indel_plan;
 
-    // alphabet: rank (1..S) of every distinct code point of both lists
-    std::vector<uint32_t> cps;
-    {
-        // (typed loops over the host mirror and a scan that stops at the largest code point seen: the generic
-        // per-unit accessor + a walk over all 1.1 M code points cost 2-15 ms per call)
-        const bool any_wide = F->char_width != 1 || T->char_width != 1;
-        std::vector<uint8_t> seen(any_wide ? 0x110000 / 8 + 1 : 32, 0);
-        uint32_t max_cp = 0;
-        for (const pfz_strings *s : {F, T}) {
-            if (s->char_width == 1) {
-                const uint8_t *u = s->h_chars.data();
-                for (int64_t p = 0; p < s->n_units; ++p) seen[u[p] >> 3] |= (uint8_t)(1u << (u[p] & 7));
-                if (s->n_units > 0 && max_cp < 255) max_cp = 255;
-            } else {
-                const uint32_t *u = (const uint32_t *)s->h_chars.data();
-                for (int64_t p = 0; p < s->n_units; ++p) {
-                    const uint32_t c = u[p];
-                    if (c < 0x110000u) {
-                        seen[c >> 3] |= (uint8_t)(1u << (c & 7));
-                        max_cp = c > max_cp ? c : max_cp;
-                    }
-                }
-            }
-        }
-        for (uint32_t c = 0; c <= max_cp; ++c)
-            if (seen[c >> 3] & (1u << (c & 7))) cps.push_back(c);
-    }
-    const int S = (int)cps.size();
-    if (S > 65535) {
-        set_error("pfz_indel: %d distinct code points exceed the 16-bit symbol space", S);
-        return PFZ_ERR_UNSUPPORTED;
-    }
-    const int idb = S <= 255 ? 8 : 16;
-    const int per = 32 / idb;
-    auto sym = [&](uint32_t c) -> uint16_t {
-        return (uint16_t)(std::lower_bound(cps.begin(), cps.end(), c) - cps.begin() + 1);
-    };
-    std::vector<uint16_t> lut;
-    if (!cps.empty() && cps.back() < 65536) {
-        lut.assign((size_t)cps.back() + 1, 0);
-        for (size_t r = 0; r < cps.size(); ++r) lut[cps[r]] = (uint16_t)(r + 1);
-    }
-    auto sym_fast = [&](uint32_t c) -> uint16_t { return !lut.empty() ? lut[c] : sym(c); };
-
-    // from side: symbol arrays + word classes by length
-    std::vector<uint16_t> a_ids((size_t)F->n_units);
-    if (F->char_width == 1 && !lut.empty()) {
-        const uint8_t *u = F->h_chars.data();
-        for (int64_t p = 0; p < F->n_units; ++p) a_ids[(size_t)p] = lut[u[p]];
-    } else {
-        for (int64_t p = 0; p < F->n_units; ++p) a_ids[(size_t)p] = sym_fast(unit_at(F, p));
-    }
+    // from side: word classes by length
     static const int kClassMax[7] = {32, 64, 128, 256, 512, 1024, INT_MAX};
     std::vector<int32_t> cls[7];
     for (int64_t i = begin; i < end; ++i) {
@@ -291,76 +416,32 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, c
                   cls[6][0]);
         return PFZ_ERR_UNSUPPORTED;
     }
-
-    // to side: sort by length, groups of 64, [step][lane] dwords of packed symbols
     const int64_t n_to = T->n;
-    std::vector<int32_t> order((size_t)n_to);
-    for (int64_t j = 0; j < n_to; ++j) order[(size_t)j] = (int32_t)j;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        return (T->h_off[(size_t)x + 1] - T->h_off[(size_t)x]) < (T->h_off[(size_t)y + 1] - T->h_off[(size_t)y]);
-    });
-    const int64_t n_groups = (n_to + 63) / 64;
-    std::vector<int64_t> g_off((size_t)n_groups);
-    std::vector<int32_t> g_steps((size_t)n_groups), b_len((size_t)n_groups * 64, 0), b_orig((size_t)n_groups * 64, -1);
-    int64_t total_dw = 0;
-    for (int64_t g = 0; g < n_groups; ++g) {
-        int64_t mx = 0;
-        for (int l = 0; l < 64 && g * 64 + l < n_to; ++l) {
-            const int32_t j = order[(size_t)(g * 64 + l)];
-            const int64_t len = T->h_off[(size_t)j + 1] - T->h_off[(size_t)j];
-            b_len[(size_t)(g * 64 + l)] = (int32_t)len;
-            b_orig[(size_t)(g * 64 + l)] = j;
-            mx = std::max(mx, len);
-        }
-        g_off[(size_t)g] = total_dw;
-        g_steps[(size_t)g] = (int32_t)((mx + per - 1) / per);
-        total_dw += (int64_t)g_steps[(size_t)g] * 64;
-    }
-    std::vector<uint32_t> packed((size_t)total_dw, 0u);
-    for (int64_t g = 0; g < n_groups; ++g)
-        for (int l = 0; l < 64 && g * 64 + l < n_to; ++l) {
-            const int32_t j = order[(size_t)(g * 64 + l)];
-            const int64_t b0 = T->h_off[(size_t)j], len = T->h_off[(size_t)j + 1] - b0;
-            uint32_t *dst = packed.data() + g_off[(size_t)g] + l;
-            if (T->char_width == 1 && !lut.empty()) {
-                const uint8_t *u = T->h_chars.data() + b0;
-                for (int64_t t = 0; t < len; ++t) dst[(t / per) * 64] |= (uint32_t)lut[u[t]] << ((t % per) * idb);
-            } else {
-                for (int64_t t = 0; t < len; ++t)
-                    dst[(t / per) * 64] |= (uint32_t)sym_fast(unit_at(T, b0 + t)) << ((t % per) * idb);
-            }
-        }
-
-    DevBuf d_a, d_aoff, d_packed, d_goff, d_gsteps, d_blen, d_borig, d_skip, d_oidx, d_oscore, d_matrix, d_rows[6];
-    for (DevBuf *b : {&d_a, &d_aoff, &d_packed, &d_goff, &d_gsteps, &d_blen, &d_borig, &d_skip, &d_oidx, &d_oscore,
-                      &d_matrix, &d_rows[0], &d_rows[1], &d_rows[2], &d_rows[3], &d_rows[4], &d_rows[5]})
+    DevBuf d_skip, d_oidx, d_oscore, d_matrix, d_rows[6];
+    for (DevBuf *b : {&d_skip, &d_oidx, &d_oscore, &d_matrix, &d_rows[0], &d_rows[1], &d_rows[2], &d_rows[3], &d_rows[4], &d_rows[5]})
         b->ctx = ctx;
-    PFZ_TRY(d_a.upload(a_ids, ctx->stream));
-    PFZ_TRY(d_aoff.upload(F->h_off, ctx->stream));
-    PFZ_TRY(d_packed.upload(packed, ctx->stream));
-    PFZ_TRY(d_goff.upload(g_off, ctx->stream));
-    PFZ_TRY(d_gsteps.upload(g_steps, ctx->stream));
-    PFZ_TRY(d_blen.upload(b_len, ctx->stream));
-    PFZ_TRY(d_borig.upload(b_orig, ctx->stream));
     if (skip_idx) {
-        std::vector<int32_t> sk(skip_idx, skip_idx + F->n);
-        PFZ_TRY(d_skip.upload(sk, ctx->stream));
+        PFZ_TRY(d_skip.alloc((size_t)F->n * sizeof(int32_t)));
+        PFZ_TRY(copy_h2d(ctx, d_skip.p, skip_idx, (size_t)F->n * sizeof(int32_t)));
     }
     PFZ_TRY(d_oidx.alloc((size_t)n_rows * sizeof(int32_t)));
     PFZ_TRY(d_oscore.alloc((size_t)n_rows * sizeof(double)));
     if (out_matrix) PFZ_TRY(d_matrix.alloc((size_t)n_rows * (size_t)n_to * sizeof(double)));
 
     IndelArgs A;
-    A.a_ids = (const uint16_t *)d_a.p;
-    A.a_off = (const int64_t *)d_aoff.p;
-    A.b_packed = (const uint32_t *)d_packed.p;
-    A.g_off = (const int64_t *)d_goff.p;
-    A.g_steps = (const int32_t *)d_gsteps.p;
-    A.b_len = (const int32_t *)d_blen.p;
-    A.b_orig = (const int32_t *)d_borig.p;
-    A.n_groups = (int32_t)n_groups;
+    A.a_chars = F->chars;
+    A.a_width = F->char_width;
+    A.a_off = F->offsets;
+    A.lut = pl->lut;
+    A.lut_len = pl->lut_len;
+    A.b_packed = pl->packed;
+    A.g_off = pl->g_off;
+    A.g_steps = pl->g_steps;
+    A.b_len = pl->b_len;
+    A.b_orig = pl->b_orig;
+    A.n_groups = (int32_t)pl->n_groups;
     A.skip_idx = skip_idx ? (const int32_t *)d_skip.p : nullptr;
-    A.n_sym1 = S + 1;
+    A.n_sym1 = pl->n_sym + 1;
     A.from_begin = begin;
     A.n_to = n_to;
     A.out_idx = (int32_t *)d_oidx.p;
@@ -369,17 +450,18 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, c
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 8;
     for (int c = 0; c < 6; ++c) {
         if (cls[c].empty()) continue;
-        PFZ_TRY(d_rows[c].upload(cls[c], ctx->stream));
+        PFZ_TRY(d_rows[c].alloc(cls[c].size() * sizeof(int32_t)));
+        PFZ_TRY(copy_h2d(ctx, d_rows[c].p, cls[c].data(), cls[c].size() * sizeof(int32_t)));
         A.rows = (const int32_t *)d_rows[c].p;
         A.n_rows = (int32_t)cls[c].size();
         const unsigned grid = (unsigned)std::min<int64_t>(A.n_rows, max_grid);
         switch (c) {
-        case 0: PFZ_TRY((launch_class<uint32_t, 1>(ctx, A, idb, grid))); break;
-        case 1: PFZ_TRY((launch_class<uint64_t, 1>(ctx, A, idb, grid))); break;
-        case 2: PFZ_TRY((launch_class<uint64_t, 2>(ctx, A, idb, grid))); break;
-        case 3: PFZ_TRY((launch_class<uint64_t, 4>(ctx, A, idb, grid))); break;
-        case 4: PFZ_TRY((launch_class<uint64_t, 8>(ctx, A, idb, grid))); break;
-        default: PFZ_TRY((launch_class<uint64_t, 16>(ctx, A, idb, grid))); break;
+        case 0: PFZ_TRY((launch_class<uint32_t, 1>(ctx, A, pl->idb, grid))); break;
+        case 1: PFZ_TRY((launch_class<uint64_t, 1>(ctx, A, pl->idb, grid))); break;
+        case 2: PFZ_TRY((launch_class<uint64_t, 2>(ctx, A, pl->idb, grid))); break;
+        case 3: PFZ_TRY((launch_class<uint64_t, 4>(ctx, A, pl->idb, grid))); break;
+        case 4: PFZ_TRY((launch_class<uint64_t, 8>(ctx, A, pl->idb, grid))); break;
+        default: PFZ_TRY((launch_class<uint64_t, 16>(ctx, A, pl->idb, grid))); break;
         }
     }
     if (out_idx) PFZ_TRY(copy_d2h(ctx, out_idx, d_oidx.p, (size_t)n_rows * sizeof(int32_t)));
@@ -408,6 +490,20 @@ int pfz_indel_matrix_host(pfz_ctx *ctx, const pfz_strings *from_strings, const p
     PFZ_REQUIRE(out_matrix, "pfz_indel_matrix_host: NULL output");
     if (to_strings && to_strings->n == 0) return PFZ_OK;
     return indel_run(ctx, from_strings, to_strings, nullptr, from_begin, from_end, nullptr, nullptr, out_matrix);
+}
+
+int pfz_indel_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_symbols, int64_t *n_groups, int64_t *char_steps)
+{
+    PFZ_REQUIRE(ctx && to_strings, "pfz_indel_plan_info: NULL argument");
+    pfz_strings *T = const_cast<pfz_strings *>(to_strings);
+    if (!T->indel_plan) {
+        PFZ_HIP(hipSetDevice(ctx->device));
+        PFZ_TRY(build_plan(ctx, T, &T->indel_plan));
+    }
+    if (n_symbols) *n_symbols = T->indel_plan->n_sym;
+    if (n_groups) *n_groups = T->indel_plan->n_groups;
+    if (char_steps) *char_steps = T->indel_plan->char_steps;
+    return PFZ_OK;
 }
 
 }  // extern "C"

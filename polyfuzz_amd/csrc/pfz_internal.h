@@ -106,9 +106,10 @@ struct pfz_strings {
     void *chars = nullptr;       // device [n_units]
     int64_t *offsets = nullptr;  // device [n+1], in code units
     int64_t max_len = 0;
-    // host mirror (a few MB): used by the host-side planning of K4
-    std::vector<uint8_t> h_chars;    // n_units * char_width bytes
+    // host mirror of the offsets: string lengths for the host-side planning of K4
     std::vector<int64_t> h_off;      // n + 1
+    // K4's to-side plan (alphabet, length-sorted packed groups), built on first use as a to-list
+    struct pfz_indel_plan *indel_plan = nullptr;
     // n-gram cache of the vectoriser (see k1_vectorize.hip): per-string slot
     // ranges holding first the packed n-gram codes, then (column id, tf) pairs
     uint64_t cache_gen = 0;      // pfz_tfidf::gen the cache was made for (0 = none)
@@ -116,6 +117,8 @@ struct pfz_strings {
     size_t slots_cap = 0;        // in uint64 entries
     int32_t *row_cnt = nullptr;  // device [n + 1]: n-grams, then distinct ids per string
 };
+
+void pfz_indel_plan_free(struct pfz_indel_plan *p);   // k4_indel.hip
 
 struct pfz_tfidf {
     pfz_ctx *ctx = nullptr;

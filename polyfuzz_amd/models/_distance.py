@@ -8,6 +8,7 @@ kernel (K4: bit-parallel LCS, fused first-max reduction); only the Indel ratio
 (`fuzz.ratio`) is implemented on the device, so any other scorer raises -- there is
 no CPU path to fall back to.
 """
+import time
 from typing import Callable, List, Union
 
 import numpy as np
@@ -15,6 +16,7 @@ import pandas as pd
 
 from .. import _lib
 from ._base import BaseMatcher
+from ._utils import object_column
 
 
 def _is_ratio(scorer) -> bool:
@@ -32,6 +34,10 @@ class EditDistance(BaseMatcher):
         scorer: "ratio" / rapidfuzz.fuzz.ratio (default).  Other scorers are not implemented on the device.
         model_id: The name of the particular instance, used when comparing models
         normalize: Whether to min-max normalize the similarity scores (_distance.py:83-86)
+
+    Limits of the device path (loud `PfzUnsupported`, there is no CPU fallback): from-strings of at most 1024
+    characters; (distinct code points of the to-list) x ceil(|from| / 64) words must fit 60 KiB of LDS --
+    e.g. 3 000 distinct CJK characters with from-strings beyond 128 characters do not.
     """
     def __init__(self,
                  n_jobs: int = 1,
@@ -47,38 +53,63 @@ class EditDistance(BaseMatcher):
         self.scorer = scorer
         self.normalize = normalize
         self.n_jobs = n_jobs
+        self._to_dev = self._to_names = None     # device copy (+ cached K4 plan) of the last to-list
+        self.last_timings = None
 
     def match(self,
               from_list: List[str],
               to_list: List[str] = None,
               **kwargs) -> pd.DataFrame:
-        """ Best match (first maximum of the ratio) of every from-string (reference _distance.py:46-87) """
-        idx, score, names = self._best(from_list, to_list)
-        to_col = [names[j] for j in idx.tolist()]
-        matches = pd.DataFrame({"From": pd.Series(list(from_list), dtype=object),
-                                "To": pd.Series(to_col, dtype=object),
-                                "Similarity": score})
+        """ Best match (first maximum of the ratio) of every from-string (reference _distance.py:46-87).
+
+        `re_train=False` (what PolyFuzz.transform passes, polyfuzz.py:234-240) matches against the to-list of
+        the previous call, whose device copy and K4 plan (alphabet, length-sorted packed groups) are still
+        resident: no upload, no preparation. """
+        t0 = time.perf_counter()
+        idx, score, names = self._best(from_list, to_list, reuse_to=kwargs.get("re_train", True) is False)
+        t1 = time.perf_counter()
+        to_col = object_column([names[j] for j in idx.tolist()])
+        matches = pd.DataFrame({"From": object_column(from_list), "To": to_col, "Similarity": score}, copy=False)
         if self.normalize:      # global min-max over the best scores, _distance.py:83-86
             matches["Similarity"] = (matches["Similarity"] -
                                      matches["Similarity"].min()) / (matches["Similarity"].max() -
                                                                      matches["Similarity"].min())
+        self.last_timings = {"device": (t1 - t0) * 1e3, "frame": (time.perf_counter() - t1) * 1e3}
         return matches
 
-    def _best(self, from_list, to_list, rows=None):
+    def _best(self, from_list, to_list, rows=None, reuse_to=False):
         ctx = _lib.Context.default()
         self_match = to_list is None
-        names = list(from_list) if self_match else list(to_list)
         skip = None
         if self_match:
+            names = from_list
             # list.remove(from_string) drops the FIRST equal element (_distance.py:93-96)
             first = {}
             for j, s in enumerate(names):
                 first.setdefault(s, j)
             skip = np.fromiter((first[s] for s in from_list), np.int32, len(from_list))
+        elif reuse_to and self._to_dev is not None:
+            names = self._to_names
+        else:
+            names = to_list
         if len(names) - (1 if self_match else 0) <= 0 and len(from_list) > 0:
             raise ValueError("attempt to get argmax of an empty sequence")   # np.argmax([]) in the reference
-        f_dev = _lib.DeviceStrings.upload(ctx, list(from_list))
-        t_dev = f_dev if self_match else _lib.DeviceStrings.upload(ctx, names)
+        f_dev = _lib.DeviceStrings.upload(ctx, from_list)
+        if self_match:
+            t_dev = f_dev
+        elif reuse_to and self._to_dev is not None:
+            t_dev = self._to_dev
+        else:
+            t_dev = _lib.DeviceStrings.upload(ctx, names)
+            self._to_dev, self._to_names = t_dev, names
         begin, end = (0, len(from_list)) if rows is None else rows
         idx, score = _lib.indel_argmax(ctx, f_dev, t_dev, skip, begin, end)
         return idx, score, names
+
+    # a matcher is pickled by joblib (reference _distance.py:77, polyfuzz.py:429-457): device handles stay behind
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in ("_to_dev", "_to_names")}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._to_dev = self._to_names = None
