@@ -93,3 +93,33 @@ def test_too_long_from_string_is_loud(ctx):
     f = _lib.DeviceStrings.upload(ctx, ["a" * 1025])
     with pytest.raises(NotImplementedError):
         _lib.indel_argmax(ctx, f, f)
+
+
+def test_rapidfuzz_matcher_extract_one_rules(oracle_mod):
+    """RapidFuzz(scorer='ratio'): process.extractOne semantics on top of K4 -- first best choice, None / 0.0 below
+    score_cutoff (a fraction of 1, compared on the 0..100 scale), Similarity = score / 100, a self-match excludes
+    only the from-string's own first occurrence and does NOT shrink the list (reference _rapidfuzz.py:99-113 with
+    its in-place `to_list.remove` fixed).  Scorer parity is unpinned (rapidfuzz is not installable): the expected
+    scores come from oracle/indel.c."""
+    from polyfuzz_amd.models import RapidFuzz
+    fl = ["apple", "apples", "appl", "recal", "house", "similarity", ""]
+    tl = ["apple", "apples", "mouse", ""]
+    with pytest.raises(NotImplementedError):
+        RapidFuzz()                                       # fuzz.WRatio, the reference's default, has no kernel
+    for cutoff in (0, 0.5, 0.95):
+        df = RapidFuzz(scorer="ratio", score_cutoff=cutoff).match(fl, tl)
+        assert list(df.columns) == ["From", "To", "Similarity"] and len(df) == len(fl)
+        o_idx, o_score = oracle_mod.indel_argmax(fl, tl)
+        exp_to = [tl[j] if s >= cutoff * 100 else None for j, s in zip(o_idx, o_score)]
+        exp_sim = [s / 100 if s >= cutoff * 100 else 0.0 for s in o_score]
+        assert df["To"].tolist() == exp_to and df["Similarity"].tolist() == exp_sim
+    df = RapidFuzz(scorer="ratio").match(fl, tl)
+    assert df["To"].tolist()[:3] == ["apple", "apples", "apple"] and df["Similarity"].tolist()[-1] == 1.0   # "" vs "": 100
+    q = RapidFuzz(scorer="QRatio").match(fl, tl)
+    assert q["To"].tolist()[-1] == "apple" and q["Similarity"].tolist()[-1] == 0.0                          # QRatio("", x) = 0
+    assert q["To"].tolist()[:-1] == df["To"].tolist()[:-1]
+    # self-match: every string keeps all OTHER strings as choices, whatever the row order
+    sl = ["apple", "apples", "appl", "apple"]
+    df = RapidFuzz(scorer="ratio").match(sl)
+    assert df["To"].tolist() == ["apple", "apple", "apple", "apple"]      # row 0 finds the duplicate at index 3, row 3 finds index 0
+    assert df["Similarity"].tolist()[0] == 1.0 and df["Similarity"].tolist()[3] == 1.0
