@@ -519,17 +519,36 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
         wave_sync();                                                         // mark[] is rewritten by the next round
 #endif
         const int left = total - r0;
-        const int ng = left >= 64 ? 8 : (left + 7) >> 3;                     // groups of two steps (8 pieces)
-        switch (ng) {
-        case 1: run_steps<2>(acc, post_bytes, addr_t, as_t, sub8); break;
-        case 2: run_steps<4>(acc, post_bytes, addr_t, as_t, sub8); break;
-        case 3: run_steps<6>(acc, post_bytes, addr_t, as_t, sub8); break;
-        case 4: run_steps<8>(acc, post_bytes, addr_t, as_t, sub8); break;
-        case 5: run_steps<10>(acc, post_bytes, addr_t, as_t, sub8); break;
-        case 6: run_steps<12>(acc, post_bytes, addr_t, as_t, sub8); break;
-        case 7: run_steps<14>(acc, post_bytes, addr_t, as_t, sub8); break;
-        default: run_steps<16>(acc, post_bytes, addr_t, as_t, sub8); break;
+        // groups of two steps (8 pieces); an explicit binary tree of wave-uniform branches (the compiler lowers a
+        // switch to a chain of compares with saved/restored condition masks -- ~40 scalar instructions per round)
+        const int ng = left >= 64 ? 8 : (left + 7) >> 3;
+#if PFZ_K3_EXP == 6      // groups of four steps only
+        if (ng <= 4) {
+            if (ng <= 2) run_steps<4>(acc, post_bytes, addr_t, as_t, sub8);
+            else run_steps<8>(acc, post_bytes, addr_t, as_t, sub8);
+        } else {
+            if (ng <= 6) run_steps<12>(acc, post_bytes, addr_t, as_t, sub8);
+            else run_steps<16>(acc, post_bytes, addr_t, as_t, sub8);
         }
+#else
+        if (ng <= 4) {
+            if (ng <= 2) {
+                if (ng == 1) run_steps<2>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<4>(acc, post_bytes, addr_t, as_t, sub8);
+            } else {
+                if (ng == 3) run_steps<6>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<8>(acc, post_bytes, addr_t, as_t, sub8);
+            }
+        } else {
+            if (ng <= 6) {
+                if (ng == 5) run_steps<10>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<12>(acc, post_bytes, addr_t, as_t, sub8);
+            } else {
+                if (ng == 7) run_steps<14>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<16>(acc, post_bytes, addr_t, as_t, sub8);
+            }
+        }
+#endif
     }
 }
 
