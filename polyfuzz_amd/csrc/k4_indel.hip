@@ -85,13 +85,53 @@ struct IndelArgs {
     double *matrix;            // optional [(from_end-from_begin) * n_to]
 };
 
+// The running best of a from-string is kept as the exact rational lcs / maximum (maximum = |a| + |b|): the ratio
+// (1 - (maximum - 2 lcs) / maximum) * 100 is monotone in it, two different rationals with denominators < 2^32 differ
+// by far more than a float64 rounding, and equal rationals give the same correctly rounded double -- so comparing
+// cross products orders the pairs exactly as the reference's float64 scores do, without a float64 division per
+// pair (it was a third of the kernel's instructions).  The double is computed once per from-string.
+struct Best {
+    int lcs, mx, idx;     // idx == INT_MAX: nothing yet;  both strings empty is stored as 1 / 1 (ratio 100)
+};
+
+__device__ inline bool better(int lcs_a, int mx_a, int idx_a, const Best &b)
+{
+    const uint64_t l = (uint64_t)(uint32_t)lcs_a * (uint32_t)b.mx, r = (uint64_t)(uint32_t)b.lcs * (uint32_t)mx_a;
+    return b.idx == INT_MAX ? idx_a != INT_MAX : (l > r || (l == r && idx_a < b.idx));
+}
+
+__device__ inline void take(Best &b, int lcs, int mx, int idx)
+{
+    if (better(lcs, mx, idx, b)) {
+        b.lcs = lcs;
+        b.mx = mx;
+        b.idx = idx;
+    }
+}
+
+__device__ inline void wave_best(Best &b)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int ol = __shfl_xor(b.lcs, d, 64), om = __shfl_xor(b.mx, d, 64), oi = __shfl_xor(b.idx, d, 64);
+        if (oi != INT_MAX) take(b, ol, om, oi);
+    }
+}
+
+// rapidfuzz: norm_dist = dist / maximum (0 when both empty); ratio = (1 - norm_dist) * 100
+__device__ inline double ratio_of(int lcs, int64_t maximum)
+{
+    const int64_t dist = maximum - 2 * (int64_t)lcs;
+    const double norm_dist = maximum != 0 ? (double)dist / (double)maximum : 0.0;
+    return (1.0 - norm_dist) * 100.0;
+}
+
 template <typename WORD, int W, int IDB>
 __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     WORD *pm = (WORD *)smem_raw;
-    __shared__ double red_s[4];
-    __shared__ int red_i[4];
+    __shared__ int red[4][3];
     constexpr int WB = sizeof(WORD) * 8;
     constexpr int PER = 32 / IDB;  // symbols per dword
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,8 +154,7 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
         __syncthreads();
 
         const int skip = A.skip_idx ? A.skip_idx[row] : -1;
-        double best = -1.0;
-        int besti = INT_MAX;
+        Best best = {0, 1, INT_MAX};
         for (int g = wave; g < A.n_groups; g += 4) {
             WORD V[W];
 #pragma unroll
@@ -138,42 +177,28 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
             const int orig = A.b_orig[slot];
             if (orig >= 0) {
                 const int lb = A.b_len[slot];
-                const int64_t maximum = (int64_t)m + lb;
-                const int64_t dist = maximum - 2 * (int64_t)lcs;
-                // rapidfuzz: norm_dist = dist / maximum (0 when both empty); ratio = (1 - norm_dist) * 100
-                const double norm_dist = maximum != 0 ? (double)dist / (double)maximum : 0.0;
-                const double score = (1.0 - norm_dist) * 100.0;
-                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = orig == skip ? -1.0 : score;
-                if (orig != skip && (score > best || (score == best && orig < besti))) {
-                    best = score;
-                    besti = orig;
+                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = orig == skip ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
+                if (orig != skip) {
+                    if (m + lb == 0) take(best, 1, 1, orig);
+                    else take(best, lcs, m + lb, orig);
                 }
             }
         }
         // first maximum: (score desc, original index asc)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double os = __shfl_xor(best, d, 64);
-            const int oi = __shfl_xor(besti, d, 64);
-            if (os > best || (os == best && oi < besti)) {
-                best = os;
-                besti = oi;
-            }
-        }
+        wave_best(best);
         if (lane == 0) {
-            red_s[wave] = best;
-            red_i[wave] = besti;
+            red[wave][0] = best.lcs;
+            red[wave][1] = best.mx;
+            red[wave][2] = best.idx;
         }
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < 4; ++w)
-                if (red_s[w] > best || (red_s[w] == best && red_i[w] < besti)) {
-                    best = red_s[w];
-                    besti = red_i[w];
-                }
+                if (red[w][2] != INT_MAX) take(best, red[w][0], red[w][1], red[w][2]);
             const int64_t o = (int64_t)row - A.from_begin;
-            A.out_idx[o] = besti == INT_MAX ? -1 : besti;
-            A.out_score[o] = besti == INT_MAX ? 0.0 : best;
+            A.out_idx[o] = best.idx == INT_MAX ? -1 : best.idx;
+            // (1 / 1 can only be the stored form of two empty strings -- maximum = 1 has lcs = 0: ratio 100)
+            A.out_score[o] = best.idx == INT_MAX ? 0.0 : (best.lcs == 1 && best.mx == 1 ? 100.0 : ratio_of(best.lcs, best.mx));
         }
         // clear the PM entries of this from-string
         for (int p = tid; p < m; p += 256) {
@@ -181,6 +206,109 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
 #pragma unroll
             for (int w = 0; w < W; ++w) pm[sy * W + w] = 0;       // (symbol 0 = padding: its entry is zero anyway)
         }
+        __syncthreads();
+    }
+}
+
+// Class 0 (from-strings of <= 32 characters: 95 % of the IMDB titles, 80 % of the company names), FOUR from-strings
+// per workgroup pass: the match table holds the four 32-bit masks of a symbol side by side, so one ds_read_b128 --
+// and one extraction of the to-symbol, one address, one load of the packed to-characters, one trip through the
+// group loop -- serves four Indel recurrences.
+template <int IDB>
+__global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *pm = (uint4 *)smem_raw;
+    __shared__ int red[4][4][3];
+    constexpr int PER = 32 / IDB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int p = tid; p < A.n_sym1; p += 256) pm[p] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    const int n_quads = (A.n_rows + 3) >> 2;
+    for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
+        int row[4], m[4], skip[4];
+        int64_t a0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = qd * 4 + k;
+            row[k] = r < A.n_rows ? A.rows[r] : -1;
+            a0[k] = row[k] >= 0 ? A.a_off[row[k]] : 0;
+            m[k] = row[k] >= 0 ? (int)(A.a_off[row[k] + 1] - a0[k]) : 0;
+            skip[k] = (A.skip_idx && row[k] >= 0) ? A.skip_idx[row[k]] : -1;
+        }
+        // thread t < 128 owns character t & 31 of string (t >> 5) & 3 (strings have at most 32 characters); the
+        // string's fields are picked with selects -- a dynamic index would push the small arrays to scratch
+        const int myk = (tid >> 5) & 3, myp = tid & 31;
+        const int my_m = myk == 0 ? m[0] : (myk == 1 ? m[1] : (myk == 2 ? m[2] : m[3]));
+        const int64_t my_a0 = myk == 0 ? a0[0] : (myk == 1 ? a0[1] : (myk == 2 ? a0[2] : a0[3]));
+        int my_sym = 0;
+        if (tid < 128 && myp < my_m) {
+            const uint32_t c = A.a_width == 1 ? (uint32_t)((const uint8_t *)A.a_chars)[my_a0 + myp] : ((const uint32_t *)A.a_chars)[my_a0 + myp];
+            my_sym = c < A.lut_len ? (int)A.lut[c] : 0;
+        }
+        if (my_sym) atomicOr((uint32_t *)&pm[my_sym] + myk, 1u << myp);
+        __syncthreads();
+
+        Best best[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) best[k] = Best{0, 1, INT_MAX};
+        for (int g = wave; g < A.n_groups; g += 4) {
+            uint32_t V0 = ~0u, V1 = ~0u, V2 = ~0u, V3 = ~0u;
+            const uint32_t *gp = A.b_packed + A.g_off[g] + lane;
+            const int steps = A.g_steps[g];
+#pragma unroll 2
+            for (int t = 0; t < steps; ++t) {
+                const uint32_t pk = gp[(int64_t)t * 64];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const uint32_t c = (pk >> (q * IDB)) & ((1u << IDB) - 1u);
+                    const uint4 M = pm[c];
+                    uint32_t u;
+                    u = V0 & M.x; V0 = (V0 + u) | (V0 ^ u);
+                    u = V1 & M.y; V1 = (V1 + u) | (V1 ^ u);
+                    u = V2 & M.z; V2 = (V2 + u) | (V2 ^ u);
+                    u = V3 & M.w; V3 = (V3 + u) | (V3 ^ u);
+                }
+            }
+            const int slot = g * 64 + lane;
+            const int orig = A.b_orig[slot];
+            if (orig >= 0) {
+                const int lb = A.b_len[slot];
+                const int lcs[4] = {(int)__popc(~V0), (int)__popc(~V1), (int)__popc(~V2), (int)__popc(~V3)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (row[k] >= 0 && orig != skip[k]) {
+                        if (m[k] + lb == 0) take(best[k], 1, 1, orig);
+                        else take(best[k], lcs[k], m[k] + lb, orig);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wave_best(best[k]);
+            if (lane == 0) {
+                red[wave][k][0] = best[k].lcs;
+                red[wave][k][1] = best[k].mx;
+                red[wave][k][2] = best[k].idx;
+            }
+        }
+        __syncthreads();
+        if (tid < 4) {
+            const int k = tid;
+            const int rk = k == 0 ? row[0] : (k == 1 ? row[1] : (k == 2 ? row[2] : row[3]));
+            if (rk >= 0) {
+                Best b = {red[0][k][0], red[0][k][1], red[0][k][2]};
+                for (int w = 1; w < 4; ++w)
+                    if (red[w][k][2] != INT_MAX) take(b, red[w][k][0], red[w][k][1], red[w][k][2]);
+                const int64_t o = (int64_t)rk - A.from_begin;
+                A.out_idx[o] = b.idx == INT_MAX ? -1 : b.idx;
+                A.out_score[o] = b.idx == INT_MAX ? 0.0 : (b.lcs == 1 && b.mx == 1 ? 100.0 : ratio_of(b.lcs, b.mx));
+            }
+        }
+        if (my_sym) *((uint32_t *)&pm[my_sym] + myk) = 0u;      // clear the entries this quad set
         __syncthreads();
     }
 }
@@ -455,6 +583,16 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         A.rows = (const int32_t *)d_rows[c].p;
         A.n_rows = (int32_t)cls[c].size();
         const unsigned grid = (unsigned)std::min<int64_t>(A.n_rows, max_grid);
+        if (c == 0 && !out_matrix && (size_t)A.n_sym1 * sizeof(uint4) <= 60 * 1024 && !getenv("PFZ_K4_NO_QUAD")) {
+            // four short from-strings per workgroup pass (PFZ_K4_NO_QUAD=1: the one-string kernel, tests)
+            ProfScope ps(ctx, "k4_indel");
+            const unsigned qgrid = (unsigned)std::min<int64_t>((A.n_rows + 3) / 4, max_grid);
+            const size_t lds = (size_t)A.n_sym1 * sizeof(uint4);
+            if (pl->idb == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8>), dim3(qgrid), dim3(256), lds, ctx->stream, A);
+            else hipLaunchKernelGGL((k4_indel_quad_kernel<16>), dim3(qgrid), dim3(256), lds, ctx->stream, A);
+            PFZ_HIP(hipGetLastError());
+            continue;
+        }
         switch (c) {
         case 0: PFZ_TRY((launch_class<uint32_t, 1>(ctx, A, pl->idb, grid))); break;
         case 1: PFZ_TRY((launch_class<uint64_t, 1>(ctx, A, pl->idb, grid))); break;

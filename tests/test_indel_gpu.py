@@ -123,3 +123,42 @@ def test_rapidfuzz_matcher_extract_one_rules(oracle_mod):
     df = RapidFuzz(scorer="ratio").match(sl)
     assert df["To"].tolist() == ["apple", "apple", "apple", "apple"]      # row 0 finds the duplicate at index 3, row 3 finds index 0
     assert df["Similarity"].tolist()[0] == 1.0 and df["Similarity"].tolist()[3] == 1.0
+
+
+def test_quad_kernel_equals_single_string_kernel_and_oracle(ctx, oracle_mod, monkeypatch):
+    """From-strings of <= 32 characters go four per workgroup pass (one ds_read_b128 serves four recurrences);
+    longer ones take the one-string word classes.  Both give the oracle's arg-max and float64 score bit for bit --
+    row counts that are not multiples of four, empty strings on both sides, duplicates, a self-match with skipped
+    first occurrences, characters the to-list never uses."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(8)
+    alpha = np.array(list("abcdefghij XYZ-'é"), dtype=object)
+
+    def mk(n, lo, hi):
+        return ["".join(rng.choice(alpha, size=int(rng.integers(lo, hi))).tolist()) for _ in range(n)]
+    fl = mk(203, 0, 33) + ["", "q" * 32, "zzzz"] + mk(7, 33, 90)         # class 0 rows (not a multiple of 4) + longer ones
+    tl = mk(530, 0, 60) + ["", "abc", "abc"]
+    for self_match in (False, True):
+        f = _lib.DeviceStrings.upload(ctx, fl)
+        t = f if self_match else _lib.DeviceStrings.upload(ctx, tl)
+        names = fl if self_match else tl
+        skip = None
+        if self_match:
+            first = {}
+            for j, s in enumerate(names):
+                first.setdefault(s, j)
+            skip = np.array([first[s] for s in fl], np.int32)
+        idx, score = _lib.indel_argmax(ctx, f, t, skip)
+        monkeypatch.setenv("PFZ_K4_NO_QUAD", "1")
+        idx1, score1 = _lib.indel_argmax(ctx, f, t, skip)
+        monkeypatch.delenv("PFZ_K4_NO_QUAD")
+        np.testing.assert_array_equal(idx, idx1)
+        np.testing.assert_array_equal(score, score1)
+        e_idx, e_score, mat = oracle_mod.indel_argmax(fl, names, want_matrix=True)
+        if self_match:                      # the oracle's self_match drops j == i; the reference drops the FIRST equal element
+            for i in range(len(fl)):
+                row = mat[i].copy()
+                row[skip[i]] = -1.0
+                e_idx[i], e_score[i] = int(np.argmax(row)), row.max()
+        np.testing.assert_array_equal(idx, e_idx)
+        np.testing.assert_array_equal(score, e_score)
