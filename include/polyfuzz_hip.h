@@ -223,6 +223,19 @@ int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
                             int32_t ntop, float lower_bound, int32_t exclude_diag,
                             int32_t *out_idx, float *out_val);
 
+/* The same operator with device-resident operands -- the to-side embeddings stay in HBM between
+ * Embeddings.match(..., re_train=False) calls (reference polyfuzz.py:234-240) and a row shard of the
+ * from-side is matched against a replicated to-side on every GPU (BASELINE config 5).  normalize != 0:
+ * rows are scaled by 1/||row|| (true cosine), 0: raw dot products.  pfz_dense_topn enqueues on the
+ * context stream and leaves (idx, score) in `out` (rows [0, n_from)); exclude_diag drops
+ * j == i + diag_offset.  1 <= ntop <= 128. */
+typedef struct pfz_dense pfz_dense;
+int pfz_dense_upload(pfz_ctx *ctx, const float *vec, int64_t n, int64_t dim, int32_t normalize, pfz_dense **out);
+int pfz_dense_shape(const pfz_dense *m, int64_t *n, int64_t *dim);
+void pfz_dense_free(pfz_dense *m);
+int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from_vectors, const pfz_dense *to_vectors, int32_t ntop,
+                   float lower_bound, int32_t exclude_diag, int64_t diag_offset, pfz_topn *out);
+
 /* ---- K6: reductions on the hot path's output --------------------------------
  * precision_recall_curve (reference polyfuzz/metrics.py:12-53): for every threshold p_k
  * (ascending, n_thresholds <= 4096) count_ge[k] = #{i : sim[i] >= p_k} and sum_ge[k] = the sum of

@@ -80,6 +80,10 @@ SIGNATURES = {
                                                   c_vp, c_vp]),
     "pfz_dense_dot_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                c_vp, c_vp]),
+    "pfz_dense_upload": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, P(c_vp)]),
+    "pfz_dense_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
+    "pfz_dense_free": (None, [c_vp]),
+    "pfz_dense_topn": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_f32, c_i32, c_i64, c_vp]),
     "pfz_pr_curve_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "pfz_linkage_top1": (ctypes.c_int, [c_vp, c_vp, c_f64, c_vp, c_vp, c_vp]),
     "pfz_comm_unique_id": (ctypes.c_int, [c_vp]),
@@ -490,6 +494,32 @@ def dense_cossim_topn_host(ctx, from_vec, to_vec, ntop, lower_bound, exclude_dia
     check(fn(ctx.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], int(ntop), float(lower_bound),
              int(bool(exclude_diag)), _ptr(idx), _ptr(val)))
     return idx, val
+
+
+class DeviceDense(_Handle):
+    """Device-resident row-major fp32 matrix + inverse row norms (K5 operand)."""
+    _free = "pfz_dense_free"
+
+    @classmethod
+    def upload(cls, ctx, vec, normalize=True):
+        a = np.ascontiguousarray(vec, np.float32)
+        if a.ndim != 2:
+            raise ValueError(f"dense vectors must be a 2-D array, got shape {a.shape}")
+        h = c_vp()
+        check(ctx.lib.pfz_dense_upload(ctx.h, _ptr(a) if a.size else None, a.shape[0], max(a.shape[1], 1), int(bool(normalize)),
+                                       ctypes.byref(h)))
+        m = cls(ctx, h)
+        m.n, m.dim, m.normalize = a.shape[0], a.shape[1], bool(normalize)
+        return m
+
+
+def dense_topn(ctx, from_dev, to_dev, ntop, lower_bound, exclude_diag=False, diag_offset=0, out=None):
+    """Enqueue K5 on resident operands; returns the (device-resident) DeviceTopN."""
+    if out is None:
+        out = DeviceTopN.alloc(ctx, from_dev.n, ntop)
+    check(ctx.lib.pfz_dense_topn(ctx.h, from_dev.h, to_dev.h, int(ntop), float(lower_bound), int(bool(exclude_diag)),
+                                 int(diag_offset), out.h))
+    return out
 
 
 def pr_curve(ctx, sims, thresholds):

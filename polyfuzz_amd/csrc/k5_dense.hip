@@ -252,7 +252,8 @@ __device__ inline uint64_t wave_max_u64_5(uint64_t v)
 // One wave per score row: top-n of the scores > thr.
 __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, int64_t ld, int64_t a0, int64_t a1,
                                                     int64_t n_b, int32_t ntop, float lower_bound, int32_t exclude_diag,
-                                                    int32_t *__restrict__ out_idx, float *__restrict__ out_val)
+                                                    int64_t diag_offset, int32_t *__restrict__ out_idx,
+                                                    float *__restrict__ out_val)
 {
     __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][kCap5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
     if (row >= a1) return;
     uint64_t *cand = cand_all[wave];
     const float *s = S + (row - a0) * ld;
-    const int64_t self_col = exclude_diag ? row : -1;
+    const int64_t self_col = exclude_diag ? row + diag_offset : -1;
     int cnt = 0;
     float thr = lower_bound;
 
@@ -351,51 +352,80 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
 
 using namespace pfz;
 
+struct pfz_dense {
+    pfz_ctx *ctx = nullptr;
+    int64_t n = 0, dim = 0;
+    int32_t normalize = 1;
+    float *x = nullptr;      // device [n][dim] row-major
+    float *inv = nullptr;    // device [n]: 1 / ||row|| (1 when normalize == 0)
+};
+
 extern "C" {
 
-static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,
-                           int64_t dim, int32_t ntop, float lower_bound, int32_t exclude_diag, int32_t normalize,
-                           int32_t *out_idx, float *out_val)
+void pfz_dense_free(pfz_dense *m)
 {
-    PFZ_REQUIRE(ctx && out_idx && out_val, "pfz_dense_cossim_topn_host: NULL argument");
-    PFZ_REQUIRE(n_from >= 0 && n_to >= 0 && dim >= 1, "pfz_dense_cossim_topn_host: bad shape");
-    PFZ_REQUIRE(ntop >= 1, "pfz_dense_cossim_topn_host: ntop must be >= 1");
-    PFZ_REQUIRE(lower_bound == lower_bound, "pfz_dense_cossim_topn_host: lower_bound is NaN");
+    if (!m) return;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->x) pool_free(m->x);
+    if (m->inv) pool_free(m->inv);
+    delete m;
+}
+
+int pfz_dense_upload(pfz_ctx *ctx, const float *vec, int64_t n, int64_t dim, int32_t normalize, pfz_dense **out)
+{
+    PFZ_REQUIRE(ctx && out && (n == 0 || vec), "pfz_dense_upload: NULL argument");
+    PFZ_REQUIRE(n >= 0 && dim >= 1, "pfz_dense_upload: bad shape %lld x %lld", (long long)n, (long long)dim);
+    if (n >= ((int64_t)1 << 31) - 256) {
+        set_error("pfz_dense_upload: %lld rows exceed the int32 result indices", (long long)n);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    PFZ_HIP(hipSetDevice(ctx->device));
+    Owner<pfz_dense, pfz_dense_free> m(new pfz_dense());
+    m->ctx = ctx;
+    m->n = n;
+    m->dim = dim;
+    m->normalize = normalize ? 1 : 0;
+    PFZ_TRY(pool_alloc(ctx, &m->x, (size_t)(n > 0 ? n : 1) * (size_t)dim * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &m->inv, (size_t)(n > 0 ? n : 1) * sizeof(float)));
+    if (n > 0) {
+        PFZ_TRY(copy_h2d(ctx, m->x, vec, (size_t)n * (size_t)dim * sizeof(float)));
+        hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, m->x, n, dim, m->inv, m->normalize);
+        PFZ_HIP(hipGetLastError());
+    }
+    *out = m.release();
+    return PFZ_OK;
+}
+
+int pfz_dense_shape(const pfz_dense *m, int64_t *n, int64_t *dim)
+{
+    PFZ_REQUIRE(m, "pfz_dense_shape: NULL matrix");
+    if (n) *n = m->n;
+    if (dim) *dim = m->dim;
+    return PFZ_OK;
+}
+
+int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int32_t ntop, float lower_bound,
+                   int32_t exclude_diag, int64_t diag_offset, pfz_topn *out)
+{
+    PFZ_REQUIRE(ctx && from && to && out, "pfz_dense_topn: NULL argument");
+    PFZ_REQUIRE(from->dim == to->dim, "pfz_dense_topn: from-vectors have %lld columns, to-vectors %lld", (long long)from->dim,
+                (long long)to->dim);
+    PFZ_REQUIRE(ntop >= 1, "pfz_dense_topn: ntop must be >= 1");
+    PFZ_REQUIRE(lower_bound == lower_bound, "pfz_dense_topn: lower_bound is NaN");
     if (ntop > 128) {
-        set_error("pfz_dense_cossim_topn_host: ntop=%d exceeds the kernel's limit of 128", ntop);
+        set_error("pfz_dense_topn: ntop=%d exceeds the kernel's limit of 128", ntop);
         return PFZ_ERR_UNSUPPORTED;
     }
-    if (n_to >= ((int64_t)1 << 31) - 256) {
-        set_error("pfz_dense_cossim_topn_host: n_to too large for int32 indices");
-        return PFZ_ERR_UNSUPPORTED;
-    }
+    PFZ_REQUIRE(out->n_rows >= from->n && out->ntop == ntop, "pfz_dense_topn: result buffer is %lldx%d, need %lldx%d",
+                (long long)out->n_rows, out->ntop, (long long)from->n, ntop);
+    const int64_t n_from = from->n, n_to = to->n, dim = from->dim;
     if (n_from == 0) return PFZ_OK;
-    PFZ_REQUIRE(from_vec && (n_to == 0 || to_vec), "pfz_dense_cossim_topn_host: NULL matrix");
     PFZ_HIP(hipSetDevice(ctx->device));
     if (lower_bound < 0.f) lower_bound = 0.f;   // non-positive similarities are "no match" (_utils.py:122-123)
-    const bool same = to_vec == from_vec && n_to == n_from;
-
     struct Buf {
         void *p = nullptr;
         ~Buf() { if (p) pool_free(p); }
-    } dA, dB, dIa, dIb, dS, dOi, dOv;
-    const size_t a_bytes = (size_t)n_from * (size_t)dim * sizeof(float);
-    const size_t b_bytes = (size_t)(n_to > 0 ? n_to : 1) * (size_t)dim * sizeof(float);
-    PFZ_TRY(pool_alloc(ctx, &dA.p, a_bytes));
-    PFZ_TRY(copy_h2d(ctx, dA.p, from_vec, a_bytes));
-    if (!same) {
-        PFZ_TRY(pool_alloc(ctx, &dB.p, b_bytes));
-        if (n_to > 0) PFZ_TRY(copy_h2d(ctx, dB.p, to_vec, (size_t)n_to * (size_t)dim * sizeof(float)));
-    }
-    const float *A = (const float *)dA.p, *B = same ? A : (const float *)dB.p;
-    PFZ_TRY(pool_alloc(ctx, &dIa.p, (size_t)n_from * sizeof(float)));
-    PFZ_TRY(pool_alloc(ctx, &dIb.p, (size_t)(n_to > 0 ? n_to : 1) * sizeof(float)));
-    PFZ_TRY(pool_alloc(ctx, &dOi.p, (size_t)n_from * ntop * sizeof(int32_t)));
-    PFZ_TRY(pool_alloc(ctx, &dOv.p, (size_t)n_from * ntop * sizeof(float)));
-    hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_from + 3) / 4)), dim3(256), 0, ctx->stream, A, n_from, dim, (float *)dIa.p, normalize);
-    if (n_to > 0)
-        hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n_to + 3) / 4)), dim3(256), 0, ctx->stream, B, n_to, dim, (float *)dIb.p, normalize);
-
+    } dS;
     const int64_t ld = ((n_to + 255) / 256) * 256;                      // whole float4 x 64-lane steps
     int64_t panel = ld > 0 ? ((int64_t)8 << 30) / (ld * 4) : n_from;     // <= 8 GiB of scores
     panel = std::max<int64_t>(kTile, std::min<int64_t>(panel / kTile * kTile, ((n_from + kTile - 1) / kTile) * kTile));
@@ -407,24 +437,43 @@ static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, 
             dim3 grid((unsigned)(ld / kTile), (unsigned)((a1 - a0 + kTile - 1) / kTile));
             // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
             if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE"))
-                hipLaunchKernelGGL(k5_gemm_panel_pipe, grid, dim3(256), 0, ctx->stream, A, B, (const float *)dIa.p,
-                                   (const float *)dIb.p, a0, a1, n_to, dim, (float *)dS.p, ld);
+                hipLaunchKernelGGL(k5_gemm_panel_pipe, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0,
+                                   a1, n_to, dim, (float *)dS.p, ld);
             else
-                hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, A, B, (const float *)dIa.p,
-                                   (const float *)dIb.p, a0, a1, n_to, dim, (float *)dS.p, ld);
+                hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
+                                   n_to, dim, (float *)dS.p, ld);
         }
         {
             ProfScope ps(ctx, "k5_row_topn");
             hipLaunchKernelGGL(k5_row_topn, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ctx->stream,
-                               (const float *)dS.p, ld, a0, a1, n_to, ntop, lower_bound, exclude_diag,
-                               (int32_t *)dOi.p, (float *)dOv.p);
+                               (const float *)dS.p, ld, a0, a1, n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx,
+                               out->val);
         }
     }
     PFZ_HIP(hipGetLastError());
-    PFZ_TRY(copy_d2h(ctx, out_idx, dOi.p, (size_t)n_from * ntop * sizeof(int32_t)));
-    PFZ_TRY(copy_d2h(ctx, out_val, dOv.p, (size_t)n_from * ntop * sizeof(float)));
-    PFZ_HIP(hipStreamSynchronize(ctx->stream));
-    return PFZ_OK;
+    return PFZ_OK;     // (the score panel goes back to the pool: stream order keeps it alive until the kernels are done)
+}
+
+static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,
+                           int64_t dim, int32_t ntop, float lower_bound, int32_t exclude_diag, int32_t normalize,
+                           int32_t *out_idx, float *out_val)
+{
+    PFZ_REQUIRE(ctx && out_idx && out_val, "pfz_dense_cossim_topn_host: NULL argument");
+    PFZ_REQUIRE(n_from >= 0 && n_to >= 0 && dim >= 1, "pfz_dense_cossim_topn_host: bad shape");
+    if (n_from == 0) return PFZ_OK;
+    PFZ_REQUIRE(from_vec && (n_to == 0 || to_vec), "pfz_dense_cossim_topn_host: NULL matrix");
+    const bool same = to_vec == from_vec && n_to == n_from;
+    pfz_dense *A = nullptr, *B = nullptr;
+    pfz_topn *res = nullptr;
+    int rc = pfz_dense_upload(ctx, from_vec, n_from, dim, normalize, &A);
+    if (rc == PFZ_OK && !same) rc = pfz_dense_upload(ctx, to_vec, n_to, dim, normalize, &B);
+    if (rc == PFZ_OK) rc = pfz_topn_alloc(ctx, n_from, ntop, &res);
+    if (rc == PFZ_OK) rc = pfz_dense_topn(ctx, A, same ? A : B, ntop, lower_bound, exclude_diag, 0, res);
+    if (rc == PFZ_OK) rc = pfz_topn_download(ctx, res, out_idx, out_val);
+    pfz_topn_free(res);
+    pfz_dense_free(B);
+    pfz_dense_free(A);
+    return rc;
 }
 
 int pfz_dense_cossim_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,

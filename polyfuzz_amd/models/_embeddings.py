@@ -14,8 +14,9 @@ from typing import Callable, List, Optional
 import numpy as np
 import pandas as pd
 
+from .. import _lib
 from ._base import BaseMatcher
-from ._utils import cosine_similarity
+from ._utils import topn_to_frame, clip_top_n, _METHODS
 
 
 class Embeddings(BaseMatcher):
@@ -48,6 +49,8 @@ class Embeddings(BaseMatcher):
         self.top_n = top_n
         self.cosine_method = cosine_method
         self.embeddings_to = None
+        self._dev_to = None            # _lib.DeviceDense of the to-side
+        self._dev_to_normalize = None
 
     def match(self,
               from_list: List[str],
@@ -69,10 +72,33 @@ class Embeddings(BaseMatcher):
                 embeddings_to = self._embed(from_list) if self.embedding_method is not None else embeddings_from
             else:
                 embeddings_to = self._embed(to_list)
-        matches = cosine_similarity(embeddings_from, embeddings_to, from_list, to_list, self.min_similarity,
-                                    top_n=self.top_n, method=self.cosine_method)
+        if self.cosine_method not in _METHODS:
+            raise ValueError(f"cosine_method must be one of {_METHODS}")
+        ctx = _lib.Context.default()
+        normalize = self.cosine_method != "sparse"        # "sparse": raw dot products (reference _utils.py:74-82)
+        lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
+        # the to-side stays in HBM: match(..., re_train=False) (PolyFuzz.transform, polyfuzz.py:234-240) uploads
+        # the new from-vectors only
+        if re_train or self._dev_to is None or self._dev_to_normalize != normalize:
+            self._dev_to = _lib.DeviceDense.upload(ctx, np.asarray(embeddings_to), normalize)
+            self._dev_to_normalize = normalize
+        self_match = to_list is None
+        same = self_match and embeddings_to is embeddings_from
+        from_dev = self._dev_to if same else _lib.DeviceDense.upload(ctx, np.asarray(embeddings_from), normalize)
+        if from_dev.dim != self._dev_to.dim:
+            raise ValueError(f"dense cosine needs two 2-D arrays with equal width, got {from_dev.dim} and {self._dev_to.dim}")
+        top_n = clip_top_n(self.top_n, to_list)
+        idx, val = _lib.dense_topn(ctx, from_dev, self._dev_to, max(top_n, 1), lower, exclude_diag=self_match).download()
         self.embeddings_to = embeddings_to
-        return matches
+        return topn_to_frame(idx, val, from_list, from_list if self_match else to_list, top_n)
+
+    # a matcher is pickled by joblib (reference polyfuzz.py:429-457): the device copy stays behind
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in ("_dev_to",)}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._dev_to = None
 
     def _embed(self, strings: List[str]) -> np.ndarray:
         """ Embed with the user's callable and L2-normalise the rows (reference _embeddings.py:136-145) """

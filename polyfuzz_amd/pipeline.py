@@ -156,6 +156,39 @@ class TfidfMatchJob:
                 "madds": float((df_from * df_to).sum())}
 
 
+class DenseMatchJob:
+    """Device-resident dense cosine top-n (K5) of a row shard of from-vectors against replicated to-vectors
+    (reference _embeddings.py:127-133 -> _utils.py:74-77,94-102 on ready-made embeddings; BASELINE config 5:
+    500k x 500k x 768 on 8 GPUs = 62.5k from-rows per rank).  Shards are independent; the only exchange is the
+    all-gather of the padded per-shard top-n blocks."""
+
+    def __init__(self, ctx, from_shard, to_vectors, top_n=1, min_similarity=0.0, normalize=True, comm=None,
+                 self_match=False, shard_offset=0, rows_per_rank=None):
+        self.ctx, self.comm = ctx, comm
+        self.top_n, self.min_similarity = int(top_n), float(min_similarity)
+        self.self_match, self.shard_offset = bool(self_match), int(shard_offset)
+        self.from_dev = _lib.DeviceDense.upload(ctx, from_shard, normalize)
+        self.to_dev = self.from_dev if to_vectors is None else _lib.DeviceDense.upload(ctx, to_vectors, normalize)
+        if to_vectors is None and (not self.self_match or self.shard_offset != 0):
+            raise ValueError("to_vectors=None means a whole-matrix self-match (self_match=True, shard_offset=0)")
+        self.n_from, self.n_to = self.from_dev.n, self.to_dev.n
+        self.rows_per_rank = self.n_from if rows_per_rank is None else int(rows_per_rank)
+        if self.rows_per_rank < self.n_from:
+            raise ValueError("rows_per_rank is smaller than this rank's shard")
+        self.local = _lib.DeviceTopN.alloc(ctx, self.rows_per_rank, self.top_n)
+        self.local.clear()
+        self.gathered = None
+        if comm is not None and comm.world > 1:
+            self.gathered = _lib.DeviceTopN.alloc(ctx, self.rows_per_rank * comm.world, self.top_n)
+
+    def step(self):
+        _lib.dense_topn(self.ctx, self.from_dev, self.to_dev, self.top_n, self.min_similarity,
+                        exclude_diag=self.self_match, diag_offset=self.shard_offset, out=self.local)
+        if self.gathered is not None:
+            self.comm.allgather_topn(self.local, self.gathered)
+        return self.gathered if self.gathered is not None else self.local
+
+
 def run_sharded_job(ctxs, comms, from_list, to_list, **job_kw):
     """One process, several contexts: run the row-sharded job with one host thread per rank and return
     (idx, val) of the full from-list (the ranks' all-gathered, un-padded result; identical on every rank).

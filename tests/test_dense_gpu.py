@@ -138,3 +138,49 @@ def golden_dense():
     g = np.load(os.path.join(HERE, "golden", "dense_golden.npz"))
     with open(os.path.join(HERE, "golden", "dense_golden.json")) as f:
         return g, json.load(f)
+
+
+def test_resident_to_side_and_sharded_dense_job(ctx):
+    """The device-resident form of K5: Embeddings keeps the to-vectors in HBM for re_train=False (PolyFuzz.transform),
+    and DenseMatchJob shards the from-rows over two contexts on one device (local transport, uneven shards) -- both
+    equal the one-shot host entry point bit for bit."""
+    import pickle
+    import concurrent.futures as cf
+    import polyfuzz_amd
+    from polyfuzz_amd import _lib, pipeline
+    from polyfuzz_amd.models import Embeddings
+    rng = np.random.default_rng(21)
+    a = rng.standard_normal((301, 96)).astype(np.float32)
+    b = rng.standard_normal((530, 96)).astype(np.float32)
+    fl, tl = [f"f{i}" for i in range(len(a))], [f"t{i}" for i in range(len(b))]
+    ref_idx, ref_val = _lib.dense_cossim_topn_host(ctx, a, b, 4, 0.0)
+
+    m = Embeddings(min_similarity=0.0, top_n=4, cosine_method="hip")
+    df = m.match(fl, tl, embeddings_from=a, embeddings_to=b)
+    assert df["To"].tolist() == [tl[j] for j in ref_idx[:, 0]]
+    df2 = m.match(fl[:50], tl, embeddings_from=a[:50], re_train=False)            # to-side: resident, not re-uploaded
+    assert df2["To_3"].tolist() == [tl[j] for j in ref_idx[:50, 2]]
+    m2 = pickle.loads(pickle.dumps(m))                                            # device copy left behind, re-created
+    assert m2.match(fl[:50], tl, embeddings_from=a[:50], re_train=False).equals(df2)
+
+    ctxs = [polyfuzz_amd.Context(0), polyfuzz_amd.Context(0)]
+    comms = _lib.Comm.local_group(ctxs)
+    bounds = [pipeline.shard_bounds(len(a), 2, r) for r in range(2)]
+    sizes = [e - s for s, e in bounds]
+
+    def rank_fn(r, self_match):
+        s, e = bounds[r]
+        job = pipeline.DenseMatchJob(ctxs[r], a[s:e], a if self_match else b, top_n=4, comm=comms[r],
+                                     rows_per_rank=max(sizes), self_match=self_match, shard_offset=s if self_match else 0)
+        idx, val = job.step().download()
+        return pipeline.TfidfMatchJob.unpad(idx, val, sizes, max(sizes))
+
+    for self_match in (False, True):
+        exp = _lib.dense_cossim_topn_host(ctx, a, a, 4, 0.0, exclude_diag=True) if self_match else (ref_idx, ref_val)
+        with cf.ThreadPoolExecutor(2) as ex:
+            outs = [f.result(timeout=120) for f in [ex.submit(rank_fn, r, self_match) for r in range(2)]]
+        for idx, val in outs:
+            np.testing.assert_array_equal(idx, exp[0])
+            np.testing.assert_array_equal(val, exp[1])
+    for c in comms:
+        c.free()
