@@ -28,6 +28,16 @@ dt = time.perf_counter() - t0
 gemm_ms, n_panels = ctx.prof_get("k5_gemm_panel")
 topn_ms, _ = ctx.prof_get("k5_row_topn")
 ctx.prof_enable(False)
+# the same shard with both operands resident in HBM (pipeline.DenseMatchJob: what a rank of the 8-GPU job times)
+from polyfuzz_amd import pipeline
+job = pipeline.DenseMatchJob(ctx, a, b, top_n=top_n)
+job.step(); ctx.sync()
+t0 = time.perf_counter()
+for _ in range(2): r = job.step()
+ctx.sync(); dt_res = (time.perf_counter() - t0) / 2
+r_idx, r_val = r.download()
+resident_equal = bool(np.array_equal(r_idx, idx) and np.array_equal(r_val, val))
+del job
 rows = rng.choice(n_from, 8, replace=False)
 bad = 0; err = 0.0
 for i in rows:
@@ -36,7 +46,9 @@ for i in rows:
     bad += int(not np.array_equal(idx[i], e_idx[0]))
 print(json.dumps({"n_from_shard": n_from, "n_to": n_to, "dim": d, "top_n": top_n, "end_to_end_s": dt,
                   "gemm_ms": gemm_ms, "gemm_panels": n_panels, "gemm_tflops": 2.0 * n_from * n_to * d / gemm_ms / 1e9,
-                  "row_topn_ms": topn_ms, "pairs_per_s_end_to_end": n_from * n_to / dt,
+                  "row_topn_ms": topn_ms, "resident_step_s": dt_res,
+                  "resident_step_tflops": 2.0 * n_from * n_to * d / dt_res / 1e12, "resident_equals_host_path": resident_equal,
+                  "pairs_per_s_end_to_end": n_from * n_to / dt,
                   "planted_match_found_top1": float((idx[:, 0] == pick).mean()),
                   "sample_rows": len(rows), "rows_with_index_diff": bad, "max_abs_score_err": err,
                   "host_generation_s": t_gen}))
