@@ -276,6 +276,12 @@ int pfz_comm_init_local(pfz_ctx *ctx, pfz_comm_group *g, int32_t rank, pfz_comm 
  * [rank*rows_per_rank, (rank+1)*rows_per_rank); `global` has world *
  * rows_per_rank rows.  Enqueues on the context stream. */
 int pfz_comm_allgather_topn(pfz_comm *c, const pfz_topn *local, pfz_topn *global);
+/* The other sharding (BASELINE north_star: "row-sharded from/to lists ... all-gather of per-shard top-n candidates"):
+ * every rank indexes a SHARD OF THE TO-ROWS and matches all from-rows against it; `local` = its top-n per from-row
+ * with to-indices local to the shard, to_offset = global index of the shard's first to-row.  All-gathers the ranks'
+ * candidates and leaves in `out` (same shape as `local`), on every rank, the top-n by (score desc, global to-index asc).
+ * Needed only when the to-side does not fit one GPU; world x ntop <= 1024.  Enqueues. */
+int pfz_comm_merge_to_shards(pfz_comm *c, const pfz_topn *local, int64_t to_offset, pfz_topn *out);
 int pfz_comm_barrier(pfz_comm *c);
 int pfz_comm_info(const pfz_comm *c, int32_t *rank, int32_t *world);
 /* pfz_tfidf_fit over a corpus that is split across the ranks of `comm`:

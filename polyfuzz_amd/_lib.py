@@ -93,6 +93,7 @@ SIGNATURES = {
     "pfz_comm_group_destroy": (None, [c_vp]),
     "pfz_comm_init_local": (ctypes.c_int, [c_vp, c_vp, c_i32, P(c_vp)]),
     "pfz_comm_allgather_topn": (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    "pfz_comm_merge_to_shards": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "pfz_comm_barrier": (ctypes.c_int, [c_vp]),
     "pfz_comm_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
     "pfz_tfidf_fit_sharded": (ctypes.c_int, [c_vp, c_vp, P(TfidfParams), c_vp, c_vp, P(c_vp)]),
@@ -605,6 +606,13 @@ class Comm(_Handle):
 
     def barrier(self):
         check(self.ctx.lib.pfz_comm_barrier(self.h))
+
+    def merge_to_shards(self, local, to_offset, out=None):
+        """All-gather the ranks' per-to-shard candidates and keep, on every rank, the global top-n."""
+        if out is None:
+            out = DeviceTopN.alloc(self.ctx, local.n_rows, local.ntop)
+        check(self.ctx.lib.pfz_comm_merge_to_shards(self.h, local.h, int(to_offset), out.h))
+        return out
 
     def allgather_topn(self, local, out=None):
         if out is None:

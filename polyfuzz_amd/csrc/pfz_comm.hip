@@ -67,6 +67,51 @@ __global__ __launch_bounds__(256) void k_sum_ranks(const T *__restrict__ gathere
     out[i] = s;
 }
 
+// Merge of per-to-shard candidates: row i has world x ntop candidates (idx local to the shard of rank p, -1 = none),
+// the result is its ntop best by (score desc, GLOBAL to-index asc).  One wave per row; a lane holds up to 16 keys
+// score_bits << 32 | ~global_idx (scores are positive floats: their bit patterns order like the values).
+constexpr int kMergeKeysPerLane = 16;
+__global__ __launch_bounds__(256) void k_merge_to_shards(const int32_t *__restrict__ g_idx, const float *__restrict__ g_val,
+                                                          const int64_t *__restrict__ offsets, int32_t world, int64_t n_rows,
+                                                          int32_t ntop, int32_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int total = world * ntop;
+    uint64_t e[kMergeKeysPerLane];
+#pragma unroll
+    for (int i = 0; i < kMergeKeysPerLane; ++i) {
+        const int c = lane + 64 * i;
+        uint64_t key = 0ull;
+        if (c < total) {
+            const int p = c / ntop, r = c - p * ntop;
+            const int64_t src = ((int64_t)p * n_rows + row) * ntop + r;
+            const int32_t j = g_idx[src];
+            if (j >= 0) key = ((uint64_t)__float_as_uint(g_val[src]) << 32) | (uint32_t)(~(uint32_t)(j + offsets[p]));
+        }
+        e[i] = key;
+    }
+    for (int r = 0; r < ntop; ++r) {
+        uint64_t m = e[0];
+#pragma unroll
+        for (int i = 1; i < kMergeKeysPerLane; ++i) m = e[i] > m ? e[i] : m;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)m, d, 64), hi = __shfl_xor((uint32_t)(m >> 32), d, 64);
+            const uint64_t o = ((uint64_t)hi << 32) | lo;
+            m = o > m ? o : m;
+        }
+#pragma unroll
+        for (int i = 0; i < kMergeKeysPerLane; ++i)
+            if (e[i] == m) e[i] = 0ull;
+        if (lane == 0) {
+            out_idx[row * ntop + r] = m ? (int32_t)(~(uint32_t)m) : -1;
+            out_val[row * ntop + r] = m ? __uint_as_float((uint32_t)(m >> 32)) : 0.f;
+        }
+    }
+}
+
 static int local_allgather(pfz_comm *c, const void *send, void *recv, size_t bytes_per_rank)
 {
     pfz_comm_group *g = c->group;
@@ -249,6 +294,40 @@ int pfz_comm_allgather_topn(pfz_comm *c, const pfz_topn *local, pfz_topn *global
     PFZ_RCCL(ncclAllGather(local->idx, global->idx, count, ncclInt32, c->comm, c->ctx->stream));
     PFZ_RCCL(ncclAllGather(local->val, global->val, count, ncclFloat32, c->comm, c->ctx->stream));
     PFZ_RCCL(ncclGroupEnd());
+    return PFZ_OK;
+}
+
+int pfz_comm_merge_to_shards(pfz_comm *c, const pfz_topn *local, int64_t to_offset, pfz_topn *out)
+{
+    PFZ_REQUIRE(c && local && out, "pfz_comm_merge_to_shards: NULL argument");
+    PFZ_REQUIRE(out->ntop == local->ntop && out->n_rows == local->n_rows,
+                "pfz_comm_merge_to_shards: result buffer is %lldx%d, need %lldx%d", (long long)out->n_rows, out->ntop,
+                (long long)local->n_rows, local->ntop);
+    if ((int64_t)c->world * local->ntop > 64 * kMergeKeysPerLane) {
+        set_error("pfz_comm_merge_to_shards: %d ranks x top-%d exceed the %d candidates a row merge holds", c->world,
+                  local->ntop, 64 * kMergeKeysPerLane);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    pfz_ctx *ctx = c->ctx;
+    PFZ_HIP(hipSetDevice(ctx->device));
+    const size_t count = (size_t)local->n_rows * (size_t)local->ntop;
+    if (count == 0) return PFZ_OK;
+    struct Buf {
+        void *p = nullptr;
+        ~Buf() { if (p) pool_free(p); }
+    } g_idx, g_val, offs;
+    PFZ_TRY(pool_alloc(ctx, &g_idx.p, (size_t)c->world * count * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &g_val.p, (size_t)c->world * count * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &offs.p, (size_t)(c->world + 1) * sizeof(int64_t)));
+    int64_t *mine = (int64_t *)offs.p + c->world;
+    PFZ_TRY(copy_h2d(ctx, mine, &to_offset, sizeof(int64_t)));
+    PFZ_TRY(comm_allgather_bytes(c, mine, offs.p, sizeof(int64_t)));
+    PFZ_TRY(comm_allgather_bytes(c, local->idx, g_idx.p, count * sizeof(int32_t)));
+    PFZ_TRY(comm_allgather_bytes(c, local->val, g_val.p, count * sizeof(float)));
+    hipLaunchKernelGGL(k_merge_to_shards, dim3((unsigned)((local->n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const int32_t *)g_idx.p, (const float *)g_val.p, (const int64_t *)offs.p, c->world, local->n_rows,
+                       local->ntop, out->idx, out->val);
+    PFZ_HIP(hipGetLastError());
     return PFZ_OK;
 }
 

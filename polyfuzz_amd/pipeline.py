@@ -156,6 +156,38 @@ class TfidfMatchJob:
                 "madds": float((df_from * df_to).sum())}
 
 
+class ToShardedMatchJob:
+    """The other sharding of the TF-IDF match: the TO-list is row-sharded over the ranks, the from-list replicated
+    (BASELINE north_star's variant; needed when the to-side index does not fit one GPU).  Every rank fits the exact
+    global vectoriser (sharded fit: the from-list counted once, its to-shard locally), indexes its to-shard, matches ALL
+    from-rows against it, and the per-shard candidates are all-gathered and merged by (score desc, global index asc)."""
+
+    def __init__(self, ctx, from_list, to_shard, to_offset, comm, top_n=1, min_similarity=0.0, n_gram_range=(3, 3),
+                 clean_string=True, remove_space_ngrams=True, self_match=False):
+        """self_match: from_list is the whole list and to_shard its rows [to_offset, to_offset + len(to_shard))."""
+        self.ctx, self.comm = ctx, comm
+        self.top_n, self.min_similarity, self.self_match = int(top_n), float(min_similarity), bool(self_match)
+        self.to_offset = int(to_offset)
+        self.params = _lib.TfidfParams(int(n_gram_range[0]), int(n_gram_range[1]), int(bool(clean_string)),
+                                       int(bool(remove_space_ngrams)))
+        self.from_dev = _lib.DeviceStrings.upload(ctx, from_list)
+        self.to_dev = _lib.DeviceStrings.upload(ctx, to_shard)
+        self.n_from = len(from_list)
+        self.local = _lib.DeviceTopN.alloc(ctx, self.n_from, self.top_n)
+        self.merged = _lib.DeviceTopN.alloc(ctx, self.n_from, self.top_n)
+
+    def step(self):
+        ctx = self.ctx
+        # a self-match fits on the list alone (reference _tfidf.py:113-116): the shards ARE the list
+        self.vec = _lib.tfidf_fit_sharded(ctx, self.comm, self.params, None if self.self_match else self.from_dev, self.to_dev)
+        self.to_csr = self.vec.transform(self.to_dev)
+        self.index = _lib.DeviceIndex.build(ctx, self.to_csr)
+        self.from_csr = self.vec.transform(self.from_dev)
+        _lib.cossim_topn(ctx, self.index, self.from_csr, self.top_n, self.min_similarity, exclude_diag=self.self_match,
+                         diag_offset=-self.to_offset, out=self.local)
+        return self.comm.merge_to_shards(self.local, self.to_offset, self.merged)
+
+
 class DenseMatchJob:
     """Device-resident dense cosine top-n (K5) of a row shard of from-vectors against replicated to-vectors
     (reference _embeddings.py:127-133 -> _utils.py:74-77,94-102 on ready-made embeddings; BASELINE config 5:

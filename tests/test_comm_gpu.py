@@ -75,3 +75,38 @@ def test_world2_local_transport_sharded_job(oracle_mod, clean):
     del res
     for c in comms:
         c.free()
+
+
+@pytest.mark.parametrize("self_match", [False, True])
+def test_world2_to_side_sharding_and_merge(oracle_mod, self_match):
+    """The north-star's variant: the TO-list sharded over two ranks (uneven: 257 = 129 + 128), every rank matches all
+    from-rows against its shard, candidates all-gathered and merged (pfz_comm_merge_to_shards).  Same result as the
+    one-context match up to near-ties (each shard has its own fixed-point scale), which is the oracle's."""
+    import concurrent.futures as cf
+    import polyfuzz_amd
+    from polyfuzz_amd import _lib, pipeline, synth
+    fl, tl = synth.company_names(301, 11), synth.company_names(257, 12)
+    if self_match:
+        tl = fl
+    ctxs = [polyfuzz_amd.Context(0), polyfuzz_amd.Context(0)]
+    comms = _lib.Comm.local_group(ctxs)
+
+    def rank_fn(r):
+        b, e = pipeline.shard_bounds(len(tl), 2, r)
+        job = pipeline.ToShardedMatchJob(ctxs[r], fl, tl[b:e], b, comms[r], top_n=4, min_similarity=0.0, self_match=self_match)
+        out = job.step().download()
+        return out, job.vec.export()[1]
+
+    with cf.ThreadPoolExecutor(2) as ex:
+        outs = [f.result(timeout=120) for f in [ex.submit(rank_fn, r) for r in range(2)]]
+    single = pipeline.TfidfMatchJob(ctxs[0], fl, None if self_match else tl, top_n=4, min_similarity=0.0, self_match=self_match)
+    s_idx, s_val = single.step().download()
+    a3, b3, n_col = single.host_matrices()
+    e_idx, e_val = oracle_mod.cossim_topn(a3, b3, n_col, 4, 0.0, exclude_diag=self_match)
+    for (idx, val), idf in outs:
+        np.testing.assert_array_equal(idf, single.vec.export()[1])          # the sharded fit is the global fit
+        assert np.abs(val - e_val).max() <= 1e-5
+        assert (idx != e_idx).any(axis=1).sum() <= 2 and (idx != s_idx).any(axis=1).sum() <= 2
+    np.testing.assert_array_equal(outs[0][0][0], outs[1][0][0])
+    for c in comms:
+        c.free()
