@@ -23,6 +23,7 @@
 #include "pfz_internal.h"
 
 #include <algorithm>
+#include <stdlib.h>
 
 namespace pfz {
 
@@ -203,21 +204,27 @@ __global__ __launch_bounds__(256) void k5_gemm_panel_pipe(const float *__restric
             }
         }
         const float *as = As[cur], *bs = Bs[cur];
+        auto mma = [&](int kk_begin, int kk_end) {
 #pragma unroll 4
-        for (int kk = 0; kk < kBK; kk += 2) {
-            const int kq = kk + (lane >> 5);
-            float a[2], b[2];
+            for (int kk = kk_begin; kk < kk_end; kk += 2) {
+                const int kq = kk + (lane >> 5);
+                float a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = as[(wm + i * 32 + (lane & 31)) * kLd + kq];
+                for (int i = 0; i < 2; ++i) a[i] = as[(wm + i * 32 + (lane & 31)) * kLd + kq];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = bs[(wn + j * 32 + (lane & 31)) * kLd + kq];
+                for (int j = 0; j < 2; ++j) b[j] = bs[(wn + j * 32 + (lane & 31)) * kLd + kq];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        // the next step's operands (in flight since the top of this step) go to the OTHER buffer half way through:
+        // the stores issue while the matrix pipe is busy with the second half instead of after it
+        mma(0, kBK / 2);
         if (more) stage(cur ^ 1);
+        mma(kBK / 2, kBK);
         __syncthreads();
         cur ^= 1;
     }
@@ -425,33 +432,59 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
     struct Buf {
         void *p = nullptr;
         ~Buf() { if (p) pool_free(p); }
-    } dS;
+    } dS[2];
     const int64_t ld = ((n_to + 255) / 256) * 256;                      // whole float4 x 64-lane steps
-    int64_t panel = ld > 0 ? ((int64_t)8 << 30) / (ld * 4) : n_from;     // <= 8 GiB of scores
+    // Two score panels of <= 4 GiB: the row top-n of panel p runs on a side stream while the GEMM of panel p + 1
+    // fills the other one (the top-n is a memory stream, the GEMM an MFMA loop: they share the chip well).
+    int64_t panel = ld > 0 ? ((int64_t)4 << 30) / (ld * 4) : n_from;
+    if (const char *forced = getenv("PFZ_K5_PANEL_ROWS")) panel = atoll(forced);   // tests: several panels on small inputs
     panel = std::max<int64_t>(kTile, std::min<int64_t>(panel / kTile * kTile, ((n_from + kTile - 1) / kTile) * kTile));
-    if (ld > 0) PFZ_TRY(pool_alloc(ctx, &dS.p, (size_t)panel * (size_t)ld * sizeof(float)));
-    for (int64_t a0 = 0; a0 < n_from; a0 += panel) {
+    const int64_t n_panels = (n_from + panel - 1) / panel;
+    const bool two = n_panels > 1 && !getenv("PFZ_K5_NO_OVERLAP");       // env: A/B timing
+    if (two && !ctx->stream2) {
+        PFZ_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (hipEvent_t &ev : ctx->side_events) PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    if (ld > 0) {
+        PFZ_TRY(pool_alloc(ctx, &dS[0].p, (size_t)panel * (size_t)ld * sizeof(float)));
+        if (two) PFZ_TRY(pool_alloc(ctx, &dS[1].p, (size_t)panel * (size_t)ld * sizeof(float)));
+    }
+    hipEvent_t *ready = ctx->side_events, *consumed = ctx->side_events + 2;
+    int64_t pi = 0;
+    for (int64_t a0 = 0; a0 < n_from; a0 += panel, ++pi) {
         const int64_t a1 = std::min(n_from, a0 + panel);
+        const int buf = two ? (int)(pi & 1) : 0;
+        float *S = (float *)dS[buf].p;
+        if (two && pi >= 2) PFZ_HIP(hipStreamWaitEvent(ctx->stream, consumed[buf], 0));   // the top-n of panel pi - 2 read this buffer
         if (ld > 0) {
             ProfScope ps(ctx, "k5_gemm_panel");
             dim3 grid((unsigned)(ld / kTile), (unsigned)((a1 - a0 + kTile - 1) / kTile));
             // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
             if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE"))
                 hipLaunchKernelGGL(k5_gemm_panel_pipe, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0,
-                                   a1, n_to, dim, (float *)dS.p, ld);
+                                   a1, n_to, dim, S, ld);
             else
                 hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
-                                   n_to, dim, (float *)dS.p, ld);
+                                   n_to, dim, S, ld);
+        }
+        hipStream_t ts = two ? ctx->stream2 : ctx->stream;
+        if (two) {
+            PFZ_HIP(hipEventRecord(ready[buf], ctx->stream));
+            PFZ_HIP(hipStreamWaitEvent(ts, ready[buf], 0));
         }
         {
-            ProfScope ps(ctx, "k5_row_topn");
-            hipLaunchKernelGGL(k5_row_topn, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ctx->stream,
-                               (const float *)dS.p, ld, a0, a1, n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx,
-                               out->val);
+            ProfScope ps(ctx, "k5_row_topn", ts);
+            hipLaunchKernelGGL(k5_row_topn, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ts, (const float *)S, ld, a0, a1,
+                               n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx, out->val);
         }
+        if (two) PFZ_HIP(hipEventRecord(consumed[buf], ts));
+    }
+    if (two) {   // later work on the context stream (downloads, the pool's reuse of the panels) is behind both top-n streams
+        PFZ_HIP(hipStreamWaitEvent(ctx->stream, consumed[0], 0));
+        if (pi >= 2) PFZ_HIP(hipStreamWaitEvent(ctx->stream, consumed[1], 0));
     }
     PFZ_HIP(hipGetLastError());
-    return PFZ_OK;     // (the score panel goes back to the pool: stream order keeps it alive until the kernels are done)
+    return PFZ_OK;     // (the score panels go back to the pool: stream order keeps them alive until the kernels are done)
 }
 
 static int dense_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from, const float *to_vec, int64_t n_to,

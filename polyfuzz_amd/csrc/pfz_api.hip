@@ -182,7 +182,7 @@ int pool_release(pfz_ctx *ctx)
     return PFZ_OK;
 }
 
-ProfScope::ProfScope(pfz_ctx *c, const char *n) : ctx(c), name(n)
+ProfScope::ProfScope(pfz_ctx *c, const char *n, hipStream_t on) : ctx(c), name(n), st(on ? on : c->stream)
 {
     if (!ctx->prof) return;
     auto take = [&]() -> hipEvent_t {
@@ -197,7 +197,7 @@ ProfScope::ProfScope(pfz_ctx *c, const char *n) : ctx(c), name(n)
     };
     b = take();
     e = take();
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, st);
 }
 
 ProfScope::~ProfScope()
@@ -206,11 +206,11 @@ ProfScope::~ProfScope()
     if (debug_sync) {  // developer aid: localise an asynchronous device fault to a kernel
         fprintf(stderr, "[pfz] %s ...", name);
         fflush(stderr);
-        hipError_t err = hipStreamSynchronize(ctx->stream);
+        hipError_t err = hipStreamSynchronize(st);
         fprintf(stderr, " %s\n", hipGetErrorString(err));
     }
     if (!ctx->prof || !b || !e) return;
-    (void)hipEventRecord(e, ctx->stream);
+    (void)hipEventRecord(e, st);
     ProfEntry &pe = ctx->prof_entries[name];
     pe.begin.push_back(b);
     pe.end.push_back(e);
@@ -396,6 +396,12 @@ void pfz_ctx_destroy(pfz_ctx *ctx)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    for (hipEvent_t ev : ctx->side_events)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     (void)pool_release(ctx);
     {   // blocks still owned by live handles of this context: free them, the handles become inert
         std::lock_guard<std::mutex> lk(g_pool_mu);

@@ -52,6 +52,8 @@ struct ProfEntry {
 struct pfz_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // side stream (K5: row top-n of one score panel beside the GEMM of the next), created on first use
+    hipEvent_t side_events[4] = {};       // K5: panel ready x2, panel consumed x2
     hipDeviceProp_t prop;
     hipEvent_t events[pfz::kEventSlots] = {};
     bool prof = false;
@@ -168,8 +170,9 @@ int copy_d2h(pfz_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 struct ProfScope {
     pfz_ctx *ctx;
     const char *name;
+    hipStream_t st;
     hipEvent_t b = nullptr, e = nullptr;
-    ProfScope(pfz_ctx *c, const char *n);
+    ProfScope(pfz_ctx *c, const char *n, hipStream_t on = nullptr);   // on: the stream the launch goes to (default ctx->stream)
     ~ProfScope();
 };
 

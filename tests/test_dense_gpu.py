@@ -184,3 +184,24 @@ def test_resident_to_side_and_sharded_dense_job(ctx):
             np.testing.assert_array_equal(val, exp[1])
     for c in comms:
         c.free()
+
+
+def test_panels_overlap_on_two_streams(ctx, monkeypatch):
+    """With more than one score panel the row top-n of panel p runs on a side stream beside the GEMM of panel p + 1
+    (two panel buffers, events both ways).  Forcing 128-row panels on a small input gives the one-panel result."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((700, 64)).astype(np.float32)
+    b = rng.standard_normal((900, 64)).astype(np.float32)
+    ref = _lib.dense_cossim_topn_host(ctx, a, b, 6, 0.0)
+    monkeypatch.setenv("PFZ_K5_PANEL_ROWS", "128")
+    for _ in range(3):                                  # 6 panels each; repeated: buffers and events are reused
+        got = _lib.dense_cossim_topn_host(ctx, a, b, 6, 0.0)
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+    monkeypatch.setenv("PFZ_K5_NO_OVERLAP", "1")
+    got = _lib.dense_cossim_topn_host(ctx, a, a, 6, 0.0, exclude_diag=True)
+    monkeypatch.delenv("PFZ_K5_NO_OVERLAP")
+    got2 = _lib.dense_cossim_topn_host(ctx, a, a, 6, 0.0, exclude_diag=True)
+    np.testing.assert_array_equal(got[0], got2[0])
+    np.testing.assert_array_equal(got[1], got2[1])
