@@ -713,8 +713,11 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
 {
     PFZ_REQUIRE(ctx && B && out, "pfz_index_build: NULL argument");
     PFZ_HIP(hipSetDevice(ctx->device));
-    // tuning knob: to-rows per block (tools/sweep_k3.sh)
-    int block = env_int("PFZ_K3_BLOCK", 2048);
+    // to-rows per block (tuning knob PFZ_K3_BLOCK, tools/sweep_k3.sh).  2048 is the best point while the padded index
+    // stays in L2 / Infinity Cache (100k to-rows: 2.94 ms against 3.75 with 4096 -- LDS occupancy); a to-side of a
+    // million rows has 6.5 M lists at 2048 (index 267 MB, past the 256 MiB Infinity Cache: 52 ms for the 125k x 1M
+    // shard) and fewer, better filled ones at 4096 (210 MB: 47 ms)
+    int block = env_int("PFZ_K3_BLOCK", B->n_rows > 400000 ? 4096 : 2048);
     if (block != 1024 && block != 1536 && block != 2048 && block != 4096) block = 2048;
     const int64_t nb = (B->n_rows + block - 1) / block;
     const int64_t slots = B->n_cols * nb;
