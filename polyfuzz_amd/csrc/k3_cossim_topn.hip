@@ -619,9 +619,12 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
         for (int b = b_lo; b < b_hi; ++b) {
             const int s = cur0, e = have0 ? nxt0 : cur0;
             cur0 = e;
-            if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];   // prefetch for block b+1 (tab has V*nb+2 slots)
             bool touched = __ballot(e > s) != 0;
             if (touched && ablate != 1) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
+            // prefetch of the table entry block b+1 ends with (tab has V*nb+2 slots): issued AFTER the block's posting
+            // loads -- the compiler drains vmcnt before a round's loads, and a table load issued just before them
+            // was a full L2 round trip in every block's critical path; here the sweep below covers it
+            if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
                 int s2 = 0, e2 = 0;
                 float as2 = 0.f;
