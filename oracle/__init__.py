@@ -19,7 +19,16 @@ Pinning status (see DESIGN.md "Oracle"):
 * Indel ratio (rapidfuzz.fuzz.ratio): rapidfuzz is not installed anywhere we
   can run -> PARITY UNPINNED for the scorer; plumbing (arg-max, self-match
   removal, normalisation) is pinned through the reference's own
-  EditDistance class run with the restated scorer.
+  EditDistance class run with the restated scorer.  The same holds for the
+  RapidFuzz matcher's scorer and for process.extractOne's first-best / cut-off
+  rules (restated from rapidfuzz's documentation): PARITY UNPINNED.
+* reference_path.py: the reference's own executable TF-IDF path (sklearn
+  vectoriser + dense cosine + full sorts + frame), the CPU arm "(i)" of
+  bench.py -- pinned cell for cell on frames the reference package produced.
+* single_linkage / precision_recall_curve have no restatement here: the
+  reference functions are pure Python and importable in the build container, so
+  the goldens under tests/golden/group_golden.json are outputs of the reference
+  itself (tests/golden/make_golden_group.py).
 """
 from .tfidf_oracle import (clean_string, create_ngrams, TfidfOracle)      # noqa: F401
 from .dense import dense_cossim, dense_cossim_topn   # noqa: F401

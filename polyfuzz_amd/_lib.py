@@ -356,12 +356,24 @@ except ImportError:  # pragma: no cover - not built
     _pack = None
 
 
+def _pack_threads():
+    """host threads of the string packer (PFZ_PACK_THREADS overrides; small hosts stay serial)"""
+    env = os.environ.get("PFZ_PACK_THREADS")
+    if env:
+        return max(1, int(env))
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return 4 if cpus >= 16 else 1
+
+
+_PACK_THREADS = _pack_threads()
+
+
 def pack_strings(strings):
     """list[str] -> (code units ndarray, offsets int64[n+1], char_width).
 
     1-byte code units (Latin-1) when every code point is <= 0xFF, UTF-32 otherwise."""
     if _pack is not None and isinstance(strings, (list, tuple)):
-        raw, off, width = _pack.pack(strings)
+        raw, off, width = _pack.pack(strings, _PACK_THREADS)
         return np.frombuffer(raw, np.uint8 if width == 1 else np.uint32), np.frombuffer(off, np.int64), width
     return _pack_strings_py(strings)
 

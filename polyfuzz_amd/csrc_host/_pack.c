@@ -12,59 +12,145 @@
 #include <string.h>
 #include <math.h>
 
-static PyObject *pack(PyObject *self, PyObject *arg)
+/* pack(list[str] [, n_threads]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)
+ *
+ * Two passes over the strings -- lengths / widest kind, then the copy of the code units -- each a walk over n
+ * scattered PyUnicode objects (a cache miss per string).  Above ~16k strings both passes are split over n_threads
+ * pthreads: the workers only READ immutable str objects (length, kind, data) while the calling thread keeps the GIL
+ * and waits, so nothing can change under them; they make no Python API call.
+ */
+#include <pthread.h>
+
+typedef struct {
+    PyObject **items;
+    Py_ssize_t lo, hi;
+    int64_t *off;        /* pass 1: off[i + 1] = len(i);  pass 2: reads the prefix sums */
+    char *cp;
+    int wide;            /* pass 1 result: a string of this range is not 1-byte;  pass 2 input: output width */
+    int bad;             /* pass 1: index + 1 of the first non-str item of the range, 0 if none */
+    Py_ssize_t bad_at;
+    int pass;
+} pack_job;
+
+static void *pack_worker(void *arg)
+{
+    pack_job *j = (pack_job *)arg;
+    if (j->pass == 1) {
+        for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
+            PyObject *s = j->items[i];
+            if (!PyUnicode_Check(s) || !PyUnicode_IS_READY(s)) {   /* (not ready: legacy wstr strings -- handled serially) */
+                if (!j->bad) {
+                    j->bad = 1;
+                    j->bad_at = i;
+                }
+                j->off[i + 1] = 0;
+                continue;
+            }
+            if (PyUnicode_KIND(s) != PyUnicode_1BYTE_KIND) j->wide = 1;
+            j->off[i + 1] = (int64_t)PyUnicode_GET_LENGTH(s);
+        }
+    } else {
+        for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
+            PyObject *s = j->items[i];
+            const Py_ssize_t len = PyUnicode_GET_LENGTH(s);
+            const int64_t pos = j->off[i];
+            if (!j->wide) {
+                memcpy(j->cp + pos, PyUnicode_1BYTE_DATA(s), (size_t)len);
+            } else {
+                uint32_t *dst = (uint32_t *)j->cp + pos;
+                const int kind = PyUnicode_KIND(s);
+                const void *data = PyUnicode_DATA(s);
+                for (Py_ssize_t k = 0; k < len; ++k) dst[k] = (uint32_t)PyUnicode_READ(kind, data, k);
+            }
+        }
+    }
+    return NULL;
+}
+
+static void run_pack_jobs(pack_job *jobs, int n_jobs)
+{
+    pthread_t th[16];
+    int started = 0;
+    for (; started < n_jobs - 1; ++started)
+        if (pthread_create(&th[started], NULL, pack_worker, &jobs[started + 1]) != 0) break;
+    pack_worker(&jobs[0]);
+    for (int t = started + 1; t < n_jobs; ++t) pack_worker(&jobs[t]);     /* threads that could not be started */
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+}
+
+static PyObject *pack(PyObject *self, PyObject *args)
 {
     (void)self;
+    PyObject *arg;
+    int n_threads = 1;
+    if (!PyArg_ParseTuple(args, "O|i", &arg, &n_threads)) return NULL;
     PyObject *seq = PySequence_Fast(arg, "pack() expects a sequence of str");
     if (!seq) return NULL;
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
     PyObject **items = PySequence_Fast_ITEMS(seq);
-    Py_ssize_t total = 0;
-    int wide = 0;
-    for (Py_ssize_t i = 0; i < n; ++i) {
-        PyObject *s = items[i];
-        if (!PyUnicode_Check(s)) {
-            Py_DECREF(seq);
-            PyErr_Format(PyExc_TypeError, "pack(): item %zd is %s, not str", i, Py_TYPE(s)->tp_name);
-            return NULL;
-        }
-        if (PyUnicode_READY(s) < 0) {
-            Py_DECREF(seq);
-            return NULL;
-        }
-        if (PyUnicode_KIND(s) != PyUnicode_1BYTE_KIND) wide = 1;
-        total += PyUnicode_GET_LENGTH(s);
-    }
-    const int width = wide ? 4 : 1;
-    PyObject *chars = PyBytes_FromStringAndSize(NULL, total * width);
     PyObject *offs = PyBytes_FromStringAndSize(NULL, (n + 1) * (Py_ssize_t)sizeof(int64_t));
-    if (!chars || !offs) {
-        Py_XDECREF(chars);
-        Py_XDECREF(offs);
+    if (!offs) {
         Py_DECREF(seq);
         return NULL;
     }
-    char *cp = PyBytes_AS_STRING(chars);
     int64_t *op = (int64_t *)PyBytes_AS_STRING(offs);
-    int64_t pos = 0;
     op[0] = 0;
-    for (Py_ssize_t i = 0; i < n; ++i) {
-        PyObject *s = items[i];
-        const Py_ssize_t len = PyUnicode_GET_LENGTH(s);
-        if (!wide) {
-            memcpy(cp + pos, PyUnicode_1BYTE_DATA(s), (size_t)len);
-        } else {
-            uint32_t *dst = (uint32_t *)cp + pos;
-            const int kind = PyUnicode_KIND(s);
-            const void *data = PyUnicode_DATA(s);
-            for (Py_ssize_t k = 0; k < len; ++k) dst[k] = (uint32_t)PyUnicode_READ(kind, data, k);
-        }
-        pos += len;
-        op[i + 1] = pos;
+    int n_jobs = n >= 16384 ? n_threads : 1;
+    if (n_jobs < 1) n_jobs = 1;
+    if (n_jobs > 16) n_jobs = 16;
+    pack_job jobs[16];
+    for (int t = 0; t < n_jobs; ++t) {
+        jobs[t].items = items;
+        jobs[t].lo = n * t / n_jobs;
+        jobs[t].hi = n * (t + 1) / n_jobs;
+        jobs[t].off = op;
+        jobs[t].cp = NULL;
+        jobs[t].wide = 0;
+        jobs[t].bad = 0;
+        jobs[t].bad_at = 0;
+        jobs[t].pass = 1;
     }
+    run_pack_jobs(jobs, n_jobs);
+    int wide = 0;
+    for (int t = 0; t < n_jobs; ++t) {
+        if (jobs[t].bad) {      /* a non-str item, or a string that is not in canonical form yet */
+            PyObject *s = items[jobs[t].bad_at];
+            if (PyUnicode_Check(s)) {          /* make every string ready (serial, needs the GIL) and start over */
+                for (Py_ssize_t i = 0; i < n; ++i)
+                    if (PyUnicode_Check(items[i]) && PyUnicode_READY(items[i]) < 0) {
+                        Py_DECREF(offs);
+                        Py_DECREF(seq);
+                        return NULL;
+                    }
+                Py_DECREF(offs);
+                PyObject *again = pack(self, args);
+                Py_DECREF(seq);
+                return again;
+            }
+            PyErr_Format(PyExc_TypeError, "pack(): item %zd is %s, not str", jobs[t].bad_at, Py_TYPE(s)->tp_name);
+            Py_DECREF(offs);
+            Py_DECREF(seq);
+            return NULL;
+        }
+        wide |= jobs[t].wide;
+    }
+    for (Py_ssize_t i = 0; i < n; ++i) op[i + 1] += op[i];
+    const Py_ssize_t total = (Py_ssize_t)op[n];
+    const int width = wide ? 4 : 1;
+    PyObject *chars = PyBytes_FromStringAndSize(NULL, total * width);
+    if (!chars) {
+        Py_DECREF(offs);
+        Py_DECREF(seq);
+        return NULL;
+    }
+    for (int t = 0; t < n_jobs; ++t) {
+        jobs[t].cp = PyBytes_AS_STRING(chars);
+        jobs[t].wide = wide;
+        jobs[t].pass = 2;
+    }
+    run_pack_jobs(jobs, n_jobs);
     Py_DECREF(seq);
-    PyObject *out = Py_BuildValue("(NNi)", chars, offs, width);
-    return out;
+    return Py_BuildValue("(NNi)", chars, offs, width);
 }
 
 /* fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads)
@@ -82,8 +168,6 @@ static PyObject *pack(PyObject *self, PyObject *arg)
  * The workers make no Python API call: they bump reference counts with atomic adds and store into disjoint
  * slots, while the calling thread keeps the GIL and waits, so no other reference-count update can race.
  */
-#include <pthread.h>
-
 typedef struct {
     PyObject **items;
     Py_ssize_t n_names, n, top_n;
@@ -266,7 +350,7 @@ done:
 
 static PyMethodDef methods[] = {
     {"linkage", linkage, METH_VARARGS, "linkage(from_ids, to_ids, n_strings) -> (cluster int32[n], order int32[k]) as bytes"},
-    {"pack", pack, METH_O, "pack(list[str]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)"},
+    {"pack", pack, METH_VARARGS, "pack(list[str] [, n_threads]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)"},
     {"fill_columns", fill_columns, METH_VARARGS,
      "fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads): the (To, Similarity) column pairs"},
     {NULL, NULL, 0, NULL},

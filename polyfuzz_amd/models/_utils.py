@@ -17,14 +17,13 @@ from scipy.sparse import issparse
 from .. import _lib
 
 _METHODS = ("sparse", "sklearn", "knn", "hip")
-# host threads that gather the To columns of a large result frame (memory-latency bound; _pack.fill_columns).
-# PFZ_FRAME_THREADS overrides; small hosts stay serial (thread start-up costs more than it saves there)
+# host threads that gather the To columns of a large result frame (_pack.fill_columns; PFZ_FRAME_THREADS overrides).
+# Measured on the MI355X host (EPYC 9575F, tools/host_glue_probe.py): the gathers are faster on ONE thread (3.0 ms for
+# 100k x top-5 against 3.9 ms on four) -- the atomic reference-count updates the workers need cost more than the
+# cache misses they overlap -- so the threaded path stays opt-in.
 def _fill_threads():
     env = os.environ.get("PFZ_FRAME_THREADS")
-    if env:
-        return max(1, int(env))
-    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return 4 if cpus >= 16 else 1
+    return max(1, int(env)) if env else 1
 
 
 _FILL_THREADS = _fill_threads()
