@@ -106,6 +106,10 @@ void pfz_topn_free(pfz_topn *t);
 int pfz_topn_clear(pfz_ctx *ctx, pfz_topn *t);
 /* blocks; out_idx / out_val are [n_rows * ntop] row-major host buffers */
 int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *out_val);
+/* download rows [row_begin, row_end) as soon as the event recorded in `event_slot` (pfz_event_record) has fired: the
+ * copy goes through a side stream, so work enqueued on the context stream after the event is not waited for.  Blocks. */
+int pfz_topn_download_rows_after(pfz_ctx *ctx, const pfz_topn *t, int64_t row_begin, int64_t row_end,
+                                 int32_t event_slot, int32_t *out_idx, float *out_val);
 /* fill a result buffer from host arrays [n_rows * ntop] (results computed elsewhere, e.g. another rank's block) */
 int pfz_topn_upload(pfz_ctx *ctx, pfz_topn *t, const int32_t *idx, const float *val);
 /* raw device pointers (for an RCCL all-gather issued by the caller) */
@@ -126,6 +130,13 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
 int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,
                     int32_t ntop, float lower_bound, int32_t exclude_diag, int64_t diag_offset,
                     pfz_topn *out);
+
+/* The same for from-rows [row_begin, row_end) only (results into the same rows of `out`; exclude_diag still means
+ * j == global from-row + diag_offset).  Lets a caller split one match into launches and consume the first part
+ * (pfz_event_record + pfz_topn_download_rows_after) while the next one runs. */
+int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,
+                         int64_t row_begin, int64_t row_end, int32_t ntop, float lower_bound,
+                         int32_t exclude_diag, int64_t diag_offset, pfz_topn *out);
 
 /* One-shot host convenience: upload both CSR matrices, build the index, run
  * pfz_cossim_topn, download.  Blocks. */

@@ -60,9 +60,11 @@ SIGNATURES = {
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pfz_topn_clear": (ctypes.c_int, [c_vp, c_vp]),
+    "pfz_topn_download_rows_after": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "pfz_topn_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pfz_topn_device_ptrs": (ctypes.c_int, [c_vp, P(c_vp), P(c_vp), P(c_i64), P(c_i32)]),
     "pfz_cossim_topn": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_f32, c_i32, c_i64, c_vp]),
+    "pfz_cossim_topn_rows": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32, c_i64, c_vp]),
     "pfz_cossim_topn_host": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_i32, c_f32, c_i32, c_vp, c_vp]),
     "pfz_strings_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, P(c_vp)]),
@@ -304,6 +306,14 @@ class DeviceTopN(_Handle):
     def clear(self):
         check(self.ctx.lib.pfz_topn_clear(self.ctx.h, self.h))
 
+    def download_rows_after(self, begin, end, event_slot):
+        """Rows [begin, end) as soon as the context's event `event_slot` has fired (side stream; later work keeps running)."""
+        idx = np.empty((end - begin, self.ntop), np.int32)
+        val = np.empty((end - begin, self.ntop), np.float32)
+        check(self.ctx.lib.pfz_topn_download_rows_after(self.ctx.h, self.h, int(begin), int(end), int(event_slot), _ptr(idx),
+                                                        _ptr(val)))
+        return idx, val
+
     @classmethod
     def from_host(cls, ctx, idx, val):
         idx = np.ascontiguousarray(idx, np.int32)
@@ -320,12 +330,16 @@ class DeviceTopN(_Handle):
         return pi.value, pv.value
 
 
-def cossim_topn(ctx, index, from_csr, ntop, lower_bound, exclude_diag=False, diag_offset=0, out=None):
-    """Enqueue K3; returns the (device-resident) DeviceTopN."""
+def cossim_topn(ctx, index, from_csr, ntop, lower_bound, exclude_diag=False, diag_offset=0, out=None, rows=None):
+    """Enqueue K3 (for from-rows `rows` = (begin, end) only, if given); returns the (device-resident) DeviceTopN."""
     if out is None:
         out = DeviceTopN.alloc(ctx, from_csr.shape[0], ntop)
-    check(ctx.lib.pfz_cossim_topn(ctx.h, index.h, from_csr.h, int(ntop), float(lower_bound),
-                                  int(bool(exclude_diag)), int(diag_offset), out.h))
+    if rows is None:
+        check(ctx.lib.pfz_cossim_topn(ctx.h, index.h, from_csr.h, int(ntop), float(lower_bound),
+                                      int(bool(exclude_diag)), int(diag_offset), out.h))
+    else:
+        check(ctx.lib.pfz_cossim_topn_rows(ctx.h, index.h, from_csr.h, int(rows[0]), int(rows[1]), int(ntop),
+                                           float(lower_bound), int(bool(exclude_diag)), int(diag_offset), out.h))
     return out
 
 

@@ -825,7 +825,17 @@ int pfz_index_pieces(const pfz_index *ix, int64_t *n_pieces, int64_t *piece_post
 int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound,
                     int32_t exclude_diag, int64_t diag_offset, pfz_topn *out)
 {
+    PFZ_REQUIRE(A, "pfz_cossim_topn: NULL argument");
+    return pfz_cossim_topn_rows(ctx, ix, A, 0, A->n_rows, ntop, lower_bound, exclude_diag, diag_offset, out);
+}
+
+int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end,
+                         int32_t ntop, float lower_bound, int32_t exclude_diag, int64_t diag_offset, pfz_topn *out)
+{
     PFZ_REQUIRE(ctx && ix && A && out, "pfz_cossim_topn: NULL argument");
+    PFZ_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= A->n_rows,
+                "pfz_cossim_topn_rows: rows [%lld, %lld) outside [0, %lld)", (long long)row_begin, (long long)row_end,
+                (long long)A->n_rows);
     PFZ_REQUIRE(ntop >= 1, "pfz_cossim_topn: ntop must be >= 1 (got %d)", ntop);
     if (ntop > kMaxTop) {
         set_error("pfz_cossim_topn: ntop=%d exceeds the kernel's limit of %d", ntop, kMaxTop);
@@ -836,7 +846,8 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     PFZ_REQUIRE(out->n_rows >= A->n_rows && out->ntop == ntop, "pfz_cossim_topn: result buffer is %lldx%d, need %lldx%d",
                 (long long)out->n_rows, out->ntop, (long long)A->n_rows, ntop);
     PFZ_REQUIRE(lower_bound == lower_bound, "pfz_cossim_topn: lower_bound is NaN");
-    if (A->n_rows == 0) return PFZ_OK;
+    const int64_t n_rows = row_end - row_begin;      // the from-rows of this launch
+    if (n_rows == 0) return PFZ_OK;
     PFZ_HIP(hipSetDevice(ctx->device));
     if (lower_bound < 0.f) lower_bound = 0.f;
     // fixed-point scale: |sum| <= ||a|| * ||b|| (Cauchy-Schwarz) must stay below 2^31
@@ -856,7 +867,7 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
         // per CU exist (measured: 1000 x 300k rows 1.07 -> 0.24 ms, 600 x 1M 2.9 -> 0.5 ms, 3000 x 100k
         // 0.36 -> 0.22 ms; a single query 1.0 ms; the 100k-row benchmark is unaffected)
         const int64_t want = (int64_t)ctx->prop.multiProcessorCount * 24;
-        n_slices = A->n_rows >= want ? 1 : (int)((want + A->n_rows - 1) / A->n_rows);
+        n_slices = n_rows >= want ? 1 : (int)((want + n_rows - 1) / n_rows);
     }
     n_slices = n_slices < 1 ? 1 : (n_slices > ix->n_blocks ? (ix->n_blocks > 0 ? ix->n_blocks : 1) : n_slices);
     if (ix->n_blocks > 0) {
@@ -867,10 +878,10 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     }
     uint64_t *part = nullptr;
     if (n_slices > 1) {
-        PFZ_TRY(ensure_scratch(ctx, (size_t)A->n_rows * (size_t)n_slices * (size_t)ntop * sizeof(uint64_t)));
+        PFZ_TRY(ensure_scratch(ctx, (size_t)n_rows * (size_t)n_slices * (size_t)ntop * sizeof(uint64_t)));
         part = (uint64_t *)ctx->scratch;
     }
-    const int64_t items = A->n_rows * n_slices;
+    const int64_t items = n_rows * n_slices;
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 16 * 64 * 8;
     const unsigned grid = (unsigned)(items < max_grid ? items : max_grid / n_slices * n_slices);
     // candidate keys: room for ntop kept keys + the 64 one sweep step can add.  LDS per workgroup decides how
@@ -880,10 +891,11 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     {
         ProfScope ps(ctx, "k3_cossim_topn");
 #define PFZ_K3_LAUNCH(CC, CAP)                                                                                  \
-    hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, CAP>), dim3(grid), dim3(64), 0, ctx->stream, A->indptr,       \
-                       A->indices, A->data, (int32_t)A->n_rows, ix->tab, ix->post, ix->n_blocks, ix->n_pieces,  \
-                       ntop, thr0, scale, inv_scale, exclude_diag, diag_offset, out->idx, out->val, ablate,     \
-                       n_slices, part)
+    hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, CAP>), dim3(grid), dim3(64), 0, ctx->stream,                  \
+                       A->indptr + row_begin, A->indices, A->data, (int32_t)n_rows, ix->tab, ix->post,          \
+                       ix->n_blocks, ix->n_pieces, ntop, thr0, scale, inv_scale, exclude_diag,                  \
+                       diag_offset + row_begin, out->idx + row_begin * ntop, out->val + row_begin * ntop,       \
+                       ablate, n_slices, part)
 #define PFZ_K3_CASE(CC)                              \
     case CC:                                         \
         if (cap == 96) PFZ_K3_LAUNCH(CC, 96);        \
@@ -904,8 +916,8 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t
     }
     if (n_slices > 1) {
         ProfScope ps(ctx, "k3_merge_slices");
-        hipLaunchKernelGGL(k3_merge_slices, dim3((unsigned)((A->n_rows + 3) / 4)), dim3(256), 0, ctx->stream, part,
-                           (int32_t)A->n_rows, n_slices, ntop, inv_scale, out->idx, out->val);
+        hipLaunchKernelGGL(k3_merge_slices, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, ctx->stream, part,
+                           (int32_t)n_rows, n_slices, ntop, inv_scale, out->idx + row_begin * ntop, out->val + row_begin * ntop);
     }
     PFZ_HIP(hipGetLastError());
     return PFZ_OK;

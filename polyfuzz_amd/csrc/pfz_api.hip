@@ -396,6 +396,7 @@ void pfz_ctx_destroy(pfz_ctx *ctx)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->stage2) (void)hipHostFree(ctx->stage2);
     for (hipEvent_t ev : ctx->side_events)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream2) {
@@ -625,6 +626,40 @@ int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *
     if (n == 0) return PFZ_OK;
     if (out_idx) PFZ_TRY(copy_d2h(ctx, out_idx, t->idx, n * sizeof(int32_t)));
     if (out_val) PFZ_TRY(copy_d2h(ctx, out_val, t->val, n * sizeof(float)));
+    return PFZ_OK;
+}
+
+int pfz_topn_download_rows_after(pfz_ctx *ctx, const pfz_topn *t, int64_t row_begin, int64_t row_end, int32_t event_slot,
+                                 int32_t *out_idx, float *out_val)
+{
+    PFZ_REQUIRE(ctx && t && out_idx && out_val, "pfz_topn_download_rows_after: NULL argument");
+    PFZ_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= t->n_rows, "pfz_topn_download_rows_after: bad row range");
+    PFZ_REQUIRE(event_slot >= 0 && event_slot < kEventSlots, "pfz_topn_download_rows_after: bad event slot %d", event_slot);
+    PFZ_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)(row_end - row_begin) * (size_t)t->ntop;
+    if (n == 0) return PFZ_OK;
+    if (!ctx->stream2) {
+        PFZ_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (hipEvent_t &ev : ctx->side_events) PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const size_t bytes = n * (sizeof(int32_t) + sizeof(float));
+    if (bytes > ctx->stage2_bytes) {
+        PFZ_HIP(hipStreamSynchronize(ctx->stream2));
+        if (ctx->stage2) PFZ_HIP(hipHostFree(ctx->stage2));
+        ctx->stage2 = nullptr;
+        ctx->stage2_bytes = 0;
+        PFZ_HIP(hipHostMalloc((void **)&ctx->stage2, bytes + bytes / 4, hipHostMallocDefault));
+        ctx->stage2_bytes = bytes + bytes / 4;
+    }
+    // the copy runs on the side stream as soon as the event has fired -- work enqueued on the context stream AFTER
+    // the event (the second half of a split match) keeps running beside it
+    PFZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->events[event_slot], 0));
+    PFZ_HIP(hipMemcpyAsync(ctx->stage2, t->idx + row_begin * t->ntop, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream2));
+    PFZ_HIP(hipMemcpyAsync(ctx->stage2 + n * sizeof(int32_t), t->val + row_begin * t->ntop, n * sizeof(float),
+                           hipMemcpyDeviceToHost, ctx->stream2));
+    PFZ_HIP(hipStreamSynchronize(ctx->stream2));
+    memcpy(out_idx, ctx->stage2, n * sizeof(int32_t));
+    memcpy(out_val, ctx->stage2 + n * sizeof(int32_t), n * sizeof(float));
     return PFZ_OK;
 }
 

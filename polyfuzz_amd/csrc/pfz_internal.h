@@ -65,6 +65,8 @@ struct pfz_ctx {
     // pinned staging buffer of the host <-> device copies (copy_h2d / copy_d2h)
     char *stage = nullptr;
     size_t stage_bytes = 0, stage_off = 0;
+    char *stage2 = nullptr;               // pinned staging of the side stream's downloads (pfz_topn_download_rows_after)
+    size_t stage2_bytes = 0;
     // caching allocator state: size class -> free blocks
     std::map<size_t, std::vector<void *>> pool_free_lists;
     size_t pool_cached_bytes = 0, pool_live_bytes = 0;

@@ -19,7 +19,10 @@ from scipy.sparse import csr_matrix
 
 from .. import _lib
 from ._base import BaseMatcher
-from ._utils import topn_to_frame, object_column, clip_top_n, _METHODS
+from ._utils import topn_to_frame, object_column, clip_top_n, FrameBuilder, _METHODS
+
+_SPLIT_MIN_ROWS = 20000      # from-rows from which match() pipelines two K3 launches with the frame building
+_SPLIT_EVENT = 62            # context event slots 62 / 63: first / second launch done
 
 
 def _clean_string(string: str) -> str:
@@ -135,18 +138,44 @@ class TFIDF(BaseMatcher):
         top_n = clip_top_n(self.top_n, to_list)                   # _utils.py:54-56
         self_match = to_list is None
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
-        res = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=self_match)
+        n = len(from_list)
+        names = from_list if self_match else to_list
+        # A big match is enqueued as two launches over the from-rows: the first half's result is downloaded on a side
+        # stream and turned into frame columns while the device works on the second half
+        split = n >= _SPLIT_MIN_ROWS and top_n >= 1 and _lib._pack is not None and isinstance(names, (list, tuple))
+        if split:
+            half = n // 2
+            res = _lib.cossim_topn(ctx, self._dev_index, from_dev, top_n, lower, exclude_diag=self_match, rows=(0, half))
+            ctx.event_record(_SPLIT_EVENT)
+            _lib.cossim_topn(ctx, self._dev_index, from_dev, top_n, lower, exclude_diag=self_match, rows=(half, n), out=res)
+            ctx.event_record(_SPLIT_EVENT + 1)
+        else:
+            res = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=self_match)
         t1 = time.perf_counter()
         from_col = object_column(from_list)        # host work while the device runs K3
         t2 = time.perf_counter()
-        idx, val = res.download()
-        t3 = time.perf_counter()
-        frame = topn_to_frame(idx, val, from_list, from_list if self_match else to_list, top_n, from_col=from_col)
-        t4 = time.perf_counter()
+        if split:
+            fb = FrameBuilder(from_list, names, top_n, from_col)
+            idx, val = res.download_rows_after(0, half, _SPLIT_EVENT)
+            ta = time.perf_counter()
+            fb.fill(idx, val, 0)                   # ... and while it runs the second launch
+            tb = time.perf_counter()
+            idx, val = res.download_rows_after(half, n, _SPLIT_EVENT + 1)
+            tc = time.perf_counter()
+            fb.fill(idx, val, half)
+            frame = fb.frame()
+            t4 = time.perf_counter()
+            waited, framed = (ta - t2) + (tc - tb), (tb - ta) + (t4 - tc)
+        else:
+            idx, val = res.download()
+            t3 = time.perf_counter()
+            frame = topn_to_frame(idx, val, from_list, names, top_n, from_col=from_col)
+            t4 = time.perf_counter()
+            waited, framed = t3 - t2, t4 - t3
         # where the wall time of the last match went (ms): pack + upload + enqueue of K1/K2/index/K3, the From
         # column (overlapped with the device), waiting for the device + D2H, the remaining frame columns
         self.last_timings = {"upload_and_enqueue": (t1 - t0) * 1e3, "from_column": (t2 - t1) * 1e3,
-                             "wait_and_download": (t3 - t2) * 1e3, "frame": (t4 - t3) * 1e3}
+                             "wait_and_download": waited * 1e3, "frame": framed * 1e3}
         return frame
 
     def match_device(self, from_list: List[str], to_list: List[str] = None, re_train: bool = True):

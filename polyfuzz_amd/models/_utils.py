@@ -36,6 +36,35 @@ def object_column(strings) -> np.ndarray:
     return arr
 
 
+class FrameBuilder:
+    """The reference's result frame (_utils.py:104-125) built in row ranges: `fill(idx, val, row0)` writes the To /
+    Similarity columns of rows [row0, row0 + len(idx)) -- so the first part of a split match can be turned into
+    columns while the device still works on the rest -- and `frame()` wraps the columns."""
+
+    def __init__(self, from_list, to_list, top_n, from_col=None):
+        self.n, self.top_n, self.to_list = len(from_list), top_n, to_list
+        self.from_col = object_column(from_list) if from_col is None else from_col
+        self.names = [np.empty(self.n, dtype=object) for _ in range(top_n)]
+        self.sims = [np.empty(self.n, np.float64) for _ in range(top_n)]
+
+    def fill(self, idx, val, row0=0):
+        m = len(idx)
+        if not m or not self.top_n:
+            return
+        idx = np.ascontiguousarray(idx, np.int32).reshape(m, self.top_n)
+        val = np.ascontiguousarray(val, np.float32).reshape(m, self.top_n)
+        _lib._pack.fill_columns(self.to_list, idx.ctypes.data, val.ctypes.data, m, self.top_n,
+                                tuple(a.ctypes.data + 8 * row0 for a in self.names),
+                                tuple(a.ctypes.data + 8 * row0 for a in self.sims), _FILL_THREADS)
+
+    def frame(self):
+        data = {"From": self.from_col}
+        for r in range(self.top_n):
+            data["To" if r == 0 else f"To_{r + 1}"] = self.names[r]
+            data["Similarity" if r == 0 else f"Similarity_{r + 1}"] = self.sims[r]
+        return pd.DataFrame(data, copy=False)
+
+
 def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_list: List[str],
                   top_n: int, from_col: np.ndarray = None) -> pd.DataFrame:
     """(idx, score) arrays -> the reference's DataFrame (_utils.py:104-125):
@@ -45,21 +74,11 @@ def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_lis
     Every (To_r, Similarity_r) pair is filled by one pass of the CPython helper
     (_pack.fill_columns: rounding, the <0.001 rule and the prefetched gather of the
     names); without the helper the numpy twin below builds the same frame."""
-    n = len(from_list)
     if _lib._pack is None or not isinstance(to_list, (list, tuple)):
         return _topn_to_frame_numpy(idx, val, from_list, to_list, top_n)
-    idx = np.ascontiguousarray(idx, np.int32).reshape(n, top_n)
-    val = np.ascontiguousarray(val, np.float32).reshape(n, top_n)
-    data = {"From": object_column(from_list) if from_col is None else from_col}
-    names = [np.empty(n, dtype=object) for _ in range(top_n)]
-    sims = [np.empty(n, np.float64) for _ in range(top_n)]
-    if n and top_n:
-        _lib._pack.fill_columns(to_list, idx.ctypes.data, val.ctypes.data, n, top_n,
-                                tuple(a.ctypes.data for a in names), tuple(a.ctypes.data for a in sims), _FILL_THREADS)
-    for r in range(top_n):
-        data["To" if r == 0 else f"To_{r + 1}"] = names[r]
-        data["Similarity" if r == 0 else f"Similarity_{r + 1}"] = sims[r]
-    return pd.DataFrame(data, copy=False)
+    fb = FrameBuilder(from_list, to_list, top_n, from_col)
+    fb.fill(idx, val, 0)
+    return fb.frame()
 
 
 def _topn_to_frame_numpy(idx, val, from_list, to_list, top_n) -> pd.DataFrame:
