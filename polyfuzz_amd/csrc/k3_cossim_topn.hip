@@ -402,7 +402,8 @@ __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int
         const int i0 = t * 128 + lane, i1 = i0 + 64;
         const int4 v0 = acc4[i0], v1 = acc4[i1];
         // (clearing with eight ds_write_addtid_b32 per step instead -- 2 LDS cycles per 256 B against 13 per
-        // KiB -- measured 6 % SLOWER: the sweep is bound by its instruction stream, not by LDS cycles)
+        // KiB -- measured 6 % SLOWER, and reading-and-clearing in one operation, ds_wrxchg2_rtn_b64 with zero, 2 %
+        // slower: the sweep is bound by its instruction stream and latencies, not by LDS cycles)
         acc4[i0] = make_int4(zero, zero, zero, zero);
         acc4[i1] = make_int4(zero, zero, zero, zero);
         const int mx = max3i(max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y), max3i(v1.z, v1.w, v1.w));
