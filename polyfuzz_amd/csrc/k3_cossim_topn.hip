@@ -603,8 +603,17 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
         st.cnt = 0;
         st.thr = thr0;
 
+        // Block order: a self-match starts with the block that holds the from-row itself and wraps around.  On a
+        // sorted list (the reference's company names are) a row's best matches sit next to it, so the threshold is
+        // high from the first block on and far fewer sums are parked as candidates in the others; any order gives the
+        // same result (the final selection is by key).  PFZ_K3_EXP 8: always start at the first block.
+        const int n_blk = b_hi - b_lo;
+        int b_first = b_lo;
+#if PFZ_K3_EXP != 8
+        if (self_col >= 0 && self_col / C >= b_lo && self_col / C < b_hi) b_first = self_col / C;
+#endif
         // registers for the first 64 n-grams of the row (covers almost every row);
-        // the offset-table entry of the next block is always one block ahead in flight
+        // the two offset-table entries of the next block are always one block ahead in flight
         int cur0 = 0, nxt0 = 0;
         float as0 = 0.f;
         const bool have0 = lane < nnz;
@@ -612,20 +621,22 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
         if (have0) {
             as0 = a_val[p0 + lane] * scale;
             trow = tab + (int64_t)a_idx[p0 + lane] * nb;
-            cur0 = trow[b_lo];
-            nxt0 = trow[b_lo + 1];
+            cur0 = trow[b_first];
+            nxt0 = trow[b_first + 1];
         }
 
         bool warmed = ablate == 3;   // (3: timing experiment without the threshold warm start)
-        for (int b = b_lo; b < b_hi; ++b) {
+        for (int it = 0, b = b_first; it < n_blk; ++it) {
             const int s = cur0, e = have0 ? nxt0 : cur0;
-            cur0 = e;
+            const int b_next = b + 1 < b_hi ? b + 1 : b_lo;
             bool touched = __ballot(e > s) != 0;
             if (touched && ablate != 1) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
-            // prefetch of the table entry block b+1 ends with (tab has V*nb+2 slots): issued AFTER the block's posting
-            // loads -- the compiler drains vmcnt before a round's loads, and a table load issued just before them
-            // was a full L2 round trip in every block's critical path; here the sweep below covers it
-            if (have0 && b + 2 <= nb) nxt0 = trow[b + 2];
+            // prefetch of the next block's table entries (tab has V*nb+2 slots): issued AFTER the block's posting
+            // loads -- the compiler drains vmcnt before a round's loads -- and covered by the sweep below
+            if (have0 && it + 1 < n_blk) {
+                cur0 = trow[b_next];
+                nxt0 = trow[b_next + 1];
+            }
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
                 int s2 = 0, e2 = 0;
                 float as2 = 0.f;
@@ -652,6 +663,7 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
                 sweep_block<N4, kCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero);
                 wave_sync();      // acc is zero again
             }
+            b = b_next;
         }
 
         compact<kCap>(cand, st, ntop, lane);
