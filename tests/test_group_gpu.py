@@ -110,3 +110,25 @@ def test_create_groups_reference_known_answers(gg):
             got = create_groups(pd.DataFrame({"From": sl, "To": sl, "Similarity": 1.0}), m, rec["min_similarity"], True)
             # (near-tie rows may pick another To than the reference's float64 run: compare sizes, not members)
             assert abs(len(got[2]) - len(rec["cluster_mapping"])) <= 0.01 * len(rec["cluster_mapping"]) + 2
+
+
+def test_k6_edge_cases(ctx):
+    """Empty / single-row results, nothing above the threshold, NaN similarities, a non-TFIDF grouper."""
+    from polyfuzz_amd import _lib
+    from polyfuzz_amd.linkage import create_groups, greedy_assign
+    from polyfuzz_amd.metrics import precision_recall_curve
+    from polyfuzz_amd.models import EditDistance
+    for g, v in (([-1], [0.0]), ([1, 0], [0.2, 0.2]), ([1, 0, 1], [0.9, 0.9, 0.1])):
+        res = _lib.DeviceTopN.from_host(ctx, np.array(g, np.int32), np.array(v, np.float32))
+        cluster, key, info = _lib.linkage_top1(ctx, res, 0.5)
+        rows = [i for i in range(len(g)) if g[i] >= 0 and round(float(np.float32(v[i])), 3) > 0.5]
+        e_cluster, _ = greedy_assign(np.array(rows, np.int32), np.array([g[i] for i in rows], np.int32), len(g))
+        np.testing.assert_array_equal(cluster, e_cluster)
+    with pytest.raises(_lib.PfzError):
+        _lib.linkage_top1(ctx, res, -0.1)                    # negative thresholds take the host walk (None can be a key)
+    p, r, ap = precision_recall_curve(pd.DataFrame({"From": list("abc"), "To": list("xyz"), "Similarity": [0.5, np.nan, 1.0]}))
+    assert r[0] == 2 / 3 and r[-1] == 1 / 3 and abs(ap[0] - 0.75) < 1e-12 and ap[-1] == 1.0      # NaN is never >= a threshold
+    df = pd.DataFrame({"From": ["a", "b", "c"], "To": ["apple", "apples", "mouse"], "Similarity": [1.0, 1.0, 1.0]})
+    out, clusters, mapping = create_groups(df, EditDistance(normalize=False), link_min_similarity=0.75)
+    assert list(out.columns) == ["From", "To", "Similarity", "Group"]                 # scores 0..100: everything links
+    assert set(mapping) == {"apple", "apples", "mouse"}
