@@ -64,7 +64,8 @@ int pfz_event_record(pfz_ctx *ctx, int32_t slot);
 /* blocks until both events completed */
 int pfz_event_elapsed_ms(pfz_ctx *ctx, int32_t slot_begin, int32_t slot_end, float *ms);
 /* per-kernel profile: when enabled, every launch of the named hot kernels is
- * bracketed by its own event pair (adds a little launch overhead). */
+ * bracketed by its own event pair (adds a little launch overhead: ~2 % of a 100k x 100k step).
+ * on = 1: every profiled kernel; on = 2: only the dominant ones (k3_cossim_topn, k4_indel, k5_gemm_panel). */
 int pfz_prof_enable(pfz_ctx *ctx, int32_t on);
 int pfz_prof_reset(pfz_ctx *ctx);
 /* total ms and launch count of kernel `name` since the last reset (blocks). */

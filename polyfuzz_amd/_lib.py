@@ -201,7 +201,8 @@ class Context:
         return float(ms.value)
 
     def prof_enable(self, on=True):
-        check(self.lib.pfz_prof_enable(self.h, int(bool(on))))
+        """on: False / True (every profiled kernel) / 2 (the dominant kernels only: least overhead)"""
+        check(self.lib.pfz_prof_enable(self.h, int(on)))
 
     def prof_reset(self):
         check(self.lib.pfz_prof_reset(self.h))

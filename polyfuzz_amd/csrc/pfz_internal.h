@@ -57,6 +57,7 @@ struct pfz_ctx {
     hipDeviceProp_t prop;
     hipEvent_t events[pfz::kEventSlots] = {};
     bool prof = false;
+    int prof_level = 0;                   // 1: every profiled kernel, 2: the dominant kernels only
     std::map<std::string, pfz::ProfEntry> prof_entries;
     std::vector<hipEvent_t> event_pool;
     // reusable scratch (grown on demand, never inside a timed region after warm-up)
