@@ -107,12 +107,24 @@ __global__ __launch_bounds__(256) void k_index_fill(const int32_t *__restrict__ 
     }
 }
 
-// pieces per list (before the scan)
-__global__ __launch_bounds__(256) void k_index_pieces(const int32_t *__restrict__ cnt, int64_t slots,
+// pieces per list (before the scan).  sub != NULL (LDS-histogram path): the counts arrive per (list, sub-block) --
+// kSub workgroups share a to-block -- and are turned in place into each sub-block's first position inside the list.
+constexpr int kSub = 4;
+__global__ __launch_bounds__(256) void k_index_pieces(int32_t *__restrict__ cnt, int32_t *__restrict__ sub, int64_t slots,
                                                        int32_t *__restrict__ tab)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < slots) tab[i] = (cnt[i] + kPiece - 1) / kPiece;
+    if (i >= slots) return;
+    int c;
+    if (sub) {
+        int4 v = ((const int4 *)sub)[i];
+        c = v.x + v.y + v.z + v.w;
+        if (c) ((int4 *)sub)[i] = make_int4(0, v.x, v.x + v.y, v.x + v.y + v.z);
+        cnt[i] = c;
+    } else {
+        c = cnt[i];
+    }
+    tab[i] = (c + kPiece - 1) / kPiece;
 }
 
 // Padding entries of every list (positions count .. 16*pieces) and the dummy piece at n_pieces: value 0
@@ -140,13 +152,16 @@ __global__ __launch_bounds__(256) void k_index_pad(const int32_t *__restrict__ c
 __global__ __launch_bounds__(1024) void k_index_count_lds(const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices, int32_t n_rows,
                                                            int32_t nb, int32_t block, int32_t words,
-                                                           int32_t *__restrict__ cnt)
+                                                           int32_t *__restrict__ sub_cnt /* [slots][kSub] */)
 {
     __shared__ uint32_t h[kHistWords];
     for (int t = threadIdx.x; t < words; t += 1024) h[t] = 0u;
     __syncthreads();
-    const int b = blockIdx.x;
-    const int lo = b * block, hi = min(n_rows, lo + block);
+    // workgroup = one quarter of a to-block's rows: the scattered 8-byte stores of the fill pass are what limits
+    // these two kernels (a workgroup per block kept 49 of 256 CUs busy at 100k rows), so a block is shared by kSub
+    const int b = blockIdx.x / kSub, q = blockIdx.x % kSub;
+    const int per = block / kSub;
+    const int lo = b * block + q * per, hi = min(n_rows, lo + per);
     // a 16-lane group takes 16 consecutive to-rows at a time: row bounds fetched in parallel by the lanes,
     // then the first 16 entries of all 16 rows loaded back to back (no dependent round trip per row)
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
@@ -179,8 +194,8 @@ __global__ __launch_bounds__(1024) void k_index_count_lds(const int32_t *__restr
     __syncthreads();
     for (int w = threadIdx.x; w < words; w += 1024) {
         const uint32_t v = h[w];
-        if (v & 0xffffu) cnt[(int64_t)(2 * w) * nb + b] = (int32_t)(v & 0xffffu);
-        if (v >> 16) cnt[(int64_t)(2 * w + 1) * nb + b] = (int32_t)(v >> 16);
+        if (v & 0xffffu) sub_cnt[((int64_t)(2 * w) * nb + b) * kSub + q] = (int32_t)(v & 0xffffu);
+        if (v >> 16) sub_cnt[((int64_t)(2 * w + 1) * nb + b) * kSub + q] = (int32_t)(v >> 16);
     }
 }
 
@@ -189,21 +204,28 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
                                                           const float *__restrict__ data, int32_t n_rows, int32_t nb,
                                                           int32_t block, int32_t words,
                                                           const int32_t *__restrict__ tab /* first pieces */,
+                                                          const int32_t *__restrict__ sub_first /* [slots][kSub] */,
                                                           int2 *__restrict__ post)
 {
     __shared__ uint32_t h[kHistWords];
     for (int t = threadIdx.x; t < words; t += 1024) h[t] = 0u;
     __syncthreads();
-    const int b = blockIdx.x;
-    const int lo = b * block, hi = min(n_rows, lo + block);
+    const int b = blockIdx.x / kSub, q = blockIdx.x % kSub;
+    const int per = block / kSub;
+    const int blk0 = b * block;
+    const int lo = blk0 + q * per, hi = min(n_rows, lo + per);
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int lane0 = (threadIdx.x & 63) & ~15;
-    // one posting: its list position = the value the LDS counter had before this row
-    // (the order inside one (k,b) list is irrelevant to the results: integer sums)
-    auto place = [&](int k, float v, int row, int start) {
+    // one posting: its list position = first position of this sub-block in the list + the value the LDS counter had
+    // before this row (the order inside one (k,b) list is irrelevant to the results: integer sums)
+    auto place = [&](int k, float v, int row, int64_t start) {
         const int sh = (k & 1) * 16;
         const uint32_t old = atomicAdd(&h[k >> 1], 1u << sh);
-        post[(int64_t)start * kPiece + (int)((old >> sh) & 0xffffu)] = make_int2((row - lo) * 4, __float_as_int(v));   // .x = byte offset into acc
+        post[start + (int)((old >> sh) & 0xffffu)] = make_int2((row - blk0) * 4, __float_as_int(v));   // .x = byte offset into acc
+    };
+    auto start_of = [&](int k) -> int64_t {
+        const int64_t slot = (int64_t)k * nb + b;
+        return (int64_t)tab[slot] * kPiece + sub_first[slot * kSub + q];
     };
     for (int rb = lo + grp * 16; rb < hi; rb += 64 * 16) {   // 16 consecutive rows per group, as in the count kernel
         const int mine = rb + sub;
@@ -212,7 +234,8 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
             q0 = indptr[mine];
             q1 = indptr[mine + 1];
         }
-        int kk[16], st[16];
+        int kk[16];
+        int64_t st[16];
         float vv[16];
         bool ok[16];
 #pragma unroll
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
             vv[i] = ok[i] ? data[a + sub] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[i] = ok[i] ? tab[(int64_t)kk[i] * nb + b] : 0;
+        for (int i = 0; i < 16; ++i) st[i] = ok[i] ? start_of(kk[i]) : 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             if (ok[i]) place(kk[i], vv[i], rb + i, st[i]);
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
             const int a = __shfl(q0, lane0 + i, 64), e = __shfl(q1, lane0 + i, 64);
             for (int p = a + 16 + sub; p < e; p += 16) {
                 const int k = indices[p];
-                place(k, data[p], rb + i, tab[(int64_t)k * nb + b]);
+                place(k, data[p], rb + i, start_of(k));
             }
         }
     }
@@ -753,15 +776,20 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     struct Tmp {
         int32_t *p = nullptr;
         ~Tmp() { if (p) pool_free(p); }
-    } cnt;
-    PFZ_TRY(pool_alloc(ctx, &ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
-    PFZ_TRY(pool_alloc(ctx, &cnt.p, (size_t)(slots + 2) * sizeof(int32_t)));
-    PFZ_HIP(hipMemsetAsync(ix->tab, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
-    PFZ_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
+    } cnt, sub;
     const bool any = B->n_rows > 0 && B->nnz > 0;
     // per-block LDS histograms when the vocabulary fits (PFZ_NO_LDS_HIST=1 forces the global-atomics
     // path of huge vocabularies: tests)
     const bool lds_hist = B->n_cols <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST");
+    PFZ_TRY(pool_alloc(ctx, &ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &cnt.p, (size_t)(slots + 2) * sizeof(int32_t)));
+    PFZ_HIP(hipMemsetAsync(ix->tab, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
+    if (lds_hist && any) {      // counts per (list, sub-block); cnt itself is written by k_index_pieces
+        PFZ_TRY(pool_alloc(ctx, &sub.p, (size_t)(slots + 1) * kSub * sizeof(int32_t)));
+        PFZ_HIP(hipMemsetAsync(sub.p, 0, (size_t)slots * kSub * sizeof(int32_t), ctx->stream));
+    } else {
+        PFZ_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
+    }
     const int32_t words = (int32_t)((B->n_cols + 1) / 2);
     const unsigned row_grid = (unsigned)((B->n_rows * 16 + 255) / 256);
     const unsigned slot_grid = (unsigned)((slots + kPiece + 255) / 256);
@@ -770,12 +798,13 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
         {
             ProfScope ps(ctx, "k_index_count");
             if (lds_hist)
-                hipLaunchKernelGGL(k_index_count_lds, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
-                                   (int32_t)B->n_rows, (int32_t)nb, block, words, cnt.p);
+                hipLaunchKernelGGL(k_index_count_lds, dim3((unsigned)nb * kSub), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
+                                   (int32_t)B->n_rows, (int32_t)nb, block, words, sub.p);
             else
                 hipLaunchKernelGGL(k_index_count, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
                                    (int32_t)B->n_rows, (int32_t)nb, block, cnt.p);
-            hipLaunchKernelGGL(k_index_pieces, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, slots, ix->tab);
+            hipLaunchKernelGGL(k_index_pieces, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, lds_hist ? sub.p : nullptr, slots,
+                               ix->tab);
         }
         PFZ_TRY(exclusive_scan_i32(ctx, ix->tab, slots));   // tab[i] = first piece of list i, tab[slots] = pieces
         PFZ_HIP(hipMemcpyAsync(&n_pieces, ix->tab + slots, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -794,8 +823,8 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
         hipLaunchKernelGGL(k_index_pad, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, ix->tab, any ? slots : 0, n_pieces,
                            ix->post);
         if (any && lds_hist)
-            hipLaunchKernelGGL(k_index_fill_lds, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
-                               B->data, (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab, ix->post);
+            hipLaunchKernelGGL(k_index_fill_lds, dim3((unsigned)nb * kSub), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
+                               B->data, (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab, sub.p, ix->post);
         else if (any)
             hipLaunchKernelGGL(k_index_fill, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices, B->data,
                                (int32_t)B->n_rows, (int32_t)nb, block, cnt.p, ix->tab, ix->post);
