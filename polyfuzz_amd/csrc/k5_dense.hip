@@ -148,13 +148,18 @@ __global__ __launch_bounds__(256) void k5_gemm_panel(const float *__restrict__ A
 // Rows beyond the matrix edge are clamped to the last row (their products are discarded by the store),
 // so the loop has no edge tests.  (Tried and dropped: a leading dimension of 36 with b128 LDS accesses
 // and k split by lane half -- 73 TFLOP/s, the fragment reads conflict.)
-__global__ __launch_bounds__(256) void k5_gemm_panel_pipe(const float *__restrict__ A, const float *__restrict__ B,
+template <int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(const float *__restrict__ A, const float *__restrict__ B,
                                                            const float *__restrict__ inv_a,
                                                            const float *__restrict__ inv_b, int64_t a0, int64_t a1,
                                                            int64_t n_b, int64_t d, float *__restrict__ S, int64_t ld)
 {
-    __shared__ float As[2][kTile * kLd];
-    __shared__ float Bs[2][kTile * kLd];
+    constexpr int LD = BK + 1;            // LDS leading dimension: conflict-free ds_read_b32 of the MFMA fragments
+    constexpr int TPR = BK / 4;           // threads per tile row (a float4 each)
+    constexpr int RPP = 256 / TPR;        // rows staged per pass
+    constexpr int NP = kTile / RPP;       // passes
+    __shared__ float As[2][kTile * LD];
+    __shared__ float Bs[2][kTile * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = a0 + (int64_t)blockIdx.y * kTile;
     const int64_t col0 = (int64_t)blockIdx.x * kTile;
@@ -168,25 +173,25 @@ __global__ __launch_bounds__(256) void k5_gemm_panel_pipe(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int lr = tid >> 3;          // 0..31
-    const int lk = (tid & 7) * 4;     // 0,4,..,28
-    const float *pa[4], *pb[4];
+    const int lr = tid / TPR;
+    const int lk = (tid % TPR) * 4;
+    const float *pa[NP], *pb[NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int64_t ga = min(row0 + lr + p * 32, a1 - 1), gb = min(col0 + lr + p * 32, n_b - 1);
+    for (int p = 0; p < NP; ++p) {
+        const int64_t ga = min(row0 + lr + p * RPP, a1 - 1), gb = min(col0 + lr + p * RPP, n_b - 1);
         pa[p] = A + ga * d + lk;
         pb[p] = B + gb * d + lk;
     }
-    float4 ra[4], rb[4];
+    float4 ra[NP], rb[NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         ra[p] = *(const float4 *)pa[p];
         rb[p] = *(const float4 *)pb[p];
     }
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float *da = As[buf] + (lr + p * 32) * kLd + lk, *db = Bs[buf] + (lr + p * 32) * kLd + lk;
+        for (int p = 0; p < NP; ++p) {
+            float *da = As[buf] + (lr + p * RPP) * LD + lk, *db = Bs[buf] + (lr + p * RPP) * LD + lk;
             da[0] = ra[p].x; da[1] = ra[p].y; da[2] = ra[p].z; da[3] = ra[p].w;
             db[0] = rb[p].x; db[1] = rb[p].y; db[2] = rb[p].z; db[3] = rb[p].w;
         }
@@ -194,13 +199,13 @@ __global__ __launch_bounds__(256) void k5_gemm_panel_pipe(const float *__restric
     stage(0);
     __syncthreads();
     int cur = 0;
-    for (int64_t k0 = 0; k0 < d; k0 += kBK) {
-        const bool more = k0 + kBK < d;
+    for (int64_t k0 = 0; k0 < d; k0 += BK) {
+        const bool more = k0 + BK < d;
         if (more) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ra[p] = *(const float4 *)(pa[p] + k0 + kBK);
-                rb[p] = *(const float4 *)(pb[p] + k0 + kBK);
+            for (int p = 0; p < NP; ++p) {
+                ra[p] = *(const float4 *)(pa[p] + k0 + BK);
+                rb[p] = *(const float4 *)(pb[p] + k0 + BK);
             }
         }
         const float *as = As[cur], *bs = Bs[cur];
@@ -210,9 +215,9 @@ __global__ __launch_bounds__(256) void k5_gemm_panel_pipe(const float *__restric
                 const int kq = kk + (lane >> 5);
                 float a[2], b[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = as[(wm + i * 32 + (lane & 31)) * kLd + kq];
+                for (int i = 0; i < 2; ++i) a[i] = as[(wm + i * 32 + (lane & 31)) * LD + kq];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = bs[(wn + j * 32 + (lane & 31)) * kLd + kq];
+                for (int j = 0; j < 2; ++j) b[j] = bs[(wn + j * 32 + (lane & 31)) * LD + kq];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -222,9 +227,9 @@ __global__ __launch_bounds__(256) void k5_gemm_panel_pipe(const float *__restric
         };
         // the next step's operands (in flight since the top of this step) go to the OTHER buffer half way through:
         // the stores issue while the matrix pipe is busy with the second half instead of after it
-        mma(0, kBK / 2);
+        mma(0, BK / 2);
         if (more) stage(cur ^ 1);
-        mma(kBK / 2, kBK);
+        mma(BK / 2, BK);
         __syncthreads();
         cur ^= 1;
     }
@@ -460,9 +465,14 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
             ProfScope ps(ctx, "k5_gemm_panel");
             dim3 grid((unsigned)(ld / kTile), (unsigned)((a1 - a0 + kTile - 1) / kTile));
             // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
-            if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE"))
-                hipLaunchKernelGGL(k5_gemm_panel_pipe, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0,
-                                   a1, n_to, dim, S, ld);
+            if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE")) {
+                if (getenv("PFZ_K5_BK16"))     // A/B knob: 16-deep k-steps (half the LDS per workgroup, twice the barriers)
+                    hipLaunchKernelGGL(k5_gemm_panel_pipe<16>, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
+                                       a0, a1, n_to, dim, S, ld);
+                else
+                    hipLaunchKernelGGL(k5_gemm_panel_pipe<32>, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
+                                       a0, a1, n_to, dim, S, ld);
+            }
             else
                 hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
                                    n_to, dim, S, ld);
