@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void k5_gemm_panel(const float *__restrict__ A
     __shared__ float As[kTile * kLd];
     __shared__ float Bs[kTile * kLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = a0 + (int64_t)blockIdx.y * kTile;   // first A row of the tile
-    const int64_t col0 = (int64_t)blockIdx.x * kTile;        // first B row of the tile
+    const int64_t row0 = a0 + (int64_t)blockIdx.x * kTile;   // first A row of the tile (x: see the launch)
+    const int64_t col0 = (int64_t)blockIdx.y * kTile;        // first B row of the tile
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;   // the wave's 64x64 corner inside the tile
 
     f32x16 acc[2][2];
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
     __shared__ float As[2][kTile * LD];
     __shared__ float Bs[2][kTile * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = a0 + (int64_t)blockIdx.y * kTile;
-    const int64_t col0 = (int64_t)blockIdx.x * kTile;
+    const int64_t row0 = a0 + (int64_t)blockIdx.x * kTile;
+    const int64_t col0 = (int64_t)blockIdx.y * kTile;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
     f32x16 acc[2][2];
@@ -463,7 +463,9 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         if (two && pi >= 2) PFZ_HIP(hipStreamWaitEvent(ctx->stream, consumed[buf], 0));   // the top-n of panel pi - 2 read this buffer
         if (ld > 0) {
             ProfScope ps(ctx, "k5_gemm_panel");
-            dim3 grid((unsigned)(ld / kTile), (unsigned)((a1 - a0 + kTile - 1) / kTile));
+            // x = the panel's row tiles, y = column tiles: workgroups that are dispatched together share a B tile (one
+            // HBM read per panel instead of one per row tile) and the panel's A rows (a few MB) stay in L2
+            dim3 grid((unsigned)((a1 - a0 + kTile - 1) / kTile), (unsigned)(ld / kTile));
             // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
             if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE")) {
                 if (getenv("PFZ_K5_BK16"))     // A/B knob: 16-deep k-steps (half the LDS per workgroup, twice the barriers)
