@@ -313,6 +313,94 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
     }
 }
 
+// The general case: from-strings beyond 1024 characters, or an alphabet x word count whose match table does not fit
+// LDS (thousands of distinct CJK characters with long strings).  Same recurrence, any number W of 64-bit words, with
+// the match table of the workgroup's from-string and every lane's V in global scratch (L2): slow -- every word-step
+// is two loads and a store -- but the reference accepts such inputs, so the engine does too.  One to-string per lane.
+template <int IDB>
+__global__ __launch_bounds__(256) void k4_indel_general_kernel(IndelArgs A, int32_t W, uint64_t *__restrict__ pm_all,
+                                                                uint64_t *__restrict__ v_all)
+{
+    __shared__ int red[4][3];
+    constexpr int PER = 32 / IDB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t *pm = pm_all + (int64_t)blockIdx.x * A.n_sym1 * W;      // zero on entry, zero again after every row
+    uint64_t *V = v_all + (int64_t)blockIdx.x * W * 256 + tid;        // V[w * 256]: this lane's word w
+    for (int r = blockIdx.x; r < A.n_rows; r += gridDim.x) {
+        const int row = A.rows[r];
+        const int64_t a0 = A.a_off[row];
+        const int m = (int)(A.a_off[row + 1] - a0);
+        auto a_sym = [&](int p) -> int {
+            const uint32_t c = A.a_width == 1 ? (uint32_t)((const uint8_t *)A.a_chars)[a0 + p] : ((const uint32_t *)A.a_chars)[a0 + p];
+            return c < A.lut_len ? (int)A.lut[c] : 0;
+        };
+        for (int p = tid; p < m; p += 256) {
+            const int sy = a_sym(p);
+            if (sy) atomicOr((unsigned long long *)&pm[(int64_t)sy * W + p / 64], 1ull << (p % 64));
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int skip = A.skip_idx ? A.skip_idx[row] : -1;
+        Best best = {0, 1, INT_MAX};
+        for (int g = wave; g < A.n_groups; g += 4) {
+            for (int w = 0; w < W; ++w) V[(int64_t)w * 256] = ~0ull;
+            const uint32_t *gp = A.b_packed + A.g_off[g] + lane;
+            const int steps = A.g_steps[g];
+            for (int t = 0; t < steps; ++t) {
+                const uint32_t pk = gp[(int64_t)t * 64];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const uint32_t c = (pk >> (q * IDB)) & ((1u << IDB) - 1u);
+                    if (c == 0) continue;                           // padding symbol: an empty mask changes nothing
+                    const uint64_t *pmc = pm + (int64_t)c * W;
+                    uint64_t carry = 0;
+                    for (int w = 0; w < W; ++w) {
+                        const uint64_t M = pmc[w], sv = V[(int64_t)w * 256], u = sv & M;
+                        uint64_t sum = sv + u;
+                        const uint64_t c1 = sum < sv ? 1 : 0;
+                        sum += carry;
+                        const uint64_t c2 = sum < carry ? 1 : 0;
+                        carry = c1 | c2;
+                        V[(int64_t)w * 256] = sum | (sv ^ u);
+                    }
+                }
+            }
+            int lcs = 0;
+            for (int w = 0; w < W; ++w) lcs += __popcll(~V[(int64_t)w * 256]);
+            const int slot = g * 64 + lane;
+            const int orig = A.b_orig[slot];
+            if (orig >= 0) {
+                const int lb = A.b_len[slot];
+                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = orig == skip ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
+                if (orig != skip) {
+                    if (m + lb == 0) take(best, 1, 1, orig);
+                    else take(best, lcs, m + lb, orig);
+                }
+            }
+        }
+        wave_best(best);
+        if (lane == 0) {
+            red[wave][0] = best.lcs;
+            red[wave][1] = best.mx;
+            red[wave][2] = best.idx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (red[w][2] != INT_MAX) take(best, red[w][0], red[w][1], red[w][2]);
+            const int64_t o = (int64_t)row - A.from_begin;
+            A.out_idx[o] = best.idx == INT_MAX ? -1 : best.idx;
+            A.out_score[o] = best.idx == INT_MAX ? 0.0 : (best.lcs == 1 && best.mx == 1 ? 100.0 : ratio_of(best.lcs, best.mx));
+        }
+        for (int p = tid; p < m; p += 256) {
+            const int sy = a_sym(p);
+            if (sy) pm[(int64_t)sy * W + p / 64] = 0ull;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // ---- to-side plan (cached on the to-list's handle) -----------------------------
 
 // distinct code units of a list: LDS bitmap for code points < 65536, global atomics beyond
@@ -492,11 +580,6 @@ template <typename WORD, int W>
 static int launch_class(pfz_ctx *ctx, const IndelArgs &A, int idb, unsigned grid)
 {
     const size_t lds = (size_t)A.n_sym1 * W * sizeof(WORD);
-    if (lds > 60 * 1024) {
-        set_error("pfz_indel: %d alphabet symbols x %d words need %zu bytes of LDS for the match table (limit 60 KiB)",
-                  A.n_sym1 - 1, W, lds);
-        return PFZ_ERR_UNSUPPORTED;
-    }
     ProfScope ps(ctx, "k4_indel");
     if (idb == 8)
         hipLaunchKernelGGL((k4_indel_kernel<WORD, W, 8>), dim3(grid), dim3(256), lds, ctx->stream, A);
@@ -539,14 +622,23 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         while (m > kClassMax[c]) ++c;
         cls[c].push_back((int32_t)i);
     }
-    if (!cls[6].empty()) {
-        set_error("pfz_indel: from-string %d has more than 1024 characters (bit-parallel word classes cover <= 1024)",
-                  cls[6][0]);
-        return PFZ_ERR_UNSUPPORTED;
+    // classes whose match table (alphabet x words) does not fit 60 KiB of LDS join the general class 6 (> 1024 characters)
+    static const int kClassWordBytes[6] = {4, 8, 16, 32, 64, 128};
+    for (int c = 0; c < 6; ++c)
+        if ((size_t)(pl->n_sym + 1) * kClassWordBytes[c] > 60 * 1024 && !cls[c].empty()) {
+            cls[6].insert(cls[6].end(), cls[c].begin(), cls[c].end());
+            cls[c].clear();
+        }
+    if (getenv("PFZ_K4_FORCE_GENERAL")) {       // tests: everything through the general kernel
+        for (int c = 0; c < 6; ++c) {
+            cls[6].insert(cls[6].end(), cls[c].begin(), cls[c].end());
+            cls[c].clear();
+        }
     }
     const int64_t n_to = T->n;
-    DevBuf d_skip, d_oidx, d_oscore, d_matrix, d_rows[6];
-    for (DevBuf *b : {&d_skip, &d_oidx, &d_oscore, &d_matrix, &d_rows[0], &d_rows[1], &d_rows[2], &d_rows[3], &d_rows[4], &d_rows[5]})
+    DevBuf d_skip, d_oidx, d_oscore, d_matrix, d_rows[7], d_pm, d_v;
+    for (DevBuf *b : {&d_skip, &d_oidx, &d_oscore, &d_matrix, &d_rows[0], &d_rows[1], &d_rows[2], &d_rows[3], &d_rows[4], &d_rows[5],
+                      &d_rows[6], &d_pm, &d_v})
         b->ctx = ctx;
     if (skip_idx) {
         PFZ_TRY(d_skip.alloc((size_t)F->n * sizeof(int32_t)));
@@ -601,6 +693,35 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         case 4: PFZ_TRY((launch_class<uint64_t, 8>(ctx, A, pl->idb, grid))); break;
         default: PFZ_TRY((launch_class<uint64_t, 16>(ctx, A, pl->idb, grid))); break;
         }
+    }
+    if (!cls[6].empty()) {
+        // the general kernel: W words for the longest of these strings, match tables and V columns in global scratch
+        int64_t longest = 1;
+        for (int32_t i : cls[6]) longest = std::max<int64_t>(longest, F->h_off[(size_t)i + 1] - F->h_off[(size_t)i]);
+        const int32_t W = (int32_t)((longest + 63) / 64);
+        int64_t gridg = std::min<int64_t>((int64_t)cls[6].size(), ctx->prop.multiProcessorCount * 2);
+        const size_t pm_per = (size_t)(pl->n_sym + 1) * (size_t)W * sizeof(uint64_t);
+        while (gridg > 1 && pm_per * (size_t)gridg > ((size_t)2 << 30)) gridg /= 2;      // <= 2 GiB of match tables
+        if (pm_per * (size_t)gridg > ((size_t)8 << 30)) {
+            set_error("pfz_indel: a from-string of %lld characters with %d alphabet symbols needs a %zu-byte match table",
+                      (long long)longest, pl->n_sym, pm_per);
+            return PFZ_ERR_UNSUPPORTED;
+        }
+        PFZ_TRY(d_pm.alloc(pm_per * (size_t)gridg));
+        PFZ_TRY(d_v.alloc((size_t)gridg * (size_t)W * 256 * sizeof(uint64_t)));
+        PFZ_HIP(hipMemsetAsync(d_pm.p, 0, pm_per * (size_t)gridg, ctx->stream));
+        PFZ_TRY(d_rows[6].alloc(cls[6].size() * sizeof(int32_t)));
+        PFZ_TRY(copy_h2d(ctx, d_rows[6].p, cls[6].data(), cls[6].size() * sizeof(int32_t)));
+        A.rows = (const int32_t *)d_rows[6].p;
+        A.n_rows = (int32_t)cls[6].size();
+        ProfScope ps(ctx, "k4_indel");
+        if (pl->idb == 8)
+            hipLaunchKernelGGL((k4_indel_general_kernel<8>), dim3((unsigned)gridg), dim3(256), 0, ctx->stream, A, W,
+                               (uint64_t *)d_pm.p, (uint64_t *)d_v.p);
+        else
+            hipLaunchKernelGGL((k4_indel_general_kernel<16>), dim3((unsigned)gridg), dim3(256), 0, ctx->stream, A, W,
+                               (uint64_t *)d_pm.p, (uint64_t *)d_v.p);
+        PFZ_HIP(hipGetLastError());
     }
     if (out_idx) PFZ_TRY(copy_d2h(ctx, out_idx, d_oidx.p, (size_t)n_rows * sizeof(int32_t)));
     if (out_score) PFZ_TRY(copy_d2h(ctx, out_score, d_oscore.p, (size_t)n_rows * sizeof(double)));

@@ -35,9 +35,9 @@ class EditDistance(BaseMatcher):
         model_id: The name of the particular instance, used when comparing models
         normalize: Whether to min-max normalize the similarity scores (_distance.py:83-86)
 
-    Limits of the device path (loud `PfzUnsupported`, there is no CPU fallback): from-strings of at most 1024
-    characters; (distinct code points of the to-list) x ceil(|from| / 64) words must fit 60 KiB of LDS --
-    e.g. 3 000 distinct CJK characters with from-strings beyond 128 characters do not.
+    From-strings of up to 1024 characters run in the register-resident word classes (four at a time up to 32
+    characters); longer ones, and alphabets whose match table (distinct code points of the to-list x words) exceeds
+    60 KiB of LDS, take a general -- slower -- kernel with its state in global memory.  There is no CPU fallback.
     """
     def __init__(self,
                  n_jobs: int = 1,

@@ -88,11 +88,30 @@ def test_self_match_removes_first_equal(ctx, oracle_mod, golden):
     np.testing.assert_array_equal(idx2, idx[40:90])
 
 
-def test_too_long_from_string_is_loud(ctx):
+def test_general_kernel_long_strings_and_forced(ctx, oracle_mod, monkeypatch):
+    """From-strings beyond 1024 characters (and alphabets whose match table does not fit LDS) take the general kernel:
+    any number of 64-bit words, match table and V columns in global scratch.  Bit-exact against the oracle; forcing
+    EVERY row through it (PFZ_K4_FORCE_GENERAL) reproduces the word-class kernels' results."""
     from polyfuzz_amd import _lib
-    f = _lib.DeviceStrings.upload(ctx, ["a" * 1025])
-    with pytest.raises(NotImplementedError):
-        _lib.indel_argmax(ctx, f, f)
+    rng = np.random.default_rng(12)
+    alpha = np.array(list("abcdefghijklmnop qrst"), dtype=object)
+
+    def mk(n, lo, hi):
+        return ["".join(rng.choice(alpha, size=int(rng.integers(lo, hi))).tolist()) for _ in range(n)]
+    fl = mk(6, 1025, 2600) + ["a" * 1025, "ab" * 2000] + mk(40, 0, 200)
+    tl = mk(150, 0, 300) + mk(5, 900, 3000) + ["", "a" * 1025]
+    f, t = _lib.DeviceStrings.upload(ctx, fl), _lib.DeviceStrings.upload(ctx, tl)
+    idx, score = _lib.indel_argmax(ctx, f, t)
+    e_idx, e_score = oracle_mod.indel_argmax(fl, tl)
+    np.testing.assert_array_equal(idx, e_idx)
+    np.testing.assert_array_equal(score, e_score)
+    m = _lib.indel_matrix(ctx, f, t, 0, 3)
+    _, _, e_m = oracle_mod.indel_argmax(fl, tl, rows=(0, 3), want_matrix=True)
+    np.testing.assert_array_equal(m, e_m)
+    monkeypatch.setenv("PFZ_K4_FORCE_GENERAL", "1")
+    idx2, score2 = _lib.indel_argmax(ctx, f, t)
+    np.testing.assert_array_equal(idx2, e_idx)
+    np.testing.assert_array_equal(score2, e_score)
 
 
 def test_rapidfuzz_matcher_extract_one_rules(oracle_mod):
