@@ -25,6 +25,10 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#ifndef PFZ_K5_EXP
+#define PFZ_K5_EXP 0
+#endif
+
 namespace pfz {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
     int cur = 0;
     for (int64_t k0 = 0; k0 < d; k0 += BK) {
         const bool more = k0 + BK < d;
+#if PFZ_K5_EXP == 0      // (what-if builds, results wrong: 1 = no global loads in the loop, 2 = nor staging / barriers)
         if (more) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -208,30 +213,53 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
                 rb[p] = *(const float4 *)(pb[p] + k0 + BK);
             }
         }
+#endif
         const float *as = As[cur], *bs = Bs[cur];
-        auto mma = [&](int kk_begin, int kk_end) {
-#pragma unroll 4
-            for (int kk = kk_begin; kk < kk_end; kk += 2) {
-                const int kq = kk + (lane >> 5);
-                float a[2], b[2];
+        // MFMA 32x32x2 fragments: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31].  The
+        // fragments are read one set (eight MFMAs) ahead of their use, into two register sets: with the reads
+        // issued right before their MFMAs, as the compiler schedules a plain loop, both waves of a SIMD sit in
+        // s_waitcnt lgkmcnt(0) once per 16 MFMAs and the matrix pipe idles ~15 % of the time
+        // (what-if builds: pure fragment-read + MFMA loop 132 of 157 TFLOP/s).
+        const float *ap = as + (wm + (lane & 31)) * LD + (lane >> 5), *bp = bs + (wn + (lane & 31)) * LD + (lane >> 5);
+        // a fragment set = two k-steps (kk and kk + 2: one ds_read2_b32 per operand tile row)
+        auto frag = [&](int kk, float (&a)[2][2], float (&b)[2][2]) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = as[(wm + i * 32 + (lane & 31)) * LD + kq];
+            for (int h = 0; h < 2; ++h) {
+                a[h][0] = ap[kk + 2 * h];
+                a[h][1] = ap[32 * LD + kk + 2 * h];
+                b[h][0] = bp[kk + 2 * h];
+                b[h][1] = bp[32 * LD + kk + 2 * h];
+            }
+        };
+        auto mfma8 = [&](const float (&a)[2][2], const float (&b)[2][2]) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = bs[(wn + j * 32 + (lane & 31)) * LD + kq];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
         };
-        // the next step's operands (in flight since the top of this step) go to the OTHER buffer half way through:
-        // the stores issue while the matrix pipe is busy with the second half instead of after it
-        mma(0, BK / 2);
-        if (more) stage(cur ^ 1);
-        mma(BK / 2, BK);
+        float fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
+        frag(0, fa0, fb0);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            frag(kk + 4, fa1, fb1);           // read eight MFMAs (512 cycles) ahead of their use
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads back to just before their use)
+            mfma8(fa0, fb0);
+            // the next step's operands (in flight since the top of this step) go to the OTHER buffer half way through:
+            // the stores issue while the matrix pipe is busy instead of after the loop
+#if PFZ_K5_EXP != 2
+            if (kk == BK / 2 - 8 && more) stage(cur ^ 1);
+#endif
+            if (kk + 8 < BK) frag(kk + 8, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(fa1, fb1);
+        }
+#if PFZ_K5_EXP != 2
         __syncthreads();
         cur ^= 1;
+#endif
     }
 
 #pragma unroll
