@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
     int cur = 0;
     for (int64_t k0 = 0; k0 < d; k0 += BK) {
         const bool more = k0 + BK < d;
-#if PFZ_K5_EXP == 0      // (what-if builds, results wrong: 1 = no global loads in the loop, 2 = nor staging / barriers)
+#if PFZ_K5_EXP == 0      // (what-if builds, results wrong: 1 = no global loads in the loop, 2 = nor staging / barriers,
+                         //  3 = nor fragment re-reads, 4 = nor the epilogue's stores)
         if (more) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -242,26 +243,70 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
         };
         float fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
         frag(0, fa0, fb0);
+#if PFZ_K5_EXP >= 3
+        frag(4, fa1, fb1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
+#if PFZ_K5_EXP < 3
             frag(kk + 4, fa1, fb1);           // read eight MFMAs (512 cycles) ahead of their use
+#endif
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads back to just before their use)
             mfma8(fa0, fb0);
             // the next step's operands (in flight since the top of this step) go to the OTHER buffer half way through:
             // the stores issue while the matrix pipe is busy instead of after the loop
-#if PFZ_K5_EXP != 2
+#if PFZ_K5_EXP < 2
             if (kk == BK / 2 - 8 && more) stage(cur ^ 1);
 #endif
+#if PFZ_K5_EXP < 3
             if (kk + 8 < BK) frag(kk + 8, fa0, fb0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mfma8(fa1, fb1);
         }
-#if PFZ_K5_EXP != 2
+#if PFZ_K5_EXP < 2
         __syncthreads();
         cur ^= 1;
 #endif
     }
 
+    // Epilogue.  MFMA 32x32 accumulator r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
+    if (row0 + kTile <= a1) {
+        // interior tile (all but the last row tile of the last panel; ld is a whole number of tiles): the 1/|a| factors
+        // come as eight float4 loads issued together, the 64 stores go out back to back from a wave-uniform base plus
+        // one 32-bit lane offset.  (Row-by-row predicated code makes the compiler wait for EVERYTHING in flight,
+        // the previous store included, before each element: 5.5 us per tile, 13 % of a tile's MFMA time.)
+        const int uwm = __builtin_amdgcn_readfirstlane(wm), uwn = __builtin_amdgcn_readfirstlane(wn);
+        const float4 *ia = (const float4 *)(inv_a + row0 + uwm) + (lane >> 5);
+        float4 sa[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sa[i][q] = ia[i * 8 + q * 2];
+        float sb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = col0 + uwn + j * 32 + (lane & 31);
+            sb[j] = col < n_b ? inv_b[col] : 0.f;
+        }
+        float *tile = S + (row0 - a0 + uwm) * ld + col0 + uwn;
+        const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * (uint32_t)ld + (uint32_t)(lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = r % 4 == 0 ? sa[i][r / 4].x : r % 4 == 1 ? sa[i][r / 4].y : r % 4 == 2 ? sa[i][r / 4].z : sa[i][r / 4].w;
+                float *rowp = tile + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#if PFZ_K5_EXP == 4
+                    if (acc[i][j][r] == 12345.678f)
+#endif
+                    (rowp + j * 32)[lane_off] = acc[i][j][r] * f * sb[j];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int64_t col = col0 + wn + j * 32 + (lane & 31);
@@ -500,7 +545,7 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
                     hipLaunchKernelGGL(k5_gemm_panel_pipe<16>, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
                                        a0, a1, n_to, dim, S, ld);
                 else
-                    hipLaunchKernelGGL(k5_gemm_panel_pipe<32>, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
+                    hipLaunchKernelGGL(k5_gemm_panel_pipe<32>, grid, dim3(256), getenv("PFZ_K5_ONE_WG") ? 48 << 10 : 0, ctx->stream, from->x, to->x, from->inv, to->inv,
                                        a0, a1, n_to, dim, S, ld);
             }
             else

@@ -1,6 +1,6 @@
 """GEMM time of K5 on n x n x 768 (default 32768): random-normal, small-integer and all-zero fills -- the MFMA rate
 on this part depends on the operand data (power), so a roofline fraction should say which fill it was measured on."""
-import sys, time; sys.path.insert(0,'.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, polyfuzz_amd
 from polyfuzz_amd import pipeline
 ctx = polyfuzz_amd.Context.default()
@@ -9,7 +9,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 fills = {"random normal": lambda: rng.standard_normal((n, 768), dtype=np.float32),
          "small integers": lambda: rng.integers(-3, 4, (n, 768)).astype(np.float32),
          "zeros": lambda: np.zeros((n, 768), np.float32)}
-for name, mk in fills.items():
+import os
+for name, mk in list(fills.items())[:int(os.environ.get('K5_FILLS', '3'))]:
     a = mk()
     job = pipeline.DenseMatchJob(ctx, a, a, top_n=10, normalize=False)
     job.step(); ctx.sync()
