@@ -28,8 +28,14 @@
 #ifndef PFZ_K5_EXP
 #define PFZ_K5_EXP 0
 #endif
+#define PFZ_K5_LOOP_EXP (PFZ_K5_EXP == 5 ? 0 : PFZ_K5_EXP)
+#ifndef PFZ_K5_STAGE_AT
+#define PFZ_K5_STAGE_AT (BK / 2 - 8)      // kk at which the next chunk's operands go to LDS
+#endif
 
 namespace pfz {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -156,7 +162,8 @@ template <int BK>
 __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(const float *__restrict__ A, const float *__restrict__ B,
                                                            const float *__restrict__ inv_a,
                                                            const float *__restrict__ inv_b, int64_t a0, int64_t a1,
-                                                           int64_t n_b, int64_t d, float *__restrict__ S, int64_t ld)
+                                                           int64_t n_b, int64_t d, float *__restrict__ S, int64_t ld,
+                                                           int tiles_m, int tiles_n, int block_map)
 {
     constexpr int LD = BK + 1;            // LDS leading dimension: conflict-free ds_read_b32 of the MFMA fragments
     constexpr int TPR = BK / 4;           // threads per tile row (a float4 each)
@@ -165,8 +172,24 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
     __shared__ float As[2][kTile * LD];
     __shared__ float Bs[2][kTile * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = a0 + (int64_t)blockIdx.x * kTile;
-    const int64_t col0 = (int64_t)blockIdx.y * kTile;
+    // Workgroup -> tile.  Consecutive workgroup ids go round-robin over the 8 XCDs and each XCD has its own L2, so the
+    // 64 workgroups an XCD runs at a time (32 CUs x 2) get one 8 x 8 block of tiles: 8 A + 8 B tiles feed 64 tile
+    // products out of that L2 (a 1-D sweep over row tiles gives every XCD 32 A tiles + 2 B tiles for the same 64).
+    // The grid is a whole number of 8-block rounds; workgroups of blocks or tiles that do not exist leave at once.
+    int tm, tn;
+    if (block_map) {
+        const int w = blockIdx.x, xcd = w & 7, idx = w >> 3, p = idx & 63;
+        const int g = (idx >> 6) * 8 + xcd, bm = (tiles_m + 7) >> 3;
+        tm = (g % bm) * 8 + (p & 7);
+        tn = (g / bm) * 8 + (p >> 3);
+        if (tm >= tiles_m || tn >= tiles_n) return;
+    }
+    else {
+        tm = blockIdx.x;
+        tn = blockIdx.y;
+    }
+    const int64_t row0 = a0 + (int64_t)tm * kTile;
+    const int64_t col0 = (int64_t)tn * kTile;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
     f32x16 acc[2][2];
@@ -182,7 +205,11 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
     const float *pa[NP], *pb[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+#if PFZ_K5_EXP == 5       // (what-if: every workgroup loads tile 0 of both operands -- L2-hot loads, same instruction stream)
+        const int64_t ga = lr + p * RPP, gb = lr + p * RPP;
+#else
         const int64_t ga = min(row0 + lr + p * RPP, a1 - 1), gb = min(col0 + lr + p * RPP, n_b - 1);
+#endif
         pa[p] = A + ga * d + lk;
         pb[p] = B + gb * d + lk;
     }
@@ -205,7 +232,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
     int cur = 0;
     for (int64_t k0 = 0; k0 < d; k0 += BK) {
         const bool more = k0 + BK < d;
-#if PFZ_K5_EXP == 0      // (what-if builds, results wrong: 1 = no global loads in the loop, 2 = nor staging / barriers,
+#if PFZ_K5_EXP == 0 || PFZ_K5_EXP == 5     // (what-if builds, results wrong: 1 = no global loads in the loop, 2 = nor staging / barriers,
                          //  3 = nor fragment re-reads, 4 = nor the epilogue's stores)
         if (more) {
 #pragma unroll
@@ -243,28 +270,28 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
         };
         float fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
         frag(0, fa0, fb0);
-#if PFZ_K5_EXP >= 3
+#if PFZ_K5_LOOP_EXP >= 3
         frag(4, fa1, fb1);
 #endif
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
-#if PFZ_K5_EXP < 3
+#if PFZ_K5_LOOP_EXP < 3
             frag(kk + 4, fa1, fb1);           // read eight MFMAs (512 cycles) ahead of their use
 #endif
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads back to just before their use)
             mfma8(fa0, fb0);
             // the next step's operands (in flight since the top of this step) go to the OTHER buffer half way through:
             // the stores issue while the matrix pipe is busy instead of after the loop
-#if PFZ_K5_EXP < 2
-            if (kk == BK / 2 - 8 && more) stage(cur ^ 1);
+#if PFZ_K5_LOOP_EXP < 2
+            if (kk == PFZ_K5_STAGE_AT && more) stage(cur ^ 1);
 #endif
-#if PFZ_K5_EXP < 3
+#if PFZ_K5_LOOP_EXP < 3
             if (kk + 8 < BK) frag(kk + 8, fa0, fb0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
             mfma8(fa1, fb1);
         }
-#if PFZ_K5_EXP < 2
+#if PFZ_K5_LOOP_EXP < 2
         __syncthreads();
         cur ^= 1;
 #endif
@@ -304,6 +331,164 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
 #endif
                     (rowp + j * 32)[lane_off] = acc[i][j][r] * f * sb[j];
                 }
+            }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t col = col0 + wn + j * 32 + (lane & 31);
+        const float sb = col < n_b ? inv_b[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a1 && col < ld) S[(row - a0) * ld + col] = acc[i][j][r] * inv_a[row] * sb;
+            }
+        }
+    }
+}
+
+__device__ inline float f4c(const float4 &v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+
+// Second-generation tile program (d % 32 == 0): what the counters and the what-if builds of the kernel above asked for.
+//  * LDS rows of 36 floats: operands staged with ds_write_b128, MFMA fragments read with ds_read_b128 -- lane (r, h)
+//    takes the four floats k = 8t + 4h .. + 3 of row r, and MFMA step s of sub-step t multiplies the k-pairs
+//    {8t + s, 8t + 4 + s} (A and B use the same assignment, so the sum is the same dot product in another order).
+//    24 LDS instructions per wave and k-chunk instead of 48; both access patterns are conflict-free
+//    (row pitch 36 = 4 (9 r mod 16) banks: the 16 lanes of a b128 group hit 16 distinct bank quads).
+//  * the global loads of chunk c + 2 and the LDS stores of chunk c + 1 are spread over the chunk, one operand pair
+//    per group of eight MFMAs (eight loads issued back to back kept the wave out of the matrix pipe for ~300 cycles
+//    per chunk: 8 % of the GEMM, with L2-hot loads just the same); addresses are a wave-uniform base + a 32-bit lane
+//    offset, so a load costs no vector ALU work.
+__global__ __launch_bounds__(256, 2) void k5_gemm_panel_pipe2(const float *__restrict__ A, const float *__restrict__ B,
+                                                              const float *__restrict__ inv_a, const float *__restrict__ inv_b,
+                                                              int64_t a0, int64_t a1, int64_t n_b, int64_t d,
+                                                              float *__restrict__ S, int64_t ld, int tiles_m, int tiles_n)
+{
+    constexpr int BK = 32, LD = 36, NP = 4;
+    __shared__ __attribute__((aligned(16))) float As[2][kTile * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kTile * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup -> tile: 8 x 8 tile blocks per XCD (see k5_gemm_panel_pipe)
+    const int w = blockIdx.x, xcd = w & 7, idx = w >> 3, pos = idx & 63;
+    const int g = (idx >> 6) * 8 + xcd, bm = (tiles_m + 7) >> 3;
+    const int tm = (g % bm) * 8 + (pos & 7), tn = (g / bm) * 8 + (pos >> 3);
+    if (tm >= tiles_m || tn >= tiles_n) return;
+    const int64_t row0 = a0 + (int64_t)tm * kTile;
+    const int64_t col0 = (int64_t)tn * kTile;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = tid >> 3, lk = (tid & 7) * 4;          // staging: 8 threads per tile row, 32 rows per pass
+    // buffer loads: descriptor = the tile's first operand row (wave-uniform), 32-bit lane offset, scalar k offset
+    const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc((void *)(A + row0 * d), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc((void *)(B + col0 * d), 0, 0x7fffffff, 0x00020000);
+    uint32_t offA[NP], offB[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {        // rows beyond the edge are clamped to the last row (their products are not stored)
+        offA[p] = (uint32_t)((min(row0 + lr + p * 32, a1 - 1) - row0) * d + lk) * 4u;
+        offB[p] = (uint32_t)((min(col0 + lr + p * 32, n_b - 1) - col0) * d + lk) * 4u;
+    }
+    u32x4 ra[NP], rb[NP];
+    auto load = [&](int p, int k) {
+        ra[p] = __builtin_amdgcn_raw_buffer_load_b128(resA, offA[p], k * 4, 0);
+        rb[p] = __builtin_amdgcn_raw_buffer_load_b128(resB, offB[p], k * 4, 0);
+    };
+    auto stage = [&](int p, int buf) {
+        *(u32x4 *)(As[buf] + (lr + p * 32) * LD + lk) = ra[p];
+        *(u32x4 *)(Bs[buf] + (lr + p * 32) * LD + lk) = rb[p];
+    };
+#pragma unroll
+    for (int p = 0; p < NP; ++p) load(p, 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) stage(p, 0);
+    const int dk = (int)d;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) load(p, min(BK, dk - BK));
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LD + 4 * (lane >> 5);
+    int cur = 0;
+    for (int k0 = 0; k0 < dk; k0 += BK) {
+        const int k2 = min(k0 + 2 * BK, dk - BK);      // (the last two chunks re-fetch the last one: no branches in the loop)
+        const float *ap = As[cur] + wm * LD + frag_off, *bp = Bs[cur] + wn * LD + frag_off;
+        auto frag = [&](int t, float4 (&a)[2], float4 (&b)[2]) {
+            a[0] = *(const float4 *)(ap + 8 * t);
+            a[1] = *(const float4 *)(ap + 32 * LD + 8 * t);
+            b[0] = *(const float4 *)(bp + 8 * t);
+            b[1] = *(const float4 *)(bp + 32 * LD + 8 * t);
+        };
+        auto mfma8 = [&](const float4 (&a)[2], const float4 (&b)[2], int s0) {
+#pragma unroll
+            for (int s = s0; s < s0 + 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a[i], s), f4c(b[j], s), acc[i][j], 0, 0, 0);
+        };
+        // one operand pair per group of eight MFMAs: groups 0..3 store chunk c + 1 (in registers since the previous
+        // chunk) to the other LDS buffer, groups 4..7 fetch chunk c + 2 into the registers just freed
+        auto item = [&](int grp) {
+            if (grp < 4) stage(grp, cur ^ 1);
+            else load(grp - 4, k2);
+        };
+        float4 fa0[2], fb0[2], fa1[2], fb1[2];
+        frag(0, fa0, fb0);
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+            frag(t + 1, fa1, fb1);                 // fragments are read one sub-step (16 MFMAs) ahead
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(fa0, fb0, 0);
+            item(2 * t);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(fa0, fb0, 2);
+            item(2 * t + 1);
+            if (t + 2 < 4) frag(t + 2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(fa1, fb1, 0);
+            item(2 * t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(fa1, fb1, 2);
+            item(2 * t + 3);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // Epilogue.  MFMA 32x32 accumulator r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
+    if (row0 + kTile <= a1) {        // interior tile: see k5_gemm_panel_pipe
+        const int uwm = __builtin_amdgcn_readfirstlane(wm), uwn = __builtin_amdgcn_readfirstlane(wn);
+        const float4 *ia = (const float4 *)(inv_a + row0 + uwm) + (lane >> 5);
+        float4 sa[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sa[i][q] = ia[i * 8 + q * 2];
+        float sb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = col0 + uwn + j * 32 + (lane & 31);
+            sb[j] = col < n_b ? inv_b[col] : 0.f;
+        }
+        float *tile = S + (row0 - a0 + uwm) * ld + col0 + uwn;
+        const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * (uint32_t)ld + (uint32_t)(lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = f4c(sa[i][r / 4], r % 4);
+                float *rowp = tile + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) (rowp + j * 32)[lane_off] = acc[i][j][r] * f * sb[j];
             }
         return;
     }
@@ -539,14 +724,20 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
             // x = the panel's row tiles, y = column tiles: workgroups that are dispatched together share a B tile (one
             // HBM read per panel instead of one per row tile) and the panel's A rows (a few MB) stay in L2
             dim3 grid((unsigned)((a1 - a0 + kTile - 1) / kTile), (unsigned)(ld / kTile));
+            const int tiles_m = (int)grid.x, tiles_n = (int)grid.y;
+            static const int block_map = getenv("PFZ_K5_LINEAR_MAP") ? 0 : 1;       // A/B knob
+            const dim3 grid_p = block_map ? dim3((unsigned)((((tiles_m + 7) / 8) * ((tiles_n + 7) / 8) + 7) / 8 * 512)) : grid;
             // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
             if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE")) {
-                if (getenv("PFZ_K5_BK16"))     // A/B knob: 16-deep k-steps (half the LDS per workgroup, twice the barriers)
-                    hipLaunchKernelGGL(k5_gemm_panel_pipe<16>, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
-                                       a0, a1, n_to, dim, S, ld);
+                if (block_map && !getenv("PFZ_K5_PIPE1"))      // (PFZ_K5_PIPE1: the first-generation pipelined kernel, A/B timing and tests)
+                    hipLaunchKernelGGL(k5_gemm_panel_pipe2, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
+                                       n_to, dim, S, ld, tiles_m, tiles_n);
+                else if (getenv("PFZ_K5_BK16"))     // A/B knob: 16-deep k-steps (half the LDS per workgroup, twice the barriers)
+                    hipLaunchKernelGGL(k5_gemm_panel_pipe<16>, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
+                                       a0, a1, n_to, dim, S, ld, tiles_m, tiles_n, block_map);
                 else
-                    hipLaunchKernelGGL(k5_gemm_panel_pipe<32>, grid, dim3(256), getenv("PFZ_K5_ONE_WG") ? 48 << 10 : 0, ctx->stream, from->x, to->x, from->inv, to->inv,
-                                       a0, a1, n_to, dim, S, ld);
+                    hipLaunchKernelGGL(k5_gemm_panel_pipe<32>, grid_p, dim3(256), getenv("PFZ_K5_ONE_WG") ? 48 << 10 : 0, ctx->stream,
+                                       from->x, to->x, from->inv, to->inv, a0, a1, n_to, dim, S, ld, tiles_m, tiles_n, block_map);
             }
             else
                 hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
