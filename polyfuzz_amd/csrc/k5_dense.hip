@@ -349,6 +349,37 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(cons
     }
 }
 
+// Row maxima of a wave's 64 x 64 corner.  x[q] (q = 16 i + r) is the lane's maximum over its two columns of
+// accumulator row-slot q; the maximum over the 32 lanes of a half-wave is wanted for all 32 slots.  Halving
+// exchange: each step pairs lanes (row_mirror, row_half_mirror, quad xor 2, quad xor 1 by DPP, then lane ^ 16 by
+// ds_swizzle), a lane keeps one half of its slots, hands the other half to its partner and folds in what it gets --
+// 16 + 8 + 4 + 2 + 1 exchanges instead of 32 x 5, and every lane ends with ONE slot's maximum:
+// slot(lane) = bit3 bit2 bit1 bit0 bit4 of the lane id (most significant first).
+template <int CTRL>
+__device__ inline float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ inline float block_row_max(float (&x)[32], int lane)
+{
+    const bool p3 = lane & 8, p2 = lane & 4, p1 = lane & 2, p0 = lane & 1, p4 = lane & 16;
+    float y[16], z[8], u[4], w[2];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) y[t] = fmaxf(p3 ? x[16 + t] : x[t], dpp_f32<0x140>(p3 ? x[t] : x[16 + t]));     // row_mirror
+#pragma unroll
+    for (int t = 0; t < 8; ++t) z[t] = fmaxf(p2 ? y[8 + t] : y[t], dpp_f32<0x141>(p2 ? y[t] : y[8 + t]));        // row_half_mirror
+#pragma unroll
+    for (int t = 0; t < 4; ++t) u[t] = fmaxf(p1 ? z[4 + t] : z[t], dpp_f32<0x4E>(p1 ? z[t] : z[4 + t]));         // quad_perm 2,3,0,1
+#pragma unroll
+    for (int t = 0; t < 2; ++t) w[t] = fmaxf(p0 ? u[2 + t] : u[t], dpp_f32<0xB1>(p0 ? u[t] : u[2 + t]));         // quad_perm 1,0,3,2
+    const float other = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(p4 ? w[0] : w[1]), 0x401F));   // lane ^ 16
+    return fmaxf(p4 ? w[1] : w[0], other);
+}
+__device__ inline int block_row_slot(int lane)
+{
+    return ((lane >> 3) & 1) << 4 | ((lane >> 2) & 1) << 3 | ((lane >> 1) & 1) << 2 | (lane & 1) << 1 | ((lane >> 4) & 1);
+}
+
 __device__ inline float f4c(const float4 &v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
 // Second-generation tile program (d % 32 == 0): what the counters and the what-if builds of the kernel above asked for.
@@ -364,7 +395,8 @@ __device__ inline float f4c(const float4 &v, int s) { return s == 0 ? v.x : s ==
 __global__ __launch_bounds__(256, 2) void k5_gemm_panel_pipe2(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ inv_a, const float *__restrict__ inv_b,
                                                               int64_t a0, int64_t a1, int64_t n_b, int64_t d,
-                                                              float *__restrict__ S, int64_t ld, int tiles_m, int tiles_n)
+                                                              float *__restrict__ S, int64_t ld, int tiles_m, int tiles_n,
+                                                              float *__restrict__ M, int64_t ldm)
 {
     constexpr int BK = 32, LD = 36, NP = 4;
     __shared__ __attribute__((aligned(16))) float As[2][kTile * LD];
@@ -465,7 +497,14 @@ __global__ __launch_bounds__(256, 2) void k5_gemm_panel_pipe2(const float *__res
     }
 
     // Epilogue.  MFMA 32x32 accumulator r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
-    if (row0 + kTile <= a1) {        // interior tile: see k5_gemm_panel_pipe
+    // Besides the scores, every wave leaves the maximum of each of its 64 rows over its 64 columns in M[row][col / 64]:
+    // the row top-n reads those block maxima (1/64 of the panel) and then only the few blocks that can hold a winner.
+    const int cb = (int)((col0 + wn) >> 6);
+    if (row0 + kTile <= a1) {
+        // interior tile (all but the last row tile of the last panel; ld is a whole number of tiles): the 1/|a| factors
+        // come as eight float4 loads issued together, the 64 stores go out back to back from a wave-uniform base plus
+        // one 32-bit lane offset.  (Row-by-row predicated code makes the compiler wait for EVERYTHING in flight,
+        // the previous store included, before each element: 5.5 us per tile, 13 % of a tile's MFMA time.)
         const int uwm = __builtin_amdgcn_readfirstlane(wm), uwn = __builtin_amdgcn_readfirstlane(wn);
         const float4 *ia = (const float4 *)(inv_a + row0 + uwm) + (lane >> 5);
         float4 sa[2][4];
@@ -481,29 +520,49 @@ __global__ __launch_bounds__(256, 2) void k5_gemm_panel_pipe2(const float *__res
         }
         float *tile = S + (row0 - a0 + uwm) * ld + col0 + uwn;
         const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * (uint32_t)ld + (uint32_t)(lane & 31);
+        float x[32];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float f = f4c(sa[i][r / 4], r % 4);
                 float *rowp = tile + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) (rowp + j * 32)[lane_off] = acc[i][j][r] * f * sb[j];
+                const float v0 = acc[i][0][r] * f * sb[0], v1 = acc[i][1][r] * f * sb[1];
+                rowp[lane_off] = v0;
+                (rowp + 32)[lane_off] = v1;
+                x[i * 16 + r] = fmaxf(v0, v1);
             }
+        if (M) {
+            const float m = block_row_max(x, lane);
+            const int q = block_row_slot(lane), rl = (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * (lane >> 5);
+            M[(row0 - a0 + uwm + rl) * ldm + cb] = m;
+        }
         return;
     }
+    const float sb0 = col0 + wn + (lane & 31) < n_b ? inv_b[col0 + wn + (lane & 31)] : 0.f;
+    const float sb1 = col0 + wn + 32 + (lane & 31) < n_b ? inv_b[col0 + wn + 32 + (lane & 31)] : 0.f;
+    float xe[32];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t col = col0 + wn + j * 32 + (lane & 31);
-        const float sb = col < n_b ? inv_b[col] : 0.f;
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < a1 && col < ld) S[(row - a0) * ld + col] = acc[i][j][r] * inv_a[row] * sb;
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const bool ok = row < a1;
+            const float f = ok ? inv_a[row] : 0.f;
+            const float v0 = acc[i][0][r] * f * sb0, v1 = acc[i][1][r] * f * sb1;
+            if (ok) {
+                float *rowp = S + (row - a0) * ld + col0 + wn + (lane & 31);
+                rowp[0] = v0;
+                rowp[32] = v1;
             }
+            xe[i * 16 + r] = ok ? fmaxf(v0, v1) : 0.f;
         }
+    }
+    if (M) {
+        const float m = block_row_max(xe, lane);
+        const int q = block_row_slot(lane);
+        const int64_t row = row0 + wm + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * (lane >> 5);
+        if (row < a1) M[(row - a0) * ldm + cb] = m;
     }
 }
 
@@ -523,7 +582,7 @@ __device__ inline uint64_t wave_max_u64_5(uint64_t v)
 __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, int64_t ld, int64_t a0, int64_t a1,
                                                     int64_t n_b, int32_t ntop, float lower_bound, int32_t exclude_diag,
                                                     int64_t diag_offset, int32_t *__restrict__ out_idx,
-                                                    float *__restrict__ out_val)
+                                                    float *__restrict__ out_val, const float *__restrict__ M, int64_t ldm)
 {
     __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][kCap5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -534,6 +593,7 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
     const int64_t self_col = exclude_diag ? row + diag_offset : -1;
     int cnt = 0;
     float thr = lower_bound;
+    int want = ntop;            // how many keys a compaction keeps
 
     // sorted == false (intermediate compactions) and a large top_n: select the ntop-th largest key bit by bit
     // (64 ballot steps) instead of one wave-max round per kept key -- the same scheme as K3's compact()
@@ -544,15 +604,15 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
 #pragma unroll
         for (int i = 0; i < kCap5 / 64; ++i) e[i] = lane + 64 * i < cnt ? cand[lane + 64 * i] : 0ull;
         __builtin_amdgcn_wave_barrier();
-        if (!sorted && ntop > 16) {
-            if (cnt <= ntop) return;
+        if (!sorted && want > 16) {
+            if (cnt <= want) return;
             uint64_t T = 0ull;
             for (int bit = 62; bit >= 0; --bit) {   // positive floats: bit 63 is never set
                 const uint64_t c = T | (1ull << bit);
                 int n = 0;
 #pragma unroll
                 for (int i = 0; i < kCap5 / 64; ++i) n += __popcll(__ballot(e[i] >= c));
-                T = n >= ntop ? c : T;
+                T = n >= want ? c : T;
             }
             int base = 0;
 #pragma unroll
@@ -569,7 +629,7 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
             __builtin_amdgcn_wave_barrier();
             return;
         }
-        const int keep = cnt < ntop ? cnt : ntop;
+        const int keep = cnt < want ? cnt : want;
         uint64_t best = 0;
         for (int r = 0; r < keep; ++r) {
             uint64_t m = e[0];
@@ -582,14 +642,58 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
             if (lane == 0) cand[r] = best;
         }
         cnt = keep;
-        if (keep == ntop) {
-            const float t = __uint_as_float((uint32_t)(best >> 32) - 1u);   // accept >= the ntop-th score
+        if (keep == want) {
+            const float t = __uint_as_float((uint32_t)(best >> 32) - 1u);   // accept >= the want-th score
             thr = t > thr ? t : thr;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
+    if (M) {
+        // With block maxima (M[row][b] = max of the row's scores in columns 64 b .. 64 b + 63, diagonal and padding
+        // included): the ntop-th largest block maximum T is a lower bound of the ntop-th best score (ntop blocks hold
+        // an element >= T each; one more when the diagonal is to be skipped), so only blocks with a maximum >= T can
+        // hold a winner -- usually ntop of the n_b / 64.  Pass 1 selects T with the machinery below, pass 2 reads
+        // those blocks' scores.
+        const float *m = M + (row - a0) * ldm;
+        const int64_t n_blocks = (n_b + 63) >> 6;
+        want = ntop + (exclude_diag ? 1 : 0);
+        for (int64_t b0 = 0; b0 < n_blocks; b0 += 64) {
+            const int64_t b = b0 + lane;
+            const float v = b < n_blocks ? m[b] : 0.f;
+            const bool pred = v > thr;
+            const uint64_t mk = __ballot(pred);
+            if (!mk) continue;
+            const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+            if (pred) cand[pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint32_t)(~(uint32_t)b);
+            cnt += __popcll(mk);
+            if (cnt > kCap5 - 64) compact(false);
+        }
+        compact(true);              // cnt == want: thr is now just below the want-th largest block maximum
+        cnt = 0;
+        want = ntop;
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t b0 = 0; b0 < n_blocks; b0 += 64) {
+            const int64_t b = b0 + lane;
+            uint64_t hot = __ballot(b < n_blocks && m[b] > thr);
+            while (hot) {
+                const int t = __builtin_ctzll(hot);
+                hot &= hot - 1;
+                const int64_t j = (b0 + t) * 64 + lane;
+                const float v = s[j];                       // (j < ld: ld is a whole number of blocks)
+                const bool pred = v > thr && j < n_b && j != self_col;
+                const uint64_t mk = __ballot(pred);
+                if (mk) {
+                    const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+                    if (pred) cand[pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint32_t)(~(uint32_t)j);
+                    cnt += __popcll(mk);
+                    if (cnt > kCap5 - 64) compact(false);
+                }
+            }
+        }
+    }
+    else
     for (int64_t c0 = 0; c0 < ld; c0 += 256) {
         const int64_t c = c0 + lane * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -695,11 +799,16 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
     struct Buf {
         void *p = nullptr;
         ~Buf() { if (p) pool_free(p); }
-    } dS[2];
+    } dS[2], dM[2];
     const int64_t ld = ((n_to + 255) / 256) * 256;                      // whole float4 x 64-lane steps
-    // Two score panels of <= 4 GiB: the row top-n of panel p runs on a side stream while the GEMM of panel p + 1
-    // fills the other one (the top-n is a memory stream, the GEMM an MFMA loop: they share the chip well).
-    int64_t panel = ld > 0 ? ((int64_t)4 << 30) / (ld * 4) : n_from;
+    // Two score panels of <= 16 GiB (4 GiB on a device with less than 128 GiB).  At 500 000 to-vectors that is 8192
+    // rows: each B tile then serves 64 row tiles per panel (+1.5 % over 2048-row panels).  The row top-n of panel p
+    // runs on a side stream while the GEMM of panel p + 1 fills the other buffer; with block maxima it is a ~0.2 ms
+    // kernel per panel and the overlap no longer matters, without them (d % 32 != 0) it is a full read of the panel.
+    size_t mem_free = 0, mem_total = 0;
+    PFZ_HIP(hipMemGetInfo(&mem_free, &mem_total));
+    const int64_t panel_bytes = mem_total >= ((size_t)128 << 30) ? (int64_t)16 << 30 : (int64_t)4 << 30;
+    int64_t panel = ld > 0 ? panel_bytes / (ld * 4) : n_from;
     if (const char *forced = getenv("PFZ_K5_PANEL_ROWS")) panel = atoll(forced);   // tests: several panels on small inputs
     panel = std::max<int64_t>(kTile, std::min<int64_t>(panel / kTile * kTile, ((n_from + kTile - 1) / kTile) * kTile));
     const int64_t n_panels = (n_from + panel - 1) / panel;
@@ -711,6 +820,9 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
     if (ld > 0) {
         PFZ_TRY(pool_alloc(ctx, &dS[0].p, (size_t)panel * (size_t)ld * sizeof(float)));
         if (two) PFZ_TRY(pool_alloc(ctx, &dS[1].p, (size_t)panel * (size_t)ld * sizeof(float)));
+        // block maxima (one float per row and 64 columns), written by the second-generation GEMM
+        PFZ_TRY(pool_alloc(ctx, &dM[0].p, (size_t)panel * (size_t)(ld / 64) * sizeof(float)));
+        if (two) PFZ_TRY(pool_alloc(ctx, &dM[1].p, (size_t)panel * (size_t)(ld / 64) * sizeof(float)));
     }
     hipEvent_t *ready = ctx->side_events, *consumed = ctx->side_events + 2;
     int64_t pi = 0;
@@ -718,6 +830,7 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         const int64_t a1 = std::min(n_from, a0 + panel);
         const int buf = two ? (int)(pi & 1) : 0;
         float *S = (float *)dS[buf].p;
+        const float *M = nullptr;          // set when the GEMM leaves block maxima
         if (two && pi >= 2) PFZ_HIP(hipStreamWaitEvent(ctx->stream, consumed[buf], 0));   // the top-n of panel pi - 2 read this buffer
         if (ld > 0) {
             ProfScope ps(ctx, "k5_gemm_panel");
@@ -730,8 +843,11 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
             // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
             if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE")) {
                 if (block_map && !getenv("PFZ_K5_PIPE1"))      // (PFZ_K5_PIPE1: the first-generation pipelined kernel, A/B timing and tests)
+                {
+                    M = getenv("PFZ_K5_NO_BLOCK_MAX") ? nullptr : (const float *)dM[buf].p;      // A/B knob, tests
                     hipLaunchKernelGGL(k5_gemm_panel_pipe2, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
-                                       n_to, dim, S, ld, tiles_m, tiles_n);
+                                       n_to, dim, S, ld, tiles_m, tiles_n, (float *)M, ld / 64);
+                }
                 else if (getenv("PFZ_K5_BK16"))     // A/B knob: 16-deep k-steps (half the LDS per workgroup, twice the barriers)
                     hipLaunchKernelGGL(k5_gemm_panel_pipe<16>, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
                                        a0, a1, n_to, dim, S, ld, tiles_m, tiles_n, block_map);
@@ -751,7 +867,7 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         {
             ProfScope ps(ctx, "k5_row_topn", ts);
             hipLaunchKernelGGL(k5_row_topn, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ts, (const float *)S, ld, a0, a1,
-                               n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx, out->val);
+                               n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx, out->val, M, ld / 64);
         }
         if (two) PFZ_HIP(hipEventRecord(consumed[buf], ts));
     }

@@ -205,3 +205,38 @@ def test_panels_overlap_on_two_streams(ctx, monkeypatch):
     got2 = _lib.dense_cossim_topn_host(ctx, a, a, 6, 0.0, exclude_diag=True)
     np.testing.assert_array_equal(got[0], got2[0])
     np.testing.assert_array_equal(got[1], got2[1])
+
+
+@pytest.mark.parametrize("ntop", [1, 10, 128])
+def test_block_maxima_shortcut_equals_full_scan(ctx, oracle_mod, monkeypatch, ntop):
+    """The second-generation GEMM leaves per-row maxima of 64-column blocks; the row top-n then reads only the blocks
+    whose maximum reaches the ntop-th largest block maximum.  Same result, bit for bit, as scanning every score
+    (PFZ_K5_NO_BLOCK_MAX) -- with exact ties from duplicated to-vectors spread over several blocks, a self-match whose
+    diagonal (score 1) must not count as a block's winner, a lower bound most rows never reach, rows with fewer than
+    ntop matches, edge tiles (n % 128 != 0) and several panels -- and the oracle's result."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(77 + ntop)
+    d = 64
+    b = rng.standard_normal((1500, d)).astype(np.float32)
+    for j in (70, 700, 1400, 1499):
+        b[j] = b[5]                                         # exact duplicates in four different 64-column blocks
+    a = rng.standard_normal((333, d)).astype(np.float32)
+    a[:40] = b[5] + 0.3 * rng.standard_normal((40, d)).astype(np.float32)     # rows whose best matches are the duplicates
+    for lb, self_match in ((0.0, False), (0.35, False), (0.0, True)):
+        x, y = (b, b) if self_match else (a, b)
+        monkeypatch.setenv("PFZ_K5_NO_BLOCK_MAX", "1")
+        full = _lib.dense_cossim_topn_host(ctx, x, y, ntop, lb, exclude_diag=self_match)
+        monkeypatch.delenv("PFZ_K5_NO_BLOCK_MAX")
+        fast = _lib.dense_cossim_topn_host(ctx, x, y, ntop, lb, exclude_diag=self_match)
+        np.testing.assert_array_equal(fast[0], full[0])
+        np.testing.assert_array_equal(fast[1], full[1])
+        monkeypatch.setenv("PFZ_K5_PANEL_ROWS", "256")
+        paneled = _lib.dense_cossim_topn_host(ctx, x, y, ntop, lb, exclude_diag=self_match)
+        monkeypatch.delenv("PFZ_K5_PANEL_ROWS")
+        np.testing.assert_array_equal(paneled[0], full[0])
+        np.testing.assert_array_equal(paneled[1], full[1])
+        e_idx, e_val = oracle_mod.dense_cossim_topn(x, y, ntop, lb, exclude_diag=self_match)
+        np.testing.assert_allclose(fast[1], e_val, rtol=0, atol=1e-5)
+        if self_match:
+            assert (fast[0] != np.arange(len(x))[:, None]).all()
+            assert fast[0][5, 0] == 70 and fast[0][70, 0] == 5          # duplicates find each other, lowest index first
