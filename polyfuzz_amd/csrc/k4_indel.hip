@@ -83,6 +83,8 @@ struct IndelArgs {
     int32_t *out_idx;          // [from_end - from_begin]
     double *out_score;
     double *matrix;            // optional [(from_end-from_begin) * n_to]
+    int32_t parts;             // the to-groups of a from-string (or quad) are split over `parts` workgroups ...
+    int32_t *partial;          // ... which leave (lcs, maximum, idx) per (class row, part) here for k4_merge_parts
 };
 
 // The running best of a from-string is kept as the exact rational lcs / maximum (maximum = |a| + |b|): the ratio
@@ -139,7 +141,9 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
     for (int p = tid; p < A.n_sym1 * W; p += 256) pm[p] = 0;
     __syncthreads();
 
-    for (int r = blockIdx.x; r < A.n_rows; r += gridDim.x) {
+    const int parts = A.parts;
+    for (int u = blockIdx.x; u < A.n_rows * parts; u += gridDim.x) {
+        const int r = u / parts, part = u - r * parts;
         const int row = A.rows[r];
         const int64_t a0 = A.a_off[row];
         const int m = (int)(A.a_off[row + 1] - a0);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
 
         const int skip = A.skip_idx ? A.skip_idx[row] : -1;
         Best best = {0, 1, INT_MAX};
-        for (int g = wave; g < A.n_groups; g += 4) {
+        for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
             WORD V[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) V[w] = ~(WORD)0;
@@ -195,10 +199,18 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
         if (tid == 0) {
             for (int w = 1; w < 4; ++w)
                 if (red[w][2] != INT_MAX) take(best, red[w][0], red[w][1], red[w][2]);
-            const int64_t o = (int64_t)row - A.from_begin;
-            A.out_idx[o] = best.idx == INT_MAX ? -1 : best.idx;
-            // (1 / 1 can only be the stored form of two empty strings -- maximum = 1 has lcs = 0: ratio 100)
-            A.out_score[o] = best.idx == INT_MAX ? 0.0 : (best.lcs == 1 && best.mx == 1 ? 100.0 : ratio_of(best.lcs, best.mx));
+            if (parts > 1) {
+                int *dst = A.partial + ((int64_t)r * parts + part) * 3;
+                dst[0] = best.lcs;
+                dst[1] = best.mx;
+                dst[2] = best.idx;
+            }
+            else {
+                const int64_t o = (int64_t)row - A.from_begin;
+                A.out_idx[o] = best.idx == INT_MAX ? -1 : best.idx;
+                // (1 / 1 can only be the stored form of two empty strings -- maximum = 1 has lcs = 0: ratio 100)
+                A.out_score[o] = best.idx == INT_MAX ? 0.0 : (best.lcs == 1 && best.mx == 1 ? 100.0 : ratio_of(best.lcs, best.mx));
+            }
         }
         // clear the PM entries of this from-string
         for (int p = tid; p < m; p += 256) {
@@ -226,8 +238,9 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
     for (int p = tid; p < A.n_sym1; p += 256) pm[p] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
-    const int n_quads = (A.n_rows + 3) >> 2;
-    for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
+    const int n_quads = (A.n_rows + 3) >> 2, parts = A.parts;
+    for (int u = blockIdx.x; u < n_quads * parts; u += gridDim.x) {
+        const int qd = u / parts, part = u - qd * parts;
         int row[4], m[4], skip[4];
         int64_t a0[4];
 #pragma unroll
@@ -254,34 +267,58 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
         Best best[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) best[k] = Best{0, 1, INT_MAX};
-        for (int g = wave; g < A.n_groups; g += 4) {
+        for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
             uint32_t V0 = ~0u, V1 = ~0u, V2 = ~0u, V3 = ~0u;
-            const uint32_t *gp = A.b_packed + A.g_off[g] + lane;
-            const int steps = A.g_steps[g];
-#pragma unroll 2
-            for (int t = 0; t < steps; ++t) {
-                const uint32_t pk = gp[(int64_t)t * 64];
-#pragma unroll
-                for (int q = 0; q < PER; ++q) {
-                    const uint32_t c = (pk >> (q * IDB)) & ((1u << IDB) - 1u);
-                    const uint4 M = pm[c];
-                    uint32_t u;
-                    u = V0 & M.x; V0 = (V0 + u) | (V0 ^ u);
-                    u = V1 & M.y; V1 = (V1 + u) | (V1 ^ u);
-                    u = V2 & M.z; V2 = (V2 + u) | (V2 ^ u);
-                    u = V3 & M.w; V3 = (V3 + u) | (V3 ^ u);
-                }
-            }
+            // (g is wave-uniform: say so, or the loop below is compiled with a per-lane trip count and exec masks)
+            const int steps = __builtin_amdgcn_readfirstlane(A.g_steps[g]);
+            const int64_t g_off_v = A.g_off[g];
+            const int64_t g_off = ((int64_t)__builtin_amdgcn_readfirstlane((int)(g_off_v >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)g_off_v);
+            const uint32_t *gp = A.b_packed + g_off + lane;
+            // V' = (V + (V & PM)) | (V & ~PM) as u = V & PM, V' = (V + u) | (V ^ u): four two-operand operations.
+            // (A complemented table and t = V & ~PM, V' = ((V ^ t) + V) | t would be three, with the xor and the add
+            // fused in v_xad_u32 -- but that one reads three registers and issues at half rate: 3.7 cycles per
+            // instruction against 2.6, tools/ubench/valu_rate.hip; no gain, tried.)
+            auto rec = [](uint32_t &V, uint32_t m) {
+                const uint32_t u = V & m;
+                V = (V + u) | (V ^ u);
+            };
+            // The packed to-characters are fetched two steps ahead of their use; the to-string's length and original
+            // index (needed after the character loop) are requested before it.
             const int slot = g * 64 + lane;
             const int orig = A.b_orig[slot];
+            const int lb = A.b_len[slot];
+            // (reads up to two steps past the group: the next group's characters or the buffer's padding, never used)
+            uint32_t pk = gp[0], pk1 = gp[64];
+#pragma unroll 2
+            for (int t = 0; t < steps; ++t) {
+                const uint32_t pk2 = gp[(int64_t)(t + 2) * 64];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const uint4 N = pm[__builtin_amdgcn_ubfe(pk, q * IDB, IDB)];
+                    rec(V0, N.x);
+                    rec(V1, N.y);
+                    rec(V2, N.z);
+                    rec(V3, N.w);
+                }
+                pk = pk1;
+                pk1 = pk2;
+            }
             if (orig >= 0) {
-                const int lb = A.b_len[slot];
                 const int lcs[4] = {(int)__popc(~V0), (int)__popc(~V1), (int)__popc(~V2), (int)__popc(~V3)};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (row[k] >= 0 && orig != skip[k]) {
-                        if (m[k] + lb == 0) take(best[k], 1, 1, orig);
-                        else take(best[k], lcs[k], m[k] + lb, orig);
+                    // lcs <= 32 and |a| + |b| < 2^24 here (checked at the launch): the cross products of better() fit
+                    // 32 bits and v_mul_u32_u24 forms them at full rate (two 64-bit products per pair were a third of
+                    // this kernel's time)
+                    const int mx = m[k] + lb;
+                    const int l_a = mx == 0 ? 1 : lcs[k], m_a = mx == 0 ? 1 : mx;       // both empty: 1 / 1 (ratio 100)
+                    const uint32_t l = __umul24((uint32_t)l_a, (uint32_t)best[k].mx), r = __umul24((uint32_t)best[k].lcs, (uint32_t)m_a);
+                    const bool wins = best[k].idx == INT_MAX || l > r || (l == r && orig < best[k].idx);
+                    if (row[k] >= 0 && orig != skip[k] && wins) {
+                        best[k].lcs = l_a;
+                        best[k].mx = m_a;
+                        best[k].idx = orig;
                     }
                 }
             }
@@ -303,14 +340,37 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
                 Best b = {red[0][k][0], red[0][k][1], red[0][k][2]};
                 for (int w = 1; w < 4; ++w)
                     if (red[w][k][2] != INT_MAX) take(b, red[w][k][0], red[w][k][1], red[w][k][2]);
-                const int64_t o = (int64_t)rk - A.from_begin;
-                A.out_idx[o] = b.idx == INT_MAX ? -1 : b.idx;
-                A.out_score[o] = b.idx == INT_MAX ? 0.0 : (b.lcs == 1 && b.mx == 1 ? 100.0 : ratio_of(b.lcs, b.mx));
+                if (parts > 1) {
+                    int *dst = A.partial + ((int64_t)(qd * 4 + k) * parts + part) * 3;
+                    dst[0] = b.lcs;
+                    dst[1] = b.mx;
+                    dst[2] = b.idx;
+                }
+                else {
+                    const int64_t o = (int64_t)rk - A.from_begin;
+                    A.out_idx[o] = b.idx == INT_MAX ? -1 : b.idx;
+                    A.out_score[o] = b.idx == INT_MAX ? 0.0 : (b.lcs == 1 && b.mx == 1 ? 100.0 : ratio_of(b.lcs, b.mx));
+                }
             }
         }
         if (my_sym) *((uint32_t *)&pm[my_sym] + myk) = 0u;      // clear the entries this quad set
         __syncthreads();
     }
+}
+
+// parts > 1: the best of a from-string over its parts (same order: score desc, original index asc) and its score
+__global__ __launch_bounds__(256) void k4_merge_parts(IndelArgs A)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= A.n_rows) return;
+    Best b = {0, 1, INT_MAX};
+    for (int p = 0; p < A.parts; ++p) {
+        const int *src = A.partial + ((int64_t)r * A.parts + p) * 3;
+        if (src[2] != INT_MAX) take(b, src[0], src[1], src[2]);
+    }
+    const int64_t o = (int64_t)A.rows[r] - A.from_begin;
+    A.out_idx[o] = b.idx == INT_MAX ? -1 : b.idx;
+    A.out_score[o] = b.idx == INT_MAX ? 0.0 : (b.lcs == 1 && b.mx == 1 ? 100.0 : ratio_of(b.lcs, b.mx));
 }
 
 // The general case: from-strings beyond 1024 characters, or an alphabet x word count whose match table does not fit
@@ -558,7 +618,7 @@ static int build_plan(pfz_ctx *ctx, const pfz_strings *T, pfz_indel_plan **out)
     PFZ_TRY(up(ctx, &pl->g_steps, g_steps));
     PFZ_TRY(up(ctx, &pl->b_len, b_len));
     PFZ_TRY(up(ctx, &pl->b_orig, b_orig));
-    PFZ_TRY(pool_alloc(ctx, &pl->packed, (size_t)(total_dw > 0 ? total_dw : 1) * sizeof(uint32_t)));
+    PFZ_TRY(pool_alloc(ctx, &pl->packed, (size_t)(total_dw + 128) * sizeof(uint32_t)));     // + two steps: the quad kernel reads ahead
     if (n_groups > 0) {
         ProfScope ps(ctx, "k4_pack");
         const unsigned grid = (unsigned)((n_groups * 64 + 255) / 256);
@@ -668,23 +728,55 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
     A.out_score = (double *)d_oscore.p;
     A.matrix = out_matrix ? (double *)d_matrix.p : nullptr;
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 8;
+    A.parts = 1;
+    A.partial = nullptr;
+    DevBuf d_partial;
+    d_partial.ctx = ctx;
+    // A class with few rows (the 33 IMDB titles beyond 64 characters ran as 33 workgroups for 178 us) or a unit count
+    // that is a small non-integer multiple of the chip's workgroup slots (5000 quads on 2048 slots: the third round is
+    // 44 % full) splits every unit's to-groups over `parts` workgroups: >= 4 rounds of work units, each part at least
+    // one group per wave.  The parts' bests meet in k4_merge_parts.
+    auto split = [&](int64_t n_units) {
+        const int64_t want = (4 * max_grid + n_units - 1) / n_units, cap = std::max<int64_t>(1, pl->n_groups / 4);
+        int64_t parts = std::max<int64_t>(1, std::min(want, cap));
+        if (const char *e = getenv("PFZ_K4_PARTS")) parts = std::max(1, atoi(e));      // tests, A/B timing
+        return (int32_t)parts;
+    };
+    auto merge = [&]() -> int {
+        if (A.parts <= 1) return PFZ_OK;
+        hipLaunchKernelGGL(k4_merge_parts, dim3((unsigned)((A.n_rows + 255) / 256)), dim3(256), 0, ctx->stream, A);
+        PFZ_HIP(hipGetLastError());
+        return PFZ_OK;
+    };
+    {
+        size_t most = 0;
+        for (int c = 0; c < 6; ++c)
+            if (!cls[c].empty()) most = std::max(most, (cls[c].size() + 3) * (size_t)split(c == 0 ? (int64_t)(cls[c].size() + 3) / 4 : (int64_t)cls[c].size()));
+        PFZ_TRY(d_partial.alloc(most * 3 * sizeof(int32_t)));
+        A.partial = (int32_t *)d_partial.p;
+    }
     for (int c = 0; c < 6; ++c) {
         if (cls[c].empty()) continue;
         PFZ_TRY(d_rows[c].alloc(cls[c].size() * sizeof(int32_t)));
         PFZ_TRY(copy_h2d(ctx, d_rows[c].p, cls[c].data(), cls[c].size() * sizeof(int32_t)));
         A.rows = (const int32_t *)d_rows[c].p;
         A.n_rows = (int32_t)cls[c].size();
-        const unsigned grid = (unsigned)std::min<int64_t>(A.n_rows, max_grid);
-        if (c == 0 && !out_matrix && (size_t)A.n_sym1 * sizeof(uint4) <= 60 * 1024 && !getenv("PFZ_K4_NO_QUAD")) {
+        if (c == 0 && !out_matrix && (size_t)A.n_sym1 * sizeof(uint4) <= 60 * 1024 && T->max_len < (1 << 24) - 64 &&
+            !getenv("PFZ_K4_NO_QUAD")) {
             // four short from-strings per workgroup pass (PFZ_K4_NO_QUAD=1: the one-string kernel, tests)
             ProfScope ps(ctx, "k4_indel");
-            const unsigned qgrid = (unsigned)std::min<int64_t>((A.n_rows + 3) / 4, max_grid);
+            const int64_t n_quads = (A.n_rows + 3) / 4;
+            A.parts = split(n_quads);
+            const unsigned qgrid = (unsigned)std::min<int64_t>(n_quads * A.parts, max_grid);
             const size_t lds = (size_t)A.n_sym1 * sizeof(uint4);
             if (pl->idb == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8>), dim3(qgrid), dim3(256), lds, ctx->stream, A);
             else hipLaunchKernelGGL((k4_indel_quad_kernel<16>), dim3(qgrid), dim3(256), lds, ctx->stream, A);
             PFZ_HIP(hipGetLastError());
+            PFZ_TRY(merge());
             continue;
         }
+        A.parts = split(A.n_rows);
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
         switch (c) {
         case 0: PFZ_TRY((launch_class<uint32_t, 1>(ctx, A, pl->idb, grid))); break;
         case 1: PFZ_TRY((launch_class<uint64_t, 1>(ctx, A, pl->idb, grid))); break;
@@ -693,7 +785,12 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         case 4: PFZ_TRY((launch_class<uint64_t, 8>(ctx, A, pl->idb, grid))); break;
         default: PFZ_TRY((launch_class<uint64_t, 16>(ctx, A, pl->idb, grid))); break;
         }
+        {
+            ProfScope ps(ctx, "k4_indel");
+            PFZ_TRY(merge());
+        }
     }
+    A.parts = 1;
     if (!cls[6].empty()) {
         // the general kernel: W words for the longest of these strings, match tables and V columns in global scratch
         int64_t longest = 1;

@@ -181,3 +181,38 @@ def test_quad_kernel_equals_single_string_kernel_and_oracle(ctx, oracle_mod, mon
                 e_idx[i], e_score[i] = int(np.argmax(row)), row.max()
         np.testing.assert_array_equal(idx, e_idx)
         np.testing.assert_array_equal(score, e_score)
+
+
+@pytest.mark.parametrize("parts", ["1", "3", "7"])
+def test_to_groups_split_over_workgroups(ctx, oracle_mod, monkeypatch, parts):
+    """A from-string's (or quad's) to-groups can be split over several workgroups whose bests meet in k4_merge_parts
+    (few long from-strings would otherwise run as a handful of workgroups).  Any split gives the oracle's first
+    arg-max and score bit for bit: ties across parts resolve to the lowest original index, skipped first occurrences
+    of a self-match stay skipped, rows with no candidate at all (a one-string self-match) stay -1."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(31)
+    alpha = np.array(list("abcdefgh ij"), dtype=object)
+
+    def mk(n, lo, hi):
+        return ["".join(rng.choice(alpha, size=int(rng.integers(lo, hi))).tolist()) for _ in range(n)]
+    fl = mk(50, 0, 33) + mk(9, 33, 64) + mk(5, 65, 200) + ["abc", "abc"]
+    tl = mk(700, 0, 40) + ["abc"] * 3 + mk(300, 0, 90) + ["abc"]         # equal best candidates in different groups
+    monkeypatch.setenv("PFZ_K4_PARTS", parts)
+    f, t = _lib.DeviceStrings.upload(ctx, fl), _lib.DeviceStrings.upload(ctx, tl)
+    idx, score = _lib.indel_argmax(ctx, f, t)
+    e_idx, e_score = oracle_mod.indel_argmax(fl, tl)
+    np.testing.assert_array_equal(idx, e_idx)
+    np.testing.assert_array_equal(score, e_score)
+    first = {}
+    for j, s in enumerate(fl):
+        first.setdefault(s, j)
+    skip = np.array([first[s] for s in fl], np.int32)
+    idx, score = _lib.indel_argmax(ctx, f, f, skip)
+    _, _, mat = oracle_mod.indel_argmax(fl, fl, want_matrix=True)
+    for i in range(len(fl)):
+        row = mat[i].copy()
+        row[skip[i]] = -1.0
+        assert idx[i] == int(np.argmax(row)) and score[i] == row.max()
+    one = _lib.DeviceStrings.upload(ctx, ["solo"])
+    idx, score = _lib.indel_argmax(ctx, one, one, np.array([0], np.int32))
+    assert idx[0] == -1 and score[0] == 0.0
