@@ -37,6 +37,10 @@
 #include <limits.h>
 #include <string.h>
 
+#ifndef PFZ_K4_EXP
+#define PFZ_K4_EXP 0
+#endif
+
 namespace pfz {
 
 template <typename WORD, int W>
@@ -222,51 +226,70 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
     }
 }
 
-// Class 0 (from-strings of <= 32 characters: 95 % of the IMDB titles, 80 % of the company names), FOUR from-strings
-// per workgroup pass: the match table holds the four 32-bit masks of a symbol side by side, so one ds_read_b128 --
-// and one extraction of the to-symbol, one address, one load of the packed to-characters, one trip through the
-// group loop -- serves four Indel recurrences.
-template <int IDB>
-__global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
+// From-strings of <= 32 characters (95 % of the IMDB titles, 80 % of the company names) go FOUR per workgroup pass:
+// the match table holds the four 32-bit masks of a symbol side by side, so one ds_read_b128 -- and one extraction of the
+// to-symbol, one address, one load of the packed to-characters, one trip through the group loop -- serves four Indel
+// recurrences.  From-strings of <= 16 characters (half of the IMDB titles) go EIGHT per pass (NS = 8): two 16-bit masks
+// per table word and the recurrence's addition as v_pk_add_u16 (no carry between the halves; and / xor / or do not
+// care) -- the same 18 vector operations per to-character then serve eight strings.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// low 32 bits of the product of the operands' low 24 bits, at full rate (v_mul_lo_u32 is quarter rate)
+__device__ inline uint32_t mul_u24(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+template <int IDB, int NS>
+__global__ __launch_bounds__(256, NS == 8 ? 6 : 7) void k4_indel_quad_kernel(IndelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *pm = (uint4 *)smem_raw;
-    __shared__ int red[4][4][3];
+    __shared__ int red[4][NS][3];
+    __shared__ int s_m[NS];
+    __shared__ int64_t s_a0[NS];
     constexpr int PER = 32 / IDB;
+    constexpr int CH = 128 / NS;          // characters per from-string: 32 (one mask per word) or 16 (two)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int p = tid; p < A.n_sym1; p += 256) pm[p] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
-    const int n_quads = (A.n_rows + 3) >> 2, parts = A.parts;
-    for (int u = blockIdx.x; u < n_quads * parts; u += gridDim.x) {
+    const int n_units = (A.n_rows + NS - 1) / NS, parts = A.parts;
+    for (int u = blockIdx.x; u < n_units * parts; u += gridDim.x) {
         const int qd = u / parts, part = u - qd * parts;
-        int row[4], m[4], skip[4];
-        int64_t a0[4];
+        int row[NS], m[NS], skip[NS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = qd * 4 + k;
+        for (int k = 0; k < NS; ++k) {
+            const int r = qd * NS + k;
             row[k] = r < A.n_rows ? A.rows[r] : -1;
-            a0[k] = row[k] >= 0 ? A.a_off[row[k]] : 0;
-            m[k] = row[k] >= 0 ? (int)(A.a_off[row[k] + 1] - a0[k]) : 0;
+            const int64_t a0 = row[k] >= 0 ? A.a_off[row[k]] : 0;
+            m[k] = row[k] >= 0 ? (int)(A.a_off[row[k] + 1] - a0) : 0;
             skip[k] = (A.skip_idx && row[k] >= 0) ? A.skip_idx[row[k]] : -1;
+            if (tid == 0) {
+                s_m[k] = m[k];
+                s_a0[k] = a0;
+            }
         }
-        // thread t < 128 owns character t & 31 of string (t >> 5) & 3 (strings have at most 32 characters); the
-        // string's fields are picked with selects -- a dynamic index would push the small arrays to scratch
-        const int myk = (tid >> 5) & 3, myp = tid & 31;
-        const int my_m = myk == 0 ? m[0] : (myk == 1 ? m[1] : (myk == 2 ? m[2] : m[3]));
-        const int64_t my_a0 = myk == 0 ? a0[0] : (myk == 1 ? a0[1] : (myk == 2 ? a0[2] : a0[3]));
+        __syncthreads();
+        // thread t < 128 owns character t % CH of string t / CH (mask bit t % CH of word (t / CH) & 3, upper half for
+        // strings 4..7)
+        const int myk = (tid / CH) & (NS - 1), myp = tid & (CH - 1);
+        const uint32_t my_bit = 1u << (myp + (NS == 8 ? 16 * (myk >> 2) : 0));
         int my_sym = 0;
-        if (tid < 128 && myp < my_m) {
-            const uint32_t c = A.a_width == 1 ? (uint32_t)((const uint8_t *)A.a_chars)[my_a0 + myp] : ((const uint32_t *)A.a_chars)[my_a0 + myp];
+        if (tid < 128 && myp < s_m[myk]) {
+            const int64_t at = s_a0[myk] + myp;
+            const uint32_t c = A.a_width == 1 ? (uint32_t)((const uint8_t *)A.a_chars)[at] : ((const uint32_t *)A.a_chars)[at];
             my_sym = c < A.lut_len ? (int)A.lut[c] : 0;
         }
-        if (my_sym) atomicOr((uint32_t *)&pm[my_sym] + myk, 1u << myp);
+        if (my_sym) atomicOr((uint32_t *)&pm[my_sym] + (myk & 3), my_bit);
         __syncthreads();
 
-        Best best[4];
+        Best best[NS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) best[k] = Best{0, 1, INT_MAX};
+        for (int k = 0; k < NS; ++k) best[k] = Best{0, 1, INT_MAX};
         for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
             uint32_t V0 = ~0u, V1 = ~0u, V2 = ~0u, V3 = ~0u;
             // (g is wave-uniform: say so, or the loop below is compiled with a per-lane trip count and exec masks)
@@ -279,9 +302,14 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
             // (A complemented table and t = V & ~PM, V' = ((V ^ t) + V) | t would be three, with the xor and the add
             // fused in v_xad_u32 -- but that one reads three registers and issues at half rate: 3.7 cycles per
             // instruction against 2.6, tools/ubench/valu_rate.hip; no gain, tried.)
-            auto rec = [](uint32_t &V, uint32_t m) {
-                const uint32_t u = V & m;
-                V = (V + u) | (V ^ u);
+            auto rec = [](uint32_t &V, uint32_t mask) {
+                const uint32_t u = V & mask;
+                if (NS == 8) {
+                    const u16x2 sum = __builtin_bit_cast(u16x2, V) + __builtin_bit_cast(u16x2, u);
+                    V = __builtin_bit_cast(uint32_t, sum) | (V ^ u);
+                }
+                else
+                    V = (V + u) | (V ^ u);
             };
             // The packed to-characters are fetched two steps ahead of their use; the to-string's length and original
             // index (needed after the character loop) are requested before it.
@@ -292,10 +320,18 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
             uint32_t pk = gp[0], pk1 = gp[64];
 #pragma unroll 2
             for (int t = 0; t < steps; ++t) {
+#if PFZ_K4_EXP == 3
+                const uint32_t pk2 = pk * 1664525u + 1013904223u;
+#else
                 const uint32_t pk2 = gp[(int64_t)(t + 2) * 64];
+#endif
 #pragma unroll
                 for (int q = 0; q < PER; ++q) {
+#if PFZ_K4_EXP == 1       // (what-if builds, results wrong: 1 = no table look-up, 2 = no per-pair epilogue, 3 = no packed-character loads)
+                    const uint4 N = make_uint4(pk, pk >> 3, pk * 5u, pk ^ (uint32_t)q);
+#else
                     const uint4 N = pm[__builtin_amdgcn_ubfe(pk, q * IDB, IDB)];
+#endif
                     rec(V0, N.x);
                     rec(V1, N.y);
                     rec(V2, N.z);
@@ -304,27 +340,39 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
                 pk = pk1;
                 pk1 = pk2;
             }
+#if PFZ_K4_EXP == 2
+            if (orig >= 0 && (V0 ^ V1 ^ V2 ^ V3) == 0x12345u) best[0].idx = orig;
+            if (false) {
+#else
             if (orig >= 0) {
-                const int lcs[4] = {(int)__popc(~V0), (int)__popc(~V1), (int)__popc(~V2), (int)__popc(~V3)};
+#endif
+                const uint32_t nv[4] = {~V0, ~V1, ~V2, ~V3};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NS; ++k) {
+                    const int lcs = NS == 8 ? (k < 4 ? (int)__popc(nv[k & 3] & 0xffffu) : (int)__popc(nv[k & 3] >> 16)) : (int)__popc(nv[k & 3]);
                     // lcs <= 32 and |a| + |b| < 2^24 here (checked at the launch): the cross products of better() fit
                     // 32 bits and v_mul_u32_u24 forms them at full rate (two 64-bit products per pair were a third of
                     // this kernel's time)
-                    const int mx = m[k] + lb;
-                    const int l_a = mx == 0 ? 1 : lcs[k], m_a = mx == 0 ? 1 : mx;       // both empty: 1 / 1 (ratio 100)
-                    const uint32_t l = __umul24((uint32_t)l_a, (uint32_t)best[k].mx), r = __umul24((uint32_t)best[k].lcs, (uint32_t)m_a);
-                    const bool wins = best[k].idx == INT_MAX || l > r || (l == r && orig < best[k].idx);
-                    if (row[k] >= 0 && orig != skip[k] && wins) {
-                        best[k].lcs = l_a;
-                        best[k].mx = m_a;
-                        best[k].idx = orig;
+                    // (the initial best 0 / 1 with index INT_MAX loses to every candidate -- equal products, lower
+                    // index -- so "nothing yet" needs no test; slots beyond the last row are never written out)
+                    int l_a = lcs, m_a = m[k] + lb;
+                    if (m[k] == 0) {                      // (uniform) an empty from-string: "" vs "" is 1 / 1 = ratio 100
+                        l_a = lb == 0 ? 1 : 0;
+                        m_a = lb == 0 ? 1 : lb;
                     }
+                    // branch-free on purpose: with && / || the compiler builds a maze of exec-mask branches here
+                    // (the per-pair epilogue was 28 % of the kernel, what-if build 2)
+                    const uint32_t l = mul_u24((uint32_t)l_a, (uint32_t)best[k].mx), r = mul_u24((uint32_t)best[k].lcs, (uint32_t)m_a);
+                    bool wins = (l > r) | ((l == r) & (orig < best[k].idx));
+                    if (A.skip_idx) wins = wins & (orig != skip[k]);
+                    best[k].lcs = wins ? l_a : best[k].lcs;
+                    best[k].mx = wins ? m_a : best[k].mx;
+                    best[k].idx = wins ? orig : best[k].idx;
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NS; ++k) {
             wave_best(best[k]);
             if (lane == 0) {
                 red[wave][k][0] = best[k].lcs;
@@ -333,27 +381,26 @@ __global__ __launch_bounds__(256) void k4_indel_quad_kernel(IndelArgs A)
             }
         }
         __syncthreads();
-        if (tid < 4) {
-            const int k = tid;
-            const int rk = k == 0 ? row[0] : (k == 1 ? row[1] : (k == 2 ? row[2] : row[3]));
-            if (rk >= 0) {
+        if (tid < NS) {
+            const int k = tid, r = qd * NS + k;
+            if (r < A.n_rows) {
                 Best b = {red[0][k][0], red[0][k][1], red[0][k][2]};
                 for (int w = 1; w < 4; ++w)
                     if (red[w][k][2] != INT_MAX) take(b, red[w][k][0], red[w][k][1], red[w][k][2]);
                 if (parts > 1) {
-                    int *dst = A.partial + ((int64_t)(qd * 4 + k) * parts + part) * 3;
+                    int *dst = A.partial + ((int64_t)r * parts + part) * 3;
                     dst[0] = b.lcs;
                     dst[1] = b.mx;
                     dst[2] = b.idx;
                 }
                 else {
-                    const int64_t o = (int64_t)rk - A.from_begin;
+                    const int64_t o = (int64_t)A.rows[r] - A.from_begin;
                     A.out_idx[o] = b.idx == INT_MAX ? -1 : b.idx;
                     A.out_score[o] = b.idx == INT_MAX ? 0.0 : (b.lcs == 1 && b.mx == 1 ? 100.0 : ratio_of(b.lcs, b.mx));
                 }
             }
         }
-        if (my_sym) *((uint32_t *)&pm[my_sym] + myk) = 0u;      // clear the entries this quad set
+        if (my_sym) atomicAnd((uint32_t *)&pm[my_sym] + (myk & 3), ~my_bit);      // clear the entries this unit set
         __syncthreads();
     }
 }
@@ -748,13 +795,18 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         PFZ_HIP(hipGetLastError());
         return PFZ_OK;
     };
-    {
-        size_t most = 0;
-        for (int c = 0; c < 6; ++c)
-            if (!cls[c].empty()) most = std::max(most, (cls[c].size() + 3) * (size_t)split(c == 0 ? (int64_t)(cls[c].size() + 3) / 4 : (int64_t)cls[c].size()));
-        PFZ_TRY(d_partial.alloc(most * 3 * sizeof(int32_t)));
+    size_t partial_cap = 0;
+    auto ensure_partial = [&]() -> int {          // room for this launch's (row, part) records
+        const size_t need = A.parts > 1 ? (size_t)A.n_rows * (size_t)A.parts * 3 * sizeof(int32_t) : 0;
+        if (need > partial_cap) {
+            if (d_partial.p) pool_free(d_partial.p);     // (stream order keeps it alive for the kernels already queued)
+            d_partial.p = nullptr;
+            PFZ_TRY(d_partial.alloc(need));
+            partial_cap = need;
+        }
         A.partial = (int32_t *)d_partial.p;
-    }
+        return PFZ_OK;
+    };
     for (int c = 0; c < 6; ++c) {
         if (cls[c].empty()) continue;
         PFZ_TRY(d_rows[c].alloc(cls[c].size() * sizeof(int32_t)));
@@ -763,19 +815,35 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         A.n_rows = (int32_t)cls[c].size();
         if (c == 0 && !out_matrix && (size_t)A.n_sym1 * sizeof(uint4) <= 60 * 1024 && T->max_len < (1 << 24) - 64 &&
             !getenv("PFZ_K4_NO_QUAD")) {
-            // four short from-strings per workgroup pass (PFZ_K4_NO_QUAD=1: the one-string kernel, tests)
+            // several short from-strings per workgroup pass (PFZ_K4_NO_QUAD=1: the one-string kernel, tests):
+            // eight of <= 16 characters, four of 17 .. 32 (PFZ_K4_NO_OCTO=1: four of <= 32)
+            std::vector<int32_t> rows8, rows4;
+            for (int32_t i : cls[0])
+                (F->h_off[(size_t)i + 1] - F->h_off[(size_t)i] <= 16 && !getenv("PFZ_K4_NO_OCTO") ? rows8 : rows4).push_back(i);
+            std::copy(rows4.begin(), rows4.end(), std::copy(rows8.begin(), rows8.end(), cls[0].begin()));
+            PFZ_TRY(copy_h2d(ctx, d_rows[0].p, cls[0].data(), cls[0].size() * sizeof(int32_t)));
             ProfScope ps(ctx, "k4_indel");
-            const int64_t n_quads = (A.n_rows + 3) / 4;
-            A.parts = split(n_quads);
-            const unsigned qgrid = (unsigned)std::min<int64_t>(n_quads * A.parts, max_grid);
             const size_t lds = (size_t)A.n_sym1 * sizeof(uint4);
-            if (pl->idb == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8>), dim3(qgrid), dim3(256), lds, ctx->stream, A);
-            else hipLaunchKernelGGL((k4_indel_quad_kernel<16>), dim3(qgrid), dim3(256), lds, ctx->stream, A);
-            PFZ_HIP(hipGetLastError());
-            PFZ_TRY(merge());
+            for (int pass = 0; pass < 2; ++pass) {
+                const int ns = pass == 0 ? 8 : 4;
+                A.rows = (const int32_t *)d_rows[0].p + (pass == 0 ? 0 : rows8.size());
+                A.n_rows = (int32_t)(pass == 0 ? rows8.size() : rows4.size());
+                if (A.n_rows == 0) continue;
+                const int64_t n_units = (A.n_rows + ns - 1) / ns;
+                A.parts = split(n_units);
+                PFZ_TRY(ensure_partial());
+                const dim3 qgrid((unsigned)std::min<int64_t>(n_units * A.parts, max_grid));
+                if (pl->idb == 8 && ns == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8, 8>), qgrid, dim3(256), lds, ctx->stream, A);
+                else if (pl->idb == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8, 4>), qgrid, dim3(256), lds, ctx->stream, A);
+                else if (ns == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<16, 8>), qgrid, dim3(256), lds, ctx->stream, A);
+                else hipLaunchKernelGGL((k4_indel_quad_kernel<16, 4>), qgrid, dim3(256), lds, ctx->stream, A);
+                PFZ_HIP(hipGetLastError());
+                PFZ_TRY(merge());
+            }
             continue;
         }
         A.parts = split(A.n_rows);
+        PFZ_TRY(ensure_partial());
         const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
         switch (c) {
         case 0: PFZ_TRY((launch_class<uint32_t, 1>(ctx, A, pl->idb, grid))); break;
