@@ -217,6 +217,32 @@ int pfz_indel_matrix_host(pfz_ctx *ctx, const pfz_strings *from_strings, const p
 int pfz_indel_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_symbols, int64_t *n_groups,
                         int64_t *char_steps);
 
+/* ---- K7: the per-pair rapidfuzz scorers -------------------------------------
+ * Replaces process.extractOne(from_string, to_list, scorer=..., score_cutoff=...) of the reference's RapidFuzz
+ * matcher (_rapidfuzz.py:99-113; scorer default fuzz.WRatio, _rapidfuzz.py:48) for the scorers that build a
+ * different string pair per (from, to): the best choice (first maximum) of every from-string.
+ * A list is handed over as three forms of every string -- 0: the string, 1: its whitespace tokens sorted and
+ * joined by one space (fuzz.token_sort_ratio's operand), 2: its DISTINCT tokens sorted and joined
+ * (fuzz.token_set_ratio's) -- each as symbol ranks 1..n_symbols of one alphabet shared by both lists
+ * (0 = a from-character the to-list never uses), CSR-style, plus the distinct tokens of every string in the
+ * order of form 2: an id that is equal for equal tokens across both lists, and the token's length.
+ * scorer: 0 WRatio, 1 partial_ratio, 2 token_set_ratio, 3 token_ratio, 4 partial_token_sort_ratio,
+ * 5 partial_token_set_ratio, 6 partial_token_ratio (ratio / QRatio / token_sort_ratio are one string per list
+ * element: pfz_indel_argmax).  skip_idx[i] (or NULL): a to-index left out for from-string i (self-match).
+ * out_idx[i] = -1 / out_score[i] = 0 when there is no choice; scores are rapidfuzz's 0..100 float64.
+ * PFZ_ERR_UNSUPPORTED (loud): a from-string form beyond 128 symbols, more than 32 distinct tokens in a string,
+ * an alphabet whose match tables exceed 60 KiB of LDS.  Host buffers; blocks. */
+typedef struct pfz_fuzz_list {
+    int64_t n;
+    const uint16_t *sym[3];     /* symbols of form v, concatenated */
+    const int64_t *off[3];      /* [n + 1] offsets into sym[v] */
+    const int32_t *tok_id;      /* distinct tokens of string i: tok_id[tok_off[i] .. tok_off[i + 1]) */
+    const int32_t *tok_len;     /* their lengths (symbols); form 2 = the tokens joined by one space */
+    const int64_t *tok_off;     /* [n + 1] */
+} pfz_fuzz_list;
+int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_fuzz_list *from, const pfz_fuzz_list *to, int32_t n_symbols,
+                         int32_t scorer, const int32_t *skip_idx, int32_t *out_idx, double *out_score);
+
 /* ---- K5: dense cosine top-n -----------------------------------------------
  * Replaces cosine_similarity on dense embedding matrices
  * (reference _utils.py:74-77,95; Embeddings.match _embeddings.py:127-133):

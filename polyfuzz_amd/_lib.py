@@ -78,6 +78,7 @@ SIGNATURES = {
     "pfz_indel_argmax": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "pfz_indel_matrix_host": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "pfz_indel_plan_info": (ctypes.c_int, [c_vp, c_vp, P(c_i64), P(c_i64), P(c_i64)]),
+    "pfz_fuzz_extract_one": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "pfz_dense_cossim_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                   c_vp, c_vp]),
     "pfz_dense_dot_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
@@ -501,6 +502,104 @@ def indel_plan_info(ctx, to_dev):
     v = [c_i64() for _ in range(3)]
     check(ctx.lib.pfz_indel_plan_info(ctx.h, to_dev.h, *[ctypes.byref(x) for x in v]))
     return {"n_symbols": v[0].value, "n_groups": v[1].value, "char_steps": v[2].value}
+
+
+class FuzzList(ctypes.Structure):
+    """pfz_fuzz_list (include/polyfuzz_hip.h): three forms of every string as symbol ranks + distinct tokens."""
+    _fields_ = [("n", c_i64), ("sym", c_vp * 3), ("off", c_vp * 3), ("tok_id", c_vp), ("tok_len", c_vp), ("tok_off", c_vp)]
+
+
+FUZZ_SCORERS = {"WRatio": 0, "partial_ratio": 1, "token_set_ratio": 2, "token_ratio": 3, "partial_token_sort_ratio": 4,
+                "partial_token_set_ratio": 5, "partial_token_ratio": 6}
+
+
+def fuzz_forms(strings):
+    """The three per-string forms rapidfuzz's token scorers work on: the string, " ".join(sorted(s.split())),
+    " ".join(sorted(set(s.split()))) -- and the sorted distinct tokens themselves."""
+    forms = ([], [], [])
+    tokens = []
+    for s in strings:
+        toks = s.split()
+        distinct = sorted(set(toks))
+        forms[0].append(s)
+        forms[1].append(" ".join(sorted(toks)))
+        forms[2].append(" ".join(distinct))
+        tokens.append(distinct)
+    return forms, tokens
+
+
+def _code_points(strings):
+    """(uint32 code points of all strings concatenated, int64 offsets)"""
+    off = np.zeros(len(strings) + 1, np.int64)
+    if len(strings):
+        np.cumsum(np.fromiter(map(len, strings), np.int64, len(strings)), out=off[1:])
+    cps = np.frombuffer("".join(strings).encode("utf-32-le", "surrogatepass"), np.uint32)
+    return cps, off
+
+
+def fuzz_extract_one(ctx, from_list, to_list, scorer, skip_idx=None):
+    """K7: process.extractOne(from_string, to_list, scorer=fuzz.<scorer>) for every from-string -- (index of the
+    first best choice int32[n] (-1: none), its score float64[n] on rapidfuzz's 0..100 scale).  The host side prepares
+    what is a property of ONE string (token forms, token ids, symbol ranks); every pair is scored on the device."""
+    mode = FUZZ_SCORERS[scorer]
+    F, T, n_sym, keep = fuzz_prepare(from_list, to_list)
+    n = len(from_list)
+    idx = np.empty(n, np.int32)
+    score = np.empty(n, np.float64)
+    if skip_idx is not None:
+        skip_idx = np.ascontiguousarray(skip_idx, np.int32)
+        if len(skip_idx) != n:
+            raise ValueError("skip_idx must have one entry per from-string")
+    check(ctx.lib.pfz_fuzz_extract_one(ctx.h, ctypes.byref(F), ctypes.byref(T), n_sym, mode, _ptr(skip_idx),
+                                       _ptr(idx), _ptr(score)))
+    del keep
+    return idx, score
+
+
+def fuzz_prepare(from_list, to_list):
+    """(pfz_fuzz_list of the from-side, of the to-side, alphabet size, the arrays they point into)"""
+    same = to_list is from_list
+    f_forms, f_tokens = fuzz_forms(from_list)
+    t_forms, t_tokens = (f_forms, f_tokens) if same else fuzz_forms(to_list)
+    # alphabet: the code points of the to-side (all forms: the same characters plus the joining space)
+    t_cp = [_code_points(f) for f in t_forms]
+    alphabet = np.unique(np.concatenate([c for c, _ in t_cp] + [np.array([32], np.uint32)]))
+    if len(alphabet) >= 65535:
+        raise PfzUnsupported("more than 65534 distinct characters in the to-list")
+
+    def ranks(cps):
+        pos = np.searchsorted(alphabet, cps)
+        pos[pos >= len(alphabet)] = 0
+        return np.where(alphabet[pos] == cps, pos + 1, 0).astype(np.uint16)
+    # token ids: equal tokens <-> equal ids across both lists
+    vocab = {}
+    for toks in (f_tokens if same else f_tokens + t_tokens):
+        for t in toks:
+            vocab.setdefault(t, len(vocab))
+
+    keep = []                                   # arrays the structures point into
+
+    def build(forms, tokens, cps):
+        L = FuzzList()
+        L.n = len(forms[0])
+        for v in range(3):
+            sym = np.ascontiguousarray(ranks(cps[v][0]))
+            off = cps[v][1]
+            keep.extend((sym, off))
+            L.sym[v], L.off[v] = _ptr(sym), _ptr(off)
+        tok_off = np.zeros(L.n + 1, np.int64)
+        if L.n:
+            np.cumsum(np.fromiter(map(len, tokens), np.int64, L.n), out=tok_off[1:])
+        flat = [t for toks in tokens for t in toks]
+        tok_id = np.fromiter((vocab[t] for t in flat), np.int32, len(flat))
+        tok_len = np.fromiter(map(len, flat), np.int32, len(flat))
+        keep.extend((tok_off, tok_id, tok_len))
+        L.tok_id, L.tok_len, L.tok_off = _ptr(tok_id), _ptr(tok_len), _ptr(tok_off)
+        return L
+    f_cp = t_cp if same else [_code_points(f) for f in f_forms]
+    F = build(f_forms, f_tokens, f_cp)
+    T = F if same else build(t_forms, t_tokens, t_cp)
+    return F, T, int(len(alphabet)), keep
 
 
 def indel_matrix(ctx, from_dev, to_dev, begin=0, end=None):

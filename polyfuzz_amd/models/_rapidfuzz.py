@@ -5,11 +5,15 @@ Same constructor and `.match()` contract: per from-string the best choice of the
 (first maximum, as rapidfuzz.process.extractOne keeps the first best), `None` / 0.0 when the best score is
 below `score_cutoff`, Similarity = score / 100.
 
-Scorers on the device: the Indel-ratio family K4 computes -- `fuzz.ratio` and `fuzz.QRatio` (= ratio, but 0 when
-either string is empty).  The reference's DEFAULT, `fuzz.WRatio`, and the partial_* / token_* scorers build a
-different string pair for every (from, to) -- token-set differences, sliding windows -- which the
-from-string-stationary bit-parallel kernel cannot express; they raise `NotImplementedError` (there is no CPU
-path in this package; run the reference's own RapidFuzz matcher for those).
+Scorers, all on the device (names or the rapidfuzz.fuzz functions of those names):
+* `ratio`, `QRatio` (= ratio, but 0 when either string is empty), `token_sort_ratio` (= ratio of the strings'
+  whitespace tokens sorted and joined by one space) -- one fixed string per list element: K4 (k4_indel.hip);
+* `WRatio` (the reference's DEFAULT), `partial_ratio`, `token_set_ratio`, `token_ratio`, `partial_token_sort_ratio`,
+  `partial_token_set_ratio`, `partial_token_ratio` -- a different string pair for every (from, to): K7
+  (k7_fuzz.hip: windows by masked match tables and prefix bit counts, token-set differences by token masks).
+rapidfuzz 3.x semantics: no default processor (strings are scored as given).  Any other callable raises
+`NotImplementedError` (there is no CPU path in this package).
+K7's limits (PfzUnsupported): from-strings of at most 128 characters, at most 32 distinct tokens per string.
 
 Deviation, on purpose: the reference removes the from-string from ONE shared copy of the list
 (`to_list.remove(from_string)`, _rapidfuzz.py:103-104), so with n_jobs=1 the list shrinks as rows are processed
@@ -28,7 +32,8 @@ from .. import _lib
 from ._base import BaseMatcher
 from ._utils import object_column
 
-_DEVICE_SCORERS = ("ratio", "QRatio")
+_K4_SCORERS = ("ratio", "QRatio", "token_sort_ratio")
+_DEVICE_SCORERS = _K4_SCORERS + tuple(_lib.FUZZ_SCORERS)
 
 
 def _scorer_name(scorer) -> str:
@@ -46,8 +51,8 @@ class RapidFuzz(BaseMatcher):
     Arguments (reference _rapidfuzz.py:17-38):
         n_jobs: accepted for compatibility; the GPU kernel ignores it
         score_cutoff: The minimum similarity for which to return a good match. Should be between 0 and 1.
-        scorer: "ratio" / fuzz.ratio or "QRatio" / fuzz.QRatio run on the device; the reference's default
-                fuzz.WRatio (scorer=None here) and the partial / token scorers raise NotImplementedError
+        scorer: a rapidfuzz.fuzz scorer or its name; default (None) = fuzz.WRatio as in the reference.  Every
+                rapidfuzz.fuzz scorer runs on the device; other callables raise NotImplementedError
         model_id: The name of the particular instance, used when comparing models
     """
     def __init__(self,
@@ -61,9 +66,8 @@ class RapidFuzz(BaseMatcher):
         name = _scorer_name(scorer)
         if name not in _DEVICE_SCORERS:
             raise NotImplementedError(
-                f"polyfuzz_amd.RapidFuzz computes {_DEVICE_SCORERS} (Indel ratio) on the GPU; scorer {name!r} "
-                "(WRatio is the reference's default) builds per-pair strings the kernel cannot express and there is no CPU "
-                "fallback -- pass scorer='ratio', or use the reference's RapidFuzz matcher")
+                f"polyfuzz_amd.RapidFuzz computes the rapidfuzz.fuzz scorers {_DEVICE_SCORERS} on the GPU; there is no "
+                f"CPU path for an arbitrary scorer such as {name!r} -- use the reference's RapidFuzz matcher for it")
         self.scorer = scorer
         self._scorer_name = name
         self.n_jobs = n_jobs
@@ -85,9 +89,18 @@ class RapidFuzz(BaseMatcher):
             skip = np.fromiter((first[s] for s in from_list), np.int32, n)
         if n == 0 or len(names) - (1 if self_match else 0) <= 0:
             idx, score = np.full(n, -1, np.int32), np.zeros(n)             # extractOne over no choices: None
+        elif self._scorer_name in _lib.FUZZ_SCORERS:
+            idx, score = _lib.fuzz_extract_one(ctx, from_list, from_list if self_match else names, self._scorer_name, skip)
         else:
-            f_dev = _lib.DeviceStrings.upload(ctx, from_list)
-            t_dev = f_dev if self_match else _lib.DeviceStrings.upload(ctx, names)
+            if self._scorer_name == "token_sort_ratio":
+                # rapidfuzz: ratio(" ".join(sorted(s1.split())), " ".join(sorted(s2.split()))); the choice that is
+                # skipped in a self-match is still the from-string's own first occurrence in the ORIGINAL list
+                scored_from = [" ".join(sorted(s.split())) for s in from_list]
+                scored_to = scored_from if self_match else [" ".join(sorted(s.split())) for s in names]
+            else:
+                scored_from, scored_to = from_list, names
+            f_dev = _lib.DeviceStrings.upload(ctx, scored_from)
+            t_dev = f_dev if self_match else _lib.DeviceStrings.upload(ctx, scored_to)
             idx, score = _lib.indel_argmax(ctx, f_dev, t_dev, skip)
         if self._scorer_name == "QRatio":
             # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string

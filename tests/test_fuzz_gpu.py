@@ -1,0 +1,113 @@
+"""GPU parity of K7 (the per-pair rapidfuzz scorers: WRatio, partial_ratio, token_set_ratio, token_ratio,
+partial_token_*_ratio) against oracle/fuzz_scorers.py -- first best choice and float64 score, bit for bit.
+PARITY UNPINNED beyond the published values the oracle is anchored on (tests/test_fuzz_oracle_cpu.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["WRatio", "partial_ratio", "token_set_ratio", "token_ratio", "partial_token_sort_ratio",
+         "partial_token_set_ratio", "partial_token_ratio"]
+
+
+def _lists(seed, n_from, n_to, long_words=False):
+    rng = np.random.default_rng(seed)
+    words = ["new", "york", "mets", "braves", "the", "atlanta", "vs", "a", "bb", "inc", "llc", "co", "yankees", "red", "sox",
+             "x", "of", "los", "angeles", "dodgers"]
+    if long_words:
+        words += ["internationalisation", "incorporated", "pharmaceuticals", "telecommunications"]
+
+    def mk(n):
+        out = []
+        for _ in range(n):
+            k = int(rng.integers(0, 7))
+            toks = list(rng.choice(words, size=k))
+            s = (" " * int(rng.integers(1, 3))).join(toks)
+            if rng.random() < 0.15:
+                s = " " + s + "  "
+            if rng.random() < 0.2 and s:
+                p = int(rng.integers(0, len(s)))
+                s = s[:p] + "q" + s[p + 1:]
+            out.append(s)
+        return out
+    return mk(n_from), mk(n_to)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_modes_bit_exact_vs_oracle(ctx, mode):
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd import _lib
+    fl, tl = _lists(3, 70, 150)
+    fl += ["this is a test", "this is a word", "fuzzy was a bear", "", "a", "mets mets mets new"]
+    tl += ["this is a new test!!!", "THIS IS A WORD", "fuzzy fuzzy was a bear", "", "this is a test!", "new mets"]
+    idx, score = _lib.fuzz_extract_one(ctx, fl, tl, mode)
+    e_idx, e_score = f.extract_one_all(fl, tl, f.SCORERS[mode])
+    np.testing.assert_array_equal(score, np.array(e_score))
+    np.testing.assert_array_equal(idx, np.array(e_idx, np.int32))
+
+
+def test_published_values_on_the_device(ctx):
+    from polyfuzz_amd import _lib
+    one = lambda a, b, m: float(_lib.fuzz_extract_one(ctx, [a], [b], m)[1][0])
+    assert one("this is a test", "this is a new test!!!", "WRatio") == 85.5
+    assert abs(one("this is a word", "THIS IS A WORD", "WRatio") - 21.42857142857143) < 1e-12
+    assert one("this is a test", "this is a test!", "partial_ratio") == 100.0
+    assert one("fuzzy was a bear", "fuzzy fuzzy was a bear", "token_set_ratio") == 100.0
+    assert abs(one("fuzzy was a bear", "fuzzy fuzzy was a bear", "token_ratio") - 100.0) < 1e-12
+
+
+def test_two_word_strings_self_match_and_parts(ctx, monkeypatch):
+    """From-strings between 65 and 128 characters (two 64-bit words), a self-match (own first occurrence skipped,
+    duplicates find each other), the to-groups split over several workgroups, one query against many choices."""
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd import _lib
+    fl, _ = _lists(9, 60, 1, long_words=True)
+    fl += [fl[3], fl[10], "internationalisation pharmaceuticals telecommunications incorporated of los angeles",
+           "telecommunications incorporated  of new york and pharmaceuticals internationalisation inc",
+           "the internationalisation of telecommunications incorporated the the pharmaceuticals of atlanta braves vs red sox x"]
+    assert max(map(len, fl)) > 64
+    first = {}
+    for j, s in enumerate(fl):
+        first.setdefault(s, j)
+    skip = np.array([first[s] for s in fl], np.int32)
+    for parts in ("1", "3"):
+        monkeypatch.setenv("PFZ_K7_PARTS", parts)
+        for mode in ("WRatio", "token_ratio", "partial_ratio"):
+            idx, score = _lib.fuzz_extract_one(ctx, fl, fl, mode, skip)
+            e_idx, e_score = f.extract_one_all(fl, fl, f.SCORERS[mode], skip)
+            np.testing.assert_array_equal(score, np.array(e_score))
+            np.testing.assert_array_equal(idx, np.array(e_idx, np.int32))
+    monkeypatch.delenv("PFZ_K7_PARTS")
+    q, choices = ["los angeles dodgers inc"], _lists(4, 1, 700)[1]
+    idx, score = _lib.fuzz_extract_one(ctx, q, choices, "WRatio")
+    e_idx, e_score = f.extract_one_all(q, choices, f.WRatio)
+    assert idx[0] == e_idx[0] and score[0] == e_score[0]
+
+
+def test_limits_are_loud(ctx):
+    from polyfuzz_amd import _lib
+    with pytest.raises(_lib.PfzUnsupported):
+        _lib.fuzz_extract_one(ctx, ["x" * 129], ["x"], "WRatio")
+    with pytest.raises(_lib.PfzUnsupported):
+        _lib.fuzz_extract_one(ctx, [" ".join(f"t{i}" for i in range(33))], ["x"], "WRatio")
+    idx, score = _lib.fuzz_extract_one(ctx, ["abc"], [], "WRatio")
+    assert idx[0] == -1 and score[0] == 0.0
+
+
+def test_rapidfuzz_matcher_default_scorer(ctx):
+    """RapidFuzz() -- what PolyFuzz("EditDistance") constructs (polyfuzz.py:128-130) -- scores with fuzz.WRatio."""
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd.models import RapidFuzz
+    fl = ["apple", "apples", "appl", "recal", "house", "similarity"]
+    tl = ["apple", "apples", "mouse"]
+    for cutoff in (0, 0.9):
+        df = RapidFuzz(score_cutoff=cutoff).match(fl, tl)
+        e_idx, e_score = f.extract_one_all(fl, tl, f.WRatio)
+        assert df["To"].tolist() == [tl[j] if s >= cutoff * 100 else None for j, s in zip(e_idx, e_score)]
+        assert df["Similarity"].tolist() == [s / 100 if s >= cutoff * 100 else 0.0 for s in e_score]
+    df = RapidFuzz(scorer="partial_ratio").match(fl)
+    first = {s: j for j, s in reversed(list(enumerate(fl)))}
+    e_idx, e_score = f.extract_one_all(fl, fl, f.partial_ratio, [first[s] for s in fl])
+    assert df["To"].tolist() == [fl[j] for j in e_idx] and df["Similarity"].tolist() == [s / 100 for s in e_score]
+    with pytest.raises(NotImplementedError):
+        RapidFuzz(scorer=lambda a, b: 1.0)

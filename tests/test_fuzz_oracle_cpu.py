@@ -1,0 +1,44 @@
+"""The oracle's restatement of the rapidfuzz.fuzz scorers (oracle/fuzz_scorers.py) against every value rapidfuzz
+publishes for them (README / API documentation) -- PARITY UNPINNED beyond these -- and its own consistency rules."""
+import itertools
+
+import pytest
+
+
+def test_published_values():
+    from oracle import fuzz_scorers as f
+    assert f.ratio("this is a test", "this is a test!") == 96.55172413793103
+    assert f.partial_ratio("this is a test", "this is a test!") == 100.0
+    assert abs(f.ratio("fuzzy wuzzy was a bear", "wuzzy fuzzy was a bear") - 90.9090909090909) < 1e-12
+    assert f.token_sort_ratio("fuzzy wuzzy was a bear", "wuzzy fuzzy was a bear") == 100.0
+    assert abs(f.token_sort_ratio("fuzzy was a bear", "fuzzy fuzzy was a bear") - 84.21052631578947) < 1e-12
+    assert f.token_set_ratio("fuzzy was a bear", "fuzzy fuzzy was a bear") == 100.0
+    assert f.WRatio("this is a test", "this is a new test!!!") == 85.5
+    assert abs(f.WRatio("this is a word", "THIS IS A WORD") - 21.42857142857143) < 1e-12
+    assert f.QRatio("this is a test", "this is a new test!!!") == 80.0 and f.QRatio("", "") == 0.0
+    assert f.WRatio("", "x") == 0.0 and f.partial_ratio("", "") == 100.0 and f.partial_ratio("abc", "") == 0.0
+    assert f.token_set_ratio("", "a") == 0.0 and f.partial_token_ratio("a b", "   ") == 0.0
+
+
+def test_relations_between_the_scorers():
+    """token_ratio = max(token_sort, token_set); partial_token_ratio = 100 on a common token, else the max of its two
+    parts; partial_ratio >= ratio-of-the-best-window by construction, symmetric; WRatio's two branches."""
+    from oracle import fuzz_scorers as f
+    words = ["new", "york", "mets", "braves", "the", "atlanta", "vs", "a", "bb", "new"]
+    strs = [" ".join(c) for n in (1, 2, 3) for c in itertools.islice(itertools.permutations(words, n), 0, 40, 7)] + ["", "x", "mets  new"]
+    for a, b in itertools.islice(itertools.product(strs, strs), 0, 600, 5):
+        assert f.token_ratio(a, b) == max(f.token_sort_ratio(a, b), f.token_set_ratio(a, b))
+        assert f.partial_ratio(a, b) == f.partial_ratio(b, a)
+        assert f.partial_ratio(a, b) >= f.ratio(a, b) - 1e-9 or not a or not b
+        if set(a.split()) & set(b.split()):
+            assert f.partial_token_ratio(a, b) == 100.0 and f.partial_token_set_ratio(a, b) == 100.0
+        w = f.WRatio(a, b)
+        assert 0.0 <= w <= 100.0 and (w >= f.ratio(a, b) or not a or not b)
+
+
+def test_extract_one_rules():
+    from oracle import fuzz_scorers as f
+    idx, score = f.extract_one_all(["apple", "zzz", ""], ["apples", "apple", "apple"], f.ratio)
+    assert idx == [1, 0, 0] and score[0] == 100.0 and score[2] == 0.0        # first best; a zero score still picks the first choice
+    idx, score = f.extract_one_all(["apple"], ["apple", "apple"], f.ratio, skip=[0])
+    assert idx == [1] and f.extract_one_all(["a"], [], f.ratio) == ([-1], [0.0])

@@ -124,7 +124,7 @@ def test_rapidfuzz_matcher_extract_one_rules(oracle_mod):
     fl = ["apple", "apples", "appl", "recal", "house", "similarity", ""]
     tl = ["apple", "apples", "mouse", ""]
     with pytest.raises(NotImplementedError):
-        RapidFuzz()                                       # fuzz.WRatio, the reference's default, has no kernel
+        RapidFuzz(scorer=len)                             # an arbitrary callable has no kernel (and there is no CPU path)
     for cutoff in (0, 0.5, 0.95):
         df = RapidFuzz(scorer="ratio", score_cutoff=cutoff).match(fl, tl)
         assert list(df.columns) == ["From", "To", "Similarity"] and len(df) == len(fl)
@@ -134,6 +134,16 @@ def test_rapidfuzz_matcher_extract_one_rules(oracle_mod):
         assert df["To"].tolist() == exp_to and df["Similarity"].tolist() == exp_sim
     df = RapidFuzz(scorer="ratio").match(fl, tl)
     assert df["To"].tolist()[:3] == ["apple", "apples", "apple"] and df["Similarity"].tolist()[-1] == 1.0   # "" vs "": 100
+    # token_sort_ratio = ratio of the sorted, single-space-joined tokens; the choice returned is the ORIGINAL string
+    fl2 = ["new york mets", "mets  york new", "atlanta braves", "", "braves"]
+    tl2 = ["york new mets", "new york yankees", "braves atlanta", "the braves", ""]
+    d2 = RapidFuzz(scorer="token_sort_ratio").match(fl2, tl2)
+    srt = lambda l: [" ".join(sorted(s.split())) for s in l]
+    o_idx, o_score = oracle_mod.indel_argmax(srt(fl2), srt(tl2))
+    assert d2["To"].tolist() == [tl2[j] for j in o_idx] and d2["Similarity"].tolist() == [s / 100 for s in o_score]
+    assert d2["To"].tolist()[:3] == ["york new mets", "york new mets", "braves atlanta"] and d2["Similarity"].tolist()[:3] == [1.0] * 3
+    d2 = RapidFuzz(scorer="token_sort_ratio").match(fl2)                   # self-match: own first occurrence skipped
+    assert d2["To"].tolist()[:2] == ["mets  york new", "new york mets"] and d2["Similarity"].tolist()[:2] == [1.0, 1.0]
     q = RapidFuzz(scorer="QRatio").match(fl, tl)
     assert q["To"].tolist()[-1] == "apple" and q["Similarity"].tolist()[-1] == 0.0                          # QRatio("", x) = 0
     assert q["To"].tolist()[:-1] == df["To"].tolist()[:-1]
