@@ -22,6 +22,10 @@ Pinning status (see DESIGN.md "Oracle"):
   EditDistance class run with the restated scorer.  The same holds for the
   RapidFuzz matcher's scorer and for process.extractOne's first-best / cut-off
   rules (restated from rapidfuzz's documentation): PARITY UNPINNED.
+* fuzz_scorers.py: the other rapidfuzz.fuzz scorers (partial_ratio, token_set_ratio, token_ratio,
+  partial_token_*, WRatio -- the RapidFuzz matcher's default) restated in plain Python from rapidfuzz 3.x's
+  published semantics: PARITY UNPINNED, anchored on the values rapidfuzz publishes
+  (tests/test_fuzz_oracle_cpu.py).
 * reference_path.py: the reference's own executable TF-IDF path (sklearn
   vectoriser + dense cosine + full sorts + frame), the CPU arm "(i)" of
   bench.py -- pinned cell for cell on frames the reference package produced.
