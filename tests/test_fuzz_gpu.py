@@ -111,3 +111,22 @@ def test_rapidfuzz_matcher_default_scorer(ctx):
     assert df["To"].tolist() == [fl[j] for j in e_idx] and df["Similarity"].tolist() == [s / 100 for s in e_score]
     with pytest.raises(NotImplementedError):
         RapidFuzz(scorer=lambda a, b: 1.0)
+
+
+def test_precomputed_oracle_cases(ctx):
+    """tests/golden/fuzz_cases.json: 8 seeded list pairs (60 x 150 strings, from-strings up to 128 characters, few and
+    many / repeated tokens, small and large alphabets) with the oracle's answers for all seven scorers, made by
+    `python tools/k7_stress.py make tests/golden/fuzz_cases.json 8` (five minutes of Python on a CPU, which is
+    why it is a fixture): first best choice and float64 score, bit for bit."""
+    import json
+    import os
+    from polyfuzz_amd import _lib
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_cases.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) == 8
+    for case in cases:
+        for mode in MODES:
+            idx, score = _lib.fuzz_extract_one(ctx, case["from"], case["to"], mode)
+            e_idx, e_score = case["expect"][mode]
+            np.testing.assert_array_equal(score, np.array(e_score))
+            np.testing.assert_array_equal(idx, np.array(e_idx, np.int32))
