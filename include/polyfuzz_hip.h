@@ -230,7 +230,7 @@ int pfz_indel_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_
  * 5 partial_token_set_ratio, 6 partial_token_ratio (ratio / QRatio / token_sort_ratio are one string per list
  * element: pfz_indel_argmax).  skip_idx[i] (or NULL): a to-index left out for from-string i (self-match).
  * out_idx[i] = -1 / out_score[i] = 0 when there is no choice; scores are rapidfuzz's 0..100 float64.
- * PFZ_ERR_UNSUPPORTED (loud): a from-string form beyond 128 symbols, more than 32 distinct tokens in a string,
+ * PFZ_ERR_UNSUPPORTED (loud): a from-string form beyond 256 symbols, more than 32 distinct tokens in a string,
  * an alphabet whose match tables exceed 60 KiB of LDS.  Host buffers; blocks. */
 typedef struct pfz_fuzz_list {
     int64_t n;

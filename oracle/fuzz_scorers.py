@@ -13,12 +13,13 @@ the 0.95 / 0.9 / 0.6 WRatio scales.  Anchored on the values rapidfuzz publishes 
 (tests/test_fuzz_oracle_cpu.py).  Two normalisations appear in rapidfuzz and are kept apart here because they round
 differently in float64:  ratio-like scores are (1 - dist / lensum) * 100,  token_set's are 100 - 100 * dist / lensum.
 
-Everything is O(|a| |b|) dynamic programming in Python: small cases only.
+Plain Python: small cases only (the LCS itself is a big-integer bit-vector, pinned on the O(|a||b|) DP).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
 
 
-def lcs_len(a: Sequence, b: Sequence) -> int:
+def lcs_len_dp(a: Sequence, b: Sequence) -> int:
+    """The definition: plain O(|a||b|) dynamic programming."""
     if not a or not b:
         return 0
     prev = [0] * (len(b) + 1)
@@ -28,6 +29,23 @@ def lcs_len(a: Sequence, b: Sequence) -> int:
             cur.append(prev[j] + 1 if ca == cb else max(prev[j + 1], cur[j]))
         prev = cur
     return prev[-1]
+
+
+def lcs_len(a: Sequence, b: Sequence) -> int:
+    """The same number from one big-integer bit-vector (Hyyro's recurrence) -- partial_ratio calls this once per
+    window and the DP above makes the test suite crawl.  tests/test_fuzz_oracle_cpu.py holds the two equal on
+    thousands of random pairs."""
+    if not a or not b:
+        return 0
+    pm = {}
+    for i, c in enumerate(a):
+        pm[c] = pm.get(c, 0) | (1 << i)
+    full = (1 << len(a)) - 1
+    v = full
+    for c in b:
+        u = v & pm.get(c, 0)
+        v = ((v + u) | (v - u)) & full
+    return len(a) - bin(v).count("1")
 
 
 def indel_distance(a: Sequence, b: Sequence) -> int:

@@ -21,7 +21,7 @@
 // Scores are float64 with rapidfuzz's two normalisations kept apart: (1 - dist / lensum) * 100 for ratio-like
 // values, 100 - 100 dist / lensum inside token_set_ratio.  Windows are compared as exact rationals.
 //
-// Limits (loud): every form of every from-string <= 128 characters (two 64-bit words), <= 32 distinct tokens per
+// Limits (loud): every form of every from-string <= 256 characters (one, two or four 64-bit words), <= 32 distinct tokens per
 // string, alphabet x forms x words within 60 KiB of LDS.   PARITY UNPINNED (rapidfuzz is not installable): the
 // oracle is oracle/fuzz_scorers.py, anchored on rapidfuzz's published values.
 #include "pfz_internal.h"
@@ -496,21 +496,22 @@ extern "C" int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_fuzz_list *from, con
     PFZ_HIP(hipSetDevice(ctx->device));
 
     // word classes of the from-strings
-    std::vector<int32_t> cls[2];
+    static const int kWords[3] = {1, 2, 4};
+    std::vector<int32_t> cls[3];
     for (int64_t i = 0; i < n_from; ++i) {
         int64_t longest = 0;
         for (int v = 0; v < 3; ++v) longest = std::max(longest, from->off[v][i + 1] - from->off[v][i]);
-        if (longest > 128) {
-            set_error("pfz_fuzz_extract_one: from-string %lld has %lld characters; the kernel holds 128 (two 64-bit words)",
+        if (longest > 256) {
+            set_error("pfz_fuzz_extract_one: from-string %lld has %lld characters; the kernel holds 256 (four 64-bit words)",
                       (long long)i, (long long)longest);
             return PFZ_ERR_UNSUPPORTED;
         }
-        cls[longest > 64].push_back((int32_t)i);
+        cls[longest > 128 ? 2 : longest > 64 ? 1 : 0].push_back((int32_t)i);
     }
-    for (int c = 0; c < 2; ++c)
-        if (!cls[c].empty() && (size_t)(n_symbols + 1) * 3 * (c + 1) * sizeof(uint64_t) > 60 * 1024) {
+    for (int c = 0; c < 3; ++c)
+        if (!cls[c].empty() && (size_t)(n_symbols + 1) * 3 * kWords[c] * sizeof(uint64_t) > 60 * 1024) {
             set_error("pfz_fuzz_extract_one: an alphabet of %d symbols x 3 forms x %d words does not fit the 60 KiB match table",
-                      n_symbols, c + 1);
+                      n_symbols, kWords[c]);
             return PFZ_ERR_UNSUPPORTED;
         }
 
@@ -606,7 +607,7 @@ extern "C" int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_fuzz_list *from, con
     A.mode = scorer;
 
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 4;
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 3; ++c) {
         if (cls[c].empty()) continue;
         PFZ_TRY(dev.up(cls[c], &A.rows));
         A.n_rows = (int32_t)cls[c].size();
@@ -619,11 +620,12 @@ extern "C" int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_fuzz_list *from, con
             PFZ_TRY(dev.alloc((size_t)A.n_rows * (size_t)A.parts, &A.part_idx));
         }
         const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
-        const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)(c + 1) * sizeof(uint64_t);
+        const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t);
         {
             ProfScope ps(ctx, "k7_fuzz");
             if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(256), lds, ctx->stream, A);
-            else hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, A);
+            else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, A);
+            else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(256), lds, ctx->stream, A);
             PFZ_HIP(hipGetLastError());
             if (A.parts > 1) {
                 hipLaunchKernelGGL(k7_merge_parts, dim3((unsigned)((A.n_rows + 255) / 256)), dim3(256), 0, ctx->stream, A);

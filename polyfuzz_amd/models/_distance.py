@@ -4,9 +4,10 @@
 The reference scores every (from, to) pair with `scorer` (default
 rapidfuzz.fuzz.ratio, _distance.py:32) in a Python loop / joblib pool and keeps the
 first arg-max per from-string.  Here the whole score matrix + arg-max is one HIP
-kernel (K4: bit-parallel LCS, fused first-max reduction); only the Indel ratio
-(`fuzz.ratio`) is implemented on the device, so any other scorer raises -- there is
-no CPU path to fall back to.
+kernel (K4: bit-parallel LCS, fused first-max reduction).  `scorer` may be any
+rapidfuzz.fuzz scorer (or its name): ratio / QRatio / token_sort_ratio run through K4,
+WRatio / partial_ratio / token_set_ratio / token_ratio / partial_token_* through K7;
+any other callable raises -- there is no CPU path to fall back to.
 """
 import time
 from typing import Callable, List, Union
@@ -19,10 +20,15 @@ from ._base import BaseMatcher
 from ._utils import object_column
 
 
-def _is_ratio(scorer) -> bool:
-    if scorer is None or scorer == "ratio":
-        return True
-    return getattr(scorer, "__name__", "") == "ratio" and "rapidfuzz" in (getattr(scorer, "__module__", "") or "")
+def _device_scorer(scorer) -> str:
+    """Name of the rapidfuzz.fuzz scorer `scorer` stands for, or '' when it has no kernel."""
+    from ._rapidfuzz import _DEVICE_SCORERS
+    if scorer is None:
+        return "ratio"                                     # the reference's default (_distance.py:32)
+    name = scorer if isinstance(scorer, str) else getattr(scorer, "__name__", "")
+    if not isinstance(scorer, str) and "rapidfuzz" not in (getattr(scorer, "__module__", "") or ""):
+        return ""
+    return name if name in _DEVICE_SCORERS else ""
 
 
 class EditDistance(BaseMatcher):
@@ -31,7 +37,8 @@ class EditDistance(BaseMatcher):
 
     Arguments (reference _distance.py:18-23):
         n_jobs: accepted for compatibility; the GPU kernel ignores it
-        scorer: "ratio" / rapidfuzz.fuzz.ratio (default).  Other scorers are not implemented on the device.
+        scorer: a rapidfuzz.fuzz scorer or its name; default "ratio" / rapidfuzz.fuzz.ratio.  Other callables
+                have no kernel (NotImplementedError).
         model_id: The name of the particular instance, used when comparing models
         normalize: Whether to min-max normalize the similarity scores (_distance.py:83-86)
 
@@ -46,9 +53,10 @@ class EditDistance(BaseMatcher):
                  normalize: bool = True):
         super().__init__(model_id)
         self.type = "EditDistance"
-        if not _is_ratio(scorer):
+        self._scorer_name = _device_scorer(scorer)
+        if not self._scorer_name:
             raise NotImplementedError(
-                "polyfuzz_amd.EditDistance runs rapidfuzz.fuzz.ratio (Indel ratio) on the GPU; "
+                "polyfuzz_amd.EditDistance runs the rapidfuzz.fuzz scorers on the GPU; "
                 f"scorer {scorer!r} has no HIP kernel and there is no CPU fallback")
         self.scorer = scorer
         self.normalize = normalize
@@ -88,12 +96,19 @@ class EditDistance(BaseMatcher):
             for j, s in enumerate(names):
                 first.setdefault(s, j)
             skip = np.fromiter((first[s] for s in from_list), np.int32, len(from_list))
-        elif reuse_to and self._to_dev is not None:
+        elif reuse_to and self._to_names is not None:
             names = self._to_names
         else:
             names = to_list
         if len(names) - (1 if self_match else 0) <= 0 and len(from_list) > 0:
             raise ValueError("attempt to get argmax of an empty sequence")   # np.argmax([]) in the reference
+        if self._scorer_name != "ratio":      # the other rapidfuzz.fuzz scorers (K4 on transformed strings, or K7)
+            from ._rapidfuzz import best_choice
+            idx, score = best_choice(ctx, self._scorer_name, from_list, names, skip, self_match)
+            if not self_match:
+                self._to_dev, self._to_names = None, names
+            begin, end = (0, len(from_list)) if rows is None else rows
+            return idx[begin:end], score[begin:end], names
         f_dev = _lib.DeviceStrings.upload(ctx, from_list)
         if self_match:
             t_dev = f_dev

@@ -13,7 +13,7 @@ Scorers, all on the device (names or the rapidfuzz.fuzz functions of those names
   (k7_fuzz.hip: windows by masked match tables and prefix bit counts, token-set differences by token masks).
 rapidfuzz 3.x semantics: no default processor (strings are scored as given).  Any other callable raises
 `NotImplementedError` (there is no CPU path in this package).
-K7's limits (PfzUnsupported): from-strings of at most 128 characters, at most 32 distinct tokens per string.
+K7's limits (PfzUnsupported): from-strings of at most 256 characters, at most 32 distinct tokens per string.
 
 Deviation, on purpose: the reference removes the from-string from ONE shared copy of the list
 (`to_list.remove(from_string)`, _rapidfuzz.py:103-104), so with n_jobs=1 the list shrinks as rows are processed
@@ -42,6 +42,31 @@ def _scorer_name(scorer) -> str:
     if isinstance(scorer, str):
         return scorer
     return getattr(scorer, "__name__", repr(scorer))
+
+
+def best_choice(ctx, name, from_list, names, skip, self_match):
+    """(index of the first best choice int32[n], its score float64[n] on the 0..100 scale) of every from-string under
+    the rapidfuzz.fuzz scorer `name`; `names` are the choices (the from-list itself in a self-match, where skip[i] is
+    the choice left out for from-string i)."""
+    if name in _lib.FUZZ_SCORERS:
+        return _lib.fuzz_extract_one(ctx, from_list, from_list if self_match else names, name, skip)
+    if name == "token_sort_ratio":
+        # rapidfuzz: ratio(" ".join(sorted(s1.split())), " ".join(sorted(s2.split()))); the choice that is
+        # skipped in a self-match is still the from-string's own first occurrence in the ORIGINAL list
+        scored_from = [" ".join(sorted(s.split())) for s in from_list]
+        scored_to = scored_from if self_match else [" ".join(sorted(s.split())) for s in names]
+    else:
+        scored_from, scored_to = from_list, names
+    f_dev = _lib.DeviceStrings.upload(ctx, scored_from)
+    t_dev = f_dev if self_match else _lib.DeviceStrings.upload(ctx, scored_to)
+    idx, score = _lib.indel_argmax(ctx, f_dev, t_dev, skip)
+    if name == "QRatio":
+        # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string
+        # scores 0 against every choice, so its first best is simply its first choice
+        for i in [i for i, s in enumerate(from_list) if len(s) == 0]:
+            first_choice = next((j for j in range(len(names)) if not (self_match and j == skip[i])), -1)
+            idx[i], score[i] = first_choice, 0.0
+    return idx, score
 
 
 class RapidFuzz(BaseMatcher):
@@ -89,25 +114,8 @@ class RapidFuzz(BaseMatcher):
             skip = np.fromiter((first[s] for s in from_list), np.int32, n)
         if n == 0 or len(names) - (1 if self_match else 0) <= 0:
             idx, score = np.full(n, -1, np.int32), np.zeros(n)             # extractOne over no choices: None
-        elif self._scorer_name in _lib.FUZZ_SCORERS:
-            idx, score = _lib.fuzz_extract_one(ctx, from_list, from_list if self_match else names, self._scorer_name, skip)
         else:
-            if self._scorer_name == "token_sort_ratio":
-                # rapidfuzz: ratio(" ".join(sorted(s1.split())), " ".join(sorted(s2.split()))); the choice that is
-                # skipped in a self-match is still the from-string's own first occurrence in the ORIGINAL list
-                scored_from = [" ".join(sorted(s.split())) for s in from_list]
-                scored_to = scored_from if self_match else [" ".join(sorted(s.split())) for s in names]
-            else:
-                scored_from, scored_to = from_list, names
-            f_dev = _lib.DeviceStrings.upload(ctx, scored_from)
-            t_dev = f_dev if self_match else _lib.DeviceStrings.upload(ctx, scored_to)
-            idx, score = _lib.indel_argmax(ctx, f_dev, t_dev, skip)
-        if self._scorer_name == "QRatio":
-            # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string
-            # scores 0 against every choice, so its first best is simply its first choice
-            for i in [i for i, s in enumerate(from_list) if len(s) == 0]:
-                first_choice = next((j for j in range(len(names)) if not (self_match and j == skip[i])), -1)
-                idx[i], score[i] = first_choice, 0.0
+            idx, score = best_choice(ctx, self._scorer_name, from_list, names, skip, self_match)
         hit = (idx >= 0) & (score >= self.score_cutoff)                       # extractOne: best score >= score_cutoff
         to_col = object_column([names[j] if ok else None for j, ok in zip(idx.tolist(), hit.tolist())])
         sim = np.where(hit, score / 100, 0.0)

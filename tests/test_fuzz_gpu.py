@@ -87,11 +87,35 @@ def test_two_word_strings_self_match_and_parts(ctx, monkeypatch):
 def test_limits_are_loud(ctx):
     from polyfuzz_amd import _lib
     with pytest.raises(_lib.PfzUnsupported):
-        _lib.fuzz_extract_one(ctx, ["x" * 129], ["x"], "WRatio")
+        _lib.fuzz_extract_one(ctx, ["x" * 257], ["x"], "WRatio")
     with pytest.raises(_lib.PfzUnsupported):
         _lib.fuzz_extract_one(ctx, [" ".join(f"t{i}" for i in range(33))], ["x"], "WRatio")
     idx, score = _lib.fuzz_extract_one(ctx, ["abc"], [], "WRatio")
     assert idx[0] == -1 and score[0] == 0.0
+
+
+def test_four_word_strings_and_editdistance_scorers(ctx):
+    """From-strings of 129 .. 256 characters (four 64-bit words: the longest company names have 145) against the
+    oracle; EditDistance(scorer=...) takes the same scorers (the reference maps any scorer over all pairs,
+    _distance.py:89-102) and keeps first arg-max / un-normalised score."""
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd import _lib
+    from polyfuzz_amd.models import EditDistance
+    rng = np.random.default_rng(2)
+    words = ["consolidated", "international", "holdings", "of", "the", "pacific", "northwest", "and", "partners", "llc",
+             "limited", "liability", "company", "trust", "fund", "series", "a", "b", "investment", "management"]
+    fl = [" ".join(rng.choice(words, size=int(k))) for k in (14, 17, 20, 22, 3, 1)]
+    tl = [" ".join(rng.choice(words, size=int(rng.integers(1, 24)))) for _ in range(80)] + [fl[1][:200], fl[2][40:]]
+    fl = [s[:256] for s in fl]
+    assert max(map(len, fl)) > 128
+    for mode in ("WRatio", "partial_ratio", "token_set_ratio"):
+        idx, score = _lib.fuzz_extract_one(ctx, fl, tl, mode)
+        e_idx, e_score = f.extract_one_all(fl, tl, f.SCORERS[mode])
+        np.testing.assert_array_equal(score, np.array(e_score))
+        np.testing.assert_array_equal(idx, np.array(e_idx, np.int32))
+    df = EditDistance(scorer="token_set_ratio", normalize=False).match(fl, tl)
+    e_idx, e_score = f.extract_one_all(fl, tl, f.token_set_ratio)
+    assert df["To"].tolist() == [tl[j] for j in e_idx] and df["Similarity"].tolist() == e_score
 
 
 def test_rapidfuzz_matcher_default_scorer(ctx):

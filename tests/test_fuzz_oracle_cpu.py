@@ -42,3 +42,15 @@ def test_extract_one_rules():
     assert idx == [1, 0, 0] and score[0] == 100.0 and score[2] == 0.0        # first best; a zero score still picks the first choice
     idx, score = f.extract_one_all(["apple"], ["apple", "apple"], f.ratio, skip=[0])
     assert idx == [1] and f.extract_one_all(["a"], [], f.ratio) == ([-1], [0.0])
+
+
+def test_bit_vector_lcs_equals_the_dp():
+    import numpy as np
+    from oracle import fuzz_scorers as f
+    rng = np.random.default_rng(0)
+    for alphabet in ("ab", "abc ", "abcdefghijklmnopqrstuvwxyz "):
+        for _ in range(1500):
+            a = "".join(rng.choice(list(alphabet), size=int(rng.integers(0, 90))))
+            b = "".join(rng.choice(list(alphabet), size=int(rng.integers(0, 90))))
+            assert f.lcs_len(a, b) == f.lcs_len_dp(a, b), (a, b)
+    assert f.lcs_len("", "abc") == 0 and f.lcs_len("abc", "abc") == 3
