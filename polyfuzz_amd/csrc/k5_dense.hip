@@ -6,32 +6,22 @@
 // (sklearn.metrics.pairwise.cosine_similarity), then the top-n of every row,
 // diagonal excluded for self-match.
 //
-// Plan (sized for 288 GB of HBM rather than for cleverness):
-//   k5_inv_norms   : 1/||row|| for both matrices (wave per row).
-//   k5_gemm_panel  : S[P x n_to] = A_panel . B^T, scaled by both inverse norms;
-//                    128x128x32 workgroup tiles, 4 waves x (2x2) v_mfma_f32_32x32x2_f32
-//                    -- exact fp32 products at the fp32 peak rate; operands staged
-//                    through LDS ([row][k], leading dimension 33: conflict-free
-//                    ds_read_b32 of the MFMA fragments).  The panel of scores IS
-//                    written to HBM: at d = 768 that is 8 B of traffic per 1536
-//                    flops, 6x below the machine balance, so the GEMM stays
-//                    MFMA-bound and the top-n logic stays out of its epilogue.
-//   k5_row_topn    : wave per row streams its scores (float4), threshold filter,
-//                    64-bit keys score_bits<<32 | ~col, compaction by wave-max rounds
-//                    (same scheme as K3), writes (idx, score) by (score desc, col asc).
-// The panel height P is chosen so the score panel is <= ~8 GiB.
+// Plan:
+//   k5_inv_norms        : 1/||row|| for both matrices (wave per row).
+//   k5_gemm_panel_pipe  : S[P x n_to] = A_panel . B^T scaled by both inverse norms (widths that are multiples of 32);
+//                         128x128x32 workgroup tiles, 4 waves x (2x2) v_mfma_f32_32x32x2_f32 -- exact fp32 products
+//                         at the fp32 peak rate -- software-pipelined through two LDS buffers, and the maximum of
+//                         every row over each 64-column block on the side (M).  k5_gemm_panel: the plain tile
+//                         program for other widths.  The score panel IS written to HBM (two panels of <= 4 GiB):
+//                         at d = 768 that is 4 B per 1536 flops, far below the machine balance.
+//   k5_row_topn         : wave per row; with M it selects the ntop-th largest block maximum and reads only the
+//                         blocks that reach it, without M it streams the row (float4); threshold filter, 64-bit
+//                         keys score_bits<<32 | ~col, compaction by wave-max rounds (same scheme as K3), writes
+//                         (idx, score) by (score desc, col asc).
 #include "pfz_internal.h"
 
 #include <algorithm>
 #include <stdlib.h>
-
-#ifndef PFZ_K5_EXP
-#define PFZ_K5_EXP 0
-#endif
-#define PFZ_K5_LOOP_EXP (PFZ_K5_EXP == 5 ? 0 : PFZ_K5_EXP)
-#ifndef PFZ_K5_STAGE_AT
-#define PFZ_K5_STAGE_AT (BK / 2 - 8)      // kk at which the next chunk's operands go to LDS
-#endif
 
 namespace pfz {
 
@@ -152,203 +142,6 @@ __global__ __launch_bounds__(256) void k5_gemm_panel(const float *__restrict__ A
     }
 }
 
-// The same tile program for d % 32 == 0 (embedding widths: 128 ... 768 ... 4096), software-pipelined:
-// the next k-step's operands travel from HBM/L2 into registers while the MFMAs of the current one run
-// out of LDS, and two LDS buffers leave one barrier per k-step (87 -> 110 TFLOP/s at 50k x 50k x 768).
-// Rows beyond the matrix edge are clamped to the last row (their products are discarded by the store),
-// so the loop has no edge tests.  (Tried and dropped: a leading dimension of 36 with b128 LDS accesses
-// and k split by lane half -- 73 TFLOP/s, the fragment reads conflict.)
-template <int BK>
-__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void k5_gemm_panel_pipe(const float *__restrict__ A, const float *__restrict__ B,
-                                                           const float *__restrict__ inv_a,
-                                                           const float *__restrict__ inv_b, int64_t a0, int64_t a1,
-                                                           int64_t n_b, int64_t d, float *__restrict__ S, int64_t ld,
-                                                           int tiles_m, int tiles_n, int block_map)
-{
-    constexpr int LD = BK + 1;            // LDS leading dimension: conflict-free ds_read_b32 of the MFMA fragments
-    constexpr int TPR = BK / 4;           // threads per tile row (a float4 each)
-    constexpr int RPP = 256 / TPR;        // rows staged per pass
-    constexpr int NP = kTile / RPP;       // passes
-    __shared__ float As[2][kTile * LD];
-    __shared__ float Bs[2][kTile * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Workgroup -> tile.  Consecutive workgroup ids go round-robin over the 8 XCDs and each XCD has its own L2, so the
-    // 64 workgroups an XCD runs at a time (32 CUs x 2) get one 8 x 8 block of tiles: 8 A + 8 B tiles feed 64 tile
-    // products out of that L2 (a 1-D sweep over row tiles gives every XCD 32 A tiles + 2 B tiles for the same 64).
-    // The grid is a whole number of 8-block rounds; workgroups of blocks or tiles that do not exist leave at once.
-    int tm, tn;
-    if (block_map) {
-        const int w = blockIdx.x, xcd = w & 7, idx = w >> 3, p = idx & 63;
-        const int g = (idx >> 6) * 8 + xcd, bm = (tiles_m + 7) >> 3;
-        tm = (g % bm) * 8 + (p & 7);
-        tn = (g / bm) * 8 + (p >> 3);
-        if (tm >= tiles_m || tn >= tiles_n) return;
-    }
-    else {
-        tm = blockIdx.x;
-        tn = blockIdx.y;
-    }
-    const int64_t row0 = a0 + (int64_t)tm * kTile;
-    const int64_t col0 = (int64_t)tn * kTile;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int lr = tid / TPR;
-    const int lk = (tid % TPR) * 4;
-    const float *pa[NP], *pb[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-#if PFZ_K5_EXP == 5       // (what-if: every workgroup loads tile 0 of both operands -- L2-hot loads, same instruction stream)
-        const int64_t ga = lr + p * RPP, gb = lr + p * RPP;
-#else
-        const int64_t ga = min(row0 + lr + p * RPP, a1 - 1), gb = min(col0 + lr + p * RPP, n_b - 1);
-#endif
-        pa[p] = A + ga * d + lk;
-        pb[p] = B + gb * d + lk;
-    }
-    float4 ra[NP], rb[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        ra[p] = *(const float4 *)pa[p];
-        rb[p] = *(const float4 *)pb[p];
-    }
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            float *da = As[buf] + (lr + p * RPP) * LD + lk, *db = Bs[buf] + (lr + p * RPP) * LD + lk;
-            da[0] = ra[p].x; da[1] = ra[p].y; da[2] = ra[p].z; da[3] = ra[p].w;
-            db[0] = rb[p].x; db[1] = rb[p].y; db[2] = rb[p].z; db[3] = rb[p].w;
-        }
-    };
-    stage(0);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t k0 = 0; k0 < d; k0 += BK) {
-        const bool more = k0 + BK < d;
-#if PFZ_K5_EXP == 0 || PFZ_K5_EXP == 5     // (what-if builds, results wrong: 1 = no global loads in the loop, 2 = nor staging / barriers,
-                         //  3 = nor fragment re-reads, 4 = nor the epilogue's stores)
-        if (more) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                ra[p] = *(const float4 *)(pa[p] + k0 + BK);
-                rb[p] = *(const float4 *)(pb[p] + k0 + BK);
-            }
-        }
-#endif
-        const float *as = As[cur], *bs = Bs[cur];
-        // MFMA 32x32x2 fragments: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31].  The
-        // fragments are read one set (eight MFMAs) ahead of their use, into two register sets: with the reads
-        // issued right before their MFMAs, as the compiler schedules a plain loop, both waves of a SIMD sit in
-        // s_waitcnt lgkmcnt(0) once per 16 MFMAs and the matrix pipe idles ~15 % of the time
-        // (what-if builds: pure fragment-read + MFMA loop 132 of 157 TFLOP/s).
-        const float *ap = as + (wm + (lane & 31)) * LD + (lane >> 5), *bp = bs + (wn + (lane & 31)) * LD + (lane >> 5);
-        // a fragment set = two k-steps (kk and kk + 2: one ds_read2_b32 per operand tile row)
-        auto frag = [&](int kk, float (&a)[2][2], float (&b)[2][2]) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                a[h][0] = ap[kk + 2 * h];
-                a[h][1] = ap[32 * LD + kk + 2 * h];
-                b[h][0] = bp[kk + 2 * h];
-                b[h][1] = bp[32 * LD + kk + 2 * h];
-            }
-        };
-        auto mfma8 = [&](const float (&a)[2][2], const float (&b)[2][2]) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
-        };
-        float fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
-        frag(0, fa0, fb0);
-#if PFZ_K5_LOOP_EXP >= 3
-        frag(4, fa1, fb1);
-#endif
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
-#if PFZ_K5_LOOP_EXP < 3
-            frag(kk + 4, fa1, fb1);           // read eight MFMAs (512 cycles) ahead of their use
-#endif
-            __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads back to just before their use)
-            mfma8(fa0, fb0);
-            // the next step's operands (in flight since the top of this step) go to the OTHER buffer half way through:
-            // the stores issue while the matrix pipe is busy instead of after the loop
-#if PFZ_K5_LOOP_EXP < 2
-            if (kk == PFZ_K5_STAGE_AT && more) stage(cur ^ 1);
-#endif
-#if PFZ_K5_LOOP_EXP < 3
-            if (kk + 8 < BK) frag(kk + 8, fa0, fb0);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(fa1, fb1);
-        }
-#if PFZ_K5_LOOP_EXP < 2
-        __syncthreads();
-        cur ^= 1;
-#endif
-    }
-
-    // Epilogue.  MFMA 32x32 accumulator r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
-    if (row0 + kTile <= a1) {
-        // interior tile (all but the last row tile of the last panel; ld is a whole number of tiles): the 1/|a| factors
-        // come as eight float4 loads issued together, the 64 stores go out back to back from a wave-uniform base plus
-        // one 32-bit lane offset.  (Row-by-row predicated code makes the compiler wait for EVERYTHING in flight,
-        // the previous store included, before each element: 5.5 us per tile, 13 % of a tile's MFMA time.)
-        const int uwm = __builtin_amdgcn_readfirstlane(wm), uwn = __builtin_amdgcn_readfirstlane(wn);
-        const float4 *ia = (const float4 *)(inv_a + row0 + uwm) + (lane >> 5);
-        float4 sa[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sa[i][q] = ia[i * 8 + q * 2];
-        float sb[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = col0 + uwn + j * 32 + (lane & 31);
-            sb[j] = col < n_b ? inv_b[col] : 0.f;
-        }
-        float *tile = S + (row0 - a0 + uwm) * ld + col0 + uwn;
-        const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * (uint32_t)ld + (uint32_t)(lane & 31);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float f = r % 4 == 0 ? sa[i][r / 4].x : r % 4 == 1 ? sa[i][r / 4].y : r % 4 == 2 ? sa[i][r / 4].z : sa[i][r / 4].w;
-                float *rowp = tile + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-#if PFZ_K5_EXP == 4
-                    if (acc[i][j][r] == 12345.678f)
-#endif
-                    (rowp + j * 32)[lane_off] = acc[i][j][r] * f * sb[j];
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t col = col0 + wn + j * 32 + (lane & 31);
-        const float sb = col < n_b ? inv_b[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < a1 && col < ld) S[(row - a0) * ld + col] = acc[i][j][r] * inv_a[row] * sb;
-            }
-        }
-    }
-}
-
 // Row maxima of a wave's 64 x 64 corner.  x[q] (q = 16 i + r) is the lane's maximum over its two columns of
 // accumulator row-slot q; the maximum over the 32 lanes of a half-wave is wanted for all 32 slots.  Halving
 // exchange: each step pairs lanes (row_mirror, row_half_mirror, quad xor 2, quad xor 1 by DPP, then lane ^ 16 by
@@ -382,7 +175,11 @@ __device__ inline int block_row_slot(int lane)
 
 __device__ inline float f4c(const float4 &v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
-// Second-generation tile program (d % 32 == 0): what the counters and the what-if builds of the kernel above asked for.
+// The tile program for d % 32 == 0 (embedding widths: 128 ... 768 ... 4096), software-pipelined: the operands of chunk
+// c + 2 travel from HBM / L2 into registers and those of chunk c + 1 from registers into the other LDS buffer while the
+// MFMAs of chunk c run out of LDS; one barrier per chunk.  Rows beyond the matrix edge are clamped to the last row
+// (their products are not stored), so the loop has no edge tests.  Its shape is what the counters and what-if builds
+// of its predecessor (round 2's first pipelined kernel, removed; DESIGN.md section 4 keeps the numbers) asked for:
 //  * LDS rows of 36 floats: operands staged with ds_write_b128, MFMA fragments read with ds_read_b128 -- lane (r, h)
 //    takes the four floats k = 8t + 4h .. + 3 of row r, and MFMA step s of sub-step t multiplies the k-pairs
 //    {8t + s, 8t + 4 + s} (A and B use the same assignment, so the sum is the same dot product in another order).
@@ -392,7 +189,7 @@ __device__ inline float f4c(const float4 &v, int s) { return s == 0 ? v.x : s ==
 //    per group of eight MFMAs (eight loads issued back to back kept the wave out of the matrix pipe for ~300 cycles
 //    per chunk: 8 % of the GEMM, with L2-hot loads just the same); addresses are a wave-uniform base + a 32-bit lane
 //    offset, so a load costs no vector ALU work.
-__global__ __launch_bounds__(256, 2) void k5_gemm_panel_pipe2(const float *__restrict__ A, const float *__restrict__ B,
+__global__ __launch_bounds__(256, 2) void k5_gemm_panel_pipe(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ inv_a, const float *__restrict__ inv_b,
                                                               int64_t a0, int64_t a1, int64_t n_b, int64_t d,
                                                               float *__restrict__ S, int64_t ld, int tiles_m, int tiles_n,
@@ -402,7 +199,10 @@ __global__ __launch_bounds__(256, 2) void k5_gemm_panel_pipe2(const float *__res
     __shared__ __attribute__((aligned(16))) float As[2][kTile * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][kTile * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // workgroup -> tile: 8 x 8 tile blocks per XCD (see k5_gemm_panel_pipe)
+    // Workgroup -> tile.  Consecutive workgroup ids go round-robin over the 8 XCDs and each XCD has its own L2, so the
+    // 64 workgroups an XCD runs at a time (32 CUs x 2) get one 8 x 8 block of tiles: 8 A + 8 B tiles feed 64 tile
+    // products out of that L2 (a 1-D sweep over row tiles gives every XCD 32 A tiles + 2 B tiles for the same 64).
+    // The grid is a whole number of 8-block rounds; workgroups of blocks or tiles that do not exist leave at once.
     const int w = blockIdx.x, xcd = w & 7, idx = w >> 3, pos = idx & 63;
     const int g = (idx >> 6) * 8 + xcd, bm = (tiles_m + 7) >> 3;
     const int tm = (g % bm) * 8 + (pos & 7), tn = (g / bm) * 8 + (pos >> 3);
@@ -834,30 +634,18 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         if (two && pi >= 2) PFZ_HIP(hipStreamWaitEvent(ctx->stream, consumed[buf], 0));   // the top-n of panel pi - 2 read this buffer
         if (ld > 0) {
             ProfScope ps(ctx, "k5_gemm_panel");
-            // x = the panel's row tiles, y = column tiles: workgroups that are dispatched together share a B tile (one
-            // HBM read per panel instead of one per row tile) and the panel's A rows (a few MB) stay in L2
-            dim3 grid((unsigned)((a1 - a0 + kTile - 1) / kTile), (unsigned)(ld / kTile));
-            const int tiles_m = (int)grid.x, tiles_n = (int)grid.y;
-            static const int block_map = getenv("PFZ_K5_LINEAR_MAP") ? 0 : 1;       // A/B knob
-            const dim3 grid_p = block_map ? dim3((unsigned)((((tiles_m + 7) / 8) * ((tiles_n + 7) / 8) + 7) / 8 * 512)) : grid;
+            const int tiles_m = (int)((a1 - a0 + kTile - 1) / kTile), tiles_n = (int)(ld / kTile);
             // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
             if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE")) {
-                if (block_map && !getenv("PFZ_K5_PIPE1"))      // (PFZ_K5_PIPE1: the first-generation pipelined kernel, A/B timing and tests)
-                {
-                    M = getenv("PFZ_K5_NO_BLOCK_MAX") ? nullptr : (const float *)dM[buf].p;      // A/B knob, tests
-                    hipLaunchKernelGGL(k5_gemm_panel_pipe2, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
-                                       n_to, dim, S, ld, tiles_m, tiles_n, (float *)M, ld / 64);
-                }
-                else if (getenv("PFZ_K5_BK16"))     // A/B knob: 16-deep k-steps (half the LDS per workgroup, twice the barriers)
-                    hipLaunchKernelGGL(k5_gemm_panel_pipe<16>, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv,
-                                       a0, a1, n_to, dim, S, ld, tiles_m, tiles_n, block_map);
-                else
-                    hipLaunchKernelGGL(k5_gemm_panel_pipe<32>, grid_p, dim3(256), getenv("PFZ_K5_ONE_WG") ? 48 << 10 : 0, ctx->stream,
-                                       from->x, to->x, from->inv, to->inv, a0, a1, n_to, dim, S, ld, tiles_m, tiles_n, block_map);
+                // 1-D grid of 8 x 8 tile blocks dealt round-robin to the XCDs (see the kernel)
+                const dim3 grid_p((unsigned)((((tiles_m + 7) / 8) * ((tiles_n + 7) / 8) + 7) / 8 * 512));
+                M = getenv("PFZ_K5_NO_BLOCK_MAX") ? nullptr : (const float *)dM[buf].p;      // A/B knob, tests
+                hipLaunchKernelGGL(k5_gemm_panel_pipe, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
+                                   n_to, dim, S, ld, tiles_m, tiles_n, (float *)M, ld / 64);
             }
-            else
-                hipLaunchKernelGGL(k5_gemm_panel, grid, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
-                                   n_to, dim, S, ld);
+            else   // x = the panel's row tiles, y = column tiles: workgroups dispatched together share a B tile
+                hipLaunchKernelGGL(k5_gemm_panel, dim3((unsigned)tiles_m, (unsigned)tiles_n), dim3(256), 0, ctx->stream, from->x,
+                                   to->x, from->inv, to->inv, a0, a1, n_to, dim, S, ld);
         }
         hipStream_t ts = two ? ctx->stream2 : ctx->stream;
         if (two) {

@@ -154,3 +154,18 @@ def test_precomputed_oracle_cases(ctx):
             e_idx, e_score = case["expect"][mode]
             np.testing.assert_array_equal(score, np.array(e_score))
             np.testing.assert_array_equal(idx, np.array(e_idx, np.int32))
+
+
+def test_reference_rapidfuzz_test_scenarios(ctx):
+    """The reference's own tests for this matcher (tests/models/test_rapidfuzz.py:9-36) on the README lists: default
+    construction, an explicit scorer, a 0.95 cut-off -- shape, columns and the means they assert."""
+    from polyfuzz_amd.models import RapidFuzz
+    from_list = ["apple", "apples", "appl", "recal", "house", "similarity"]
+    to_list = ["apple", "apples", "mouse"]
+    import pandas as pd
+    for kwargs, check in (({}, lambda m: m > 0.0), ({"scorer": "ratio"}, lambda m: m > 0.0), ({"score_cutoff": 0.95}, lambda m: m < 0.5)):
+        model = RapidFuzz(**kwargs)
+        matches = model.match(from_list, to_list)
+        assert model.type == "EditDistance" and isinstance(matches, pd.DataFrame) and len(matches) == 6
+        assert list(matches.columns) == ["From", "To", "Similarity"]
+        assert check(matches.Similarity.mean())
