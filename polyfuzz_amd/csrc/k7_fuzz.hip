@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
     __shared__ uint64_t s_tmask[32][W], s_smask[32][W];
     __shared__ double red_s[4];
     __shared__ int red_i[4];
+    __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup holds so far (>= 0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
 
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             }
         }
         if (tid == 0) {
+            s_best = 0ull;
             const int64_t t0 = A.a_tok_off[row];
             const int ta = (int)(A.a_tok_off[row + 1] - t0);
             s_ta = ta;
@@ -168,7 +170,19 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         double best_score = -1.0;
         int best_idx = INT_MAX;
 
+        // WRatio: the groups whose lengths are within a factor 1.5 of the from-string first -- that is where scores
+        // above 90 live -- then the others, where whole branches can be left out once the workgroup holds a score they
+        // cannot reach (see `cur` below).  Other scorers: one pass.
+        const int n_pass = mode == kWRatio ? 2 : 1;
+        for (int pass = 0; pass < n_pass; ++pass)
         for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
+            if (mode == kWRatio) {
+                const int lbmin = __builtin_amdgcn_readfirstlane(A.b_len[0][g * 64]);       // lanes are sorted by length
+                const int lbmax = __builtin_amdgcn_readfirstlane(A.b_gmax[0][g]);
+                const bool near_group = 3 * lbmax > 2 * la0 && 2 * lbmin < 3 * la0;
+                if (near_group != (pass == 0)) continue;
+            }
+            const double cur = __longlong_as_double((long long)*(volatile unsigned long long *)&s_best);
             const int slot = g * 64 + lane;
             const int orig = A.b_orig[slot];
             const int lb0 = A.b_len[0][slot], lb1 = A.b_len[1][slot], lb2 = A.b_len[2][slot], tb = A.b_ntok[slot];
@@ -316,20 +330,41 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                     const int lmax = max(la0, lb0), lmin = min(la0, lb0);
                     // (uniformity: lanes of a group have similar lengths, most groups take one branch as a whole)
                     const bool near = 2 * lmax < 3 * lmin;                  // len_ratio < 1.5
+                    // extractOne keeps the maximum, so a COMPONENT of this pair's score that cannot reach `cur` -- a score
+                    // some valid choice of this from-string already has -- need not be computed: if the pair wins, it wins
+                    // through another component.  Bounds (each through the same floating-point expressions as the value
+                    // it bounds, which are monotone):  token scorers <= 100;  a window of either string has LCS <= the
+                    // LCS of the whole strings (just computed) and at least that many characters, so partial_ratio <=
+                    // ratio_of(lcs, |shorter| + lcs);  the distinct-token form is a subsequence of the sorted-token form.
+                    const int lcs0 = zeros_below<W>(V, la0);
+                    const double scale = lmax < 8 * lmin ? 0.9 : 0.6;       // len_ratio < 8
+                    const bool want_tok = near && !(100.0 * 0.95 < cur);
+                    const bool want_ps = !near && !(ratio_of(lcs0, lmin + lcs0) * scale < cur);
                     double tok = 0.0, ps = 0.0, pt = 0.0;
-                    if (__any(near)) {
+                    if (__any(want_tok)) {
                         const double t1 = token_sort(), t2 = token_set();     // (no tokens on either side: ratio("", "") = 100, as rapidfuzz)
                         tok = fmax(t1, t2);
                     }
-                    if (__any(!near)) {
-                        ps = partial(0, near ? 0 : la0, near ? 0 : lb0);
-                        pt = near ? 0.0 : partial_token();
+                    if (__any(want_ps)) ps = partial(0, want_ps ? la0 : 0, want_ps ? lb0 : 0);
+                    if (!near && ta != 0 && tb != 0) {
+                        if (ca) pt = 100.0;
+                        else if (!(100.0 * 0.95 * scale < cur)) {
+                            uint64_t V1[W];
+                            lcs_pass(1, all, false, 0u, 0, V1);
+                            const int lcs1 = zeros_below<W>(V1, la1);
+                            const int c1 = min(lcs1, min(la1, lb1)), c2 = min(lcs1, min(la2, lb2));
+                            const bool want1 = !(ratio_of(c1, min(la1, lb1) + c1) * 0.95 * scale < cur);
+                            const bool want2 = !(ratio_of(c2, min(la2, lb2) + c2) * 0.95 * scale < cur);
+                            double p1 = 0.0, p2 = 0.0;
+                            if (__any(want1)) p1 = partial(1, want1 ? la1 : 0, want1 ? lb1 : 0);
+                            if (__any(want2)) p2 = partial(2, want2 ? la2 : 0, want2 ? lb2 : 0);
+                            pt = fmax(want1 ? p1 : 0.0, want2 ? p2 : 0.0);
+                        }
                     }
                     if (near)
-                        score = fmax(end_ratio, tok * 0.95);
+                        score = want_tok ? fmax(end_ratio, tok * 0.95) : end_ratio;
                     else {
-                        const double scale = lmax < 8 * lmin ? 0.9 : 0.6;   // len_ratio < 8
-                        end_ratio = fmax(end_ratio, ps * scale);
+                        end_ratio = fmax(end_ratio, (want_ps ? ps : 0.0) * scale);
                         score = fmax(end_ratio, pt * 0.95 * scale);
                     }
                 }
@@ -345,6 +380,12 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             if (orig >= 0 && orig != skip && (score > best_score || (score == best_score && orig < best_idx))) {
                 best_score = score;
                 best_idx = orig;
+            }
+            if (mode == kWRatio) {          // publish the wave's best score to the workgroup
+                double wb = fmax(best_score, 0.0);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) wb = fmax(wb, __shfl_xor(wb, d, 64));
+                if (lane == 0) atomicMax(&s_best, (unsigned long long)__double_as_longlong(wb));
             }
         }
         // first best choice: (score desc, original index asc)
