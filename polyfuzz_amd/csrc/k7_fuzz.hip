@@ -170,13 +170,14 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         double best_score = -1.0;
         int best_idx = INT_MAX;
 
-        // WRatio: the groups whose lengths are within a factor 1.5 of the from-string first -- that is where scores
-        // above 90 live -- then the others, where whole branches can be left out once the workgroup holds a score they
-        // cannot reach (see `cur` below).  Other scorers: one pass.
-        const int n_pass = mode == kWRatio ? 2 : 1;
+        // WRatio and the partial_* scorers: the groups whose lengths are within a factor 1.5 of the from-string first
+        // -- that is where WRatio's scores above 90 live -- then the others, where whole components can be left out
+        // once the workgroup holds a score they cannot reach (see `cur` below).  The token scorers: one pass.
+        const bool pruning = mode == kWRatio || mode == kPartialRatio || mode >= kPartialTokenSortRatio;
+        const int n_pass = pruning ? 2 : 1;
         for (int pass = 0; pass < n_pass; ++pass)
         for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
-            if (mode == kWRatio) {
+            if (pruning) {
                 const int lbmin = __builtin_amdgcn_readfirstlane(A.b_len[0][g * 64]);       // lanes are sorted by length
                 const int lbmax = __builtin_amdgcn_readfirstlane(A.b_gmax[0][g]);
                 const bool near_group = 3 * lbmax > 2 * la0 && 2 * lbmin < 3 * la0;
@@ -314,10 +315,22 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                 lcs_pass(1, all, false, 0u, 0, V);
                 return ratio_of(zeros_below<W>(V, la1), la1 + lb1);
             };
+            // partial_ratio, left out (0: a lower bound) when it cannot reach the workgroup's best score: a window has
+            // at most the LCS of the whole strings -- one cheap pass -- and at least that many characters
+            auto partial_pruned = [&](int v, int la, int lb) -> double {
+                if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
+                uint64_t Vv[W];
+                lcs_pass(v, all, false, 0u, 0, Vv);
+                const int l = zeros_below<W>(Vv, la), lm = min(la, lb);
+                const bool want = !(ratio_of(l, lm + l) < cur);
+                double p = 0.0;
+                if (__any(want)) p = partial(v, want ? la : 0, want ? lb : 0);
+                return want ? p : 0.0;
+            };
             auto partial_token = [&]() -> double {          // partial_token_ratio
                 if (ta == 0 || tb == 0) return 0.0;
                 if (ca) return 100.0;
-                return fmax(partial(1, la1, lb1), partial(2, la2, lb2));
+                return fmax(partial_pruned(1, la1, lb1), partial_pruned(2, la2, lb2));
             };
 
             double score = 0.0;
@@ -369,19 +382,19 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                     }
                 }
             }
-            else if (mode == kPartialRatio) score = partial(0, la0, lb0);
+            else if (mode == kPartialRatio) score = partial_pruned(0, la0, lb0);
             else if (mode == kTokenSetRatio) score = token_set();
             else if (mode == kTokenRatio) score = fmax(token_sort(), token_set());
-            else if (mode == kPartialTokenSortRatio) score = partial(1, la1, lb1);
+            else if (mode == kPartialTokenSortRatio) score = partial_pruned(1, la1, lb1);
             else if (mode == kPartialTokenSetRatio)
-                score = (ta == 0 || tb == 0) ? 0.0 : (ca ? 100.0 : partial(2, la2, lb2));
+                score = (ta == 0 || tb == 0) ? 0.0 : (ca ? 100.0 : partial_pruned(2, la2, lb2));
             else score = partial_token();
 
             if (orig >= 0 && orig != skip && (score > best_score || (score == best_score && orig < best_idx))) {
                 best_score = score;
                 best_idx = orig;
             }
-            if (mode == kWRatio) {          // publish the wave's best score to the workgroup
+            if (pruning) {                  // publish the wave's best score to the workgroup
                 double wb = fmax(best_score, 0.0);
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) wb = fmax(wb, __shfl_xor(wb, d, 64));
