@@ -8,12 +8,12 @@
 //
 // Plan:
 //   k5_inv_norms        : 1/||row|| for both matrices (wave per row).
-//   k5_gemm_panel_pipe  : S[P x n_to] = A_panel . B^T scaled by both inverse norms (widths that are multiples of 32);
-//                         128x128x32 workgroup tiles, 4 waves x (2x2) v_mfma_f32_32x32x2_f32 -- exact fp32 products
-//                         at the fp32 peak rate -- software-pipelined through two LDS buffers, and the maximum of
-//                         every row over each 64-column block on the side (M).  k5_gemm_panel: the plain tile
-//                         program for other widths.  The score panel IS written to HBM (two panels of <= 4 GiB):
-//                         at d = 768 that is 4 B per 1536 flops, far below the machine balance.
+//   k5_gemm_panel_pipe  : S[P x n_to] = A_panel . B^T scaled by both inverse norms (matrices are stored with their
+//                         width padded to a multiple of 32); 128x128x32 workgroup tiles, 4 waves x (2x2)
+//                         v_mfma_f32_32x32x2_f32 -- exact fp32 products at the fp32 peak rate -- software-pipelined
+//                         through two LDS buffers, and the maximum of every row over each 64-column block on the
+//                         side (M).  The score panel IS written to HBM (two panels of <= 4 GiB): at d = 768 that is
+//                         4 B per 1536 flops, far below the machine balance.
 //   k5_row_topn         : wave per row; with M it selects the ntop-th largest block maximum and reads only the
 //                         blocks that reach it, without M it streams the row (float4); threshold filter, 64-bit
 //                         keys score_bits<<32 | ~col, compaction by wave-max rounds (same scheme as K3), writes
@@ -31,7 +31,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 128;   // workgroup tile (rows of A x rows of B)
 constexpr int kBK = 32;      // k-depth staged per step
-constexpr int kLd = kBK + 1; // LDS leading dimension
 constexpr int kCap5 = 256;
 
 // normalize == 0: raw dot products are wanted, every scale factor is 1
@@ -51,95 +50,6 @@ __global__ __launch_bounds__(256) void k5_inv_norms(const float *__restrict__ x,
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if (lane == 0) inv[row] = ss > 0.0 ? (float)(1.0 / sqrt(ss)) : 0.f;   // zero rows stay zero (sklearn normalize)
-}
-
-// S[(i - a0) * ld + j] = inv_a[i] * inv_b[j] * sum_k A[i][k] * B[j][k]   for i in [a0, a1), j in [0, n_b)
-__global__ __launch_bounds__(256) void k5_gemm_panel(const float *__restrict__ A, const float *__restrict__ B,
-                                                      const float *__restrict__ inv_a, const float *__restrict__ inv_b,
-                                                      int64_t a0, int64_t a1, int64_t n_b, int64_t d,
-                                                      float *__restrict__ S, int64_t ld)
-{
-    __shared__ float As[kTile * kLd];
-    __shared__ float Bs[kTile * kLd];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = a0 + (int64_t)blockIdx.x * kTile;   // first A row of the tile (x: see the launch)
-    const int64_t col0 = (int64_t)blockIdx.y * kTile;        // first B row of the tile
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;   // the wave's 64x64 corner inside the tile
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // staging map: thread t -> 4 consecutive k of one row, 4 rows apart in steps of 32 rows
-    const int lr = tid >> 3;          // 0..31
-    const int lk = (tid & 7) * 4;     // 0,4,..,28
-    for (int64_t k0 = 0; k0 < d; k0 += kBK) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int r = lr + p * 32;
-            const int64_t ga = row0 + r, gb = col0 + r;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (ga < a1) {
-                const float *src = A + ga * d + k0 + lk;
-                if (k0 + lk + 3 < d && ((d & 3) == 0)) va = *(const float4 *)src;
-                else {
-                    if (k0 + lk + 0 < d) va.x = src[0];
-                    if (k0 + lk + 1 < d) va.y = src[1];
-                    if (k0 + lk + 2 < d) va.z = src[2];
-                    if (k0 + lk + 3 < d) va.w = src[3];
-                }
-            }
-            if (gb < n_b) {
-                const float *src = B + gb * d + k0 + lk;
-                if (k0 + lk + 3 < d && ((d & 3) == 0)) vb = *(const float4 *)src;
-                else {
-                    if (k0 + lk + 0 < d) vb.x = src[0];
-                    if (k0 + lk + 1 < d) vb.y = src[1];
-                    if (k0 + lk + 2 < d) vb.z = src[2];
-                    if (k0 + lk + 3 < d) vb.w = src[3];
-                }
-            }
-            float *da = As + r * kLd + lk, *db = Bs + r * kLd + lk;
-            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
-            db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < kBK; kk += 2) {
-            // MFMA 32x32x2 fragments: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]
-            const int kq = kk + (lane >> 5);
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(wm + i * 32 + (lane & 31)) * kLd + kq];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(wn + j * 32 + (lane & 31)) * kLd + kq];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t col = col0 + wn + j * 32 + (lane & 31);
-        const float sb = col < n_b ? inv_b[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < a1 && col < ld) S[(row - a0) * ld + col] = acc[i][j][r] * inv_a[row] * sb;
-            }
-        }
-    }
 }
 
 // Row maxima of a wave's 64 x 64 corner.  x[q] (q = 16 i + r) is the lane's maximum over its two columns of
@@ -529,8 +439,9 @@ using namespace pfz;
 struct pfz_dense {
     pfz_ctx *ctx = nullptr;
     int64_t n = 0, dim = 0;
+    int64_t ld = 0;          // dim rounded up to a multiple of 32 (the GEMM's k-chunk), the extra columns are zero
     int32_t normalize = 1;
-    float *x = nullptr;      // device [n][dim] row-major
+    float *x = nullptr;      // device [n][ld] row-major
     float *inv = nullptr;    // device [n]: 1 / ||row|| (1 when normalize == 0)
 };
 
@@ -558,12 +469,27 @@ int pfz_dense_upload(pfz_ctx *ctx, const float *vec, int64_t n, int64_t dim, int
     m->ctx = ctx;
     m->n = n;
     m->dim = dim;
+    // Widths that are not a multiple of the GEMM's 32-column k-chunk (300-d word vectors) are padded with zero columns
+    // on the device: dot products and norms do not change and every width takes the pipelined tile program.
+    const int64_t ld = (dim + kBK - 1) / kBK * kBK;
+    m->ld = ld;
     m->normalize = normalize ? 1 : 0;
-    PFZ_TRY(pool_alloc(ctx, &m->x, (size_t)(n > 0 ? n : 1) * (size_t)dim * sizeof(float)));
+    PFZ_TRY(pool_alloc(ctx, &m->x, (size_t)(n > 0 ? n : 1) * (size_t)ld * sizeof(float)));
     PFZ_TRY(pool_alloc(ctx, &m->inv, (size_t)(n > 0 ? n : 1) * sizeof(float)));
     if (n > 0) {
-        PFZ_TRY(copy_h2d(ctx, m->x, vec, (size_t)n * (size_t)dim * sizeof(float)));
-        hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, m->x, n, dim, m->inv, m->normalize);
+        if (ld == dim)
+            PFZ_TRY(copy_h2d(ctx, m->x, vec, (size_t)n * (size_t)dim * sizeof(float)));
+        else {
+            const int64_t rows_per = std::max<int64_t>(1, ((int64_t)32 << 20) / (ld * (int64_t)sizeof(float)));
+            std::vector<float> padded((size_t)std::min(rows_per, n) * (size_t)ld, 0.f);
+            for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
+                const int64_t rows = std::min(rows_per, n - r0);
+                for (int64_t r = 0; r < rows; ++r)
+                    std::copy(vec + (r0 + r) * dim, vec + (r0 + r + 1) * dim, padded.begin() + (size_t)r * (size_t)ld);
+                PFZ_TRY(copy_h2d(ctx, m->x + r0 * ld, padded.data(), (size_t)rows * (size_t)ld * sizeof(float)));
+            }
+        }
+        hipLaunchKernelGGL(k5_inv_norms, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, m->x, n, ld, m->inv, m->normalize);
         PFZ_HIP(hipGetLastError());
     }
     *out = m.release();
@@ -592,7 +518,7 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
     }
     PFZ_REQUIRE(out->n_rows >= from->n && out->ntop == ntop, "pfz_dense_topn: result buffer is %lldx%d, need %lldx%d",
                 (long long)out->n_rows, out->ntop, (long long)from->n, ntop);
-    const int64_t n_from = from->n, n_to = to->n, dim = from->dim;
+    const int64_t n_from = from->n, n_to = to->n, dim = from->ld;        // the padded width: a multiple of 32
     if (n_from == 0) return PFZ_OK;
     PFZ_HIP(hipSetDevice(ctx->device));
     if (lower_bound < 0.f) lower_bound = 0.f;   // non-positive similarities are "no match" (_utils.py:122-123)
@@ -635,17 +561,13 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         if (ld > 0) {
             ProfScope ps(ctx, "k5_gemm_panel");
             const int tiles_m = (int)((a1 - a0 + kTile - 1) / kTile), tiles_n = (int)(ld / kTile);
-            // PFZ_K5_NO_PIPE=1: the unpipelined kernel for every width (tests, A/B timing)
-            if (dim % kBK == 0 && n_to > 0 && !getenv("PFZ_K5_NO_PIPE")) {
+            if (n_to > 0) {
                 // 1-D grid of 8 x 8 tile blocks dealt round-robin to the XCDs (see the kernel)
                 const dim3 grid_p((unsigned)((((tiles_m + 7) / 8) * ((tiles_n + 7) / 8) + 7) / 8 * 512));
                 M = getenv("PFZ_K5_NO_BLOCK_MAX") ? nullptr : (const float *)dM[buf].p;      // A/B knob, tests
                 hipLaunchKernelGGL(k5_gemm_panel_pipe, grid_p, dim3(256), 0, ctx->stream, from->x, to->x, from->inv, to->inv, a0, a1,
                                    n_to, dim, S, ld, tiles_m, tiles_n, (float *)M, ld / 64);
             }
-            else   // x = the panel's row tiles, y = column tiles: workgroups dispatched together share a B tile
-                hipLaunchKernelGGL(k5_gemm_panel, dim3((unsigned)tiles_m, (unsigned)tiles_n), dim3(256), 0, ctx->stream, from->x,
-                                   to->x, from->inv, to->inv, a0, a1, n_to, dim, S, ld);
         }
         hipStream_t ts = two ? ctx->stream2 : ctx->stream;
         if (two) {
