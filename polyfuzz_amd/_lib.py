@@ -567,10 +567,11 @@ def fuzz_prepare(from_list, to_list):
     if len(alphabet) >= 65535:
         raise PfzUnsupported("more than 65534 distinct characters in the to-list")
 
+    lut = np.zeros(int(alphabet[-1]) + 2, np.uint16)        # code point -> rank (0: not in the to-side alphabet)
+    lut[alphabet] = np.arange(1, len(alphabet) + 1, dtype=np.uint16)
+
     def ranks(cps):
-        pos = np.searchsorted(alphabet, cps)
-        pos[pos >= len(alphabet)] = 0
-        return np.where(alphabet[pos] == cps, pos + 1, 0).astype(np.uint16)
+        return lut[np.minimum(cps, len(lut) - 1)]
     # token ids: equal tokens <-> equal ids across both lists
     vocab = {}
     for toks in (f_tokens if same else f_tokens + t_tokens):
