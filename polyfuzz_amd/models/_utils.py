@@ -32,7 +32,10 @@ _FILL_THREADS = _fill_threads()
 def object_column(strings) -> np.ndarray:
     """list[str] -> 1-D object ndarray (the From column; built while the GPU is still busy)."""
     arr = np.empty(len(strings), dtype=object)
-    arr[:] = strings
+    if _lib._pack is not None and isinstance(strings, (list, tuple)) and hasattr(_lib._pack, "fill_objects"):
+        _lib._pack.fill_objects(strings, arr.ctypes.data, len(strings))      # (numpy's own assignment is 10x slower)
+    else:
+        arr[:] = strings
     return arr
 
 
