@@ -21,8 +21,8 @@ from .. import _lib
 from ._base import BaseMatcher
 from ._utils import topn_to_frame, object_column, clip_top_n, FrameBuilder, _METHODS
 
-_SPLIT_MIN_ROWS = 20000      # from-rows from which match() pipelines two K3 launches with the frame building
-_SPLIT_EVENT = 62            # context event slots 62 / 63: first / second launch done
+_SPLIT_MIN_ROWS = 20000      # from-rows from which match() pipelines several K3 launches with the frame building
+_SPLIT_EVENT = 60            # context event slots 60 .. 63: launch i done
 
 
 def _clean_string(string: str) -> str:
@@ -140,15 +140,18 @@ class TFIDF(BaseMatcher):
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
         n = len(from_list)
         names = from_list if self_match else to_list
-        # A big match is enqueued as two launches over the from-rows: the first half's result is downloaded on a side
-        # stream and turned into frame columns while the device works on the second half
+        # A big match is enqueued as two (four from 40k rows) launches over the from-rows: each part's result is
+        # downloaded on a side stream and turned into frame columns while the device works on the next parts, so only
+        # the last part's columns are built after the device has finished
         split = n >= _SPLIT_MIN_ROWS and top_n >= 1 and _lib._pack is not None and isinstance(names, (list, tuple))
         if split:
-            half = n // 2
-            res = _lib.cossim_topn(ctx, self._dev_index, from_dev, top_n, lower, exclude_diag=self_match, rows=(0, half))
-            ctx.event_record(_SPLIT_EVENT)
-            _lib.cossim_topn(ctx, self._dev_index, from_dev, top_n, lower, exclude_diag=self_match, rows=(half, n), out=res)
-            ctx.event_record(_SPLIT_EVENT + 1)
+            n_parts = 4 if n >= 2 * _SPLIT_MIN_ROWS else 2
+            cuts = [n * i // n_parts for i in range(n_parts + 1)]
+            res = None
+            for i in range(n_parts):
+                res = _lib.cossim_topn(ctx, self._dev_index, from_dev, top_n, lower, exclude_diag=self_match, out=res,
+                                       rows=(cuts[i], cuts[i + 1]))
+                ctx.event_record(_SPLIT_EVENT + i)
         else:
             res = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=self_match)
         t1 = time.perf_counter()
@@ -156,16 +159,17 @@ class TFIDF(BaseMatcher):
         t2 = time.perf_counter()
         if split:
             fb = FrameBuilder(from_list, names, top_n, from_col)
-            idx, val = res.download_rows_after(0, half, _SPLIT_EVENT)
-            ta = time.perf_counter()
-            fb.fill(idx, val, 0)                   # ... and while it runs the second launch
-            tb = time.perf_counter()
-            idx, val = res.download_rows_after(half, n, _SPLIT_EVENT + 1)
-            tc = time.perf_counter()
-            fb.fill(idx, val, half)
+            waited = framed = 0.0
+            tp = t2
+            for i in range(n_parts):
+                idx, val = res.download_rows_after(cuts[i], cuts[i + 1], _SPLIT_EVENT + i)
+                ta = time.perf_counter()
+                fb.fill(idx, val, cuts[i])         # ... while the device runs the later launches
+                tb = time.perf_counter()
+                waited, framed, tp = waited + (ta - tp), framed + (tb - ta), tb
             frame = fb.frame()
             t4 = time.perf_counter()
-            waited, framed = (ta - t2) + (tc - tb), (tb - ta) + (t4 - tc)
+            framed += t4 - tp
         else:
             idx, val = res.download()
             t3 = time.perf_counter()
