@@ -17,7 +17,7 @@ import pandas as pd
 
 from .. import _lib
 from ._base import BaseMatcher
-from ._utils import object_column
+from ._utils import gather_column, object_column
 
 
 def _device_scorer(scorer) -> str:
@@ -76,7 +76,7 @@ class EditDistance(BaseMatcher):
         t0 = time.perf_counter()
         idx, score, names = self._best(from_list, to_list, reuse_to=kwargs.get("re_train", True) is False)
         t1 = time.perf_counter()
-        to_col = object_column([names[j] for j in idx.tolist()])
+        to_col = gather_column(names, idx)
         matches = pd.DataFrame({"From": object_column(from_list), "To": to_col, "Similarity": score}, copy=False)
         if self.normalize:      # global min-max over the best scores, _distance.py:83-86
             matches["Similarity"] = (matches["Similarity"] -

@@ -30,7 +30,7 @@ import pandas as pd
 
 from .. import _lib
 from ._base import BaseMatcher
-from ._utils import object_column
+from ._utils import gather_column, object_column
 
 _K4_SCORERS = ("ratio", "QRatio", "token_sort_ratio")
 _DEVICE_SCORERS = _K4_SCORERS + tuple(_lib.FUZZ_SCORERS)
@@ -117,6 +117,6 @@ class RapidFuzz(BaseMatcher):
         else:
             idx, score = best_choice(ctx, self._scorer_name, from_list, names, skip, self_match)
         hit = (idx >= 0) & (score >= self.score_cutoff)                       # extractOne: best score >= score_cutoff
-        to_col = object_column([names[j] if ok else None for j, ok in zip(idx.tolist(), hit.tolist())])
+        to_col = gather_column(names, idx, hit)
         sim = np.where(hit, score / 100, 0.0)
         return pd.DataFrame({"From": object_column(from_list), "To": to_col, "Similarity": sim}, copy=False)

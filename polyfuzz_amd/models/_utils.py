@@ -39,6 +39,16 @@ def object_column(strings) -> np.ndarray:
     return arr
 
 
+def gather_column(names, idx, keep=None) -> np.ndarray:
+    """object column of names[idx[i]] (None where `keep[i]` is false or idx[i] < 0): one fancy-index instead of a Python loop"""
+    pool = np.empty(len(names) + 1, dtype=object)
+    pool[:len(names)] = object_column(names)
+    pool[len(names)] = None
+    j = np.asarray(idx, np.int64)
+    bad = j < 0 if keep is None else (j < 0) | ~np.asarray(keep, bool)
+    return pool[np.where(bad, len(names), j)]
+
+
 class FrameBuilder:
     """The reference's result frame (_utils.py:104-125) built in row ranges: `fill(idx, val, row0)` writes the To /
     Similarity columns of rows [row0, row0 + len(idx)) -- so the first part of a split match can be turned into
