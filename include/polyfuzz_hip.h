@@ -124,7 +124,7 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
  * _utils.py:84-87; diag_offset = global index of from-row 0 when the from
  * side is a row shard).  lower_bound < 0 is treated as 0 (non-positive scores
  * are "no match" in the reference's output contract, _utils.py:122-123).
- * Limits: 1 <= ntop <= 128 (PFZ_ERR_UNSUPPORTED beyond); fewer than 2^25
+ * Limits: 1 <= ntop <= 1024 (PFZ_ERR_UNSUPPORTED beyond; above 128 a larger, slower candidate buffer); fewer than 2^25
  * 16-posting index pieces (4 GiB) in the to-side; n_cols equal on both sides.  `out` may have MORE rows than the from-matrix (a padded
  * shard buffer for the equal-sized all-gather): the extra rows are not touched.
  * Enqueues on the context stream. */
@@ -266,7 +266,7 @@ int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
  * from-side is matched against a replicated to-side on every GPU (BASELINE config 5).  normalize != 0:
  * rows are scaled by 1/||row|| (true cosine), 0: raw dot products.  pfz_dense_topn enqueues on the
  * context stream and leaves (idx, score) in `out` (rows [0, n_from)); exclude_diag drops
- * j == i + diag_offset.  1 <= ntop <= 128. */
+ * j == i + diag_offset.  1 <= ntop <= 1024. */
 typedef struct pfz_dense pfz_dense;
 int pfz_dense_upload(pfz_ctx *ctx, const float *vec, int64_t n, int64_t dim, int32_t normalize, pfz_dense **out);
 int pfz_dense_shape(const pfz_dense *m, int64_t *n, int64_t *dim);

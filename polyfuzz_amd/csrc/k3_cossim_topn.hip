@@ -62,7 +62,7 @@
 namespace pfz {
 
 constexpr int kMergeCap = 256;   // candidate keys per wave in k3_merge_slices
-constexpr int kMaxTop = 128;
+constexpr int kMaxTop = 1024;     // (beyond 128: a 1152-key candidate buffer -- half the resident workgroups -- and no to-slicing)
 constexpr int kSelectMinTop = 16;  // above this top_n, intermediate compactions select instead of sorting
 constexpr int kWarmMaxTop = 8;    // threshold warm start (one wave-max round per rank) up to this top_n
 constexpr int kPiece = 16;        // postings per piece (one 128-byte line, one 16-lane DPP row)
@@ -911,6 +911,7 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
         const int64_t want = (int64_t)ctx->prop.multiProcessorCount * 24;
         n_slices = n_rows >= want ? 1 : (int)((want + n_rows - 1) / n_rows);
     }
+    if (ntop > 128) n_slices = 1;      // (k3_merge_slices holds kMergeCap = 256 keys)
     n_slices = n_slices < 1 ? 1 : (n_slices > ix->n_blocks ? (ix->n_blocks > 0 ? ix->n_blocks : 1) : n_slices);
     if (ix->n_blocks > 0) {
         // no empty trailing slice (nb = 9, 8 slices -> 2 blocks per slice -> only 5 slices have blocks): an empty
@@ -928,7 +929,7 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     const unsigned grid = (unsigned)(items < max_grid ? items : max_grid / n_slices * n_slices);
     // candidate keys: room for ntop kept keys + the 64 one sweep step can add.  LDS per workgroup decides how
     // many from-rows a CU works on at once: 8 KiB of accumulators + 96 keys is 8960 B = 18 workgroups per CU
-    const int cap = ntop <= 32 ? 96 : (ntop <= 64 ? 128 : 256);
+    const int cap = ntop <= 32 ? 96 : (ntop <= 64 ? 128 : (ntop <= 128 ? 256 : 1152));
     const int ablate = env_int("PFZ_K3_ABLATE", 0);   // timing experiments only: 1 = no scatter, 2 = no sweep
     {
         ProfScope ps(ctx, "k3_cossim_topn");
@@ -942,7 +943,8 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     case CC:                                         \
         if (cap == 96) PFZ_K3_LAUNCH(CC, 96);        \
         else if (cap == 128) PFZ_K3_LAUNCH(CC, 128); \
-        else PFZ_K3_LAUNCH(CC, 256);                 \
+        else if (cap == 256) PFZ_K3_LAUNCH(CC, 256); \
+        else PFZ_K3_LAUNCH(CC, 1152);                \
         break;
         switch (ix->block_cols) {
             PFZ_K3_CASE(1024)

@@ -31,7 +31,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 128;   // workgroup tile (rows of A x rows of B)
 constexpr int kBK = 32;      // k-depth staged per step
-constexpr int kCap5 = 256;
 
 // normalize == 0: raw dot products are wanted, every scale factor is 1
 __global__ __launch_bounds__(256) void k5_inv_norms(const float *__restrict__ x, int64_t n, int64_t d,
@@ -288,7 +287,8 @@ __device__ inline uint64_t wave_max_u64_5(uint64_t v)
     return v;
 }
 
-// One wave per score row: top-n of the scores > thr.
+// One wave per score row: top-n of the scores > thr.  kCap5: candidate keys per wave (>= ntop + 1 + 64).
+template <int kCap5>
 __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, int64_t ld, int64_t a0, int64_t a1,
                                                     int64_t n_b, int32_t ntop, float lower_bound, int32_t exclude_diag,
                                                     int64_t diag_offset, int32_t *__restrict__ out_idx,
@@ -512,8 +512,8 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
                 (long long)to->dim);
     PFZ_REQUIRE(ntop >= 1, "pfz_dense_topn: ntop must be >= 1");
     PFZ_REQUIRE(lower_bound == lower_bound, "pfz_dense_topn: lower_bound is NaN");
-    if (ntop > 128) {
-        set_error("pfz_dense_topn: ntop=%d exceeds the kernel's limit of 128", ntop);
+    if (ntop > 1024) {
+        set_error("pfz_dense_topn: ntop=%d exceeds the kernel's limit of 1024", ntop);
         return PFZ_ERR_UNSUPPORTED;
     }
     PFZ_REQUIRE(out->n_rows >= from->n && out->ntop == ntop, "pfz_dense_topn: result buffer is %lldx%d, need %lldx%d",
@@ -576,8 +576,12 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         }
         {
             ProfScope ps(ctx, "k5_row_topn", ts);
-            hipLaunchKernelGGL(k5_row_topn, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ts, (const float *)S, ld, a0, a1,
-                               n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx, out->val, M, ld / 64);
+            if (ntop <= 128)
+                hipLaunchKernelGGL(k5_row_topn<256>, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ts, (const float *)S, ld, a0,
+                                   a1, n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx, out->val, M, ld / 64);
+            else
+                hipLaunchKernelGGL(k5_row_topn<1152>, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ts, (const float *)S, ld, a0,
+                                   a1, n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx, out->val, M, ld / 64);
         }
         if (two) PFZ_HIP(hipEventRecord(consumed[buf], ts));
     }

@@ -22,7 +22,7 @@ def _check(idx, val, e_idx, e_val, dense, tol=1e-5):
 
 
 @pytest.mark.parametrize("n_a,n_b,d,ntop", [(6, 3, 300, 2), (1, 1, 1, 1), (130, 257, 768, 5), (300, 1000, 33, 10),
-                                            (513, 129, 64, 128)])
+                                            (513, 129, 64, 128), (70, 2000, 96, 400)])
 def test_random_dense_vs_oracle(ctx, oracle_mod, n_a, n_b, d, ntop):
     from polyfuzz_amd import _lib
     rng = np.random.default_rng(n_a + n_b + d)

@@ -70,6 +70,7 @@ def test_company_self_match(ctx, oracle_mod, golden):
 @pytest.mark.parametrize("n_a,n_b,n_col,dens,ntop", [
     (1, 1, 5, 0.9, 1), (3, 5000, 40, 0.2, 7), (257, 2049, 300, 0.05, 4), (64, 4097, 64, 0.5, 128),
     (100, 70, 2000, 0.09, 3),   # rows with > 64 n-grams
+    (40, 3000, 50, 0.4, 300), (9, 5000, 30, 0.6, 1024),   # top_n beyond 128: the 1152-key candidate buffer
 ])
 def test_random_csr_shapes(ctx, oracle_mod, n_a, n_b, n_col, dens, ntop):
     rng = np.random.default_rng(n_a * 7 + n_b)
@@ -146,7 +147,7 @@ def test_bad_arguments(ctx):
     with pytest.raises(PfzError):
         _lib.cossim_topn_host(ctx, e3, e3, 4, 0, 0.0)
     with pytest.raises(NotImplementedError):
-        _lib.cossim_topn_host(ctx, e3, e3, 4, 1000, 0.0)
+        _lib.cossim_topn_host(ctx, e3, e3, 4, 1025, 0.0)
 
 
 @pytest.mark.parametrize("fa,fb", [(7.5, 3.0), (1e-3, 2e-2), (300.0, 1e-4)])
