@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
     __shared__ double red_s[4];
     __shared__ int red_i[4];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup holds so far (>= 0)
+    // the to-characters of the form a lane is working on, [position][lane] per wave (groups of up to 64 positions):
+    // the window sweeps re-read them |from| times, and a global load per recurrence step is a dependent ~500-cycle
+    // round trip (waves sat in s_waitcnt two thirds of their cycles)
+    __shared__ uint16_t s_sym[4][64][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
 
@@ -191,6 +195,18 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
 #pragma unroll
             for (int w = 0; w < W; ++w) all[w] = ~0ull;
 
+            int staged = -1;            // (per lane: a lane stages and reads only its own column)
+            auto stage = [&](int v, int steps, int64_t off) {
+                if (steps > 64 || staged == v) return;
+#pragma unroll 4
+                for (int pos = 0; pos < steps; ++pos) s_sym[wave][pos][lane] = A.b_sym[v][off + (int64_t)pos * 64];
+                staged = v;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            };
+            auto sym_at = [&](int v, int steps, int64_t off, int pos) -> int {
+                return steps <= 64 ? (int)s_sym[wave][pos][lane] : (int)A.b_sym[v][off + (int64_t)pos * 64];
+            };
+
             // LCS of the from-form v (restricted to `amask`) and the lane's to-form v; with `rb` only the to-tokens
             // whose bit is set are fed (form 2), the space after the last of them left out
             auto lcs_pass = [&](int v, const uint64_t (&amask)[W], bool tagged, uint32_t rb, int last_rb, uint64_t (&V)[W]) {
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                 for (int w = 0; w < W; ++w) V[w] = ~0ull;
                 const int steps = __builtin_amdgcn_readfirstlane(A.b_gmax[v][g]);
                 const int64_t off = A.b_goff[v][g] + lane;
-                for (int pos = 0; pos < steps; ++pos) {
+                for (int pos = 0; pos < steps; ++pos) {        // (one pass: straight from global memory, staging would cost more)
                     int sy = A.b_sym[v][off + (int64_t)pos * 64];
                     if (tagged) {
                         const int tag = A.b_tag[off + (int64_t)pos * 64], j = tag & 31;
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                 };
                 const int steps = __builtin_amdgcn_readfirstlane(A.b_gmax[v][g]);
                 const int64_t off = A.b_goff[v][g] + lane;
+                stage(v, steps, off);
                 uint64_t V[W];
                 if (__any(lb >= la)) {
                     // the from-form is the shorter (or equal): windows of the to-form starting at s
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                         for (int w = 0; w < W; ++w) V[w] = ~0ull;
                         for (int k = 0; k < la; ++k) {
                             const int pos = s + k;
-                            const int sy = (on && k < wlen && pos < steps) ? A.b_sym[v][off + (int64_t)pos * 64] : 0;
+                            const int sy = (on && k < wlen && pos < steps) ? sym_at(v, steps, off, pos) : 0;
                             bv_step<W>(V, pm + (sy * 3 + v) * W, all);
                             if (s == 0 && on && k + 1 < la) cand(zeros_below<W>(V, la), la + k + 1);       // prefixes
                         }
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
 #pragma unroll
                         for (int w = 0; w < W; ++w) V[w] = ~0ull;
                         for (int pos = 0; pos < steps; ++pos) {
-                            const int sy = on ? A.b_sym[v][off + (int64_t)pos * 64] : 0;
+                            const int sy = on ? sym_at(v, steps, off, pos) : 0;
                             bv_step<W>(V, pm + (sy * 3 + v) * W, m);
                         }
                         if (on) {
