@@ -221,6 +221,45 @@ class DenseMatchJob:
         return self.gathered if self.gathered is not None else self.local
 
 
+class BestChoiceJob:
+    """The edit-distance matchers on a row shard ("shard from-strings, replicate to-strings"):
+    every rank scores its from-strings against the whole to-list -- K4 for ratio / QRatio / token_sort_ratio, K7 for
+    WRatio and the other per-pair scorers (reference _distance.py:89-102, _rapidfuzz.py:99-113) -- and the per-shard
+    (first best index, float64 score) blocks are all-gathered, padded to the largest shard.  The float64 scores travel
+    as two 32-bit words in the value lanes of a two-column result buffer (the gather moves bytes), so every rank ends with
+    the exact scores of all from-strings -- which is also all the reference's global min-max normalisation needs."""
+
+    def __init__(self, ctx, from_shard, to_list, scorer="ratio", comm=None, skip=None, rows_per_rank=None):
+        from .models._rapidfuzz import _DEVICE_SCORERS
+        if scorer not in _DEVICE_SCORERS:
+            raise NotImplementedError(f"scorer {scorer!r} has no kernel")
+        self.ctx, self.comm, self.scorer = ctx, comm, scorer
+        self.from_shard, self.to_list, self.skip = list(from_shard), to_list, skip
+        self.n_from = len(self.from_shard)
+        self.rows_per_rank = self.n_from if rows_per_rank is None else int(rows_per_rank)
+        if self.rows_per_rank < self.n_from:
+            raise ValueError("rows_per_rank is smaller than this rank's shard")
+
+    def step(self):
+        from .models._rapidfuzz import best_choice
+        idx, score = best_choice(self.ctx, self.scorer, self.from_shard, self.to_list, self.skip, False)
+        if self.comm is None or self.comm.world == 1:
+            return idx, score
+        pad = self.rows_per_rank
+        pi = np.full((pad, 2), -1, np.int32)
+        pv = np.zeros((pad, 2), np.float32)
+        pi[:self.n_from, 0] = idx
+        pv[:self.n_from] = np.ascontiguousarray(score, np.float64).view(np.float32).reshape(-1, 2)
+        local = _lib.DeviceTopN.from_host(self.ctx, pi, pv)
+        g_idx, g_val = self.comm.allgather_topn(local).download()
+        return g_idx[:, 0].copy(), np.ascontiguousarray(g_val).view(np.float64).reshape(-1)
+
+    @staticmethod
+    def unpad(idx, score, sizes, rows_per_rank):
+        keep = np.concatenate([np.arange(r * rows_per_rank, r * rows_per_rank + m) for r, m in enumerate(sizes)])
+        return idx[keep], score[keep]
+
+
 def run_sharded_job(ctxs, comms, from_list, to_list, **job_kw):
     """One process, several contexts: run the row-sharded job with one host thread per rank and return
     (idx, val) of the full from-list (the ranks' all-gathered, un-padded result; identical on every rank).

@@ -110,3 +110,38 @@ def test_world2_to_side_sharding_and_merge(oracle_mod, self_match):
     np.testing.assert_array_equal(outs[0][0][0], outs[1][0][0])
     for c in comms:
         c.free()
+
+
+def test_world2_best_choice_job_edit_distance_and_wratio(oracle_mod):
+    """SURVEY section 8e for the edit-distance matchers: from-strings sharded over two ranks (uneven: 61 = 31 + 30), the
+    to-list replicated, (index, float64 score) blocks all-gathered through the library's transport -- the exact
+    scores arrive on every rank (K4 ratio and K7 WRatio), equal to the single-context result and to the oracles."""
+    import concurrent.futures as cf
+    import polyfuzz_amd
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd import _lib, pipeline, synth
+    fl, tl = synth.company_names(61, 21), synth.company_names(150, 22)
+    ctxs = [polyfuzz_amd.Context(0), polyfuzz_amd.Context(0)]
+    comms = _lib.Comm.local_group(ctxs)
+    bounds = [pipeline.shard_bounds(len(fl), 2, r) for r in range(2)]
+    sizes = [e - b for b, e in bounds]
+    rpr = max(sizes)
+    for scorer in ("ratio", "WRatio"):
+        def rank_fn(r):
+            b, e = bounds[r]
+            job = pipeline.BestChoiceJob(ctxs[r], fl[b:e], tl, scorer=scorer, comm=comms[r], rows_per_rank=rpr)
+            return pipeline.BestChoiceJob.unpad(*job.step(), sizes, rpr)
+        with cf.ThreadPoolExecutor(2) as ex:
+            outs = [x.result(timeout=120) for x in [ex.submit(rank_fn, r) for r in range(2)]]
+        single = pipeline.BestChoiceJob(ctxs[0], fl, tl, scorer=scorer).step()
+        if scorer == "ratio":
+            e_idx, e_score = oracle_mod.indel_argmax(fl, tl)
+        else:
+            e_idx, e_score = f.extract_one_all(fl, tl, f.WRatio)
+        for idx, score in outs:
+            np.testing.assert_array_equal(idx, single[0])
+            np.testing.assert_array_equal(score, single[1])
+            np.testing.assert_array_equal(idx, np.array(e_idx, np.int32))
+            np.testing.assert_array_equal(score, np.array(e_score, np.float64))
+    for c in comms:
+        c.free()
