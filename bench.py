@@ -60,8 +60,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-match-wall", action="store_true", help="skip the .match() wall time and the latency leg")
-    ap.add_argument("--config", choices=("tfidf", "editdistance"), default="tfidf",
-                    help="editdistance: BASELINE.json config 3 (EditDistance, 20k x 20k IMDB titles), single GPU")
+    ap.add_argument("--config", choices=("tfidf", "editdistance", "dense"), default="tfidf",
+                    help="editdistance: BASELINE.json config 3 (EditDistance, 20k x 20k IMDB titles), single GPU; "
+                         "dense: one GPU's shard of config 5 (62.5k x 500k x 768 embeddings, cosine top-10)")
     return ap.parse_args()
 
 
@@ -301,12 +302,76 @@ def bench_editdistance(args):
     print(json.dumps(out))
 
 
+def bench_dense(args):
+    """BASELINE.json config 5 / SURVEY.md section 8d: dense cosine top-10 of 500k x 500k 768-d embeddings on 8 GPUs --
+    here ONE GPU's share: a 62 500-row from-shard against all 500 000 to-vectors (K5), operands resident in HBM.
+    One step = the shard's GEMM panels + row top-n.  Roofline: exact-fp32 MFMA."""
+    import polyfuzz_amd
+    from polyfuzz_amd import pipeline
+    ctx = polyfuzz_amd.Context.default()
+    n_to, n_from, d, top_n = 500_000, 62_500, 768, 10
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal((n_to, d), dtype=np.float32)
+    a = rng.standard_normal((n_from, d), dtype=np.float32)
+    pick = rng.choice(n_to, n_from, replace=False)
+    a += 2.0 * b[pick]                       # planted near-duplicates: the top rank is known
+    job = pipeline.DenseMatchJob(ctx, a, b, top_n=top_n)
+    for _ in range(max(1, args.warmup)):
+        job.step()
+    ctx.sync()
+    ctx.prof_enable(2)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = job.step()
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    gemm_ms, launches = ctx.prof_get("k5_gemm_panel")
+    idx, val = res.download()
+    flop = 2.0 * n_from * n_to * d
+    # CPU arm + parity on a bounded sample: float64 BLAS cosine + top-n of a few from-rows (oracle/dense.py)
+    import oracle
+    rows = rng.choice(n_from, 8, replace=False)
+    c0 = time.perf_counter()
+    bad, err = 0, 0.0
+    for i in rows:
+        e_idx, e_val = oracle.dense_cossim_topn(a[i:i + 1], b, top_n, 0.0)
+        err = max(err, float(np.abs(val[i] - e_val[0]).max()))
+        bad += int(not np.array_equal(idx[i], e_idx[0]))
+    dt = time.perf_counter() - c0
+    gemm_s = gemm_ms / max(1, launches) * 1e-3 * (launches / args.steps)       # GEMM time per step
+    out = {
+        "metric": "vector pairs/sec, dense cosine top-10, one GPU's shard of 500k x 500k x 768 (BASELINE config 5)",
+        "value": float(n_from) * n_to * args.steps / wall, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (SURVEY.md section 8d config 5: standard normal rows, planted near-duplicates)",
+        "config": {"workload": "Embeddings-style cosine top-10: 62 500 from-vectors (one of 8 row shards) x 500 000 to-vectors x 768, "
+                               "operands resident, pipeline.DenseMatchJob", "n_from": n_from, "n_to": n_to, "dim": d, "top_n": top_n},
+        "kernel_ms_per_step": {"k5_gemm_panel": round(gemm_ms / args.steps, 3), "launches_per_step": launches / args.steps},
+        "roofline": {"kernel": "k5_gemm_panel_pipe", "bound": "mfma", "achieved": flop / gemm_s / 1e12, "peak": 157.3,
+                     "unit": "TFLOP/s", "frac": flop / gemm_s / 1e12 / 157.3, "traffic": None,
+                     "end_to_end_frac": flop * args.steps / wall / 1e12 / 157.3,
+                     "what": "2 n_from n_to d flops of exact fp32 products (v_mfma_f32_32x32x2_f32) over the GEMM panels' "
+                             "summed launch time; end_to_end_frac = over the whole step (row top-n included)"},
+        "cpu_baseline": {"value": len(rows) * float(n_to) / dt, "unit": "pairs/s", "cores": int(os.cpu_count() or 1), "kind": "port",
+                         "sample": f"{len(rows)} from-rows x all {n_to} to-vectors, oracle/dense.py (float64 numpy / BLAS), {dt:.1f} s"},
+        "parity_check": {"rows_checked": int(len(rows)), "rows_with_index_diff": bad, "max_abs_score_err": err,
+                         "planted_match_found_top1": float((idx[:, 0] == pick).mean())},
+    }
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     if args.config == "editdistance":
         if args.gpus != 1:
             raise SystemExit("--config editdistance is a single-GPU configuration")
         return bench_editdistance(args)
+    if args.config == "dense":
+        if args.gpus != 1:
+            raise SystemExit("--config dense times one GPU's shard; the 8-GPU job is eight of them (pipeline.DenseMatchJob)")
+        return bench_dense(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
