@@ -13,6 +13,7 @@ echo "bench rc=$?"
 tail -c 600 gpurun_out/${tag}_bench.err
 timeout 300 python bench.py --config editdistance > gpurun_out/${tag}_editdistance.json 2>> gpurun_out/${tag}_bench.err
 timeout 400 python tools/scale_dense_500k.py 2>&1 | tail -1 > gpurun_out/${tag}_scale_dense_500k_shard.json
+timeout 400 python bench.py --config dense --steps 5 --warmup 1 > gpurun_out/${tag}_dense.json 2>> gpurun_out/${tag}_bench.err
 timeout 400 python tools/scale_1m.py 2>&1 | tail -1 > gpurun_out/${tag}_scale_1m_shard.json
 timeout 300 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio > gpurun_out/${tag}_k7.log 2>&1
 timeout 700 bash tools/profile_bench.sh gpurun_out/${tag}_profile > gpurun_out/${tag}_profile.log 2>&1
