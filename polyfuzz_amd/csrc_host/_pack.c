@@ -168,6 +168,28 @@ static PyObject *pack(PyObject *self, PyObject *args)
  * The workers make no Python API call: they bump reference counts with atomic adds and store into disjoint
  * slots, while the calling thread keeps the GIL and waits, so no other reference-count update can race.
  */
+/* Reference counts are only ever edited directly where that is exact: CPython < 3.12 (every object mortal, ob_refcnt a
+ * plain Py_ssize_t).  From 3.12 on None and interned strings are IMMORTAL -- Py_INCREF / Py_DECREF of them are no-ops
+ * and their count must not be touched -- so there the threaded fill is off (Py_INCREF under the GIL only) and the
+ * references to None that np.empty(n, object) "held" need no release. */
+#ifdef Py_GIL_DISABLED
+#error "_pack.c relies on the GIL (free-threaded CPython is not supported)"
+#endif
+#if PY_VERSION_HEX >= 0x030C0000
+#define PFZ_DIRECT_REFCNT 0
+#else
+#define PFZ_DIRECT_REFCNT 1
+#endif
+
+static void release_overwritten_none(Py_ssize_t k)
+{
+#if PFZ_DIRECT_REFCNT
+    Py_None->ob_refcnt -= k;                   /* None stays alive: the interpreter holds references of its own */
+#else
+    (void)k;                                   /* immortal None: np.empty's Py_INCREF(None) was a no-op too */
+#endif
+}
+
 typedef struct {
     PyObject **items;
     Py_ssize_t n_names, n, top_n;
@@ -200,8 +222,13 @@ static void fill_range(const fill_job *job, Py_ssize_t r, Py_ssize_t lo, Py_ssiz
         if (s < 0.001 || j < 0 || j >= n_names) s = 0.0;
         else o = items[j];
         sim[i] = s;
+#if PFZ_DIRECT_REFCNT
         if (atomic) __atomic_fetch_add(&o->ob_refcnt, 1, __ATOMIC_RELAXED);
         else Py_INCREF(o);
+#else
+        (void)atomic;
+        Py_INCREF(o);
+#endif
         obj[i] = o;
     }
 }
@@ -270,6 +297,9 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
     const long n_tasks = (long)(job.n_chunks * top_n);
     if (n_threads > 16) n_threads = 16;
     if (n_threads > n_tasks) n_threads = (int)n_tasks;
+#if !PFZ_DIRECT_REFCNT
+    n_threads = 1;                             /* no atomic reference counts next to immortal objects */
+#endif
     int started = 0;
     pthread_t th[16];
     if (n * top_n >= 65536 && n_threads > 1) {
@@ -282,7 +312,7 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
     } else {
         for (Py_ssize_t r = 0; r < top_n; ++r) fill_range(&job, r, 0, n, 0);
     }
-    Py_None->ob_refcnt -= old_none;            /* the references the overwritten slots held (None stays alive) */
+    release_overwritten_none(old_none);        /* the references the overwritten slots held */
     Py_DECREF(seq);
     Py_RETURN_NONE;
 }
@@ -320,7 +350,7 @@ static PyObject *fill_objects(PyObject *self, PyObject *args)
         Py_INCREF(items[i]);
         dst[i] = items[i];
     }
-    Py_None->ob_refcnt -= old_none;
+    release_overwritten_none(old_none);
     Py_DECREF(seq);
     Py_RETURN_NONE;
 }

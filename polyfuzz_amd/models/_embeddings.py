@@ -62,7 +62,8 @@ class Embeddings(BaseMatcher):
         (reference _embeddings.py:87-135) """
         if not isinstance(embeddings_from, np.ndarray):
             embeddings_from = self._embed(from_list)
-        if not isinstance(embeddings_to, np.ndarray):
+        explicit_to = isinstance(embeddings_to, np.ndarray)     # the caller's own to-side always wins (_embeddings.py:117-133)
+        if not explicit_to:
             if not re_train:
                 embeddings_to = self.embeddings_to
                 if embeddings_to is None:
@@ -78,8 +79,9 @@ class Embeddings(BaseMatcher):
         normalize = self.cosine_method != "sparse"        # "sparse": raw dot products (reference _utils.py:74-82)
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
         # the to-side stays in HBM: match(..., re_train=False) (PolyFuzz.transform, polyfuzz.py:234-240) uploads
-        # the new from-vectors only
-        if re_train or self._dev_to is None or self._dev_to_normalize != normalize:
+        # the new from-vectors only; an explicitly passed to-side is uploaded unless it IS the resident one
+        stale = explicit_to and embeddings_to is not self.embeddings_to
+        if re_train or stale or self._dev_to is None or self._dev_to_normalize != normalize:
             self._dev_to = _lib.DeviceDense.upload(ctx, np.asarray(embeddings_to), normalize)
             self._dev_to_normalize = normalize
         self_match = to_list is None

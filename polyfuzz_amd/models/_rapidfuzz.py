@@ -37,10 +37,14 @@ _DEVICE_SCORERS = _K4_SCORERS + tuple(_lib.FUZZ_SCORERS)
 
 
 def _scorer_name(scorer) -> str:
+    """Name of the rapidfuzz.fuzz scorer `scorer` stands for; a callable from anywhere else (Levenshtein.ratio on
+    its 0..1 scale, a user's own `ratio`) must not be mistaken for the rapidfuzz function of the same name."""
     if scorer is None:
         return "WRatio"                                   # the reference's default, fuzz.WRatio
     if isinstance(scorer, str):
         return scorer
+    if "rapidfuzz" not in (getattr(scorer, "__module__", "") or ""):
+        return repr(scorer)
     return getattr(scorer, "__name__", repr(scorer))
 
 
@@ -64,7 +68,7 @@ def best_choice(ctx, name, from_list, names, skip, self_match):
         # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string
         # scores 0 against every choice, so its first best is simply its first choice
         for i in [i for i, s in enumerate(from_list) if len(s) == 0]:
-            first_choice = next((j for j in range(len(names)) if not (self_match and j == skip[i])), -1)
+            first_choice = next((j for j in range(len(names)) if not (skip is not None and j == skip[i])), -1)
             idx[i], score[i] = first_choice, 0.0
     return idx, score
 

@@ -66,6 +66,22 @@ def test_edit_distance_scorer_gate():
     EditDistance(scorer=ratio())
 
 
+def test_rapidfuzz_scorer_gate_checks_the_module():
+    """a callable merely NAMED like a rapidfuzz scorer (Levenshtein.ratio, a user's own WRatio) has no kernel"""
+    from polyfuzz_amd.models import RapidFuzz
+
+    def ratio(a, b):
+        return 1.0
+    with pytest.raises(NotImplementedError):
+        RapidFuzz(scorer=ratio)
+
+    class WRatio:
+        __name__ = "WRatio"
+        __module__ = "rapidfuzz.fuzz_py"
+    assert RapidFuzz(scorer=WRatio())._scorer_name == "WRatio"
+    assert RapidFuzz()._scorer_name == "WRatio" and RapidFuzz(scorer="token_set_ratio")._scorer_name == "token_set_ratio"
+
+
 def test_base_matcher_is_abstract():
     from polyfuzz_amd.models import BaseMatcher, TFIDF
     with pytest.raises(TypeError):
