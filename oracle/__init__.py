@@ -25,7 +25,8 @@ Pinning status (see DESIGN.md "Oracle"):
 * fuzz_scorers.py: the other rapidfuzz.fuzz scorers (partial_ratio, token_set_ratio, token_ratio,
   partial_token_*, WRatio -- the RapidFuzz matcher's default) restated in plain Python from rapidfuzz 3.x's
   published semantics: PARITY UNPINNED, anchored on the values rapidfuzz publishes
-  (tests/test_fuzz_oracle_cpu.py).
+  (tests/test_fuzz_oracle_cpu.py).  fuzz_scorers.c is the same statement in plain C (held equal to the Python file
+  bit for bit by the same test): the fast checker of K7 at full list sizes and bench.py's CPU arm for RapidFuzz.
 * reference_path.py: the reference's own executable TF-IDF path (sklearn
   vectoriser + dense cosine + full sorts + frame), the CPU arm "(i)" of
   bench.py -- pinned cell for cell on frames the reference package produced.
@@ -36,5 +37,5 @@ Pinning status (see DESIGN.md "Oracle"):
 """
 from .tfidf_oracle import (clean_string, create_ngrams, TfidfOracle)      # noqa: F401
 from .dense import dense_cossim, dense_cossim_topn   # noqa: F401
-from .native import (cossim_topn, cossim_dense, indel_ratio, indel_argmax,  # noqa: F401
+from .native import (cossim_topn, cossim_dense, indel_ratio, indel_argmax, fuzz_score, fuzz_extract_one,  # noqa: F401
                      build as build_native)

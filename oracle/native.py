@@ -17,7 +17,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force=False):
     """Compile the C restatement with gcc (no GPU needed)."""
-    srcs = [os.path.join(_HERE, f) for f in ("cossim_topn.c", "indel.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("cossim_topn.c", "indel.c", "fuzz_scorers.c")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -50,6 +50,12 @@ def _load():
         _u32p, _i64p, ctypes.c_int64, _u32p, _i64p, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
         _i32p, _f64p, ctypes.c_void_p]
+    lib.oracle_fuzz_score.restype = ctypes.c_double
+    lib.oracle_fuzz_score.argtypes = [_u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int32]
+    lib.oracle_fuzz_extract_one.restype = ctypes.c_int
+    lib.oracle_fuzz_extract_one.argtypes = [
+        _u32p, _i64p, ctypes.c_int64, _u32p, _i64p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.c_int64, _i32p, _f64p]
     _lib = lib
     return lib
 
@@ -124,3 +130,37 @@ def indel_argmax(from_list, to_list, self_match=False, rows=None, want_matrix=Fa
     if rc != 0:
         raise MemoryError("oracle_indel_argmax failed")
     return (out_idx, out_score, mat) if want_matrix else (out_idx, out_score)
+
+
+# the order of oracle/fuzz_scorers.c's scorer enum
+FUZZ_SCORER_IDS = {name: i for i, name in enumerate(
+    ("ratio", "QRatio", "partial_ratio", "token_sort_ratio", "token_set_ratio", "token_ratio", "partial_token_sort_ratio",
+     "partial_token_set_ratio", "partial_token_ratio", "WRatio"))}
+
+
+def fuzz_score(a, b, scorer):
+    """One pair under the rapidfuzz.fuzz scorer `scorer` (oracle/fuzz_scorers.c, == oracle/fuzz_scorers.py)."""
+    lib = _load()
+    ca = np.array([ord(c) for c in a] or [0], np.uint32)
+    cb = np.array([ord(c) for c in b] or [0], np.uint32)
+    return lib.oracle_fuzz_score(ca, len(a), cb, len(b), FUZZ_SCORER_IDS[scorer])
+
+
+def fuzz_extract_one(from_list, to_list, scorer, skip=None, rows=None):
+    """process.extractOne(from_string, to_list, scorer=fuzz.<scorer>) for from-rows `rows` = (begin, end):
+    (index of the first best choice int32 (-1: none), its score float64 on the 0..100 scale)."""
+    lib = _load()
+    acp, aoff = _codepoints(from_list)
+    bcp, boff = _codepoints(to_list)
+    r0, r1 = (0, len(from_list)) if rows is None else rows
+    out_idx = np.empty(r1 - r0, np.int32)
+    out_score = np.empty(r1 - r0, np.float64)
+    sk = None
+    if skip is not None:
+        sk = np.ascontiguousarray(skip, np.int32)
+        assert len(sk) == len(from_list)
+    rc = lib.oracle_fuzz_extract_one(acp, aoff, len(from_list), bcp, boff, len(to_list), FUZZ_SCORER_IDS[scorer],
+                                     sk.ctypes.data_as(ctypes.c_void_p) if sk is not None else None, r0, r1, out_idx, out_score)
+    if rc != 0:
+        raise ValueError(f"oracle_fuzz_extract_one failed ({rc})")
+    return out_idx, out_score

@@ -51,19 +51,43 @@ def build_host_helpers(force=False, verbose=False):
     return PACK_PATH
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source of the package into polyfuzz_amd/libpolyfuzz_hip.so (and the host helper)."""
-    build_host_helpers(force, verbose)
-    if not force and not is_stale():
-        return LIB_PATH
-    rocm_lib = "/opt/rocm/lib"
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC] + sources() + \
-          ["-L", rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib, "-o", LIB_PATH + ".tmp"]
+OBJ_DIR = os.path.join(CSRC, "_obj")
+
+
+def _compile_one(src, force, verbose):
+    """one translation unit -> csrc/_obj/<name>.o (skipped when newer than the source and every header)"""
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+        return obj, False
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PFZ_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [_hipcc()] + flags + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=REPO)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(obj + ".tmp", obj)
+    return obj, True
+
+
+def build(force=False, verbose=False, out=None):
+    """Compile every HIP source of the package (one object per source, in parallel, re-used while up to date) and link
+    them into polyfuzz_amd/libpolyfuzz_hip.so; also builds the host helper.  `out`: link to another path (variants)."""
+    build_host_helpers(force, verbose)
+    lib = out or LIB_PATH
+    if not force and out is None and not is_stale():
+        return lib
+    import concurrent.futures as cf
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with cf.ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
+        objs = [o for o, _ in ex.map(lambda s: _compile_one(s, force, verbose), sources())]
+    rocm_lib = "/opt/rocm/lib"
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + \
+          ["-L", rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib, "-o", lib + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=REPO)
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":

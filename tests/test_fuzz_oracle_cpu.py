@@ -54,3 +54,37 @@ def test_bit_vector_lcs_equals_the_dp():
             b = "".join(rng.choice(list(alphabet), size=int(rng.integers(0, 90))))
             assert f.lcs_len(a, b) == f.lcs_len_dp(a, b), (a, b)
     assert f.lcs_len("", "abc") == 0 and f.lcs_len("abc", "abc") == 3
+
+
+def test_c_restatement_equals_the_python_one_bit_for_bit(oracle_mod):
+    """oracle/fuzz_scorers.c (the fast checker of K7 at full list sizes, bench.py's CPU arm) == oracle/fuzz_scorers.py:
+    every scorer, real titles and names, empty / blank / repeated-token / non-ASCII-whitespace strings; extractOne with
+    and without a skipped choice."""
+    import random
+    import numpy as np
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd import datasets, synth
+    fl, tl = datasets.c3_lists(400)
+    rng = random.Random(1)
+    names = fl + tl + synth.company_names(150, 3) + ["", " ", "a", "a a", "b a a", "  x  y ", "the the", "new york mets",
+                                                      "new york mets vs atlanta braves", "été　x", "a\tb\nc\x1fd\x85e\xa0f"]
+    for name, fn in f.SCORERS.items():
+        for _ in range(400):
+            a, b = rng.choice(names), rng.choice(names)
+            if rng.random() < 0.25:
+                b = a[:rng.randint(0, len(a))] + " " + rng.choice(names)[:5]
+            assert fn(a, b) == oracle_mod.fuzz_score(a, b, name), (name, a, b)
+    a_list, b_list = fl[:12] + ["", "x"], tl[:150] + ["", "The"]
+    for name in ("WRatio", "token_set_ratio", "partial_ratio", "QRatio"):
+        idx, score = f.extract_one_all(a_list, b_list, f.SCORERS[name])
+        c_idx, c_score = oracle_mod.fuzz_extract_one(a_list, b_list, name)
+        assert idx == c_idx.tolist() and score == c_score.tolist(), name
+    own = fl[:40] + fl[:5]
+    first = {}
+    for j, s in enumerate(own):
+        first.setdefault(s, j)
+    skip = [first[s] for s in own]
+    idx, score = f.extract_one_all(own, own, f.WRatio, skip=skip)
+    c_idx, c_score = oracle_mod.fuzz_extract_one(own, own, "WRatio", skip=skip, rows=(3, 45))
+    assert idx[3:] == c_idx.tolist() and score[3:] == c_score.tolist()
+    assert np.array_equal(oracle_mod.fuzz_extract_one(["a"], [], "WRatio")[0], [-1])
