@@ -1,29 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- string-pairs/sec + top-1 match latency of the TF-IDF cosine top-n hot path on MI355X.
+"""bench.py -- string-pairs/sec + top-1 match latency of the TF-IDF cosine top-n hot path on MI355X, with every other
+BASELINE.json configuration measured beside it in the same run.
 
-Workload (BASELINE.json metric "TF-IDF cosine 100k x 100k"; SURVEY.md §8d "Headline"): the 100 000 real
-SEC-EDGAR company names of the reference's data/company_names.json (shipped gzipped in polyfuzz_amd/data/,
-the GPU box has no network), SELF-MATCH, char-3-gram TF-IDF, cosine top-5, min_similarity 0 -- i.e.
+Headline workload (BASELINE.json metric "TF-IDF cosine 100k x 100k"; SURVEY.md section 8d "Headline"): the 100 000 real
+SEC-EDGAR company names of the reference's data/company_names.json (shipped gzipped in polyfuzz_amd/data/, the GPU
+box has no network), SELF-MATCH, char-3-gram TF-IDF, cosine top-5, min_similarity 0 -- i.e.
 `TFIDF(min_similarity=0, top_n=5).match(names)` (reference docs/tutorial/datasets/datasets.md:36-41).
 
-One "step" = one pass of the hot path with the string list already resident in HBM: fit vocabulary + idf on
-the list, vectorise it, build the inverted index, run the fused cosine top-n with the diagonal excluded --
-everything `TFIDF.match` does between receiving the list and assembling the DataFrame (reference
-_tfidf.py:93-98,113-116, _utils.py:54-102).  `value` = N_from * N_to * steps / wall.
+One "step" = one pass of the hot path with the string list already resident in HBM: fit vocabulary + idf on the list,
+vectorise it, build the inverted index, run the fused cosine top-n with the diagonal excluded -- everything
+`TFIDF.match` does between receiving the list and assembling the DataFrame (reference _tfidf.py:93-98,113-116,
+_utils.py:54-102).  `value` = N_from * N_to * steps / wall of those steps (the bench contract: inputs resident in HBM
+when the timed region starts; a PCIe-inclusive rate is never `value`).  SURVEY.md section 8d defines the metric over the
+wall time of `.match()` (Python list in, DataFrame out: pack, H2D, the same device step, D2H, frame): that number is
+`match_pairs_per_s` / `match_wall_ms` of the same line, measured on the same workload right after the timed region.
 
 The same JSON line also carries, measured after the timed region on rank 0 at N = 1:
-  match_wall_ms / match_pairs_per_s  `TFIDF(...).match(names)` from a Python list to the DataFrame
-                                     (packing, H2D, device step, D2H, frame) -- what a user sees
+  match_wall_ms / match_pairs_per_s  the section-8d metric (see above)
   latency.top1_single_query_ms       one query string against the fitted 100k list, top-1, re_train=False
-  roofline, cpu_baseline (+ cpu_baseline_arms), parity_check
+  roofline, cpu_baseline (+ cpu_baseline_arms), parity_check (a seeded RANDOM sample of from-rows vs the oracle)
+  configs                            compact sub-records, each with ms_per_step, match_wall_ms, roofline, cpu_baseline and
+                                     a random-row parity_check:  c2_tfidf_10k (config 2), editdistance (config 3),
+                                     rapidfuzz_wratio (RapidFuzz() = what PolyFuzz("EditDistance") runs, on config 3's
+                                     lists), dense_shard (one GPU's share of config 5), tfidf_1m_shard (of config 4)
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU):
-  --scaling weak   (default) every rank matches its own 100k from-rows against the replicated real list:
-                   the global from-list is N x 100k names (rank 0: the real names = the headline self-match,
-                   rank r > 0: synthetic names of the same token statistics); fit on the replicated list,
-                   no data-path collective except the all-gather of the per-shard top-n blocks (RCCL)
-  --scaling strong the one 100k x 100k self-match, its from-rows split over the N ranks
-torch is used for rendezvous / barrier / the max-over-ranks only, never in the data path.
+Multi-GPU (--gpus N; launched by torch.distributed.run, one process per GPU, RCCL -- or `--transport local`: one
+process, N contexts, one host thread per rank, the library's in-process transport: a rehearsal of the same rank
+logic on however many GPUs are visible, down to one):
+  --config tfidf         --scaling weak (default): every rank matches its own 100k from-rows against the replicated
+                         real list (rank 0: the real names = the headline self-match; rank r > 0: synthetic names of the
+                         same token statistics); --scaling strong: the one 100k x 100k self-match split over the ranks
+  --config dense         weak: 62 500 from-vectors per rank against 500 000 replicated to-vectors (N = 8 IS config 5)
+  --config editdistance  strong: config 3's 20 000 from-titles split over the ranks
+  --config rapidfuzz     strong: the same lists under RapidFuzz's default scorer (WRatio)
+The only data-path exchange is the all-gather of the per-shard result blocks.  torch is used for rendezvous / barrier /
+the max-over-ranks only, never in the data path.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +42,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -46,9 +58,12 @@ HBM_PEAK_GBS = 8000.0            # HBM3E 8.0 TB/s spec
 LDS_BYTES_PER_CLK_CU = 128.0     # LDS bandwidth per CU
 N_CU, CLK_HZ = 256, 2.4e9
 LDS_ATOMIC_LANES_PER_S = 4.0e12  # measured ds_add_u32 rate, all CUs (tools/ubench/lds_atomic.hip: 6.6 lanes/clk/CU)
+INT32_PEAK_TOPS = N_CU * 4 * 32 * CLK_HZ / 1e12      # 32-bit integer issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T/s
+FP32_MFMA_PEAK_TFLOPS = 157.3
+SEED = 20260924                  # of every random row sample below
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -56,14 +71,115 @@ def parse():
     ap.add_argument("--n", type=int, default=N_NAMES,
                     help="list length: <= 100000 takes the first n real names, more takes synthetic names")
     ap.add_argument("--top-n", type=int, default=TOP_N)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: weak for tfidf / dense, strong for editdistance / rapidfuzz")
+    ap.add_argument("--transport", choices=("rccl", "local"), default="rccl",
+                    help="local: one process, --gpus contexts (round-robin over the visible devices), host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-match-wall", action="store_true", help="skip the .match() wall time and the latency leg")
-    ap.add_argument("--config", choices=("tfidf", "editdistance", "dense"), default="tfidf",
-                    help="editdistance: BASELINE.json config 3 (EditDistance, 20k x 20k IMDB titles), single GPU; "
-                         "dense: one GPU's shard of config 5 (62.5k x 500k x 768 embeddings, cosine top-10)")
-    return ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip the `configs` sub-records")
+    ap.add_argument("--small", action="store_true",
+                    help="rehearsal sizes (tests of the launch / rank logic): 2 000 x 2 000 titles, 4 000 x 20 000 x 256 vectors; "
+                         "the line says so in config.rehearsal")
+    ap.add_argument("--config", choices=("tfidf", "c2", "editdistance", "rapidfuzz", "dense", "tfidf_1m"), default="tfidf",
+                    help="tfidf: the headline (+ every other config as a sub-record at N = 1); the others: that "
+                         "configuration alone as the line")
+    return ap.parse_args(argv)
+
+
+# ---- who am I: single process, one process per GPU (torch.distributed), or one thread per rank ------------------
+
+class World:
+    """rank / size + the two collectives the bench itself needs (barrier, max of a host float)."""
+    rank, size, kind = 0, 1, "single"
+
+    def barrier(self, ctx):
+        ctx.sync()
+
+    def max(self, x):
+        return x
+
+    def comm(self, ctx):
+        return None, "none (single GPU)"
+
+
+class TorchWorld(World):
+    kind = "rccl"
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.size = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+
+    def barrier(self, ctx):
+        ctx.sync()
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+        ctx.sync()
+
+    def max(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def comm(self, ctx):
+        """the library's own RCCL communicator (bootstrap: broadcast of the 128-byte id through torch)"""
+        from polyfuzz_amd import _lib
+        err, comm = "", None
+        try:
+            comm = _lib.Comm.from_torch_distributed(ctx, self.dist)
+        except Exception as e:       # keep every rank in step: agree on the outcome before going on
+            err = f"{type(e).__name__}: {e}"
+        ok = self.torch.tensor([0 if err else 1], dtype=self.torch.int32, device="cuda")
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return comm, "RCCL all-gather of the per-shard result blocks"
+        if comm is not None:
+            comm.free()
+        return None, f"DISABLED -- library RCCL communicator failed ({err or 'on another rank'}); ranks ran as independent replicas"
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class LocalWorld(World):
+    """N ranks as N host threads of this process, each with its own context (its own stream, allocator, staging
+    buffer) on device rank % visible-devices and a communicator of the library's in-process transport."""
+    kind = "local"
+
+    def __init__(self, rank, size, shared):
+        self.rank, self.size, self.shared = rank, size, shared
+
+    def barrier(self, ctx):
+        ctx.sync()
+        self.shared["barrier"].wait()
+
+    def max(self, x):
+        self.shared["vals"][self.rank] = x
+        self.shared["barrier"].wait()
+        m = max(self.shared["vals"])
+        self.shared["barrier"].wait()
+        return m
+
+    def comm(self, ctx):
+        return self.shared["comms"][self.rank], ("in-process transport (host rendezvous + device-to-device copies) all-gather "
+                                                 "of the per-shard result blocks")
+
+
+def the_list(args):
+    from polyfuzz_amd import datasets, synth
+    if args.n <= N_NAMES:
+        return datasets.load_company_names()[:args.n], "real"
+    return synth.company_names(args.n, seed=5678), "synthetic"
+
+
+def workload_key(args):
+    return f"company_names[:{args.n}] self-match top-{args.top_n}"
 
 
 def recorded_traffic(args):
@@ -79,98 +195,135 @@ def recorded_traffic(args):
         return None, None
 
 
-def workload_key(args):
-    return f"company_names[:{args.n}] self-match top-{args.top_n}"
+def n_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def the_list(args):
-    from polyfuzz_amd import datasets, synth
-    if args.n <= N_NAMES:
-        return datasets.load_company_names()[:args.n], "real"
-    return synth.company_names(args.n, seed=5678), "synthetic"
+def median(xs):
+    return sorted(xs)[len(xs) // 2]
 
 
-# ---- CPU baselines + parity check (rank 0, N = 1, outside the timed region) -------------------------------
+# ---- K3: roofline object, CPU arms, random-row parity ------------------------------------------------------------
 
-def cpu_baselines_and_check(job, idx, val, seconds, names):
-    """Three CPU arms on bounded samples of the same workload, and the parity spot check:
-    (ii) oracle/cossim_topn.c on ONE core -- how PolyFuzz calls sparse_dot_topn (_utils.py:82) -- primary;
-    (iii) the same on all host cores (row ranges on threads; ctypes releases the GIL);
-    (i) the reference's own executable back-end, restated (oracle/reference_path.py: sklearn vectoriser +
-        dense cosine + full sorts + frame) at the C2 size, where its dense matrix fits."""
+def k3_roofline(job, stats, k3_ms, k3_launches, top_n, traffic=None, traffic_note=None):
+    """The contract's figure prices SURVEY section 8d's ALGORITHMIC bytes (one 8-byte posting per multiply-add + the
+    from-side CSR once + the results once) against the HBM peak -- that is `hbm_priced_*` and can exceed 1, because the
+    postings are served by L2 / Infinity Cache.  `frac` is against the resource that binds the kernel: the LDS floor =
+    every multiply-add is one ds_add_u32 lane at the measured atomic rate + every accumulator cell of every
+    (from-row, to-block) read and cleared once."""
+    k3_avg_s = (k3_ms / max(1, k3_launches)) * 1e-3
+    ix = job.index.info()
+    bytes_alg = 8.0 * stats["madds"] + 8.0 * stats["nnz_from"] + 8.0 * job.n_from * top_n
+    hbm_priced = bytes_alg / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0
+    cells = float(job.n_from) * ix["n_blocks"] * ix["block_cols"]
+    lds_bw = N_CU * LDS_BYTES_PER_CLK_CU * CLK_HZ
+    lds_floor_s = stats["madds"] / LDS_ATOMIC_LANES_PER_S + cells * 8.0 / lds_bw
+    return {
+        "kernel": "k3_cossim_topn", "bound": "lds",
+        # LDS bytes of the launch (an atomic lane priced at the measured ds_add_u32 rate: 128 B/clk / 6.6 lanes/clk = 19.4 B)
+        # over the launch time, against the LDS bandwidth of the chip
+        "achieved": lds_floor_s * lds_bw / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0, "peak": lds_bw / 1e9,
+        "unit": "GB/s of LDS bandwidth",
+        "frac": lds_floor_s / k3_avg_s if k3_avg_s > 0 else 0.0,
+        "frac_of_lds_floor": lds_floor_s / k3_avg_s if k3_avg_s > 0 else 0.0,
+        "lds_floor_ms": lds_floor_s * 1e3, "avg_launch_ms": k3_avg_s * 1e3, "launches": k3_launches,
+        "lds_floor_what": f"{stats['madds']:.4g} ds_add_u32 lanes at {LDS_ATOMIC_LANES_PER_S:.1e}/s + {cells:.4g} accumulator "
+                          f"cells x 8 B (read + clear) at {lds_bw / 1e12:.1f} TB/s of LDS bandwidth",
+        "hbm_priced_achieved_gbs": hbm_priced, "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_priced_frac": hbm_priced / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": bytes_alg,
+        "traffic": traffic,
+        "traffic_note": traffic_note or "no PMC record for this workload (profiles/k3_hbm_traffic.json)",
+        "bound_note": "frac = LDS floor / measured launch time (the binding resource: LDS atomics + the accumulator sweep); "
+                      "hbm_priced_frac prices the ALGORITHMIC bytes of SURVEY section 8d against the 8 TB/s HBM peak and is "
+                      "not a utilisation -- the padded index (tens of MB) is served by L2 / Infinity Cache",
+    }
+
+
+def k3_parity(job, idx, val, rows, e_idx, e_val, a3, b3, n_col):
+    """GPU rows vs the float64 oracle on the same (random) rows: scores within 1e-5; an index mismatch is a real error
+    unless the oracle itself has the two scores within 2e-6 (a near-tie fp32 cannot order)."""
+    import oracle
+    g_idx, g_val = idx[rows], val[rows].astype(np.float64)
+    max_err = float(np.abs(g_val - e_val).max()) if len(rows) else 0.0
+    mism = np.nonzero((g_idx != e_idx).any(axis=1))[0]
+    ties = int((np.diff(e_val, axis=1) == 0).any(axis=1).sum()) if job.top_n > 1 else 0
+    hard = 0
+    for t in mism[:2000]:
+        i = int(rows[t])
+        dense = oracle.cossim_dense(a3, b3, n_col, rows=(i, i + 1))[0]
+        for r in range(job.top_n):
+            if g_idx[t, r] != e_idx[t, r]:
+                s = dense[g_idx[t, r]] if g_idx[t, r] >= 0 else 0.0
+                if abs(s - e_val[t, r]) >= 2e-6:
+                    hard += 1
+    return {"rows_checked": int(len(rows)), "rows": "seeded random sample of the from-rows", "max_abs_score_err": max_err,
+            "rows_with_index_diff": int(len(mism)), "index_diffs_not_near_ties": hard, "rows_with_exact_ties_in_top_n": ties,
+            "ok": bool(max_err <= 1e-5 and hard == 0)}
+
+
+def k3_cpu_and_parity(job, idx, val, seconds, all_cores=True, min_rows=0):
+    """CPU arm (ii): oracle/cossim_topn.c on ONE core -- how PolyFuzz calls sparse_dot_topn (_utils.py:82) -- over a
+    seeded random sample of from-rows sized to `seconds` (at least min_rows); arm (iii): the same on all host cores (row
+    ranges on threads; ctypes releases the GIL).  The sample's results are also the parity check of the GPU result."""
     import concurrent.futures as cf
     import oracle
-    from oracle.reference_path import sklearn_backend_match
     oracle.build_native()
     a3, b3, n_col = job.host_matrices()
-    n_from = len(a3[0]) - 1
-    excl = job.self_match
+    n_from, excl = len(a3[0]) - 1, job.self_match
+    rng = np.random.default_rng(SEED)
 
-    def run(r0, r1):
-        return oracle.cossim_topn(a3, b3, n_col, job.top_n, job.min_similarity, exclude_diag=excl, rows=(r0, r1))
+    def run(rows):
+        return oracle.cossim_topn(a3, b3, n_col, job.top_n, job.min_similarity, exclude_diag=excl, rows=rows)
 
-    probe = min(200, n_from)
+    probe = rng.choice(n_from, min(200, n_from), replace=False)
     t0 = time.perf_counter()
-    run(0, probe)
-    per_row = (time.perf_counter() - t0) / max(probe, 1)
-    rows = int(max(probe, min(n_from, seconds / max(per_row, 1e-9))))
+    run(probe)
+    per_row = (time.perf_counter() - t0) / max(len(probe), 1)
+    n_rows = int(min(n_from, max(len(probe), min_rows, seconds / max(per_row, 1e-9))))
+    rows = np.sort(rng.choice(n_from, n_rows, replace=False))
     t0 = time.perf_counter()
-    e_idx, e_val = run(0, rows)
+    e_idx, e_val = run(rows)
     dt = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    base = {"value": rows * float(job.n_to) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": f"first {rows} of {n_from} from-rows x all {job.n_to} to-rows, oracle/cossim_topn.c "
-                      f"(Gustavson + strict bound + top-{job.top_n}, float64), {dt:.1f} s on 1 of {cores} host "
-                      "cores; vectorisation not included"}
-    arms = [dict(base, arm="ii: sparse product as PolyFuzz calls it (single thread)")]
+    cores = n_cores()
+    base = {"value": n_rows * float(job.n_to) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n_rows} random from-rows (seed {SEED}) of {n_from} x all {job.n_to} to-rows, oracle/cossim_topn.c "
+                      f"(Gustavson + strict bound + top-{job.top_n}, float64), {dt:.1f} s on 1 of {cores} host cores; "
+                      "vectorisation not included"}
+    arms = [dict(base, arm="ii: sparse product as PolyFuzz calls sparse_dot_topn (single thread), restated")]
+    if all_cores:
+        per_thread = int(max(50, min(n_from // max(cores, 1), 0.5 * seconds / max(per_row, 1e-9))))
+        ranges = [(t * per_thread, (t + 1) * per_thread) for t in range(cores) if (t + 1) * per_thread <= n_from]
+        if ranges:
+            t0 = time.perf_counter()
+            with cf.ThreadPoolExecutor(len(ranges)) as ex:
+                list(ex.map(run, ranges))
+            dt3 = time.perf_counter() - t0
+            arms.append({"arm": "iii: the same on all host cores", "value": len(ranges) * per_thread * float(job.n_to) / dt3,
+                         "unit": "pairs/s", "cores": len(ranges), "kind": "port",
+                         "sample": f"{len(ranges)} threads x {per_thread} from-rows x all {job.n_to} to-rows, {dt3:.1f} s"})
+    return base, arms, k3_parity(job, idx, val, rows, e_idx, e_val, a3, b3, n_col)
 
-    # (iii) all cores: one row range per thread, about half the budget of wall time
-    per_thread = int(max(50, min(n_from // max(cores, 1), 0.5 * seconds / max(per_row, 1e-9))))
-    ranges = [(t * per_thread, (t + 1) * per_thread) for t in range(cores) if (t + 1) * per_thread <= n_from]
-    if ranges:
-        t0 = time.perf_counter()
-        with cf.ThreadPoolExecutor(len(ranges)) as ex:
-            list(ex.map(lambda r: run(*r), ranges))
-        dt3 = time.perf_counter() - t0
-        arms.append({"arm": "iii: the same on all host cores", "value": len(ranges) * per_thread * float(job.n_to) / dt3,
-                     "unit": "pairs/s", "cores": len(ranges), "kind": "port",
-                     "sample": f"{len(ranges)} threads x {per_thread} from-rows x all {job.n_to} to-rows, {dt3:.1f} s"})
 
-    # (i) the reference's executable path at C2 (10k x 10k of the same names; the dense matrix is 800 MB)
+def reference_backend_arm(names, top_n):
+    """CPU arm (i): the reference's own EXECUTABLE back-end -- sklearn vectoriser + dense cosine + full sorts + frame,
+    _utils.py:94-125 -- RESTATED (oracle/reference_path.py, pinned on frames the reference package produced; the package
+    itself is not on the GPU box) at the C2 size, where its dense matrix fits."""
     try:
+        from oracle.reference_path import sklearn_backend_match
         from polyfuzz_amd import datasets
         n2 = 10_000 if len(names) >= 20_000 else max(100, len(names) // 2)
         fl, tl = datasets.c2_lists(n2) if len(names) == N_NAMES else (names[:n2], names[n2:2 * n2])
         tm = {}
-        sklearn_backend_match(fl, tl, top_n=job.top_n, timings=tm)
-        arms.append({"arm": "i: the reference's sklearn back-end, restated (vectorise + dense cosine + full sorts + frame)",
-                     "value": float(n2) * float(n2) / tm["total_s"], "unit": "pairs/s", "cores": "BLAS threads",
-                     "kind": "port", "sample": f"config 2: {n2} x {n2} company names, top-{job.top_n}, end to end "
-                     f"{tm['total_s']:.1f} s (vectorise {tm['vectorise_s']:.1f}, cosine+sort {tm['cosine_sort_s']:.1f}, "
-                     f"frame {tm['frame_s']:.1f})"})
+        sklearn_backend_match(fl, tl, top_n=top_n, timings=tm)
+        return {"arm": "i: restated reference path (the reference's sklearn back-end: vectorise + dense cosine + full sorts + frame)",
+                "value": float(n2) * float(n2) / tm["total_s"], "unit": "pairs/s", "cores": "BLAS threads", "kind": "port",
+                "sample": f"config 2: {n2} x {n2} company names, top-{top_n}, end to end {tm['total_s']:.1f} s (vectorise "
+                          f"{tm['vectorise_s']:.1f}, cosine+sort {tm['cosine_sort_s']:.1f}, frame {tm['frame_s']:.1f})"}
     except Exception as e:      # a CPU arm must never take the bench line down
-        arms.append({"arm": "i: reference sklearn back-end", "error": f"{type(e).__name__}: {e}"})
-
-    g_idx, g_val = idx[:rows], val[:rows].astype(np.float64)
-    max_err = float(np.abs(g_val - e_val).max()) if rows else 0.0
-    mism = np.nonzero((g_idx != e_idx).any(axis=1))[0]
-    ties = int((np.diff(e_val, axis=1) == 0).any(axis=1).sum()) if job.top_n > 1 else 0
-    # an index mismatch is a real error unless the float64 oracle itself has the two scores within 2e-6
-    hard = 0
-    for i in mism[:2000]:
-        dense = oracle.cossim_dense(a3, b3, n_col, rows=(int(i), int(i) + 1))[0]
-        for r in range(job.top_n):
-            if g_idx[i, r] != e_idx[i, r]:
-                s = dense[g_idx[i, r]] if g_idx[i, r] >= 0 else 0.0
-                if abs(s - e_val[i, r]) >= 2e-6:
-                    hard += 1
-    check = {"rows_checked": rows, "max_abs_score_err": max_err, "rows_with_index_diff": int(len(mism)),
-             "index_diffs_not_near_ties": hard, "rows_with_exact_ties_in_top_n": ties,
-             "ok": bool(max_err <= 1e-5 and hard == 0)}
-    return base, arms, check
+        return {"arm": "i: restated reference path", "error": f"{type(e).__name__}: {e}"}
 
 
-# ---- what a user sees: .match() wall time and single-query latency ----------------------------------------
+# ---- what a user sees: .match() wall time and single-query latency ------------------------------------------------
 
 def match_wall(names, top_n, result_idx, reps=7):
     from polyfuzz_amd.models import TFIDF
@@ -186,21 +339,22 @@ def match_wall(names, top_n, result_idx, reps=7):
         stages.append(m.last_timings)
     order = np.argsort(ts)
     med = int(order[len(ts) // 2])
-    # the frame is the device result: To == names[idx] wherever the rounded score survives
+    # the frame is the device result: To == names[idx] wherever the rounded score survives (a random sample of rows)
     same = True
     if result_idx is not None:
         to0 = df["To"].tolist()
-        same = all(t is None or t == names[j] for t, j in zip(to0[:5000], result_idx[:5000, 0].tolist()))
+        for i in np.random.default_rng(SEED).choice(len(names), min(5000, len(names)), replace=False).tolist():
+            same = same and (to0[i] is None or to0[i] == names[result_idx[i, 0]])
     n = float(len(names))
     out = {"match_wall_ms": ts[med], "match_wall_ms_min": min(ts), "match_pairs_per_s": n * n / (ts[med] * 1e-3),
            "match_stages_ms": {k: round(v, 3) for k, v in stages[med].items()},
-           "match_what": f"TFIDF(min_similarity=0, top_n={top_n}).match(names): Python list in, DataFrame out "
-                         f"(pack, H2D, device step, D2H, frame), median of {reps}",
+           "match_what": f"the SURVEY section 8d metric: TFIDF(min_similarity=0, top_n={top_n}).match(names), Python list in, "
+                         f"DataFrame out (pack, H2D, device step, D2H, frame), median of {reps}",
            "match_frame_consistent_with_device_result": bool(same)}
-    return out, m
+    return out
 
 
-def top1_latency(m_fit, names, reps=50):
+def top1_latency(names, reps=50):
     """The other half of BASELINE.json's metric: top-1 match latency.  One query string against the fitted
     100k list through the drop-in matcher (host str in, DataFrame out: upload, vectorise, K3, download, frame)."""
     from polyfuzz_amd.models import TFIDF
@@ -225,331 +379,463 @@ def top1_latency(m_fit, names, reps=50):
                     "TFIDF(top_n=1).match(names), the whole self-match"}
 
 
-def bench_editdistance(args):
-    """BASELINE.json config 3 / SURVEY.md §8d: EditDistance (rapidfuzz.fuzz.ratio = Indel ratio) all pairs of
-    20 000 x 20 000 IMDB titles (default_rng(0) permutation, first from-title 'Polly Blue Eyes'), first arg-max
-    per from-title.  One step = one pass of K4 over all pairs with both lists and the to-side plan resident."""
-    import polyfuzz_amd
-    from polyfuzz_amd import _lib, datasets
-    from polyfuzz_amd.models import EditDistance
-    ctx = polyfuzz_amd.Context.default()
-    fl, tl = datasets.c3_lists()
-    f, t = _lib.DeviceStrings.upload(ctx, fl), _lib.DeviceStrings.upload(ctx, tl)
-    plan = _lib.indel_plan_info(ctx, t)
-    for _ in range(args.warmup):
-        idx, score = _lib.indel_argmax(ctx, f, t)
-    ctx.sync()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        idx, score = _lib.indel_argmax(ctx, f, t)
-    ctx.sync()
-    wall = time.perf_counter() - t0
-    ctx.prof_enable(False)
-    k4_ms, k4_launches = ctx.prof_get("k4_indel")
-    k4_step_s = k4_ms / args.steps * 1e-3
-    # algorithmic work: one 5-operation word update (u = V & M; V = (V + u) | (V ^ u), + the table look-up) per
-    # to-character per 32/64-bit word of the from-string -- counted as 32-bit integer operations
-    words32 = np.array([(1 if len(a) <= 32 else 2 * ((len(a) + 63) // 64)) for a in fl], np.float64)
-    int_ops = 5.0 * float(words32.sum()) * float(plan["char_steps"])
-    cells = float(sum(map(len, fl))) * float(sum(map(len, tl)))
-    peak = 256 * 4 * 32 * 2.4e9 / 1e12       # 32-bit integer issue, Tera-op/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
-    import oracle
-    oracle.build_native()
-    rows = 40
-    c0 = time.perf_counter()
-    e_idx, e_score = oracle.indel_argmax(fl, tl, rows=(0, rows))
-    dt = time.perf_counter() - c0
-    rows2 = int(max(rows, min(len(fl), rows * args.cpu_seconds / max(dt, 1e-6))))
-    c0 = time.perf_counter()
-    e_idx, e_score = oracle.indel_argmax(fl, tl, rows=(0, rows2))
-    dt = time.perf_counter() - c0
-    m = EditDistance(normalize=False)
-    m.match(fl, tl)
-    ts, ts2 = [], []
-    for _ in range(7):
-        c0 = time.perf_counter()
-        m.match(fl, tl)
-        ts.append((time.perf_counter() - c0) * 1e3)
-        c0 = time.perf_counter()
-        m.match(fl, tl, re_train=False)
-        ts2.append((time.perf_counter() - c0) * 1e3)
-    out = {
-        "metric": "string-pairs/sec, EditDistance (Indel ratio) all pairs + first arg-max, 20k x 20k IMDB titles",
-        "value": float(len(fl)) * float(len(tl)) * args.steps / wall, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32/int64 bit-vectors, f64 score",
-        "data": "real: reference data/movie_titles.json (IMDB), gzipped in polyfuzz_amd/data/",
-        "config": {"workload": "EditDistance(scorer=fuzz.ratio).match(from, to): 20000 x 20000 IMDB titles "
-                               "(SURVEY.md §8d config 3), lists and to-side plan resident", "n_from": len(fl), "n_to": len(tl),
-                   "alphabet": plan["n_symbols"], "dp_cells": cells, "to_char_steps": plan["char_steps"]},
-        "kernel_ms_per_step": {"k4_indel": round(k4_ms / args.steps, 4), "launches_per_step": k4_launches / args.steps},
-        "roofline": {"kernel": "k4_indel", "bound": "int32 VALU issue (+ LDS look-ups)", "achieved": int_ops / k4_step_s / 1e12,
-                     "peak": peak, "unit": "Tera int-op/s", "frac": int_ops / k4_step_s / 1e12 / peak, "traffic": None,
-                     "algorithmic_int_ops_per_step": int_ops, "dp_cell_updates_per_s": cells / k4_step_s,
-                     "what": "5 integer operations per to-character per 32-bit word of the from-string (bit-parallel LCS), "
-                             "against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"},
-        "cpu_baseline": {"value": rows2 * float(len(tl)) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-                         "sample": f"first {rows2} from-titles x all {len(tl)} to-titles, oracle/indel.c (plain O(|a||b|) LCS "
-                                   f"DP), {dt:.1f} s on 1 host core"},
-        "parity_check": {"rows_checked": rows2, "bit_exact": bool(np.array_equal(idx[:rows2], e_idx) and
-                                                                  np.array_equal(score[:rows2], e_score))},
-        "match_wall_ms": sorted(ts)[len(ts) // 2], "match_wall_ms_to_list_resident": sorted(ts2)[len(ts2) // 2],
-        "match_what": "EditDistance(normalize=False).match(from, to): Python lists in, DataFrame out; "
-                      "..._to_list_resident = match(from, to, re_train=False), the to-list and its K4 plan kept on the device",
-    }
-    print(json.dumps(out))
+# ---- the timed loop every configuration shares ---------------------------------------------------------------------
 
-
-def bench_dense(args):
-    """BASELINE.json config 5 / SURVEY.md section 8d: dense cosine top-10 of 500k x 500k 768-d embeddings on 8 GPUs --
-    here ONE GPU's share: a 62 500-row from-shard against all 500 000 to-vectors (K5), operands resident in HBM.
-    One step = the shard's GEMM panels + row top-n.  Roofline: exact-fp32 MFMA."""
-    import polyfuzz_amd
-    from polyfuzz_amd import pipeline
-    ctx = polyfuzz_amd.Context.default()
-    n_to, n_from, d, top_n = 500_000, 62_500, 768, 10
-    rng = np.random.default_rng(7)
-    b = rng.standard_normal((n_to, d), dtype=np.float32)
-    a = rng.standard_normal((n_from, d), dtype=np.float32)
-    pick = rng.choice(n_to, n_from, replace=False)
-    a += 2.0 * b[pick]                       # planted near-duplicates: the top rank is known
-    job = pipeline.DenseMatchJob(ctx, a, b, top_n=top_n)
-    for _ in range(max(1, args.warmup)):
-        job.step()
-    ctx.sync()
-    ctx.prof_enable(2)
-    ctx.prof_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = job.step()
-    ctx.sync()
-    wall = time.perf_counter() - t0
-    ctx.prof_enable(False)
-    gemm_ms, launches = ctx.prof_get("k5_gemm_panel")
-    idx, val = res.download()
-    flop = 2.0 * n_from * n_to * d
-    # CPU arm + parity on a bounded sample: float64 BLAS cosine + top-n of a few from-rows (oracle/dense.py)
-    import oracle
-    rows = rng.choice(n_from, 8, replace=False)
-    c0 = time.perf_counter()
-    bad, err = 0, 0.0
-    for i in rows:
-        e_idx, e_val = oracle.dense_cossim_topn(a[i:i + 1], b, top_n, 0.0)
-        err = max(err, float(np.abs(val[i] - e_val[0]).max()))
-        bad += int(not np.array_equal(idx[i], e_idx[0]))
-    dt = time.perf_counter() - c0
-    gemm_s = gemm_ms / max(1, launches) * 1e-3 * (launches / args.steps)       # GEMM time per step
-    out = {
-        "metric": "vector pairs/sec, dense cosine top-10, one GPU's shard of 500k x 500k x 768 (BASELINE config 5)",
-        "value": float(n_from) * n_to * args.steps / wall, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic (SURVEY.md section 8d config 5: standard normal rows, planted near-duplicates)",
-        "config": {"workload": "Embeddings-style cosine top-10: 62 500 from-vectors (one of 8 row shards) x 500 000 to-vectors x 768, "
-                               "operands resident, pipeline.DenseMatchJob", "n_from": n_from, "n_to": n_to, "dim": d, "top_n": top_n},
-        "kernel_ms_per_step": {"k5_gemm_panel": round(gemm_ms / args.steps, 3), "launches_per_step": launches / args.steps},
-        "roofline": {"kernel": "k5_gemm_panel_pipe", "bound": "mfma", "achieved": flop / gemm_s / 1e12, "peak": 157.3,
-                     "unit": "TFLOP/s", "frac": flop / gemm_s / 1e12 / 157.3, "traffic": None,
-                     "end_to_end_frac": flop * args.steps / wall / 1e12 / 157.3,
-                     "what": "2 n_from n_to d flops of exact fp32 products (v_mfma_f32_32x32x2_f32) over the GEMM panels' "
-                             "summed launch time; end_to_end_frac = over the whole step (row top-n included)"},
-        "cpu_baseline": {"value": len(rows) * float(n_to) / dt, "unit": "pairs/s", "cores": int(os.cpu_count() or 1), "kind": "port",
-                         "sample": f"{len(rows)} from-rows x all {n_to} to-vectors, oracle/dense.py (float64 numpy / BLAS), {dt:.1f} s"},
-        "parity_check": {"rows_checked": int(len(rows)), "rows_with_index_diff": bad, "max_abs_score_err": err,
-                         "planted_match_found_top1": float((idx[:, 0] == pick).mean())},
-    }
-    print(json.dumps(out))
-
-
-def main():
-    args = parse()
-    if args.config == "editdistance":
-        if args.gpus != 1:
-            raise SystemExit("--config editdistance is a single-GPU configuration")
-        return bench_editdistance(args)
-    if args.config == "dense":
-        if args.gpus != 1:
-            raise SystemExit("--config dense times one GPU's shard; the 8-GPU job is eight of them (pipeline.DenseMatchJob)")
-        return bench_dense(args)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    dist = torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import polyfuzz_amd
-    from polyfuzz_amd import _lib, pipeline, synth
-
-    ctx = polyfuzz_amd.Context(local_rank)
-    info = ctx.info()
-    comm, exchange = None, "none (single GPU)"
-    if world > 1:
-        # the library's own RCCL communicator (bootstrap: broadcast of the 128-byte id through torch)
-        err = ""
-        try:
-            comm = _lib.Comm.from_torch_distributed(ctx, dist)
-        except Exception as e:       # keep every rank in step: agree on the outcome before going on
-            err = f"{type(e).__name__}: {e}"
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            exchange = "RCCL all-gather of the per-shard top-n blocks (the fit runs on the replicated list: no exchange)"
-        else:
-            if comm is not None:
-                comm.free()
-            comm = None
-            exchange = f"DISABLED -- library RCCL communicator failed ({err or 'on another rank'}); ranks ran as independent replicas"
-
-    # ---- inputs (resident in HBM before timing) ----
-    names, kind = the_list(args)
-    n = len(names)
-    if world == 1:
-        job = pipeline.TfidfMatchJob(ctx, names, None, top_n=args.top_n, min_similarity=MIN_SIM, self_match=True)
-        n_from_total, shard_desc = n, "the whole list"
-    elif args.scaling == "strong":
-        b, e = pipeline.shard_bounds(n, world, rank)
-        rpr = pipeline.shard_bounds(n, world, 0)[1]
-        job = pipeline.TfidfMatchJob(ctx, names[b:e], names, top_n=args.top_n, min_similarity=MIN_SIM, self_match=True,
-                                     shard_offset=b, comm=comm, rows_per_rank=rpr)
-        n_from_total, shard_desc = n, f"rows [{b}, {e}) of the list"
-    else:
-        shard = names if rank == 0 else synth.company_names(n, seed=1234 + rank)
-        job = pipeline.TfidfMatchJob(ctx, shard, names, top_n=args.top_n, min_similarity=MIN_SIM, self_match=True,
-                                     shard_offset=rank * n, comm=comm, rows_per_rank=n)
-        n_from_total = n * world
-        shard_desc = "rank 0: the list itself, rank r > 0: synthetic names of the same token statistics"
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-            ctx.sync()
-
-    for _ in range(args.warmup):
-        job.step()
-    barrier()
-    ctx.prof_enable(2)          # live HIP-event timing of every K3 launch (the dominant kernel) inside the timed region
+def timed_steps(world, ctx, step, steps, warmup, prof_level=2):
+    """`warmup` untimed steps, then exactly `steps` steps bracketed by barrier + device sync, max over the ranks;
+    the library's HIP-event timers (prof_level 2: the dominant kernels only) run inside the timed region."""
+    result = None
+    for _ in range(warmup):
+        result = step()
+    world.barrier(ctx)
+    ctx.prof_enable(prof_level)
     ctx.prof_reset()
     t0 = time.perf_counter()
     ctx.event_record(0)
-    for _ in range(args.steps):
-        result = job.step()
+    for _ in range(steps):
+        result = step()
     ctx.event_record(1)
-    barrier()
+    world.barrier(ctx)
     wall = time.perf_counter() - t0
     ctx.prof_enable(False)
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    return world.max(wall), result
 
+
+def contract(metric, value, unit, world, args, steps, warmup, wall, scaling, dtype, data, config):
+    return {"metric": metric, "value": value, "unit": unit, "n_gpus": world.size, "steps": steps, "warmup": warmup,
+            "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": dtype, "data": data, "config": config}
+
+
+# ---- configuration: the headline (and config 2 / config 4's shard, the same job at other sizes) --------------------
+
+def run_tfidf(world, ctx, args, from_shard=None, to_list=None, top_n=None, steps=None, warmup=None, self_match=True,
+              shard_desc="the whole list", n_from_total=None, label=None, cpu_seconds=None, min_parity_rows=0,
+              all_cores_arm=True, kind="real", shard_offset=0, rows_per_rank=None):
+    """One TfidfMatchJob under the clock.  Returns (contract-shaped record incl. roofline / cpu_baseline / parity_check,
+    job, (idx, val) of the last step)."""
+    from polyfuzz_amd import pipeline
+    top_n = args.top_n if top_n is None else top_n
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    comm, exchange = world.comm(ctx) if world.size > 1 else (None, "none (single GPU)")
+    job = pipeline.TfidfMatchJob(ctx, from_shard, to_list, top_n=top_n, min_similarity=MIN_SIM, self_match=self_match,
+                                 shard_offset=shard_offset, comm=comm, rows_per_rank=rows_per_rank)
+    n_to = job.n_to
+    n_from_total = job.n_from if n_from_total is None else n_from_total
+    wall, result = timed_steps(world, ctx, job.step, steps, warmup)
+    k3_timed = ctx.prof_get("k3_cossim_topn")
+    gpu_ms = ctx.event_elapsed_ms(0, 1)
     # the per-kernel breakdown of a step: three more steps with every profiled kernel bracketed, outside the timed region
-    k3_timed = ctx.prof_get("k3_cossim_topn") if rank == 0 else None
     ctx.prof_enable(True)
     ctx.prof_reset()
     for _ in range(3):
         result = job.step()
-    barrier()
+    world.barrier(ctx)
     ctx.prof_enable(False)
-    out = None
-    if rank == 0:
-        kernel_ms = {name: round(ctx.prof_get(name)[0] / 3, 4) for name in pipeline.PROFILED_KERNELS}
-        stats = job.stats()
-        k3_ms, k3_launches = k3_timed
-        gpu_ms = ctx.event_elapsed_ms(0, 1)
-        pairs_per_step = float(n_from_total) * float(n)
-        value = pairs_per_step * args.steps / wall
-        k3_avg_s = (k3_ms / max(1, k3_launches)) * 1e-3
-        ix = job.index.info()
-        # algorithmic bytes of one K3 launch (SURVEY.md §8d / DESIGN.md): one 8-byte posting per
-        # multiply-add + the from-side CSR once + the (idx, score) results once
-        bytes_alg = 8.0 * stats["madds"] + 8.0 * stats["nnz_from"] + 8.0 * job.n_from * args.top_n
-        achieved = bytes_alg / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0
-        # what the kernel is really bound by: LDS.  Floor = every multiply-add is one ds_add_u32 lane (measured
-        # atomic rate) + every accumulator cell of every (from-row, to-block) is read and cleared once
-        cells = float(job.n_from) * ix["n_blocks"] * ix["block_cols"]
-        lds_floor_s = stats["madds"] / LDS_ATOMIC_LANES_PER_S + cells * 8.0 / (N_CU * LDS_BYTES_PER_CLK_CU * CLK_HZ)
-        traffic, traffic_note = recorded_traffic(args)
-        out = {
-            "metric": "string-pairs/sec, TF-IDF cosine top-n 100k x 100k (value = device-resident step; "
-                      "match_wall_ms = .match() list -> DataFrame; latency.top1_single_query_ms = top-1 match latency)",
-            "value": value,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "real: reference data/company_names.json (100 000 SEC-EDGAR names, gzipped in polyfuzz_amd/data/)"
-                    if kind == "real" else "synthetic",
-            "config": {
-                "workload": f"TFIDF(min_similarity={MIN_SIM}, top_n={args.top_n}).match(names): self-match of "
-                            f"{'the first ' + str(n) + ' of the ' if n < N_NAMES else 'all '}"
-                            f"{N_NAMES if kind == 'real' else n} {kind} company names, char-3-gram TF-IDF cosine "
-                            f"(SURVEY.md §8d headline; reference docs/tutorial/datasets/datasets.md:36-41)",
-                "n_from_total": n_from_total, "n_from_this_rank": job.n_from, "n_to": n, "top_n": args.top_n,
-                "from_rows": shard_desc,
-                "vocab": stats["vocab"], "nnz_from": stats["nnz_from"], "nnz_to": stats["nnz_to"],
-                "multiply_adds_rank0": stats["madds"],
-                "step": job.step_description(),
-                "parallelism": f"from-rows sharded x{world}, list replicated",
-                "exchange": exchange,
-                "device": info["name"],
-            },
-            "gpu_ms_per_step_rank0": gpu_ms / args.steps,
-            "kernel_ms_per_step": kernel_ms,
-            "roofline": {
-                "kernel": "k3_cossim_topn",
-                "bound": "lds",
-                "bound_note": "the contract's figure (achieved/peak/frac) prices the ALGORITHMIC bytes against the HBM "
-                              "peak; the postings are served by L2 / Infinity Cache, so HBM is not the limiter -- the "
-                              "kernel is bound by LDS atomics + the accumulator sweep and by instruction issue: see "
-                              "lds_floor_ms / frac_of_lds_floor",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_note": traffic_note or "no PMC record for this workload (profiles/k3_hbm_traffic.json)",
-                "algorithmic_bytes_per_launch": bytes_alg,
-                "avg_launch_ms": k3_avg_s * 1e3,
-                "launches": k3_launches,
-                "lds_floor_ms": lds_floor_s * 1e3,
-                "frac_of_lds_floor": lds_floor_s / k3_avg_s if k3_avg_s > 0 else 0.0,
-                "lds_floor_what": f"{stats['madds']:.4g} ds_add_u32 lanes at {LDS_ATOMIC_LANES_PER_S:.1e}/s + "
-                                  f"{cells:.4g} accumulator cells x 8 B (read + clear) at "
-                                  f"{N_CU * LDS_BYTES_PER_CLK_CU * CLK_HZ / 1e12:.1f} TB/s of LDS bandwidth",
-            },
-        }
-        idx = val = None
-        if world == 1:
-            idx, val = result.download()
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_arms"], out["parity_check"] = \
-                cpu_baselines_and_check(job, idx, val, args.cpu_seconds, names)
-        if world == 1 and not args.no_match_wall:
-            # (profiling is off again: these launches do not enter the K3 average above)
-            mw, m_fit = match_wall(names, args.top_n, idx)
-            out.update(mw)
-            out["latency"] = top1_latency(m_fit, names)
-    barrier()
-    if dist is not None:
-        dist.destroy_process_group()
-    if rank == 0:
+    if world.rank != 0:
+        return None, job, None
+    kernel_ms = {name: round(ctx.prof_get(name)[0] / 3, 4) for name in pipeline.PROFILED_KERNELS}
+    stats = job.stats()
+    traffic, traffic_note = recorded_traffic(args) if label is None else (None, "not recorded for this configuration")
+    out = contract(
+        "string-pairs/sec, TF-IDF cosine top-n 100k x 100k (value = device-resident step; match_pairs_per_s = the "
+        "SURVEY section 8d metric over .match() wall; latency.top1_single_query_ms = top-1 match latency)"
+        if label is None else f"string-pairs/sec, TF-IDF cosine top-{top_n}, {label}",
+        float(n_from_total) * float(n_to) * steps / wall, "pairs/s", world, args, steps, warmup, wall,
+        (args.scaling or "weak") if world.size > 1 else "weak", "f32",
+        "real: reference data/company_names.json (100 000 SEC-EDGAR names, gzipped in polyfuzz_amd/data/)" if kind == "real"
+        else "synthetic: token recombination of the real names (polyfuzz_amd/synth.py, SURVEY section 8d config 4)",
+        {"workload": label or (f"TFIDF(min_similarity={MIN_SIM}, top_n={top_n}).match(names): self-match of "
+                               f"{'the first ' + str(n_to) + ' of the ' if n_to < N_NAMES else 'all '}{N_NAMES} real company names, "
+                               "char-3-gram TF-IDF cosine (SURVEY.md section 8d headline; reference "
+                               "docs/tutorial/datasets/datasets.md:36-41)"),
+         "n_from_total": n_from_total, "n_from_this_rank": job.n_from, "n_to": n_to, "top_n": top_n, "from_rows": shard_desc,
+         "vocab": stats["vocab"], "nnz_from": stats["nnz_from"], "nnz_to": stats["nnz_to"], "multiply_adds_rank0": stats["madds"],
+         "step": job.step_description(), "parallelism": f"from-rows sharded x{world.size}, list replicated",
+         "exchange": exchange, "transport": world.kind, "device": ctx.info()["name"]})
+    out["gpu_ms_per_step_rank0"] = gpu_ms / steps
+    out["kernel_ms_per_step"] = kernel_ms
+    out["roofline"] = k3_roofline(job, stats, k3_timed[0], k3_timed[1], top_n, traffic, traffic_note)
+    res = None
+    if world.size == 1:
+        res = result.download()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], out["cpu_baseline_arms"], out["parity_check"] = k3_cpu_and_parity(
+                job, res[0], res[1], args.cpu_seconds if cpu_seconds is None else cpu_seconds, all_cores=all_cores_arm,
+                min_rows=min_parity_rows)
+    return out, job, res
+
+
+def headline(world, ctx, args):
+    from polyfuzz_amd import pipeline, synth
+    names, kind = the_list(args)
+    n, rank, size = len(names), world.rank, world.size
+    scaling = args.scaling or "weak"
+    if size == 1:
+        kw = dict(from_shard=names, to_list=None, shard_desc="the whole list", n_from_total=n)
+    elif scaling == "strong":
+        b, e = pipeline.shard_bounds(n, size, rank)
+        kw = dict(from_shard=names[b:e], to_list=names, shard_offset=b, rows_per_rank=pipeline.shard_bounds(n, size, 0)[1],
+                  shard_desc=f"rows [{b}, {e}) of the list", n_from_total=n)
+    else:
+        shard = names if rank == 0 else synth.company_names(n, seed=1234 + rank)
+        kw = dict(from_shard=shard, to_list=names, shard_offset=rank * n, rows_per_rank=n, n_from_total=n * size,
+                  shard_desc="rank 0: the list itself, rank r > 0: synthetic names of the same token statistics")
+    out, job, res = run_tfidf(world, ctx, args, kind=kind, min_parity_rows=5000 if n >= 50_000 else 0, **kw)
+    if out is None:
+        return None
+    out["value_definition"] = ("device-resident step: N_from x N_to x steps / wall of the timed steps, list in HBM (the bench "
+                               "contract).  The SURVEY section 8d metric -- pairs/s over the wall time of .match(), host list "
+                               "to DataFrame -- is match_pairs_per_s.")
+    if size == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline_arms"].append(reference_backend_arm(names, args.top_n))
+    if size == 1 and not args.no_match_wall:
+        out.update(match_wall(names, args.top_n, res[0]))       # (profiling is off again: these launches do not enter the K3 average)
+        out["latency"] = top1_latency(names)
+    return out
+
+
+def compact(rec, extra=()):
+    """the sub-record form of a configuration's line"""
+    keep = ("value", "unit", "steps", "ms_per_step", "match_wall_ms", "match_what", "dtype", "data", "kernel_ms_per_step", "roofline",
+            "cpu_baseline", "parity_check") + tuple(extra)
+    out = {"workload": rec["config"]["workload"]}
+    out.update({k: rec[k] for k in keep if k in rec})
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        out["roofline"] = {k: v for k, v in rf.items() if k not in ("bound_note", "traffic_note", "lds_floor_what", "what")}
+    return out
+
+
+def run_c2(world, ctx, args, steps=20, warmup=3):
+    """BASELINE config 2: TF-IDF char-3-gram cosine top-5, 10k x 10k of the real company names (two lists)."""
+    from polyfuzz_amd import datasets
+    from polyfuzz_amd.models import TFIDF
+    fl, tl = datasets.c2_lists()
+    out, job, res = run_tfidf(world, ctx, args, from_shard=fl, to_list=tl, top_n=5, steps=steps, warmup=warmup, self_match=False,
+                              label="TFIDF(min_similarity=0, top_n=5).match(from, to): config 2, 10 000 x 10 000 real company "
+                                    "names (default_rng(0) permutation; SURVEY section 8d)",
+                              shard_desc="the whole from-list", cpu_seconds=min(args.cpu_seconds, 3.0), min_parity_rows=2000,
+                              all_cores_arm=False)
+    if out is not None and world.size == 1 and not args.no_match_wall:
+        m = TFIDF(n_gram_range=(3, 3), min_similarity=0, top_n=5)
+        m.match(fl, tl)
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            m.match(fl, tl)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out["match_wall_ms"] = median(ts)
+        out["match_what"] = "TFIDF(min_similarity=0, top_n=5).match(from, to), Python lists in, DataFrame out, median of 7"
+    return out
+
+
+def run_tfidf_1m(world, ctx, args, steps=3, warmup=1):
+    """BASELINE config 4, one GPU's share: a 125 000-row from-shard against 1 000 000 to-strings, top-10 (the 8-GPU job
+    is 8 such shards; the to-side is replicated)."""
+    from polyfuzz_amd import synth
+    n_to, n_from = 1_000_000, 125_000
+    t0 = time.perf_counter()
+    tl, fl = synth.company_names(n_to, 5678), synth.company_names(n_from, 1234)
+    t_gen = time.perf_counter() - t0
+    out, job, res = run_tfidf(world, ctx, args, from_shard=fl, to_list=tl, top_n=10, steps=steps, warmup=warmup, self_match=False,
+                              label="one GPU's shard of config 4: 125 000 synthetic from-names x 1 000 000 synthetic to-names, "
+                                    "top-10 (TfidfMatchJob, lists resident)", kind="synthetic",
+                              shard_desc="rows of rank 0 of 8", cpu_seconds=min(args.cpu_seconds, 4.0), min_parity_rows=64,
+                              all_cores_arm=False)
+    if out is not None:
+        out["host_generation_s"] = round(t_gen, 2)
+        out["index"] = job.index.info()
+    return out
+
+
+# ---- configuration 3 and the RapidFuzz default: the edit-distance matchers -------------------------------------------
+
+def edit_rows_sample(n, k):
+    return np.sort(np.random.default_rng(SEED).choice(n, min(k, n), replace=False))
+
+
+def run_editdistance(world, ctx, args, steps=None, warmup=None, cpu_seconds=None):
+    """BASELINE.json config 3 / SURVEY.md section 8d: EditDistance (rapidfuzz.fuzz.ratio = Indel ratio) all pairs of
+    20 000 x 20 000 IMDB titles (default_rng(0) permutation, first from-title 'Polly Blue Eyes'), first arg-max
+    per from-title.  One step = one pass of K4 over all pairs with both lists and the to-side plan resident.
+    N > 1 (strong scaling): the from-titles are split over the ranks, the per-shard (index, score) blocks all-gathered."""
+    from polyfuzz_amd import _lib, datasets, pipeline
+    from polyfuzz_amd.models import EditDistance
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    fl, tl = datasets.c3_lists(2_000 if args.small else 20_000)
+    n = len(fl)
+    b, e = pipeline.shard_bounds(n, world.size, world.rank)
+    comm, exchange = world.comm(ctx) if world.size > 1 else (None, "none (single GPU)")
+    job = pipeline.BestChoiceJob(ctx, fl[b:e], tl, scorer="ratio", comm=comm, rows_per_rank=pipeline.shard_bounds(n, world.size, 0)[1])
+    plan = job.plan_info()
+    wall, result = timed_steps(world, ctx, job.step, steps, warmup)
+    k4_ms, k4_launches = ctx.prof_get("k4_indel")
+    if world.rank != 0:
+        return None
+    idx, score = job.result_host(result)
+    if world.size > 1:
+        sizes = [pipeline.shard_bounds(n, world.size, r)[1] - pipeline.shard_bounds(n, world.size, r)[0] for r in range(world.size)]
+        idx, score = pipeline.BestChoiceJob.unpad(idx, score, sizes, job.rows_per_rank)
+    k4_step_s = k4_ms / steps * 1e-3
+    # algorithmic work: one 5-operation word update (u = V & M; V = (V + u) | (V ^ u), + the table look-up) per
+    # to-character per 32/64-bit word of the from-string -- counted as 32-bit integer operations (this rank's rows)
+    words32 = np.array([(1 if len(a) <= 32 else 2 * ((len(a) + 63) // 64)) for a in fl[b:e]], np.float64)
+    int_ops = 5.0 * float(words32.sum()) * float(plan["char_steps"])
+    cells = float(sum(map(len, fl[b:e]))) * float(sum(map(len, tl)))
+    out = contract("string-pairs/sec, EditDistance (Indel ratio) all pairs + first arg-max, 20k x 20k IMDB titles",
+                   float(n) * float(len(tl)) * steps / wall, "pairs/s", world, args, steps, warmup, wall,
+                   (args.scaling or "strong") if world.size > 1 else "weak", "int32/int64 bit-vectors, f64 score",
+                   "real: reference data/movie_titles.json (IMDB), gzipped in polyfuzz_amd/data/",
+                   {"workload": "EditDistance(scorer=fuzz.ratio).match(from, to): 20000 x 20000 IMDB titles (SURVEY.md section 8d "
+                                "config 3), lists and to-side plan resident", "n_from": n, "n_from_this_rank": e - b, "n_to": len(tl),
+                    "alphabet": plan["n_symbols"], "dp_cells_rank0": cells, "to_char_steps": plan["char_steps"],
+                    "parallelism": f"from-titles sharded x{world.size}, to-list replicated", "exchange": exchange,
+                    "transport": world.kind})
+    out["kernel_ms_per_step"] = {"k4_indel": round(k4_ms / steps, 4), "launches_per_step": k4_launches / steps}
+    out["roofline"] = {"kernel": "k4_indel", "bound": "int32 VALU issue (+ LDS look-ups)", "achieved": int_ops / k4_step_s / 1e12,
+                       "peak": INT32_PEAK_TOPS, "unit": "Tera int-op/s", "frac": int_ops / k4_step_s / 1e12 / INT32_PEAK_TOPS,
+                       "traffic": None, "algorithmic_int_ops_per_step": int_ops, "dp_cell_updates_per_s": cells / k4_step_s,
+                       "what": "5 integer operations per to-character per 32-bit word of the from-string (bit-parallel LCS), "
+                               "against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}
+    if not args.no_cpu_baseline:
+        import oracle
+        oracle.build_native()
+        seconds = args.cpu_seconds if cpu_seconds is None else cpu_seconds
+        c0 = time.perf_counter()
+        oracle.indel_argmax(fl[:20], tl)
+        per_row = (time.perf_counter() - c0) / 20
+        rows = edit_rows_sample(n, int(max(200, seconds / max(per_row, 1e-9))))
+        sample = [fl[i] for i in rows]
+        c0 = time.perf_counter()
+        e_idx, e_score = oracle.indel_argmax(sample, tl)
+        dt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": len(rows) * float(len(tl)) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"{len(rows)} random from-titles (seed {SEED}) x all {len(tl)} to-titles, oracle/indel.c "
+                                         f"(plain O(|a||b|) LCS DP), {dt:.1f} s on 1 of {n_cores()} host cores"}
+        out["parity_check"] = {"rows_checked": int(len(rows)), "rows": "seeded random sample of the from-titles",
+                               "bit_exact": bool(np.array_equal(idx[rows], e_idx) and np.array_equal(score[rows], e_score))}
+    if world.size == 1 and not args.no_match_wall:
+        m = EditDistance(normalize=False)
+        m.match(fl, tl)
+        ts, ts2 = [], []
+        for _ in range(7):
+            c0 = time.perf_counter()
+            m.match(fl, tl)
+            ts.append((time.perf_counter() - c0) * 1e3)
+            c0 = time.perf_counter()
+            m.match(fl, tl, re_train=False)
+            ts2.append((time.perf_counter() - c0) * 1e3)
+        out["match_wall_ms"], out["match_wall_ms_to_list_resident"] = median(ts), median(ts2)
+        out["match_what"] = ("EditDistance(normalize=False).match(from, to): Python lists in, DataFrame out; "
+                             "..._to_list_resident = match(from, to, re_train=False), the to-list and its K4 plan kept on the device")
+    return out
+
+
+def run_rapidfuzz(world, ctx, args, steps=3, warmup=1, cpu_seconds=None):
+    """RapidFuzz() -- default scorer fuzz.WRatio, what PolyFuzz("EditDistance") dispatches to (polyfuzz.py:128-130,
+    _rapidfuzz.py:45-113) -- on config 3's 20 000 x 20 000 IMDB titles: process.extractOne per from-title (K7)."""
+    from polyfuzz_amd import datasets, pipeline
+    from polyfuzz_amd.models import RapidFuzz
+    fl, tl = datasets.c3_lists(2_000 if args.small else 20_000)
+    n = len(fl)
+    b, e = pipeline.shard_bounds(n, world.size, world.rank)
+    comm, exchange = world.comm(ctx) if world.size > 1 else (None, "none (single GPU)")
+    job = pipeline.BestChoiceJob(ctx, fl[b:e], tl, scorer="WRatio", comm=comm, rows_per_rank=pipeline.shard_bounds(n, world.size, 0)[1])
+    wall, result = timed_steps(world, ctx, job.step, steps, warmup, prof_level=True)
+    k7_ms, k7_launches = ctx.prof_get("k7_fuzz")
+    if world.rank != 0:
+        return None
+    idx, score = job.result_host(result)
+    if world.size > 1:
+        sizes = [pipeline.shard_bounds(n, world.size, r)[1] - pipeline.shard_bounds(n, world.size, r)[0] for r in range(world.size)]
+        idx, score = pipeline.BestChoiceJob.unpad(idx, score, sizes, job.rows_per_rank)
+    out = contract("string-pairs/sec, RapidFuzz() = process.extractOne(scorer=fuzz.WRatio) per from-string, 20k x 20k IMDB titles",
+                   float(n) * float(len(tl)) * steps / wall, "pairs/s", world, args, steps, warmup, wall,
+                   (args.scaling or "strong") if world.size > 1 else "weak", "int32/int64 bit-vectors, f64 score",
+                   "real: reference data/movie_titles.json (IMDB), gzipped in polyfuzz_amd/data/",
+                   {"workload": "RapidFuzz().match(from, to) (scorer fuzz.WRatio, the reference's default EditDistance path): 20000 x "
+                                "20000 IMDB titles, the lists' token forms and the to-side plan resident",
+                    "n_from": n, "n_from_this_rank": e - b, "n_to": len(tl),
+                    "parallelism": f"from-titles sharded x{world.size}, to-list replicated", "exchange": exchange,
+                    "transport": world.kind})
+    out["kernel_ms_per_step"] = {"k7_fuzz": round(k7_ms / steps, 3), "launches_per_step": k7_launches / steps}
+    out["roofline"] = job.roofline(k7_ms / steps * 1e-3, INT32_PEAK_TOPS)
+    if not args.no_cpu_baseline:
+        import concurrent.futures as cf
+        import oracle
+        oracle.build_native()
+        seconds = args.cpu_seconds if cpu_seconds is None else cpu_seconds
+        c0 = time.perf_counter()
+        oracle.fuzz_extract_one(fl[:4], tl, "WRatio")
+        per_row = (time.perf_counter() - c0) / 4
+        n1 = int(max(8, seconds / max(per_row, 1e-9)))                     # single-thread sample: the CPU arm
+        rows = edit_rows_sample(n, max(n1, 256))                           # parity sample: >= 256 rows, on threads
+        c0 = time.perf_counter()
+        e1_idx, e1_score = oracle.fuzz_extract_one([fl[i] for i in rows[:n1]], tl, "WRatio")
+        dt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": n1 * float(len(tl)) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"{n1} random from-titles (seed {SEED}) x all {len(tl)} to-titles, oracle/fuzz_scorers.c "
+                                         f"(rapidfuzz 3.x WRatio restated, plain LCS DP per window), {dt:.1f} s on 1 of {n_cores()} host cores"}
+        rest = rows[n1:]
+        e_idx, e_score = e1_idx, e1_score
+        if len(rest):
+            chunks = np.array_split(rest, min(len(rest), max(1, min(n_cores(), 64))))
+            with cf.ThreadPoolExecutor(len(chunks)) as ex:
+                parts = list(ex.map(lambda c: oracle.fuzz_extract_one([fl[i] for i in c], tl, "WRatio"), chunks))
+            e_idx = np.concatenate([e1_idx] + [p[0] for p in parts])
+            e_score = np.concatenate([e1_score] + [p[1] for p in parts])
+        out["parity_check"] = {"rows_checked": int(len(rows)), "rows": "seeded random sample of the from-titles",
+                               "bit_exact": bool(np.array_equal(idx[rows], e_idx) and np.array_equal(score[rows], e_score)),
+                               "rows_differing": int(((idx[rows] != e_idx) | (score[rows] != e_score)).sum())}
+    if world.size == 1 and not args.no_match_wall:
+        m = RapidFuzz()
+        m.match(fl, tl)
+        ts = []
+        for _ in range(5):
+            c0 = time.perf_counter()
+            m.match(fl, tl)
+            ts.append((time.perf_counter() - c0) * 1e3)
+        out["match_wall_ms"] = median(ts)
+        out["match_what"] = "RapidFuzz().match(from, to): Python lists in, DataFrame out, median of 5"
+    return out
+
+
+# ---- configuration 5: dense cosine top-n (K5) ------------------------------------------------------------------------
+
+def run_dense(world, ctx, args, steps=None, warmup=None):
+    """BASELINE.json config 5 / SURVEY.md section 8d: dense cosine top-10 of 500k x 500k 768-d embeddings on 8 GPUs --
+    per rank a 62 500-row from-shard against all 500 000 to-vectors (K5), operands resident in HBM (weak scaling: N = 8 is
+    config 5 itself).  One step = the shard's GEMM panels + row top-n.  Roofline: exact-fp32 MFMA."""
+    from polyfuzz_amd import pipeline
+    steps = args.steps if steps is None else steps
+    warmup = max(1, args.warmup if warmup is None else warmup)
+    n_to, n_from, d, top_n = (20_000, 4_000, 256, 10) if args.small else (500_000, 62_500, 768, 10)
+    b = np.random.default_rng(7).standard_normal((n_to, d), dtype=np.float32)          # replicated: the same on every rank
+    rng = np.random.default_rng(70 + world.rank)
+    a = rng.standard_normal((n_from, d), dtype=np.float32)
+    pick = rng.choice(n_to, n_from, replace=False)
+    a += 2.0 * b[pick]                       # planted near-duplicates: the top rank is known
+    comm, exchange = world.comm(ctx) if world.size > 1 else (None, "none (single GPU)")
+    job = pipeline.DenseMatchJob(ctx, a, b, top_n=top_n, comm=comm, rows_per_rank=n_from)
+    wall, res = timed_steps(world, ctx, job.step, steps, warmup)
+    gemm_ms, launches = ctx.prof_get("k5_gemm_panel")
+    if world.rank != 0:
+        return None
+    idx, val = res.download()
+    idx, val = idx[:n_from], val[:n_from]            # (rank 0's block of the gathered result)
+    flop = 2.0 * n_from * n_to * d
+    gemm_s = gemm_ms / max(1, launches) * 1e-3 * (launches / steps)       # GEMM time per step
+    out = contract("vector pairs/sec, dense cosine top-10, 62 500-row shards of 500k x 500k x 768 (BASELINE config 5)",
+                   float(n_from) * world.size * n_to * steps / wall, "pairs/s", world, args, steps, warmup, wall, "weak", "f32",
+                   "synthetic (SURVEY.md section 8d config 5: standard normal rows, planted near-duplicates)",
+                   {"workload": "Embeddings-style cosine top-10: 62 500 from-vectors per GPU (config 5's row shard) x 500 000 "
+                                "to-vectors x 768, operands resident, pipeline.DenseMatchJob", "n_from_per_rank": n_from,
+                    "n_to": n_to, "dim": d, "top_n": top_n, "parallelism": f"from-rows sharded x{world.size}, to-vectors replicated",
+                    "exchange": exchange, "transport": world.kind})
+    out["kernel_ms_per_step"] = {"k5_gemm_panel": round(gemm_ms / steps, 3), "launches_per_step": launches / steps}
+    out["roofline"] = {"kernel": "k5_gemm_panel_pipe", "bound": "mfma", "achieved": flop / gemm_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                       "unit": "TFLOP/s", "frac": flop / gemm_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                       "end_to_end_frac": flop * steps / (wall / 1.0) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                       "what": "2 n_from n_to d flops of exact fp32 products (v_mfma_f32_32x32x2_f32) over the GEMM panels' "
+                               "summed launch time; end_to_end_frac = over the whole step (row top-n included)"}
+    if not args.no_cpu_baseline:
+        # CPU arm + parity on a bounded random sample: float64 BLAS cosine + canonical top-n (oracle/dense.py)
+        import oracle
+        rows = np.sort(rng.choice(n_from, 64, replace=False))
+        c0 = time.perf_counter()
+        e_idx, e_val = oracle.dense_cossim_topn(a[rows], b, top_n, 0.0)
+        dt = time.perf_counter() - c0
+        err = float(np.abs(val[rows] - e_val).max())
+        bad = int((idx[rows] != e_idx).any(axis=1).sum())
+        out["cpu_baseline"] = {"value": len(rows) * float(n_to) / dt, "unit": "pairs/s", "cores": int(os.cpu_count() or 1), "kind": "port",
+                               "sample": f"{len(rows)} random from-rows x all {n_to} to-vectors, oracle/dense.py (float64 numpy / BLAS "
+                                         f"incl. the float64 conversion of the to-side), {dt:.1f} s"}
+        out["parity_check"] = {"rows_checked": int(len(rows)), "rows": "seeded random sample of the from-rows",
+                               "rows_with_index_diff": bad, "max_abs_score_err": err,
+                               "planted_match_found_top1": float((idx[:, 0] == pick).mean()), "ok": bool(err <= 1e-5 and bad == 0)}
+    return out
+
+
+RUNNERS = {"c2": run_c2, "editdistance": run_editdistance, "rapidfuzz": run_rapidfuzz, "dense": run_dense, "tfidf_1m": run_tfidf_1m}
+
+
+def sub_records(world, ctx, args):
+    """Every other BASELINE configuration as a compact sub-record of the default line (N = 1).  A configuration that
+    fails reports its error instead of taking the headline down."""
+    plan = (("c2_tfidf_10k", lambda: run_c2(world, ctx, args)),
+            ("editdistance", lambda: run_editdistance(world, ctx, args, steps=20, warmup=3, cpu_seconds=min(args.cpu_seconds, 4.0))),
+            ("rapidfuzz_wratio", lambda: run_rapidfuzz(world, ctx, args, cpu_seconds=min(args.cpu_seconds, 6.0))),
+            ("dense_shard", lambda: run_dense(world, ctx, args, steps=3, warmup=1)),
+            ("tfidf_1m_shard", lambda: run_tfidf_1m(world, ctx, args)))
+    out = {}
+    for name, fn in plan:
+        t0 = time.perf_counter()
+        try:
+            out[name] = compact(fn(), extra=("match_wall_ms_to_list_resident", "host_generation_s"))
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["bench_wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def run_rank(world, ctx, args):
+    if args.config == "tfidf":
+        out = headline(world, ctx, args)
+        if out is not None and world.size == 1 and not args.no_configs:
+            out["configs"] = sub_records(world, ctx, args)
+    else:
+        out = RUNNERS[args.config](world, ctx, args)
+    world.barrier(ctx)
+    return out
+
+
+def main():
+    args = parse()
+    import polyfuzz_amd
+    from polyfuzz_amd import _lib
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.transport == "local" and args.gpus > 1:
+        n_dev = max(1, _lib.device_count())
+        ctxs = [polyfuzz_amd.Context(r % n_dev) for r in range(args.gpus)]
+        shared = {"barrier": threading.Barrier(args.gpus), "vals": [0.0] * args.gpus, "comms": _lib.Comm.local_group(ctxs)}
+        outs, errs = [None] * args.gpus, [None] * args.gpus
+
+        def rank_main(r):
+            try:
+                outs[r] = run_rank(LocalWorld(r, args.gpus, shared), ctxs[r], args)
+            except BaseException as e:      # a dead rank must not leave the others waiting at a barrier
+                errs[r] = e
+                shared["barrier"].abort()
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(args.gpus)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        first = next((e for e in errs if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or \
+            next((e for e in errs if e is not None), None)
+        if first is not None:
+            raise first
+        out = outs[0]
+        out["config"]["devices_visible"] = n_dev
+    else:
+        if env_world != args.gpus:
+            if env_world == 1 and args.gpus > 1:
+                raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU), "
+                                 "or with --transport local")
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}")
+        world = TorchWorld() if env_world > 1 else World()
+        # one process, one GPU: the matchers' own default context, so that the library's kernel timers see their launches too
+        ctx = polyfuzz_amd.Context(world.local_rank) if env_world > 1 else polyfuzz_amd.Context.default()
+        out = run_rank(world, ctx, args)
+        if env_world > 1:
+            world.close()
+    if out is not None:
+        if args.small:
+            out["config"]["rehearsal"] = "--small: reduced sizes, NOT the BASELINE configuration"
         print(json.dumps(out))
 
 

@@ -69,14 +69,13 @@ static void csr_transpose(int64_t n_rows, int64_t n_cols,
  * exclude_diag != 0: column j == global row i is never a candidate
  * (reference _utils.py:84-87).  Returns 0, or -1 on allocation failure.
  */
-int oracle_cossim_topn(int64_t n_a, int64_t n_b, int64_t n_col,
-                       const int64_t *a_indptr, const int32_t *a_idx, const double *a_val,
-                       const int64_t *b_indptr, const int32_t *b_idx, const double *b_val,
-                       int64_t row_begin, int64_t row_end,
-                       int32_t ntop, double lower_bound, int32_t exclude_diag,
-                       int32_t *out_idx, double *out_val)
+static int cossim_topn_core(int64_t n_b, int64_t n_col,
+                            const int64_t *a_indptr, const int32_t *a_idx, const double *a_val,
+                            const int64_t *b_indptr, const int32_t *b_idx, const double *b_val,
+                            int64_t row_begin, int64_t row_end, const int64_t *row_ids,
+                            int32_t ntop, double lower_bound, int32_t exclude_diag,
+                            int32_t *out_idx, double *out_val)
 {
-    (void)n_a;
     int64_t nnz_b = b_indptr[n_b];
     int64_t *t_indptr = (int64_t *)malloc((size_t)(n_col + 1) * sizeof(int64_t));
     int32_t *t_idx = (int32_t *)malloc((size_t)(nnz_b > 0 ? nnz_b : 1) * sizeof(int32_t));
@@ -88,7 +87,8 @@ int oracle_cossim_topn(int64_t n_a, int64_t n_b, int64_t n_col,
     if (!t_indptr || !t_idx || !t_val || !sums || !touched || !mark || !cand) return -1;
     csr_transpose(n_b, n_col, b_indptr, b_idx, b_val, t_indptr, t_idx, t_val);
 
-    for (int64_t i = row_begin; i < row_end; ++i) {
+    for (int64_t at = row_begin; at < row_end; ++at) {
+        const int64_t i = row_ids ? row_ids[at] : at;      /* the row of A (its global index: the diagonal test below) */
         int64_t n_touched = 0;
         for (int64_t p = a_indptr[i]; p < a_indptr[i + 1]; ++p) {
             int32_t k = a_idx[p];
@@ -110,8 +110,8 @@ int oracle_cossim_topn(int64_t n_a, int64_t n_b, int64_t n_col,
             if (s > lower_bound) { cand[n_cand].s = s; cand[n_cand].j = j; ++n_cand; }
         }
         qsort(cand, (size_t)n_cand, sizeof(cand_t), cand_cmp);
-        int32_t *oi = out_idx + (i - row_begin) * ntop;
-        double *ov = out_val + (i - row_begin) * ntop;
+        int32_t *oi = out_idx + (at - row_begin) * ntop;
+        double *ov = out_val + (at - row_begin) * ntop;
         for (int32_t r = 0; r < ntop; ++r) {
             if (r < n_cand) { oi[r] = cand[r].j; ov[r] = cand[r].s; }
             else { oi[r] = -1; ov[r] = 0.0; }
@@ -119,6 +119,33 @@ int oracle_cossim_topn(int64_t n_a, int64_t n_b, int64_t n_col,
     }
     free(t_indptr); free(t_idx); free(t_val); free(sums); free(touched); free(mark); free(cand);
     return 0;
+}
+
+int oracle_cossim_topn(int64_t n_a, int64_t n_b, int64_t n_col,
+                       const int64_t *a_indptr, const int32_t *a_idx, const double *a_val,
+                       const int64_t *b_indptr, const int32_t *b_idx, const double *b_val,
+                       int64_t row_begin, int64_t row_end,
+                       int32_t ntop, double lower_bound, int32_t exclude_diag,
+                       int32_t *out_idx, double *out_val)
+{
+    (void)n_a;
+    return cossim_topn_core(n_b, n_col, a_indptr, a_idx, a_val, b_indptr, b_idx, b_val, row_begin, row_end, NULL, ntop,
+                            lower_bound, exclude_diag, out_idx, out_val);
+}
+
+/* The same for an arbitrary selection of rows of A (a seeded random sample: bench.py's parity check);
+ * out_idx / out_val are n_sel x ntop in the order of row_ids. */
+int oracle_cossim_topn_rows(int64_t n_a, int64_t n_b, int64_t n_col,
+                            const int64_t *a_indptr, const int32_t *a_idx, const double *a_val,
+                            const int64_t *b_indptr, const int32_t *b_idx, const double *b_val,
+                            const int64_t *row_ids, int64_t n_sel,
+                            int32_t ntop, double lower_bound, int32_t exclude_diag,
+                            int32_t *out_idx, double *out_val)
+{
+    for (int64_t t = 0; t < n_sel; ++t)
+        if (row_ids[t] < 0 || row_ids[t] >= n_a) return -2;
+    return cossim_topn_core(n_b, n_col, a_indptr, a_idx, a_val, b_indptr, b_idx, b_val, 0, n_sel, row_ids, ntop,
+                            lower_bound, exclude_diag, out_idx, out_val);
 }
 
 /* Full dense score row(s) for small cases: out is (row_end-row_begin) x n_b. */

@@ -38,6 +38,12 @@ def _load():
         _i64p, _i32p, _f64p, _i64p, _i32p, _f64p,
         ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
         _i32p, _f64p]
+    lib.oracle_cossim_topn_rows.restype = ctypes.c_int
+    lib.oracle_cossim_topn_rows.argtypes = [
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+        _i64p, _i32p, _f64p, _i64p, _i32p, _f64p,
+        _i64p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
+        _i32p, _f64p]
     lib.oracle_cossim_dense.restype = ctypes.c_int
     lib.oracle_cossim_dense.argtypes = [
         ctypes.c_int64, ctypes.c_int64,
@@ -67,11 +73,21 @@ def _csr(m):
 
 
 def cossim_topn(a_csr, b_csr, n_col, ntop, lower_bound, exclude_diag=False, rows=None):
-    """a_csr/b_csr = (indptr, indices, data).  Returns (idx int32, val float64), shape (n, ntop)."""
+    """a_csr/b_csr = (indptr, indices, data).  Returns (idx int32, val float64), shape (n, ntop).
+    rows: None (all), (begin, end), or an int64 ndarray of row ids (results in that order)."""
     lib = _load()
     ap, ai, av = _csr(a_csr)
     bp, bi, bv = _csr(b_csr)
     n_a, n_b = len(ap) - 1, len(bp) - 1
+    if isinstance(rows, np.ndarray):                       # an arbitrary selection of rows (e.g. a seeded random sample)
+        ids = np.ascontiguousarray(rows, np.int64)
+        out_idx = np.empty((len(ids), ntop), np.int32)
+        out_val = np.empty((len(ids), ntop), np.float64)
+        rc = lib.oracle_cossim_topn_rows(n_a, n_b, n_col, ap, ai, av, bp, bi, bv, ids, len(ids), ntop, float(lower_bound),
+                                         int(bool(exclude_diag)), out_idx, out_val)
+        if rc != 0:
+            raise ValueError(f"oracle_cossim_topn_rows failed ({rc})")
+        return out_idx, out_val
     r0, r1 = (0, n_a) if rows is None else rows
     out_idx = np.empty((r1 - r0, ntop), np.int32)
     out_val = np.empty((r1 - r0, ntop), np.float64)

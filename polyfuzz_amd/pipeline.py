@@ -227,10 +227,11 @@ class BestChoiceJob:
     WRatio and the other per-pair scorers (reference _distance.py:89-102, _rapidfuzz.py:99-113) -- and the per-shard
     (first best index, float64 score) blocks are all-gathered, padded to the largest shard.  The float64 scores travel
     as two 32-bit words in the value lanes of a two-column result buffer (the gather moves bytes), so every rank ends with
-    the exact scores of all from-strings -- which is also all the reference's global min-max normalisation needs."""
+    the exact scores of all from-strings -- which is also all the reference's global min-max normalisation needs.
+    Both lists (for K4 also the to-side plan) are uploaded once, at construction: a step is device work only."""
 
     def __init__(self, ctx, from_shard, to_list, scorer="ratio", comm=None, skip=None, rows_per_rank=None):
-        from .models._rapidfuzz import _DEVICE_SCORERS
+        from .models._rapidfuzz import _DEVICE_SCORERS, _K4_SCORERS
         if scorer not in _DEVICE_SCORERS:
             raise NotImplementedError(f"scorer {scorer!r} has no kernel")
         self.ctx, self.comm, self.scorer = ctx, comm, scorer
@@ -239,10 +240,23 @@ class BestChoiceJob:
         self.rows_per_rank = self.n_from if rows_per_rank is None else int(rows_per_rank)
         if self.rows_per_rank < self.n_from:
             raise ValueError("rows_per_rank is smaller than this rank's shard")
+        self.k4 = scorer in _K4_SCORERS
+        self.f_dev = self.t_dev = None
+        if self.k4 and scorer != "QRatio":
+            tr = (lambda s: " ".join(sorted(s.split()))) if scorer == "token_sort_ratio" else (lambda s: s)
+            self.f_dev = _lib.DeviceStrings.upload(ctx, [tr(s) for s in self.from_shard])
+            self.t_dev = _lib.DeviceStrings.upload(ctx, [tr(s) for s in to_list])
+
+    def plan_info(self):
+        """K4's cached to-side plan (alphabet, groups, character steps); {} for the K7 scorers"""
+        return _lib.indel_plan_info(self.ctx, self.t_dev) if self.t_dev is not None else {}
 
     def step(self):
         from .models._rapidfuzz import best_choice
-        idx, score = best_choice(self.ctx, self.scorer, self.from_shard, self.to_list, self.skip, False)
+        if self.f_dev is not None:
+            idx, score = _lib.indel_argmax(self.ctx, self.f_dev, self.t_dev, self.skip)
+        else:
+            idx, score = best_choice(self.ctx, self.scorer, self.from_shard, self.to_list, self.skip, False)
         if self.comm is None or self.comm.world == 1:
             return idx, score
         pad = self.rows_per_rank
@@ -253,6 +267,16 @@ class BestChoiceJob:
         local = _lib.DeviceTopN.from_host(self.ctx, pi, pv)
         g_idx, g_val = self.comm.allgather_topn(local).download()
         return g_idx[:, 0].copy(), np.ascontiguousarray(g_val).view(np.float64).reshape(-1)
+
+    def result_host(self, result):
+        """(index int32[n], score float64[n]) of what step() returned (all ranks' rows, padded, when sharded)"""
+        return result
+
+    def roofline(self, step_s, peak_tops):
+        return {"kernel": "k7_fuzz" if not self.k4 else "k4_indel", "bound": "int32 VALU issue (+ LDS look-ups)", "achieved": None,
+                "peak": peak_tops, "unit": "Tera int-op/s", "frac": None, "traffic": None,
+                "pairs_per_s_kernel": self.n_from * float(len(self.to_list)) / step_s if step_s > 0 else None,
+                "what": "no work count for this scorer yet"}
 
     @staticmethod
     def unpad(idx, score, sizes, rows_per_rank):
