@@ -4,8 +4,7 @@ every frame compared with the oracle path (TF-IDF) / the oracle scorers (edit di
 import numpy as np
 import pytest
 
-from facade_standin import FacadeStandIn
-from helpers import vectorize_pair
+from tests.facade_standin import FacadeStandIn
 
 pytestmark = pytest.mark.gpu
 

@@ -6,9 +6,8 @@ mkdir -p gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -x "$@" > gpurun_out/${tag}_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/${tag}_tests.log
 tail -15 gpurun_out/${tag}_tests.log
-/usr/bin/time -v timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench rc=$?"
-grep -E "Elapsed|Maximum resident" gpurun_out/${tag}_bench.err
 grep -v -E "^\s" gpurun_out/${tag}_bench.err | tail -c 1500
 python - <<PY
 import json
