@@ -1,0 +1,443 @@
+// K7's per-pair arithmetic: the rapidfuzz.fuzz scorers that build a different string pair for every (from, to) --
+// partial_ratio, token_set_ratio, token_ratio, partial_token_*_ratio, WRatio (reference polyfuzz/models/_rapidfuzz.py:45-58,
+// 106-108) -- as the exact score of ONE pair and as a cheap UPPER BOUND of it.
+//
+// Everything here is a plain function of one from-string's tables and one to-string's arrays: no wave-level operation,
+// no shared memory, no global state -- k7_fuzz.hip calls it from its lanes, and tests/k7_core_host.cpp compiles the same
+// header with g++ to hold both functions against the oracle on the CPU build box (test infrastructure; the product has
+// no host path).
+//
+// Exact score.  Every scorer is the Indel similarity of a sub-string / sub-token-set of three per-string forms
+//   form 0  the string;   form 1  its whitespace tokens sorted and joined by one space (token_sort);
+//   form 2  its DISTINCT tokens sorted and joined (token_set), with token ids (equal ids <=> equal tokens), lengths
+// computed with the bit-parallel LCS recurrence  V' = (V + (V & PM)) | (V & ~PM)  over 64-bit words (W per form):
+//   * a SUB-RANGE of the from-form is matched by masking PM, and the LCS against every PREFIX of it is the number of
+//     zero bits of V below the prefix length -- one pass over the to-string scores all windows of the from-string
+//     that start at one position (partial_ratio, from-string the longer one);
+//   * windows of the TO-string are separate passes, the prefixes falling out of the first pass step by step;
+//   * token_set's differences: a mask over the from-form's token positions and a per-character skip on the to-side
+//     (a tag per character: token number, separating space or not).
+// Scores are float64 with rapidfuzz's two normalisations kept apart ((1 - dist / lensum) * 100 for ratio-like values,
+// 100 - 100 dist / lensum inside token_set_ratio); windows compare as exact rationals.
+// `cur` (a score some valid choice of this from-string already has) lets a COMPONENT of the score be left out when an
+// upper bound of it is below `cur`: process.extractOne keeps only the maximum, so a pair that can win wins through
+// another component; every bound goes through the same monotone float64 expressions as the value it bounds.
+//
+// Upper bound (k7_upper_bound).  U = sum over character classes c of min(count_a(c), count_b(c)) >= LCS of ANY two
+// sub-multisets of the strings' characters, hence of every form, window and token difference.  With per-class counts
+// packed four to a dword, U = (|a| + |b| - SAD(hist_a, hist_b)) / 2 -- one v_sad_u8 per four classes.  The bound is
+// float32 and the caller prunes a pair only when bound + slack < cur, so float32 rounding never decides.
+//
+// PARITY UNPINNED (rapidfuzz is not installable): the oracle is oracle/fuzz_scorers.{py,c}.
+#pragma once
+
+#include <stdint.h>
+
+#ifndef PFZ_HD
+#define PFZ_HD __host__ __device__ inline
+#endif
+
+namespace pfz {
+
+enum FuzzMode { kWRatio = 0, kPartialRatio = 1, kTokenSetRatio = 2, kTokenRatio = 3, kPartialTokenSortRatio = 4,
+                kPartialTokenSetRatio = 5, kPartialTokenRatio = 6 };
+
+constexpr int kFuzzMaxTokens = 32;     // distinct tokens per string in the register / LDS kernels (token sets are 32-bit masks)
+constexpr int kFuzzHistWords = 8;      // character classes: 8 dwords x 4 one-byte counters
+
+// one from-string: match tables of its three forms, its distinct tokens
+template <int W> struct FuzzFrom {
+    const uint64_t *pm;          // [symbol][form][W]; symbol 0 (padding / not in the to-alphabet) is all zero
+    int la[3];                   // form lengths
+    int ta;                      // distinct tokens (<= kFuzzMaxTokens)
+    const int32_t *tid, *tlen;   // [ta]
+    const uint64_t *tmask;       // [ta][W] positions of token i in form 2
+    const uint64_t *smask;       // [ta][W] position of the space after token i (empty for the last token)
+};
+
+// one to-string: element pos of form v is sym[v][pos * stride]
+struct FuzzTo {
+    const uint16_t *sym[3];
+    const uint8_t *tag;          // form 2: token number (5 bits) | 0x80 for the space that follows that token
+    const int32_t *tok_id, *tok_len;   // [j * stride]
+    int stride;
+    int lb[3], tb;
+};
+
+PFZ_HD double fz_ratio_of(int lcs, int lensum)
+{
+    const int dist = lensum - 2 * lcs;
+    const double norm_dist = lensum != 0 ? (double)dist / (double)lensum : 0.0;
+    return (1.0 - norm_dist) * 100.0;
+}
+
+PFZ_HD double fz_norm_distance(int dist, int lensum)
+{
+    return lensum != 0 ? 100.0 - (double)(100 * dist) / (double)lensum : 100.0;
+}
+
+PFZ_HD int fz_popc64(uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(v);
+#else
+    return __builtin_popcountll(v);
+#endif
+}
+
+PFZ_HD int fz_popc32(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(v);
+#else
+    return __builtin_popcount(v);
+#endif
+}
+
+PFZ_HD int fz_last_bit(uint32_t v) { return v ? 31 - __builtin_clz(v) : -1; }
+PFZ_HD int fz_min(int a, int b) { return a < b ? a : b; }
+PFZ_HD int fz_max(int a, int b) { return a > b ? a : b; }
+PFZ_HD double fz_fmax(double a, double b) { return a > b ? a : b; }      // (no NaNs here)
+
+template <int W>
+PFZ_HD void fz_step(uint64_t (&V)[W], const uint64_t *pm, const uint64_t (&mask)[W])
+{
+    uint64_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint64_t u = V[w] & pm[w] & mask[w];
+        const uint64_t sum = V[w] + u + carry;
+        carry = (sum < V[w]) | (carry & (sum == V[w]));
+        V[w] = sum | (V[w] ^ u);
+    }
+}
+
+// zero bits of V in positions [0, k)
+template <int W>
+PFZ_HD int fz_zeros_below(const uint64_t (&V)[W], int k)
+{
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int bits = fz_min(fz_max(k - 64 * w, 0), 64);
+        const uint64_t m = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+        n += fz_popc64(~V[w] & m);
+    }
+    return n;
+}
+
+template <int W>
+PFZ_HD void fz_range_mask(uint64_t (&m)[W], int lo, int hi)      // bits [lo, hi)
+{
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int a = fz_min(fz_max(lo - 64 * w, 0), 64), b = fz_min(fz_max(hi - 64 * w, 0), 64);
+        const uint64_t below_b = b >= 64 ? ~0ull : ((1ull << b) - 1ull), below_a = a >= 64 ? ~0ull : ((1ull << a) - 1ull);
+        m[w] = below_b & ~below_a;
+    }
+}
+
+// LCS state of the from-form v (restricted to `amask`) against the to-form v; with `tagged` only the to-tokens whose bit
+// is set in `rb` are fed (form 2), the space after the last of them (`last_rb`) left out
+template <int W>
+PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint64_t (&amask)[W], bool tagged, uint32_t rb,
+                        int last_rb, uint64_t (&V)[W])
+{
+#pragma unroll
+    for (int w = 0; w < W; ++w) V[w] = ~0ull;
+    const int lb = T.lb[v];
+    for (int pos = 0; pos < lb; ++pos) {
+        int sy = T.sym[v][(int64_t)pos * T.stride];
+        if (tagged) {
+            const int tag = T.tag[(int64_t)pos * T.stride], j = tag & 31;
+            const bool keep = ((rb >> j) & 1u) && !((tag & 0x80) && j == last_rb);
+            sy = keep ? sy : 0;
+        }
+        fz_step<W>(V, F.pm + (sy * 3 + v) * W, amask);
+    }
+}
+
+// rapidfuzz.fuzz.partial_ratio of the two v-forms: every window, compared as exact rationals lcs / (|shorter| + |window|)
+template <int W>
+PFZ_HD double fz_partial(const FuzzFrom<W> &F, const FuzzTo &T, int v)
+{
+    const int la = F.la[v], lb = T.lb[v];
+    if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
+    int bl = 0, bs = 1;
+    auto cand = [&](int lcs, int sum) {
+        if ((int64_t)lcs * bs > (int64_t)bl * sum) {
+            bl = lcs;
+            bs = sum;
+        }
+    };
+    uint64_t all[W], V[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) all[w] = ~0ull;
+    const uint16_t *sym = T.sym[v];
+    const int64_t st = T.stride;
+    if (lb >= la) {
+        // the from-form is the shorter (or equal): windows of the to-form starting at s (its prefixes shorter than the
+        // from-form fall out of the first window step by step)
+        for (int s = 0; s < lb; ++s) {
+            const int wlen = fz_min(la, lb - s);
+#pragma unroll
+            for (int w = 0; w < W; ++w) V[w] = ~0ull;
+            for (int k = 0; k < wlen; ++k) {
+                fz_step<W>(V, F.pm + ((int)sym[(int64_t)(s + k) * st] * 3 + v) * W, all);
+                if (s == 0 && k + 1 < la) cand(fz_zeros_below<W>(V, la), la + k + 1);
+            }
+            cand(fz_zeros_below<W>(V, la), la + wlen);
+        }
+    }
+    if (lb <= la) {
+        // the from-form is the longer (or equal): windows of the from-form starting at i, one pass over the to-form each
+        for (int i = 0; i < la; ++i) {
+            uint64_t m[W];
+            fz_range_mask<W>(m, i, la);
+#pragma unroll
+            for (int w = 0; w < W; ++w) V[w] = ~0ull;
+            for (int pos = 0; pos < lb; ++pos) fz_step<W>(V, F.pm + ((int)sym[(int64_t)pos * st] * 3 + v) * W, m);
+            const int wlen = fz_min(lb, la - i);
+            cand(fz_zeros_below<W>(V, i + wlen) - fz_zeros_below<W>(V, i), lb + wlen);
+            if (i == 0)
+                for (int k = 1; k < lb; ++k) cand(fz_zeros_below<W>(V, k), lb + k);          // prefixes
+        }
+    }
+    return fz_ratio_of(bl, bs);
+}
+
+// common distinct tokens: bit i of ca (from-tokens), bit j of cb (to-tokens)
+template <int W>
+PFZ_HD void fz_intersect(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t &ca, uint32_t &cb)
+{
+    ca = cb = 0u;
+    for (int j = 0; j < T.tb; ++j) {
+        const int idb = T.tok_id[(int64_t)j * T.stride];
+        for (int i = 0; i < F.ta; ++i)
+            if (F.tid[i] == idb) {
+                ca |= 1u << i;
+                cb |= 1u << j;
+            }
+    }
+}
+
+template <int W>
+PFZ_HD double fz_token_set(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t ca, uint32_t cb)
+{
+    const int ta = F.ta, tb = T.tb;
+    if (ta == 0 || tb == 0) return 0.0;
+    const int nc = fz_popc32(ca);
+    if (nc > 0 && (nc == ta || nc == tb)) return 100.0;
+    // lengths of the joined differences and of the joined intersection
+    const uint32_t ra = ~ca & (ta >= 32 ? ~0u : ((1u << ta) - 1u)), rb = ~cb & (tb >= 32 ? ~0u : ((1u << tb) - 1u));
+    int ab_len = fz_popc32(ra) - 1, ba_len = fz_popc32(rb) - 1, sect_len = nc > 0 ? nc - 1 : 0;
+    uint64_t amask[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) amask[w] = 0ull;
+    const int last_ra = fz_last_bit(ra), last_rb = fz_last_bit(rb);
+    for (int i = 0; i < ta; ++i) {
+        const bool rem = (ra >> i) & 1u;
+        ab_len += rem ? F.tlen[i] : 0;
+        sect_len += rem ? 0 : F.tlen[i];
+#pragma unroll
+        for (int w = 0; w < W; ++w) amask[w] |= rem ? (F.tmask[i * W + w] | (i != last_ra ? F.smask[i * W + w] : 0ull)) : 0ull;
+    }
+    for (int j = 0; j < tb; ++j)
+        if ((rb >> j) & 1u) ba_len += T.tok_len[(int64_t)j * T.stride];
+    uint64_t V[W];
+    fz_lcs_pass<W>(F, T, 2, amask, true, rb, last_rb, V);
+    const int lcs = fz_zeros_below<W>(V, F.la[2]);
+    const int sect_sep = sect_len != 0 ? 1 : 0;
+    const int sect_ab_len = sect_len + sect_sep + ab_len, sect_ba_len = sect_len + sect_sep + ba_len;
+    const double result = fz_norm_distance(ab_len + ba_len - 2 * lcs, sect_ab_len + sect_ba_len);
+    if (sect_len == 0) return result;
+    const double r_ab = fz_norm_distance(sect_sep + ab_len, sect_len + sect_ab_len);
+    const double r_ba = fz_norm_distance(sect_sep + ba_len, sect_len + sect_ba_len);
+    return fz_fmax(result, fz_fmax(r_ab, r_ba));
+}
+
+template <int W>
+PFZ_HD double fz_token_sort(const FuzzFrom<W> &F, const FuzzTo &T)
+{
+    uint64_t all[W], V[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) all[w] = ~0ull;
+    fz_lcs_pass<W>(F, T, 1, all, false, 0u, 0, V);
+    return fz_ratio_of(fz_zeros_below<W>(V, F.la[1]), F.la[1] + T.lb[1]);
+}
+
+// partial_ratio of the v-forms, left out (0: a lower bound) when it cannot reach `cur`: a window has at most the LCS of
+// the whole forms -- one cheap pass -- and at least that many characters
+template <int W>
+PFZ_HD double fz_partial_pruned(const FuzzFrom<W> &F, const FuzzTo &T, int v, double cur)
+{
+    const int la = F.la[v], lb = T.lb[v];
+    if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
+    uint64_t all[W], V[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) all[w] = ~0ull;
+    fz_lcs_pass<W>(F, T, v, all, false, 0u, 0, V);
+    const int l = fz_zeros_below<W>(V, la), lm = fz_min(la, lb);
+    if (fz_ratio_of(l, lm + l) < cur) return 0.0;
+    return fz_partial<W>(F, T, v);
+}
+
+// The score of the pair under `mode`, exact whenever it is >= cur (below cur it may come out lower than the true score,
+// never higher: components that cannot reach cur are left out).
+template <int W>
+PFZ_HD double fz_score(const FuzzFrom<W> &F, const FuzzTo &T, int mode, double cur)
+{
+    const int la0 = F.la[0], lb0 = T.lb[0], ta = F.ta, tb = T.tb;
+    uint32_t ca = 0u, cb = 0u;
+    if (mode != kPartialRatio && mode != kPartialTokenSortRatio) fz_intersect<W>(F, T, ca, cb);
+    if (mode == kWRatio) {
+        if (la0 == 0 || lb0 == 0) return 0.0;
+        uint64_t all[W], V[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) all[w] = ~0ull;
+        fz_lcs_pass<W>(F, T, 0, all, false, 0u, 0, V);
+        const int lcs0 = fz_zeros_below<W>(V, la0);
+        double end_ratio = fz_ratio_of(lcs0, la0 + lb0);
+        const int lmax = fz_max(la0, lb0), lmin = fz_min(la0, lb0);
+        if (2 * lmax < 3 * lmin) {                                // len_ratio < 1.5
+            if (100.0 * 0.95 < cur) return end_ratio;             // the token scorers are <= 100
+            const double t1 = fz_token_sort<W>(F, T), t2 = fz_token_set<W>(F, T, ca, cb);     // (no tokens on either side: ratio("", "") = 100, as rapidfuzz)
+            return fz_fmax(end_ratio, fz_fmax(t1, t2) * 0.95);
+        }
+        const double scale = lmax < 8 * lmin ? 0.9 : 0.6;       // len_ratio < 8
+        // a window of either string has LCS <= the LCS of the whole strings and at least that many characters
+        if (!(fz_ratio_of(lcs0, lmin + lcs0) * scale < cur)) end_ratio = fz_fmax(end_ratio, fz_partial<W>(F, T, 0) * scale);
+        double pt = 0.0;
+        if (ta != 0 && tb != 0) {
+            if (ca) pt = 100.0;
+            else if (!(100.0 * 0.95 * scale < cur)) {
+                // the distinct-token form is a subsequence of the sorted-token form: one pass bounds both
+                fz_lcs_pass<W>(F, T, 1, all, false, 0u, 0, V);
+                const int lcs1 = fz_zeros_below<W>(V, F.la[1]);
+                const int m1 = fz_min(F.la[1], T.lb[1]), m2 = fz_min(F.la[2], T.lb[2]);
+                const int c1 = fz_min(lcs1, m1), c2 = fz_min(lcs1, m2);
+                double p1 = 0.0, p2 = 0.0;
+                if (!(fz_ratio_of(c1, m1 + c1) * 0.95 * scale < cur)) p1 = fz_partial<W>(F, T, 1);
+                if (!(fz_ratio_of(c2, m2 + c2) * 0.95 * scale < cur)) p2 = fz_partial<W>(F, T, 2);
+                pt = fz_fmax(p1, p2);
+            }
+        }
+        return fz_fmax(end_ratio, pt * 0.95 * scale);
+    }
+    if (mode == kPartialRatio) return fz_partial_pruned<W>(F, T, 0, cur);
+    if (mode == kTokenSetRatio) return fz_token_set<W>(F, T, ca, cb);
+    if (mode == kTokenRatio) return fz_fmax(fz_token_sort<W>(F, T), fz_token_set<W>(F, T, ca, cb));
+    if (mode == kPartialTokenSortRatio) return fz_partial_pruned<W>(F, T, 1, cur);
+    if (mode == kPartialTokenSetRatio) return (ta == 0 || tb == 0) ? 0.0 : (ca ? 100.0 : fz_partial_pruned<W>(F, T, 2, cur));
+    // partial_token_ratio
+    if (ta == 0 || tb == 0) return 0.0;
+    if (ca) return 100.0;
+    return fz_fmax(fz_partial_pruned<W>(F, T, 1, cur), fz_partial_pruned<W>(F, T, 2, cur));
+}
+
+// ---- upper bound -------------------------------------------------------------------------------------------------------
+
+// what the bound needs of one string: form lengths, distinct tokens, the character-class histogram (one byte per class,
+// four classes per dword) with its sum -- usum < 0: no histogram (a class count beyond 255) -- and a 64-bit signature
+// of the token ids (bit = hash of the id: disjoint signatures <=> certainly no common token)
+struct FuzzSummary {
+    int len[3], ntok;
+    uint32_t hist[kFuzzHistWords];
+    int usum;
+    uint64_t sig;
+};
+
+PFZ_HD uint64_t fz_sig_bit(int32_t tok_id) { return 1ull << (((uint32_t)tok_id * 0x9E3779B1u) >> 26); }
+
+PFZ_HD int fz_sad_u8(uint32_t a, uint32_t b, int acc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__builtin_amdgcn_sad_u8(a, b, (uint32_t)acc);
+#else
+    for (int k = 0; k < 4; ++k) {
+        const int x = (a >> (8 * k)) & 255, y = (b >> (8 * k)) & 255;
+        acc += x > y ? x - y : y - x;
+    }
+    return acc;
+#endif
+}
+
+// sum over the character classes of min(count_a, count_b): >= the LCS of any two sub-multisets of the strings' characters
+PFZ_HD int fz_common_chars(const FuzzSummary &a, const FuzzSummary &b)
+{
+    if (a.usum < 0 || b.usum < 0) return fz_min(a.len[0], b.len[0]);      // (no form is longer than the string itself)
+    int sad = 0;
+#pragma unroll
+    for (int d = 0; d < kFuzzHistWords; ++d) sad = fz_sad_u8(a.hist[d], b.hist[d], sad);
+    return (a.usum + b.usum - sad) >> 1;
+}
+
+PFZ_HD float fz_r32(int lcs, int lensum) { return lensum > 0 ? 200.0f * (float)lcs / (float)lensum : 100.0f; }
+
+// token_set_ratio's bound once the common tokens are known (ca / cb as fz_intersect leaves them): the two "sect" ratios
+// are length arithmetic -- exact -- and the LCS of the joined differences is at most the shorter difference and at most
+// u minus the characters of the common tokens (they sit in both histograms and in neither difference)
+template <int W>
+PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t ca, uint32_t cb, int u)
+{
+    const int ta = F.ta, tb = T.tb;
+    if (ta == 0 || tb == 0) return 0.0f;
+    const int nc = fz_popc32(ca);
+    if (nc > 0 && (nc == ta || nc == tb)) return 100.0f;
+    const uint32_t ra = ~ca & (ta >= 32 ? ~0u : ((1u << ta) - 1u)), rb = ~cb & (tb >= 32 ? ~0u : ((1u << tb) - 1u));
+    int ab_len = fz_popc32(ra) - 1, ba_len = fz_popc32(rb) - 1, sect_chars = 0;
+    for (int i = 0; i < ta; ++i) {
+        const bool rem = (ra >> i) & 1u;
+        ab_len += rem ? F.tlen[i] : 0;
+        sect_chars += rem ? 0 : F.tlen[i];
+    }
+    for (int j = 0; j < tb; ++j)
+        if ((rb >> j) & 1u) ba_len += T.tok_len[(int64_t)j * T.stride];
+    const int sect_len = sect_chars + (nc > 0 ? nc - 1 : 0), sect_sep = sect_len != 0 ? 1 : 0;
+    const int sect_ab_len = sect_len + sect_sep + ab_len, sect_ba_len = sect_len + sect_sep + ba_len;
+    const int m = fz_min(fz_min(ab_len, ba_len), fz_max(u - sect_chars, 0));
+    const float total = (float)(sect_ab_len + sect_ba_len);
+    const float result = total > 0.0f ? 100.0f - 100.0f * (float)(ab_len + ba_len - 2 * m) / total : 100.0f;
+    if (sect_len == 0) return result;
+    const float r_ab = 100.0f - 100.0f * (float)(sect_sep + ab_len) / (float)(sect_len + sect_ab_len);
+    const float r_ba = 100.0f - 100.0f * (float)(sect_sep + ba_len) / (float)(sect_len + sect_ba_len);
+    return fmaxf(result, fmaxf(r_ab, r_ba));
+}
+
+// An upper bound of fz_score(F, T, mode, .) -- of the TRUE score -- from the two summaries alone.  `common` says what is
+// known about common tokens: -1 unknown (the signatures intersect; assume the best), 0 none, 1 some -- then `tset` is
+// fz_token_set_bound (pass a negative value to assume 100).  float32: the caller keeps a slack (prune only when
+// bound + 0.05 < cur).
+PFZ_HD float fz_upper_bound(const FuzzSummary &a, const FuzzSummary &b, int mode, int u, int common, float tset = -1.0f)
+{
+    auto lcs_ub = [&](int v) { return fz_min(u, fz_min(a.len[v], b.len[v])); };
+    auto ratio_ub = [&](int v) { return fz_r32(lcs_ub(v), a.len[v] + b.len[v]); };
+    auto partial_ub = [&](int v) -> float {
+        if (a.len[v] == 0 || b.len[v] == 0) return a.len[v] == 0 && b.len[v] == 0 ? 100.0f : 0.0f;
+        const int m = lcs_ub(v);
+        return fz_r32(m, fz_min(a.len[v], b.len[v]) + m);      // a window has at most m matches and at least m characters
+    };
+    const bool toks = a.ntok != 0 && b.ntok != 0;
+    // token_set_ratio: 100 is possible as soon as there may be a common token; without one it is the (other
+    // normalisation of the) ratio of the distinct-token forms
+    auto token_set_ub = [&]() -> float { return !toks ? 0.0f : (common != 0 ? (tset >= 0.0f ? tset : 100.0f) : ratio_ub(2)); };
+    auto ptoken_ub = [&]() -> float { return !toks ? 0.0f : (common != 0 ? 100.0f : fmaxf(partial_ub(1), partial_ub(2))); };
+    switch (mode) {
+    case kWRatio: {
+        const int la = a.len[0], lb = b.len[0];
+        if (la == 0 || lb == 0) return 0.0f;
+        const int lmax = fz_max(la, lb), lmin = fz_min(la, lb);
+        if (2 * lmax < 3 * lmin) return fmaxf(ratio_ub(0), 0.95f * fmaxf(ratio_ub(1), token_set_ub()));
+        const float scale = lmax < 8 * lmin ? 0.9f : 0.6f;
+        return fmaxf(ratio_ub(0), fmaxf(scale * partial_ub(0), 0.95f * scale * ptoken_ub()));
+    }
+    case kPartialRatio: return partial_ub(0);
+    case kTokenSetRatio: return token_set_ub();
+    case kTokenRatio: return fmaxf(ratio_ub(1), token_set_ub());
+    case kPartialTokenSortRatio: return partial_ub(1);
+    case kPartialTokenSetRatio: return !toks ? 0.0f : (common != 0 ? 100.0f : partial_ub(2));
+    default: return ptoken_ub();
+    }
+}
+
+}  // namespace pfz
