@@ -310,3 +310,24 @@ int oracle_fuzz_extract_one(const uint32_t *a_cp, const int64_t *a_off, int64_t 
     work_free(&w);
     return 0;
 }
+
+/* every score of from-rows [row_begin, row_end) x all choices, row-major (tests of the kernels' per-pair arithmetic) */
+int oracle_fuzz_matrix(const uint32_t *a_cp, const int64_t *a_off, int64_t n_a, const uint32_t *b_cp, const int64_t *b_off,
+                       int64_t n_b, int32_t scorer, int64_t row_begin, int64_t row_end, double *out)
+{
+    if (scorer < 0 || scorer >= S_COUNT || row_begin < 0 || row_end > n_a || row_begin > row_end) return 1;
+    prep_t *pb = (prep_t *)malloc((size_t)(n_b > 0 ? n_b : 1) * sizeof(prep_t));
+    if (!pb) return 2;
+    for (int64_t j = 0; j < n_b; ++j) prepare(&pb[j], b_cp + b_off[j], b_off[j + 1] - b_off[j]);
+    work_t w = {0};
+    for (int64_t i = row_begin; i < row_end; ++i) {
+        prep_t pa;
+        prepare(&pa, a_cp + a_off[i], a_off[i + 1] - a_off[i]);
+        for (int64_t j = 0; j < n_b; ++j) out[(i - row_begin) * n_b + j] = score_pair(&pa, &pb[j], scorer, &w);
+        release(&pa);
+    }
+    for (int64_t j = 0; j < n_b; ++j) release(&pb[j]);
+    free(pb);
+    work_free(&w);
+    return 0;
+}

@@ -62,6 +62,9 @@ def _load():
     lib.oracle_fuzz_extract_one.argtypes = [
         _u32p, _i64p, ctypes.c_int64, _u32p, _i64p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_int64, ctypes.c_int64, _i32p, _f64p]
+    lib.oracle_fuzz_matrix.restype = ctypes.c_int
+    lib.oracle_fuzz_matrix.argtypes = [_u32p, _i64p, ctypes.c_int64, _u32p, _i64p, ctypes.c_int64, ctypes.c_int32,
+                                       ctypes.c_int64, ctypes.c_int64, _f64p]
     _lib = lib
     return lib
 
@@ -180,3 +183,16 @@ def fuzz_extract_one(from_list, to_list, scorer, skip=None, rows=None):
     if rc != 0:
         raise ValueError(f"oracle_fuzz_extract_one failed ({rc})")
     return out_idx, out_score
+
+
+def fuzz_matrix(from_list, to_list, scorer, rows=None):
+    """float64 [rows, len(to_list)]: every pair's score under the rapidfuzz.fuzz scorer `scorer`."""
+    lib = _load()
+    acp, aoff = _codepoints(from_list)
+    bcp, boff = _codepoints(to_list)
+    r0, r1 = (0, len(from_list)) if rows is None else rows
+    out = np.empty((r1 - r0, len(to_list)), np.float64)
+    rc = lib.oracle_fuzz_matrix(acp, aoff, len(from_list), bcp, boff, len(to_list), FUZZ_SCORER_IDS[scorer], r0, r1, out)
+    if rc != 0:
+        raise ValueError(f"oracle_fuzz_matrix failed ({rc})")
+    return out

@@ -1,0 +1,112 @@
+"""K7's per-pair arithmetic (polyfuzz_amd/csrc/k7_core.h) on the CPU: the header the HIP kernel calls from its lanes,
+compiled with g++ (tests/k7_core_host.cpp), against oracle/fuzz_scorers.c on every pair of seeded lists:
+  * the exact score, bit for bit, in every mode and word class;
+  * with a running best `cur`: exact whenever the true score reaches cur, never above the true score otherwise (that is
+    what lets process.extractOne's maximum skip components);
+  * the float32 upper bound the kernel prunes with: bound + slack >= the true score, always.
+PARITY UNPINNED beyond the oracle (rapidfuzz is not installable)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import k7_prep
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+MODES = ["WRatio", "partial_ratio", "token_set_ratio", "token_ratio", "partial_token_sort_ratio", "partial_token_set_ratio",
+         "partial_token_ratio"]
+SLACK = 0.05          # the kernel prunes a pair only when bound + SLACK < cur
+
+
+@pytest.fixture(scope="module")
+def host():
+    so = os.path.join(REPO, "oracle", "_build", "k7_core_host.so")
+    src = [os.path.join(HERE, "k7_core_host.cpp"), os.path.join(REPO, "polyfuzz_amd", "csrc", "k7_core.h")]
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src[0], "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.k7_host_pairs.restype = ctypes.c_int
+    return lib
+
+
+def run_pairs(lib, W, alpha, A, B, mode, cur):
+    out = np.empty((A["n"], B["n"]), np.float64)
+    ub = np.empty((A["n"], B["n"]), np.float32)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+
+    def args(L):
+        return [ctypes.c_int64(L["n"]), p(L["sym"][0]), p(L["off"][0]), p(L["sym"][1]), p(L["off"][1]), p(L["sym"][2]), p(L["off"][2]),
+                p(L["tag"]), p(L["tok_off"]), p(L["tok_id"]), p(L["tok_len"]), p(L["hist"]), p(L["usum"])]
+    cur = np.ascontiguousarray(cur, np.float64)
+    rc = lib.k7_host_pairs(W, alpha.n_sym, *args(A), *args(B), MODES.index(mode), p(cur), p(out), p(ub))
+    assert rc == 0
+    return out, ub
+
+
+def _lists(seed, n_from, n_to, long_words=False):
+    rng = np.random.default_rng(seed)
+    words = ["new", "york", "mets", "braves", "the", "atlanta", "vs", "a", "bb", "inc", "llc", "co", "yankees", "red", "sox",
+             "x", "of", "los", "angeles", "dodgers"]
+    if long_words:
+        words += ["internationalisation", "incorporated", "pharmaceuticals", "telecommunications"]
+
+    def mk(n):
+        out = []
+        for _ in range(n):
+            k = int(rng.integers(0, 7 if not long_words else 10))
+            s = (" " * int(rng.integers(1, 3))).join(rng.choice(words, size=k))
+            if rng.random() < 0.15:
+                s = " " + s + "\t "
+            if rng.random() < 0.2 and s:
+                q = int(rng.integers(0, len(s)))
+                s = s[:q] + "q" + s[q + 1:]
+            out.append(s)
+        return out
+    return mk(n_from), mk(n_to)
+
+
+CASES = [(1, 3, False), (2, 9, True), (4, 5, True)]
+
+
+@pytest.mark.parametrize("W,seed,long_words", CASES)
+@pytest.mark.parametrize("mode", MODES)
+def test_score_and_bound_vs_oracle(host, oracle_mod, mode, W, seed, long_words):
+    from polyfuzz_amd import datasets
+    fl, tl = _lists(seed, 40, 90, long_words)
+    titles_f, titles_t = datasets.c3_lists(60)
+    fl += titles_f[:25] + ["this is a test", "fuzzy was a bear", "", "a", "mets mets mets new", "zzz"]
+    tl += titles_t[:50] + ["this is a new test!!!", "fuzzy fuzzy was a bear", "", "this is a test!", "new mets", "a\tb  a"]
+    if W == 1:
+        fl = [s for s in fl if len(s) <= 64]
+    fl = [s for s in fl if len(s) <= 64 * W and len(set(s.split())) <= 32]
+    alpha = k7_prep.Alphabet(tl)
+    A, B = k7_prep.prepare(fl, alpha, False), k7_prep.prepare(tl, alpha, True)
+    truth = oracle_mod.fuzz_matrix(fl, tl, mode)
+    score, ub = run_pairs(host, W, alpha, A, B, mode, np.zeros(len(fl)))
+    np.testing.assert_array_equal(score, truth)
+    assert (ub > -999).all(), "a refined bound exceeded the coarse one"
+    assert (ub + SLACK >= truth).all(), (mode, float((truth - ub).max()))
+    # a running best: the 80th percentile of the row (some pairs above, most below)
+    cur = np.quantile(truth, 0.8, axis=1)
+    score2, _ = run_pairs(host, W, alpha, A, B, mode, cur)
+    reach = truth >= cur[:, None]
+    np.testing.assert_array_equal(score2[reach], truth[reach])
+    assert (score2 <= truth).all()
+
+
+def test_bound_is_useful(host, oracle_mod):
+    """not only valid: with the row's true best as cur, the bound prunes nearly every pair of real title lists"""
+    from polyfuzz_amd import datasets
+    fl, tl = datasets.c3_lists(4000)
+    fl = [s for s in fl if len(s) <= 64 and len(set(s.split())) <= 32][:40]
+    alpha = k7_prep.Alphabet(tl)
+    A, B = k7_prep.prepare(fl, alpha, False), k7_prep.prepare(tl, alpha, True)
+    truth = oracle_mod.fuzz_matrix(fl, tl, "WRatio")
+    _, ub = run_pairs(host, 1, alpha, A, B, "WRatio", np.zeros(len(fl)))
+    assert (ub + SLACK >= truth).all()
+    kept = (ub + SLACK >= truth.max(axis=1)[:, None]).mean()
+    assert kept < 0.15, kept
