@@ -204,6 +204,11 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
 int pfz_indel_argmax(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
                      const int32_t *skip_idx, int64_t from_begin, int64_t from_end,
                      int32_t *out_idx, double *out_score);
+/* pfz_indel_argmax with the result left on the device in the layout the sharded jobs all-gather: `out` must have 2
+ * columns and >= from_end - from_begin rows; row r gets idx[r][0] = the first arg-max (idx[r][1] = -1) and the
+ * float64 ratio's bits in its two value lanes.  Enqueues. */
+int pfz_indel_argmax_dev(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
+                         const int32_t *skip_idx, int64_t from_begin, int64_t from_end, pfz_topn *out);
 /* every ratio of rows [from_begin, from_end) x all to-strings as float64,
  * row-major host buffer (test / small-input entry point).  Blocks. */
 int pfz_indel_matrix_host(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
@@ -220,28 +225,36 @@ int pfz_indel_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_
 /* ---- K7: the per-pair rapidfuzz scorers -------------------------------------
  * Replaces process.extractOne(from_string, to_list, scorer=..., score_cutoff=...) of the reference's RapidFuzz
  * matcher (_rapidfuzz.py:99-113; scorer default fuzz.WRatio, _rapidfuzz.py:48) for the scorers that build a
- * different string pair per (from, to): the best choice (first maximum) of every from-string.
- * A list is handed over as three forms of every string -- 0: the string, 1: its whitespace tokens sorted and
- * joined by one space (fuzz.token_sort_ratio's operand), 2: its DISTINCT tokens sorted and joined
- * (fuzz.token_set_ratio's) -- each as symbol ranks 1..n_symbols of one alphabet shared by both lists
- * (0 = a from-character the to-list never uses), CSR-style, plus the distinct tokens of every string in the
- * order of form 2: an id that is equal for equal tokens across both lists, and the token's length.
+ * different string pair per (from, to): the best choice (first maximum) of every from-string of rows
+ * [from_begin, from_end) among all to-strings.
+ * Everything is prepared on the device from the two resident lists: the three forms of every string -- 0: the string,
+ * 1: its whitespace tokens (Python's str.split()) sorted and joined by one space (fuzz.token_sort_ratio's operand),
+ * 2: its DISTINCT tokens sorted and joined (fuzz.token_set_ratio's) -- are built once per list and cached on its
+ * handle; the to-side plan (alphabet of the to-list, token table, length-sorted groups of 64 with symbols / token ids /
+ * character-class histograms) once per to-list, cached on ITS handle, so matching further from-lists against the same
+ * pfz_strings (reference PolyFuzz.transform, polyfuzz.py:234-240) costs no preparation.
  * scorer: 0 WRatio, 1 partial_ratio, 2 token_set_ratio, 3 token_ratio, 4 partial_token_sort_ratio,
  * 5 partial_token_set_ratio, 6 partial_token_ratio (ratio / QRatio / token_sort_ratio are one string per list
- * element: pfz_indel_argmax).  skip_idx[i] (or NULL): a to-index left out for from-string i (self-match).
+ * element: pfz_indel_argmax).  skip_idx (host, one entry per from-string of the whole list, or NULL): a to-index
+ * left out for from-string i (self-match: the first list element equal to it, _rapidfuzz.py:103-104).
  * out_idx[i] = -1 / out_score[i] = 0 when there is no choice; scores are rapidfuzz's 0..100 float64.
- * PFZ_ERR_UNSUPPORTED (loud): a from-string form beyond 256 symbols, more than 32 distinct tokens in a string,
- * an alphabet whose match tables exceed 60 KiB of LDS.  Host buffers; blocks. */
-typedef struct pfz_fuzz_list {
-    int64_t n;
-    const uint16_t *sym[3];     /* symbols of form v, concatenated */
-    const int64_t *off[3];      /* [n + 1] offsets into sym[v] */
-    const int32_t *tok_id;      /* distinct tokens of string i: tok_id[tok_off[i] .. tok_off[i + 1]) */
-    const int32_t *tok_len;     /* their lengths (symbols); form 2 = the tokens joined by one space */
-    const int64_t *tok_off;     /* [n + 1] */
-} pfz_fuzz_list;
-int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_fuzz_list *from, const pfz_fuzz_list *to, int32_t n_symbols,
-                         int32_t scorer, const int32_t *skip_idx, int32_t *out_idx, double *out_score);
+ * Strings of any length and token count are accepted: from-strings beyond 256 characters or 32 distinct tokens (and
+ * to-strings beyond 32 distinct tokens) take a general -- slow -- kernel.  out_idx / out_score: host buffers of
+ * from_end - from_begin entries.  Blocks. */
+int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings, int32_t scorer,
+                         const int32_t *skip_idx, int64_t from_begin, int64_t from_end, int32_t *out_idx, double *out_score);
+/* The same with the result left on the device, in the layout the sharded jobs all-gather ("shard
+ * from-strings, replicate to-strings"): `out` must have 2 columns and >= from_end - from_begin rows; row r gets
+ * idx[r][0] = the first best index (idx[r][1] = -1) and the float64 score's bits in its two value lanes.  Enqueues.
+ * work_counters (host, 4 entries, or NULL): pairs whose upper bound was computed, pairs scored exactly, 64-bit
+ * word-steps of the scored pairs (an estimate from their lengths), 0 -- the bench's work accounting; blocks if given. */
+int pfz_fuzz_extract_one_dev(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings, int32_t scorer,
+                             const int32_t *skip_idx, int64_t from_begin, int64_t from_end, pfz_topn *out,
+                             uint64_t *work_counters);
+/* builds (once) and describes K7's cached plan of a to-list: alphabet size, groups of 64, distinct tokens over all
+ * strings, strings with more than 32 distinct tokens (scored by the general kernel) */
+int pfz_fuzz_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_symbols, int64_t *n_groups, int64_t *n_tokens,
+                       int64_t *n_general_strings);
 
 /* ---- K5: dense cosine top-n -----------------------------------------------
  * Replaces cosine_similarity on dense embedding matrices

@@ -78,7 +78,10 @@ SIGNATURES = {
     "pfz_indel_argmax": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "pfz_indel_matrix_host": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "pfz_indel_plan_info": (ctypes.c_int, [c_vp, c_vp, P(c_i64), P(c_i64), P(c_i64)]),
-    "pfz_fuzz_extract_one": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "pfz_indel_argmax_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "pfz_fuzz_extract_one": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "pfz_fuzz_extract_one_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "pfz_fuzz_plan_info": (ctypes.c_int, [c_vp, c_vp, P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
     "pfz_dense_cossim_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
                                                   c_vp, c_vp]),
     "pfz_dense_dot_topn_host": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_f32, c_i32,
@@ -504,103 +507,73 @@ def indel_plan_info(ctx, to_dev):
     return {"n_symbols": v[0].value, "n_groups": v[1].value, "char_steps": v[2].value}
 
 
-class FuzzList(ctypes.Structure):
-    """pfz_fuzz_list (include/polyfuzz_hip.h): three forms of every string as symbol ranks + distinct tokens."""
-    _fields_ = [("n", c_i64), ("sym", c_vp * 3), ("off", c_vp * 3), ("tok_id", c_vp), ("tok_len", c_vp), ("tok_off", c_vp)]
-
-
 FUZZ_SCORERS = {"WRatio": 0, "partial_ratio": 1, "token_set_ratio": 2, "token_ratio": 3, "partial_token_sort_ratio": 4,
                 "partial_token_set_ratio": 5, "partial_token_ratio": 6}
 
 
-def fuzz_forms(strings):
-    """The three per-string forms rapidfuzz's token scorers work on: the string, " ".join(sorted(s.split())),
-    " ".join(sorted(set(s.split()))) -- and the sorted distinct tokens themselves."""
-    forms = ([], [], [])
-    tokens = []
-    for s in strings:
-        toks = s.split()
-        distinct = sorted(set(toks))
-        forms[0].append(s)
-        forms[1].append(" ".join(sorted(toks)))
-        forms[2].append(" ".join(distinct))
-        tokens.append(distinct)
-    return forms, tokens
+def _skip_array(skip_idx, n):
+    if skip_idx is None:
+        return None
+    skip_idx = np.ascontiguousarray(skip_idx, np.int32)
+    if len(skip_idx) != n:
+        raise ValueError("skip_idx must have one entry per from-string")
+    return skip_idx
 
 
-def _code_points(strings):
-    """(uint32 code points of all strings concatenated, int64 offsets)"""
-    off = np.zeros(len(strings) + 1, np.int64)
-    if len(strings):
-        np.cumsum(np.fromiter(map(len, strings), np.int64, len(strings)), out=off[1:])
-    cps = np.frombuffer("".join(strings).encode("utf-32-le", "surrogatepass"), np.uint32)
-    return cps, off
+def _as_device_strings(ctx, strings):
+    return strings if isinstance(strings, DeviceStrings) else DeviceStrings.upload(ctx, strings)
 
 
-def fuzz_extract_one(ctx, from_list, to_list, scorer, skip_idx=None):
-    """K7: process.extractOne(from_string, to_list, scorer=fuzz.<scorer>) for every from-string -- (index of the
-    first best choice int32[n] (-1: none), its score float64[n] on rapidfuzz's 0..100 scale).  The host side prepares
-    what is a property of ONE string (token forms, token ids, symbol ranks); every pair is scored on the device."""
-    mode = FUZZ_SCORERS[scorer]
-    F, T, n_sym, keep = fuzz_prepare(from_list, to_list)
-    n = len(from_list)
+def fuzz_extract_one(ctx, from_list, to_list, scorer, skip_idx=None, begin=0, end=None):
+    """K7: process.extractOne(from_string, to_list, scorer=fuzz.<scorer>) for every from-string of rows [begin, end) --
+    (index of the first best choice int32[n] (-1: none), its score float64[n] on rapidfuzz's 0..100 scale).
+    from_list / to_list: lists of str (uploaded here) or resident DeviceStrings -- the token forms of a list and the
+    plan of a to-list are built on the device on first use and stay cached on the handle; every pair is bounded, the
+    promising ones scored, on the device."""
+    same = to_list is from_list
+    f_dev = _as_device_strings(ctx, from_list)
+    t_dev = f_dev if same else _as_device_strings(ctx, to_list)
+    end = f_dev.n if end is None else end
+    n = end - begin
     idx = np.empty(n, np.int32)
     score = np.empty(n, np.float64)
-    if skip_idx is not None:
-        skip_idx = np.ascontiguousarray(skip_idx, np.int32)
-        if len(skip_idx) != n:
-            raise ValueError("skip_idx must have one entry per from-string")
-    check(ctx.lib.pfz_fuzz_extract_one(ctx.h, ctypes.byref(F), ctypes.byref(T), n_sym, mode, _ptr(skip_idx),
+    skip_idx = _skip_array(skip_idx, f_dev.n)
+    check(ctx.lib.pfz_fuzz_extract_one(ctx.h, f_dev.h, t_dev.h, FUZZ_SCORERS[scorer], _ptr(skip_idx), int(begin), int(end),
                                        _ptr(idx), _ptr(score)))
-    del keep
     return idx, score
 
 
-def fuzz_prepare(from_list, to_list):
-    """(pfz_fuzz_list of the from-side, of the to-side, alphabet size, the arrays they point into)"""
-    same = to_list is from_list
-    f_forms, f_tokens = fuzz_forms(from_list)
-    t_forms, t_tokens = (f_forms, f_tokens) if same else fuzz_forms(to_list)
-    # alphabet: the code points of the to-side (all forms: the same characters plus the joining space)
-    t_cp = [_code_points(f) for f in t_forms]
-    alphabet = np.unique(np.concatenate([c for c, _ in t_cp] + [np.array([32], np.uint32)]))
-    if len(alphabet) >= 65535:
-        raise PfzUnsupported("more than 65534 distinct characters in the to-list")
+def fuzz_extract_one_dev(ctx, from_dev, to_dev, scorer, out, skip_idx=None, begin=0, end=None, counters=False):
+    """K7 with the (index, float64 score) rows left in the 2-column DeviceTopN `out` (see best_from_topn); returns the work
+    counters {bounded, scored, word_steps} when asked (that waits for the kernel)."""
+    end = from_dev.n if end is None else end
+    skip_idx = _skip_array(skip_idx, from_dev.n)
+    work = np.zeros(4, np.uint64) if counters else None
+    check(ctx.lib.pfz_fuzz_extract_one_dev(ctx.h, from_dev.h, to_dev.h, FUZZ_SCORERS[scorer], _ptr(skip_idx), int(begin), int(end),
+                                           out.h, _ptr(work)))
+    if counters:
+        return {"pairs_bounded": int(work[0]), "pairs_scored": int(work[1]), "word_steps_scored": int(work[2])}
+    return None
 
-    lut = np.zeros(int(alphabet[-1]) + 2, np.uint16)        # code point -> rank (0: not in the to-side alphabet)
-    lut[alphabet] = np.arange(1, len(alphabet) + 1, dtype=np.uint16)
 
-    def ranks(cps):
-        return lut[np.minimum(cps, len(lut) - 1)]
-    # token ids: equal tokens <-> equal ids across both lists
-    vocab = {}
-    for toks in (f_tokens if same else f_tokens + t_tokens):
-        for t in toks:
-            vocab.setdefault(t, len(vocab))
+def indel_argmax_dev(ctx, from_dev, to_dev, out, skip_idx=None, begin=0, end=None):
+    """K4 with the (first arg-max, float64 ratio) rows left in the 2-column DeviceTopN `out` (see best_from_topn)."""
+    end = from_dev.n if end is None else end
+    skip_idx = _skip_array(skip_idx, from_dev.n)
+    check(ctx.lib.pfz_indel_argmax_dev(ctx.h, from_dev.h, to_dev.h, _ptr(skip_idx), int(begin), int(end), out.h))
 
-    keep = []                                   # arrays the structures point into
 
-    def build(forms, tokens, cps):
-        L = FuzzList()
-        L.n = len(forms[0])
-        for v in range(3):
-            sym = np.ascontiguousarray(ranks(cps[v][0]))
-            off = cps[v][1]
-            keep.extend((sym, off))
-            L.sym[v], L.off[v] = _ptr(sym), _ptr(off)
-        tok_off = np.zeros(L.n + 1, np.int64)
-        if L.n:
-            np.cumsum(np.fromiter(map(len, tokens), np.int64, L.n), out=tok_off[1:])
-        flat = [t for toks in tokens for t in toks]
-        tok_id = np.fromiter((vocab[t] for t in flat), np.int32, len(flat))
-        tok_len = np.fromiter(map(len, flat), np.int32, len(flat))
-        keep.extend((tok_off, tok_id, tok_len))
-        L.tok_id, L.tok_len, L.tok_off = _ptr(tok_id), _ptr(tok_len), _ptr(tok_off)
-        return L
-    f_cp = t_cp if same else [_code_points(f) for f in f_forms]
-    F = build(f_forms, f_tokens, f_cp)
-    T = F if same else build(t_forms, t_tokens, t_cp)
-    return F, T, int(len(alphabet)), keep
+def best_from_topn(idx2, val2):
+    """(index int32[n], score float64[n]) out of the downloaded arrays of a 2-column result buffer: column 0 of idx, the
+    two fp32 value lanes of a row read as one float64"""
+    return idx2[:, 0].copy(), np.ascontiguousarray(val2).view(np.float64).reshape(-1)
+
+
+def fuzz_plan_info(ctx, to_dev):
+    """Build (once) and describe K7's cached plan of a DeviceStrings handle used as a to-list."""
+    v = [c_i64() for _ in range(4)]
+    check(ctx.lib.pfz_fuzz_plan_info(ctx.h, to_dev.h, *[ctypes.byref(x) for x in v]))
+    return {"n_symbols": v[0].value, "n_groups": v[1].value, "n_tokens": v[2].value, "n_general_strings": v[3].value}
 
 
 def indel_matrix(ctx, from_dev, to_dev, begin=0, end=None):

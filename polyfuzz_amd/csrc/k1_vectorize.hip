@@ -871,6 +871,8 @@ void pfz_strings_free(pfz_strings *s)
     if (s->offsets) pool_free(s->offsets);
     if (s->slots) pool_free(s->slots);
     if (s->indel_plan) pfz_indel_plan_free(s->indel_plan);
+    if (s->fuzz_plan) pfz_fuzz_plan_free(s->fuzz_plan);
+    if (s->fuzz_forms) pfz_fuzz_forms_free(s->fuzz_forms);
     if (s->row_cnt) pool_free(s->row_cnt);
     delete s;
 }

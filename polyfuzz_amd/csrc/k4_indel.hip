@@ -704,7 +704,7 @@ struct DevBuf {
 };
 
 static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c, const int32_t *skip_idx, int64_t begin,
-                     int64_t end, int32_t *out_idx, double *out_score, double *out_matrix)
+                     int64_t end, int32_t *out_idx, double *out_score, double *out_matrix, pfz_topn *out_dev = nullptr)
 {
     PFZ_REQUIRE(ctx && F && T_c, "pfz_indel: NULL argument");
     PFZ_REQUIRE(begin >= 0 && begin <= end && end <= F->n, "pfz_indel: row range [%lld,%lld) outside [0,%lld)",
@@ -888,6 +888,7 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
                                (uint64_t *)d_pm.p, (uint64_t *)d_v.p);
         PFZ_HIP(hipGetLastError());
     }
+    if (out_dev) return best_to_topn(ctx, (const int32_t *)d_oidx.p, (const double *)d_oscore.p, n_rows, out_dev);     // (no copy, no wait)
     if (out_idx) PFZ_TRY(copy_d2h(ctx, out_idx, d_oidx.p, (size_t)n_rows * sizeof(int32_t)));
     if (out_score) PFZ_TRY(copy_d2h(ctx, out_score, d_oscore.p, (size_t)n_rows * sizeof(double)));
     if (out_matrix) PFZ_TRY(copy_d2h(ctx, out_matrix, d_matrix.p, (size_t)n_rows * (size_t)n_to * sizeof(double)));
@@ -906,6 +907,14 @@ int pfz_indel_argmax(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_st
 {
     PFZ_REQUIRE(out_idx && out_score, "pfz_indel_argmax: NULL output");
     return indel_run(ctx, from_strings, to_strings, skip_idx, from_begin, from_end, out_idx, out_score, nullptr);
+}
+
+int pfz_indel_argmax_dev(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
+                         const int32_t *skip_idx, int64_t from_begin, int64_t from_end, pfz_topn *out)
+{
+    PFZ_REQUIRE(out && out->ntop == 2 && out->n_rows >= from_end - from_begin,
+                "pfz_indel_argmax_dev: the result buffer must have 2 columns and >= %lld rows", (long long)(from_end - from_begin));
+    return indel_run(ctx, from_strings, to_strings, skip_idx, from_begin, from_end, nullptr, nullptr, nullptr, out);
 }
 
 int pfz_indel_matrix_host(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,

@@ -1,0 +1,40 @@
+// The argument block of K7's match kernels (k7_fuzz.hip: the register / LDS kernel; k7_general.hip: the general one).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pfz {
+
+struct FuzzArgs {
+    // from side: the three forms as code units + the distinct tokens (forms layout), mapped through the to-list's alphabet here
+    const void *a_form[3];
+    int32_t a_width;
+    const int64_t *a_off;
+    const int32_t *a_len1, *a_len2, *a_ntok, *a_ntok_all, *a_tok_len, *a_tok_id;
+    const uint16_t *lut;
+    uint32_t lut_len;
+    const uint8_t *cls;
+    int32_t space_rank, space_class;
+    const int32_t *rows;         // from-rows of this launch
+    int32_t n_rows;
+    // to side (the plan)
+    const uint16_t *b_sym[3];
+    const uint8_t *b_tag;
+    const int64_t *b_goff, *b_tgoff;
+    const int32_t *b_tok_id, *b_tok_len;
+    const int4 *b_meta, *b_meta2;
+    const uint4 *b_hist;
+    const int32_t *big_slots;    // general kernel: only these to-slots (n_big > 0), else all
+    int32_t n_big;
+    int32_t n_groups, n_sym1, mode;
+    const int32_t *skip_idx;     // [n_from] or NULL
+    // every launch leaves the best of its (row, part) in part_*[row_slot * n_parts_total + part0 + part]
+    int32_t parts, part0, n_parts_total;
+    const int32_t *row_slot;     // [n_rows] position of the row in the output range
+    double *part_score;
+    int32_t *part_idx;
+    unsigned long long *counters;    // [0] pairs bounded, [1] pairs scored, [2] 64-bit word-steps of the scored pairs (or NULL)
+};
+
+}  // namespace pfz

@@ -3,114 +3,630 @@
 // matcher (polyfuzz/models/_rapidfuzz.py:45-58, 106-108) -- all pairs + process.extractOne's first best choice.
 // (ratio / QRatio / token_sort_ratio are one fixed string per list element: K4, k4_indel.hip.)
 //
-// Everything is the Indel similarity of SOME pair of strings, and every such pair is a sub-string / sub-token-set of
-// three per-string forms the host prepares once per list (polyfuzz_amd/models/_rapidfuzz.py):
-//   form 0  the string;   form 1  its whitespace tokens sorted and joined by one space (token_sort);
-//   form 2  its DISTINCT tokens sorted and joined (token_set), plus their global ids, lengths.
-// As in K4 the from-string is stationary: a workgroup holds the bit-parallel match tables of its from-string's three
-// forms in LDS (64-bit words, W words per form) and every lane scores one to-string, lists sorted by length and
-// stored [position][lane].  On top of K4's recurrence  V' = (V + (V & PM)) | (V & ~PM):
-//   * a SUB-RANGE of the from-form is matched by masking PM (bits below the range never match, the adder's carry
-//     chain starts at the range) and the LCS against every PREFIX of it is the number of zero bits of V below the
-//     prefix length -- so one pass over the to-string scores all windows of the from-string that start at one
-//     position (partial_ratio, from-string the longer one);
-//   * windows of the TO-string are separate passes over its characters, the prefixes falling out of the first pass
-//     step by step (partial_ratio, from-string the shorter one);
-//   * token_set's "tokens of a not in b" / "tokens of b not in a": a mask over the from-form's token positions
-//     and a per-character skip on the to-side (a tag per character: token number, separating space or not).
-// Scores are float64 with rapidfuzz's two normalisations kept apart: (1 - dist / lensum) * 100 for ratio-like
-// values, 100 - 100 dist / lensum inside token_set_ratio.  Windows are compared as exact rationals.
+// The arithmetic of one pair -- exact score, and a cheap upper bound of it -- is k7_core.h.  This file is everything
+// around it, all of it on the device:
 //
-// Limits (loud): every form of every from-string <= 256 characters (one, two or four 64-bit words), <= 32 distinct tokens per
-// string, alphabet x forms x words within 60 KiB of LDS.   PARITY UNPINNED (rapidfuzz is not installable): the
-// oracle is oracle/fuzz_scorers.py, anchored on rapidfuzz's published values.
+//  * the three FORMS of a list (the strings; their whitespace tokens sorted and joined; their distinct tokens sorted and
+//    joined, with the tokens' positions / lengths / hashes) -- k7_tokenize, one thread per string, cached on the list's
+//    pfz_strings handle: a property of the list alone;
+//  * the to-side PLAN, cached on the to-list's handle: alphabet (ranks of the distinct code points of the to-list plus
+//    the joining space) and character classes by frequency, a hash table of the to-list's distinct tokens (token id =
+//    the table's representative: equal ids <=> equal tokens), to-strings sorted by length into groups of 64 with
+//    everything a lane needs stored [position][lane] -- symbols of the three forms, token tags, token ids / lengths,
+//    lengths, class histogram, token signature (k7_pack);
+//  * per call: the from-list's token ids by look-up in the plan's table, then the match kernel.
+//
+// The match kernel (k7_fuzz_kernel<W>): a workgroup holds ONE from-string -- the bit-parallel match tables of its three
+// forms in LDS (W 64-bit words per form) -- and process.extractOne keeps only the maximum, so almost every pair can be
+// dismissed without scoring it:
+//    sweep 1  every lane walks its to-strings computing only the UPPER BOUND of the pair's score (lengths, common
+//             character classes by v_sad_u8, token signatures) and remembers its best-bounded one; those 256 pairs are
+//             scored exactly: the best of them is `cur`, a score some valid choice really has;
+//    sweep 2  every to-string again: a pair whose bound (+ slack) is below `cur` cannot be the answer, nor tie with it;
+//             the survivors are compacted (ballot) into a per-wave queue and scored 64 at a time, one pair per lane,
+//             each raising `cur` for everybody.
+// Pruned pairs are strictly worse than the final best, so the first-best rule (score desc, original index asc) over the
+// scored pairs is the exact answer.  On the 20 000 x 20 000 IMDB title lists fewer than 1 % of the pairs are scored.
+//
+// From-strings beyond 256 characters or 32 distinct tokens (and to-strings beyond 32 distinct tokens, for every
+// from-string) take k7_general_kernel: the same scorers with any number of words and tokens, all state in global
+// scratch -- slow, but the reference accepts such inputs.   PARITY UNPINNED (rapidfuzz is not installable): the oracle
+// is oracle/fuzz_scorers.{py,c}, anchored on rapidfuzz's published values.
 #include "pfz_internal.h"
 
 #include <algorithm>
 #include <climits>
-#include <numeric>
+
+#undef PFZ_HD
+#define PFZ_HD __device__ inline
+#include "k7_core.h"
+#include "k7_args.h"
 
 namespace pfz {
 
-enum FuzzMode { kWRatio = 0, kPartialRatio = 1, kTokenSetRatio = 2, kTokenRatio = 3, kPartialTokenSortRatio = 4,
-                kPartialTokenSetRatio = 5, kPartialTokenRatio = 6 };
+constexpr float kBoundSlack = 0.05f;      // a pair is dismissed only when bound + slack < cur (float32 bound, float64 scores)
 
-struct FuzzArgs {
-    // from side (CSR as given by the host)
-    const uint16_t *a_sym[3];
-    const int64_t *a_off[3];
-    const int32_t *a_tok_id, *a_tok_len;
-    const int64_t *a_tok_off;
-    const int32_t *rows;         // from-rows of this word class
-    int32_t n_rows;
-    // to side, groups of 64 strings sorted by the length of form 0, [position][lane]
-    const uint16_t *b_sym[3];
-    const int64_t *b_goff[3];    // [n_groups] element offset of the group in b_sym[v] (and b_tag for v = 2)
-    const int32_t *b_gmax[3];    // [n_groups] longest form v in the group
-    const int32_t *b_len[3];     // [n_groups * 64]
-    const uint8_t *b_tag;        // form 2: token number (5 bits) | 0x80 for the space that follows that token
-    const int32_t *b_orig;       // [n_groups * 64] original index, -1 = padding lane
-    const int32_t *b_ntok;       // [n_groups * 64]
-    const int64_t *b_tgoff;      // [n_groups] element offset of the group's token arrays
-    const int32_t *b_tgmax;      // [n_groups] most tokens in the group
-    const int32_t *b_tok_id, *b_tok_len;      // [token number][lane]
-    int32_t n_groups, n_sym1, mode;
-    const int32_t *skip_idx;     // [n_from] or NULL
-    int32_t parts;
-    double *part_score;          // [n_rows * parts] (parts > 1)
-    int32_t *part_idx;
-    int32_t *out_idx;            // [n_from]
-    double *out_score;
+__device__ inline uint32_t load_unit(const void *p, int width, int64_t i)
+{
+    return width == 1 ? (uint32_t)((const uint8_t *)p)[i] : ((const uint32_t *)p)[i];
+}
+
+__device__ inline void store_unit(void *p, int width, int64_t i, uint32_t c)
+{
+    if (width == 1) ((uint8_t *)p)[i] = (uint8_t)c;
+    else ((uint32_t *)p)[i] = c;
+}
+
+// str.isspace(): what str.split() splits on (the oracle restates rapidfuzz's tokenisation with Python's)
+__device__ inline bool is_space_cp(uint32_t c)
+{
+    return (c >= 0x09u && c <= 0x0Du) || (c >= 0x1Cu && c <= 0x20u) || c == 0x85u || c == 0xA0u || c == 0x1680u ||
+           (c >= 0x2000u && c <= 0x200Au) || c == 0x2028u || c == 0x2029u || c == 0x202Fu || c == 0x205Fu || c == 0x3000u;
+}
+
+// distinct tokens of string i live at [tok_base(i), tok_base(i) + ntok[i]) of the token arrays (a string of len
+// code units has at most (len + 1) / 2 tokens)
+__host__ __device__ inline int64_t tok_base(int64_t off_i, int64_t i) { return (off_i >> 1) + i; }
+
+}  // namespace pfz
+
+struct pfz_fuzz_forms {
+    pfz_ctx *ctx = nullptr;
+    void *form1 = nullptr, *form2 = nullptr;      // code units of the list's width; string i at offsets[i], lengths below
+    int32_t *len1 = nullptr, *len2 = nullptr;     // [n]
+    int32_t *ntok = nullptr, *ntok_all = nullptr; // [n] distinct tokens / tokens
+    int32_t *tok_pos = nullptr, *tok_len = nullptr;   // [tok_cap] start within form 2, length
+    uint64_t *tok_hash = nullptr;                 // [tok_cap] FNV-1a over the code points
+    int64_t tok_cap = 0;
+    std::vector<int32_t> h_ntok;                  // host copy (which from-strings fit the 32-token kernels)
+    ~pfz_fuzz_forms()
+    {
+        for (void *p : {form1, form2, (void *)len1, (void *)len2, (void *)ntok, (void *)ntok_all, (void *)tok_pos, (void *)tok_len,
+                        (void *)tok_hash})
+            if (p) pfz::pool_free(p);
+    }
 };
 
-__device__ inline double ratio_of(int lcs, int lensum)
+struct pfz_fuzz_plan {
+    pfz_ctx *ctx = nullptr;
+    int32_t n_sym = 0, space_rank = 0, space_class = 0;
+    uint32_t lut_len = 0;
+    uint16_t *lut = nullptr;             // code unit -> rank (0: not in the alphabet)
+    uint8_t *cls = nullptr;              // [n_sym + 1] rank -> character class (0 .. 31)
+    int32_t *table = nullptr;            // token hash table: slot -> token reference (index into the forms' token arrays), -1 empty
+    uint32_t table_mask = 0;
+    int32_t *t_tok_id = nullptr;         // [tok_cap of the to-list's forms] id of every distinct token (its table representative)
+    int64_t n_groups = 0;
+    int32_t *b_orig = nullptr;           // [n_groups * 64] original index, -1 = padding lane
+    int64_t *goff = nullptr;             // [n_groups] element offset of the group in sym[v] / tag (capacity: longest string x 64)
+    int64_t *tgoff = nullptr;            // [n_groups] element offset in tok_id / tok_len
+    uint16_t *sym[3] = {nullptr, nullptr, nullptr};
+    uint8_t *tag = nullptr;
+    int32_t *tok_id = nullptr, *tok_len = nullptr;
+    int4 *meta = nullptr;                // [n_groups * 64] {len0, len1, len2, distinct tokens}
+    int4 *meta2 = nullptr;               // [n_groups * 64] {signature lo, hi, histogram sum (-1: none), original index}
+    uint4 *hist = nullptr;               // [n_groups][2][64]
+    std::vector<int32_t> big_slots;      // to-strings with more than 32 distinct tokens (scored by the general kernel)
+    int32_t *d_big_slots = nullptr;
+    ~pfz_fuzz_plan()
+    {
+        for (void *p : {(void *)lut, (void *)cls, (void *)table, (void *)t_tok_id, (void *)b_orig, (void *)goff, (void *)tgoff, (void *)sym[0],
+                        (void *)sym[1], (void *)sym[2], (void *)tag, (void *)tok_id, (void *)tok_len, (void *)meta, (void *)meta2, (void *)hist,
+                        (void *)d_big_slots})
+            if (p) pfz::pool_free(p);
+    }
+};
+
+void pfz_fuzz_forms_free(pfz_fuzz_forms *f) { delete f; }
+void pfz_fuzz_plan_free(pfz_fuzz_plan *p) { delete p; }
+
+namespace pfz {
+
+// ---- forms of a list ---------------------------------------------------------------------------------------------------
+
+// lexicographic order of two tokens of the same string by code unit (= by code point, Python's str order)
+__device__ inline int cmp_tokens(const void *chars, int cw, int64_t base, int s1, int l1, int s2, int l2)
 {
-    const int dist = lensum - 2 * lcs;
-    const double norm_dist = lensum != 0 ? (double)dist / (double)lensum : 0.0;
-    return (1.0 - norm_dist) * 100.0;
+    const int n = l1 < l2 ? l1 : l2;
+    for (int k = 0; k < n; ++k) {
+        const uint32_t x = load_unit(chars, cw, base + s1 + k), y = load_unit(chars, cw, base + s2 + k);
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return l1 < l2 ? -1 : (l1 > l2 ? 1 : 0);
 }
 
-__device__ inline double norm_distance(int dist, int lensum)
+// one thread per string: split on whitespace, sort the tokens, write " ".join(sorted(tokens)) and
+// " ".join(sorted(set(tokens))) with the distinct tokens' positions, lengths and hashes
+__global__ __launch_bounds__(128) void k7_tokenize(const void *__restrict__ chars, int cw, const int64_t *__restrict__ off, int64_t n,
+                                                    void *__restrict__ form1, void *__restrict__ form2, int32_t *__restrict__ len1,
+                                                    int32_t *__restrict__ len2, int32_t *__restrict__ ntok, int32_t *__restrict__ ntok_all,
+                                                    int32_t *__restrict__ tok_pos, int32_t *__restrict__ tok_len,
+                                                    uint64_t *__restrict__ tok_hash)
 {
-    return lensum != 0 ? 100.0 - (double)(100 * dist) / (double)lensum : 100.0;
+    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = off[i];
+    const int len = (int)(off[i + 1] - o);
+    const int64_t tb = tok_base(o, i);
+    int32_t *ts = tok_pos + tb, *tl = tok_len + tb;       // first: token starts / lengths within the string
+    int nt = 0;
+    for (int p = 0; p < len;) {
+        while (p < len && is_space_cp(load_unit(chars, cw, o + p))) ++p;
+        const int b = p;
+        while (p < len && !is_space_cp(load_unit(chars, cw, o + p))) ++p;
+        if (p > b) {
+            ts[nt] = b;
+            tl[nt] = p - b;
+            ++nt;
+        }
+    }
+    for (int k = 1; k < nt; ++k) {                          // insertion sort (a handful of tokens per string)
+        const int ks = ts[k], kl = tl[k];
+        int j = k - 1;
+        while (j >= 0 && cmp_tokens(chars, cw, o, ts[j], tl[j], ks, kl) > 0) {
+            ts[j + 1] = ts[j];
+            tl[j + 1] = tl[j];
+            --j;
+        }
+        ts[j + 1] = ks;
+        tl[j + 1] = kl;
+    }
+    int o1 = 0, o2 = 0, nd = 0, prev_s = 0, prev_l = -1;
+    for (int k = 0; k < nt; ++k) {
+        const int s = ts[k], l = tl[k];                     // (read before entry nd <= k is overwritten below)
+        if (k) store_unit(form1, cw, o + o1++, 0x20u);
+        for (int q = 0; q < l; ++q) store_unit(form1, cw, o + o1 + q, load_unit(chars, cw, o + s + q));
+        o1 += l;
+        if (prev_l >= 0 && cmp_tokens(chars, cw, o, prev_s, prev_l, s, l) == 0) continue;      // a repeated token
+        prev_s = s;
+        prev_l = l;
+        if (nd) store_unit(form2, cw, o + o2++, 0x20u);
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (int q = 0; q < l; ++q) {
+            const uint32_t c = load_unit(chars, cw, o + s + q);
+            store_unit(form2, cw, o + o2 + q, c);
+            h = (h ^ c) * 0x100000001b3ull;
+        }
+        ts[nd] = o2;
+        tl[nd] = l;
+        tok_hash[tb + nd] = h;
+        o2 += l;
+        ++nd;
+    }
+    len1[i] = o1;
+    len2[i] = o2;
+    ntok[i] = nd;
+    ntok_all[i] = nt;
 }
 
-template <int W>
-__device__ inline void bv_step(uint64_t (&V)[W], const uint64_t *pm, const uint64_t (&mask)[W])
+static int ensure_forms(pfz_ctx *ctx, pfz_strings *S)
 {
-    uint64_t carry = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) {
-        const uint64_t u = V[w] & pm[w] & mask[w];
-        const uint64_t sum = V[w] + u + carry;
-        carry = (sum < V[w]) | (carry & (sum == V[w]));
-        V[w] = sum | (V[w] ^ u);
+    if (S->fuzz_forms) return PFZ_OK;
+    Owner<pfz_fuzz_forms, pfz_fuzz_forms_free> f(new pfz_fuzz_forms());
+    f->ctx = ctx;
+    const size_t units = (size_t)std::max<int64_t>(S->n_units, 1) * (size_t)S->char_width + 16;
+    const size_t nn = (size_t)std::max<int64_t>(S->n, 1);
+    f->tok_cap = S->n_units / 2 + S->n + 2;
+    PFZ_TRY(pool_alloc(ctx, &f->form1, units));
+    PFZ_TRY(pool_alloc(ctx, &f->form2, units));
+    PFZ_TRY(pool_alloc(ctx, &f->len1, nn * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &f->len2, nn * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &f->ntok, nn * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &f->ntok_all, nn * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &f->tok_pos, (size_t)f->tok_cap * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &f->tok_len, (size_t)f->tok_cap * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &f->tok_hash, (size_t)f->tok_cap * sizeof(uint64_t)));
+    f->h_ntok.assign((size_t)S->n, 0);
+    if (S->n > 0) {
+        {
+            ProfScope ps(ctx, "k7_prepare");
+            hipLaunchKernelGGL(k7_tokenize, dim3((unsigned)((S->n + 127) / 128)), dim3(128), 0, ctx->stream, S->chars, S->char_width,
+                               S->offsets, S->n, f->form1, f->form2, f->len1, f->len2, f->ntok, f->ntok_all, f->tok_pos, f->tok_len,
+                               f->tok_hash);
+            PFZ_HIP(hipGetLastError());
+        }
+        PFZ_TRY(copy_d2h(ctx, f->h_ntok.data(), f->ntok, (size_t)S->n * sizeof(int32_t)));
+    }
+    S->fuzz_forms = f.release();
+    return PFZ_OK;
+}
+
+// ---- the to-side plan ---------------------------------------------------------------------------------------------------
+
+template <int CW>
+__global__ __launch_bounds__(256) void k7_mark_alphabet(const void *__restrict__ chars, int64_t n_units, uint32_t *__restrict__ present)
+{
+    __shared__ uint32_t bm[2048];
+    for (int t = threadIdx.x; t < 2048; t += 256) bm[t] = 0u;
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_units; p += (int64_t)gridDim.x * 256) {
+        const uint32_t c = CW == 1 ? (uint32_t)((const uint8_t *)chars)[p] : ((const uint32_t *)chars)[p];
+        if (c < 65536u) {
+            if (!((bm[c >> 5] >> (c & 31)) & 1u)) atomicOr(&bm[c >> 5], 1u << (c & 31));
+        } else if (c < 0x110000u) {
+            atomicOr(&present[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2048; t += 256)
+        if (bm[t]) atomicOr(&present[t], bm[t]);
+}
+
+// occurrences of every alphabet symbol in the list (the character classes go to the most frequent symbols first)
+__global__ __launch_bounds__(256) void k7_sym_count(const void *__restrict__ chars, int cw, int64_t n_units, const uint16_t *__restrict__ lut,
+                                                     uint32_t lut_len, int32_t n_sym1, unsigned int *__restrict__ count)
+{
+    __shared__ unsigned int h[4096];
+    const bool in_lds = n_sym1 <= 4096;
+    if (in_lds) {
+        for (int t = threadIdx.x; t < n_sym1; t += 256) h[t] = 0u;
+        __syncthreads();
+    }
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_units; p += (int64_t)gridDim.x * 256) {
+        const uint32_t c = load_unit(chars, cw, p);
+        const int sy = c < lut_len ? (int)lut[c] : 0;
+        if (in_lds) atomicAdd(&h[sy], 1u);
+        else atomicAdd(&count[sy], 1u);
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_sym1; t += 256)
+            if (h[t]) atomicAdd(&count[t], h[t]);
     }
 }
 
-// zero bits of V in positions [0, k)
-template <int W>
-__device__ inline int zeros_below(const uint64_t (&V)[W], int k)
+struct TokenLists {       // the token arrays of one list's forms
+    const void *form2;
+    int cw;
+    const int64_t *off;
+    const int32_t *ntok, *tok_pos, *tok_len;
+    const uint64_t *tok_hash;
+};
+
+__device__ inline bool same_token(const TokenLists &A, int64_t ia, int64_t ra, const TokenLists &B, int64_t ib, int64_t rb)
 {
-    int n = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) {
-        const int bits = min(max(k - 64 * w, 0), 64);
-        const uint64_t m = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
-        n += __popcll(~V[w] & m);
-    }
-    return n;
+    if (A.tok_hash[ra] != B.tok_hash[rb] || A.tok_len[ra] != B.tok_len[rb]) return false;
+    const int64_t pa = A.off[ia] + A.tok_pos[ra], pb = B.off[ib] + B.tok_pos[rb];
+    for (int k = 0; k < A.tok_len[ra]; ++k)
+        if (load_unit(A.form2, A.cw, pa + k) != load_unit(B.form2, B.cw, pb + k)) return false;
+    return true;
 }
 
-template <int W>
-__device__ inline void range_mask(uint64_t (&m)[W], int lo, int hi)      // bits [lo, hi)
+// string index of a token reference (binary search over the token bases: tok_base is increasing in i)
+__device__ inline int64_t owner_of(const int64_t *off, int64_t n, int64_t ref)
+{
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (tok_base(off[mid], mid) <= ref) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// insert = true: the list's own tokens into its table (id = the representative that got the slot first -- which one is
+// a race, that it is ONE per distinct token is not); insert = false: another list's tokens looked up (absent: a
+// negative id no other token has)
+template <bool INSERT>
+__global__ __launch_bounds__(128) void k7_token_ids(TokenLists L, int64_t n, TokenLists T, int64_t n_t, int32_t *__restrict__ table,
+                                                     uint32_t mask, int32_t *__restrict__ ids)
+{
+    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t tb = tok_base(L.off[i], i);
+    for (int k = 0; k < L.ntok[i]; ++k) {
+        const int64_t ref = tb + k;
+        uint32_t h = (uint32_t)(L.tok_hash[ref] ^ (L.tok_hash[ref] >> 32)) & mask;
+        int32_t id;
+        for (;;) {
+            const int32_t cur = INSERT ? atomicCAS(&table[h], -1, (int32_t)ref) : table[h];
+            if (cur == -1) {
+                id = INSERT ? (int32_t)ref : (int32_t)(-2 - ref);
+                break;
+            }
+            if (INSERT && cur == (int32_t)ref) {
+                id = cur;
+                break;
+            }
+            const int64_t owner = owner_of(T.off, n_t, cur);
+            if (same_token(L, i, ref, T, owner, cur)) {
+                id = cur;
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+        ids[ref] = id;
+    }
+}
+
+struct PackArgs {
+    const void *form[3];
+    int cw;
+    const int64_t *off;
+    const int32_t *len1, *len2, *ntok, *ntok_all, *tok_len, *tok_id;
+    const uint16_t *lut;
+    uint32_t lut_len;
+    const uint8_t *cls;
+    int32_t space_rank, space_class;
+    const int32_t *b_orig;
+    const int64_t *goff, *tgoff;
+    uint16_t *sym[3];
+    uint8_t *tag;
+    int32_t *p_tok_id, *p_tok_len;
+    int4 *meta, *meta2;
+    uint4 *hist;
+    int64_t n_slots;
+};
+
+// slot (group g, lane l) = to-string b_orig[slot]: everything the match kernel reads of it, [position][lane]
+__global__ __launch_bounds__(256) void k7_pack(PackArgs A)
+{
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= A.n_slots) return;
+    const int64_t g = slot >> 6;
+    const int lane = (int)(slot & 63);
+    const int32_t j = A.b_orig[slot];
+    uint32_t hw[kFuzzHistWords];
+#pragma unroll
+    for (int d = 0; d < kFuzzHistWords; ++d) hw[d] = 0u;
+    if (j < 0) {
+        A.meta[slot] = make_int4(0, 0, 0, 0);
+        A.meta2[slot] = make_int4(0, 0, 0, -1);
+        A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+        A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    const int64_t o = A.off[j];
+    const int len[3] = {(int)(A.off[j + 1] - o), A.len1[j], A.len2[j]};
+    const int nt = A.ntok[j], nt_all = A.ntok_all[j];
+    const bool with_hist = len[0] + (nt_all > 0 ? nt_all - 1 : 0) <= 255;      // no class counter can pass 255
+    int n_space = 0, usum = 0;
+    for (int v = 0; v < 3; ++v) {
+        uint16_t *dst = A.sym[v] + A.goff[g] + lane;
+        for (int p = 0; p < len[v]; ++p) {
+            const uint32_t c = load_unit(A.form[v], A.cw, o + p);
+            const int sy = c < A.lut_len ? (int)A.lut[c] : 0;
+            dst[(int64_t)p * 64] = (uint16_t)sy;
+            if (v == 0 && with_hist && sy) {
+                const int cl = A.cls[sy];
+                hw[cl >> 2] += 1u << (8 * (cl & 3));
+                ++usum;
+                n_space += sy == A.space_rank;
+            }
+        }
+    }
+    if (with_hist) {
+        const int extra = (nt_all - 1) - n_space;          // form 1 may hold more joining spaces than the string has
+        if (extra > 0) {
+            hw[A.space_class >> 2] += (uint32_t)extra << (8 * (A.space_class & 3));
+            usum += extra;
+        }
+    }
+    // distinct tokens: ids, lengths, and the tag of every character of form 2
+    const int64_t tb = tok_base(o, j);
+    uint8_t *tg = A.tag + A.goff[g] + lane;
+    int32_t *pid = A.p_tok_id + A.tgoff[g] + lane, *pln = A.p_tok_len + A.tgoff[g] + lane;
+    uint64_t sig = 0ull;
+    int pos = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int32_t id = A.tok_id[tb + t], l = A.tok_len[tb + t];
+        pid[(int64_t)t * 64] = id;
+        pln[(int64_t)t * 64] = l;
+        sig |= fz_sig_bit(id);
+        for (int q = 0; q < l; ++q) tg[(int64_t)(pos + q) * 64] = (uint8_t)(t & 31);
+        if (t + 1 < nt) tg[(int64_t)(pos + l) * 64] = (uint8_t)((t & 31) | 0x80);
+        pos += l + 1;
+    }
+    A.meta[slot] = make_int4(len[0], len[1], len[2], nt);
+    A.meta2[slot] = make_int4((int)(uint32_t)sig, (int)(uint32_t)(sig >> 32), with_hist ? usum : -1, j);
+    A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+}
+
+template <typename T> static int up(pfz_ctx *ctx, T **dst, const std::vector<T> &v)
+{
+    PFZ_TRY(pool_alloc(ctx, dst, (v.empty() ? 1 : v.size()) * sizeof(T)));
+    if (!v.empty()) PFZ_TRY(copy_h2d(ctx, *dst, v.data(), v.size() * sizeof(T)));
+    return PFZ_OK;
+}
+
+static TokenLists token_lists(const pfz_strings *S)
+{
+    const pfz_fuzz_forms *f = S->fuzz_forms;
+    return TokenLists{f->form2, S->char_width, S->offsets, f->ntok, f->tok_pos, f->tok_len, f->tok_hash};
+}
+
+static int build_plan(pfz_ctx *ctx, pfz_strings *T)
+{
+    PFZ_TRY(ensure_forms(ctx, T));
+    const pfz_fuzz_forms *f = T->fuzz_forms;
+    Owner<pfz_fuzz_plan, pfz_fuzz_plan_free> pl(new pfz_fuzz_plan());
+    pl->ctx = ctx;
+    ProfScope ps(ctx, "k7_prepare");
+    // alphabet: presence bitmap on the device, ranks on the host; the joining space is always a symbol
+    const size_t words = 0x110000 / 32, used_words = T->char_width == 1 ? 8 : words;
+    uint32_t *present = nullptr;
+    PFZ_TRY(pool_alloc(ctx, &present, words * sizeof(uint32_t)));
+    struct Free {
+        void *p;
+        ~Free() { if (p) pool_free(p); }
+    } free_present{present};
+    PFZ_HIP(hipMemsetAsync(present, 0, used_words * sizeof(uint32_t), ctx->stream));
+    if (T->n_units > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>((T->n_units + 255) / 256, 2048);
+        if (T->char_width == 1) hipLaunchKernelGGL(k7_mark_alphabet<1>, dim3(grid), dim3(256), 0, ctx->stream, T->chars, T->n_units, present);
+        else hipLaunchKernelGGL(k7_mark_alphabet<4>, dim3(grid), dim3(256), 0, ctx->stream, T->chars, T->n_units, present);
+        PFZ_HIP(hipGetLastError());
+    }
+    std::vector<uint32_t> h(used_words);
+    PFZ_TRY(copy_d2h(ctx, h.data(), present, used_words * sizeof(uint32_t)));
+    h[0x20 >> 5] |= 1u << (0x20 & 31);
+    std::vector<uint16_t> lut;
+    std::vector<uint32_t> cp_of_rank(1, 0u);
+    for (size_t wi = used_words; wi-- > 0;)
+        if (h[wi]) {
+            lut.assign((wi + 1) * 32, 0);
+            break;
+        }
+    int32_t S = 0;
+    for (size_t wi = 0; wi * 32 < lut.size(); ++wi) {
+        uint32_t word = h[wi];
+        while (word) {
+            const int bit = __builtin_ctz(word);
+            word &= word - 1;
+            if (S >= 65534) {
+                set_error("pfz_fuzz: more than 65534 distinct code points in the to-list exceed the 16-bit symbol space");
+                return PFZ_ERR_UNSUPPORTED;
+            }
+            lut[wi * 32 + (size_t)bit] = (uint16_t)(++S);
+            cp_of_rank.push_back((uint32_t)(wi * 32 + (size_t)bit));
+        }
+    }
+    pl->n_sym = S;
+    pl->lut_len = (uint32_t)lut.size();
+    pl->space_rank = lut[0x20];
+    PFZ_TRY(up(ctx, &pl->lut, lut));
+    // character classes: symbols in order of decreasing frequency take classes 0, 1, ..., 31, 0, 1, ...
+    unsigned int *d_count = nullptr;
+    PFZ_TRY(pool_alloc(ctx, &d_count, (size_t)(S + 1) * sizeof(unsigned int)));
+    Free free_count{d_count};
+    PFZ_HIP(hipMemsetAsync(d_count, 0, (size_t)(S + 1) * sizeof(unsigned int), ctx->stream));
+    if (T->n_units > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>((T->n_units + 255) / 256, 1024);
+        hipLaunchKernelGGL(k7_sym_count, dim3(grid), dim3(256), 0, ctx->stream, T->chars, T->char_width, T->n_units, pl->lut, pl->lut_len,
+                           S + 1, d_count);
+        PFZ_HIP(hipGetLastError());
+    }
+    std::vector<unsigned int> count((size_t)S + 1);
+    PFZ_TRY(copy_d2h(ctx, count.data(), d_count, count.size() * sizeof(unsigned int)));
+    std::vector<int32_t> order((size_t)S);
+    for (int32_t r = 0; r < S; ++r) order[(size_t)r] = r + 1;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return count[(size_t)x] > count[(size_t)y]; });
+    std::vector<uint8_t> cls((size_t)S + 1, 0);
+    for (int32_t k = 0; k < S; ++k) cls[(size_t)order[(size_t)k]] = (uint8_t)(k % (4 * kFuzzHistWords));
+    pl->space_class = cls[(size_t)pl->space_rank];
+    PFZ_TRY(up(ctx, &pl->cls, cls));
+    // token table of the to-list
+    const int64_t n_to = T->n;
+    int64_t total_tok = 0;
+    for (int64_t j = 0; j < n_to; ++j) total_tok += f->h_ntok[(size_t)j];
+    uint32_t cap = 1024;
+    while ((int64_t)cap < 2 * total_tok + 16) cap <<= 1;
+    pl->table_mask = cap - 1;
+    PFZ_TRY(pool_alloc(ctx, &pl->table, (size_t)cap * sizeof(int32_t)));
+    PFZ_HIP(hipMemsetAsync(pl->table, 0xff, (size_t)cap * sizeof(int32_t), ctx->stream));
+    PFZ_TRY(pool_alloc(ctx, &pl->t_tok_id, (size_t)f->tok_cap * sizeof(int32_t)));
+    if (n_to > 0) {
+        const TokenLists L = token_lists(T);
+        hipLaunchKernelGGL(k7_token_ids<true>, dim3((unsigned)((n_to + 127) / 128)), dim3(128), 0, ctx->stream, L, n_to, L, n_to, pl->table,
+                           pl->table_mask, pl->t_tok_id);
+        PFZ_HIP(hipGetLastError());
+    }
+    // groups of 64 to-strings of similar length: counting sort by length on the host (O(n) ints)
+    std::vector<int64_t> start((size_t)T->max_len + 2, 0);
+    for (int64_t j = 0; j < n_to; ++j) start[(size_t)(T->h_off[(size_t)j + 1] - T->h_off[(size_t)j]) + 1]++;
+    for (size_t l = 1; l < start.size(); ++l) start[l] += start[l - 1];
+    const int64_t n_groups = (n_to + 63) / 64;
+    std::vector<int32_t> b_orig((size_t)n_groups * 64, -1);
+    std::vector<int64_t> goff((size_t)n_groups), tgoff((size_t)n_groups);
+    for (int64_t j = 0; j < n_to; ++j) {      // ascending j inside one length: a stable sort
+        const int64_t len = T->h_off[(size_t)j + 1] - T->h_off[(size_t)j];
+        b_orig[(size_t)start[(size_t)len]++] = (int32_t)j;
+    }
+    int64_t total = 0, ttotal = 0;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int32_t last = b_orig[(size_t)(std::min<int64_t>(n_to, (g + 1) * 64) - 1)];     // sorted: the group's longest string
+        const int64_t gmax = T->h_off[(size_t)last + 1] - T->h_off[(size_t)last];
+        goff[(size_t)g] = total;
+        tgoff[(size_t)g] = ttotal;
+        total += gmax * 64;                   // (no form is longer than the string; a string has at most (len + 1) / 2 tokens)
+        ttotal += ((gmax + 1) / 2) * 64;
+    }
+    for (int64_t s = 0; s < n_groups * 64; ++s)
+        if (b_orig[(size_t)s] >= 0 && f->h_ntok[(size_t)b_orig[(size_t)s]] > kFuzzMaxTokens) pl->big_slots.push_back((int32_t)s);
+    pl->n_groups = n_groups;
+    PFZ_TRY(up(ctx, &pl->b_orig, b_orig));
+    PFZ_TRY(up(ctx, &pl->goff, goff));
+    PFZ_TRY(up(ctx, &pl->tgoff, tgoff));
+    PFZ_TRY(up(ctx, &pl->d_big_slots, pl->big_slots));
+    for (int v = 0; v < 3; ++v) PFZ_TRY(pool_alloc(ctx, &pl->sym[v], (size_t)(total + 64) * sizeof(uint16_t)));
+    PFZ_TRY(pool_alloc(ctx, &pl->tag, (size_t)(total + 64)));
+    PFZ_TRY(pool_alloc(ctx, &pl->tok_id, (size_t)(ttotal + 64) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &pl->tok_len, (size_t)(ttotal + 64) * sizeof(int32_t)));
+    const size_t n_slots = (size_t)std::max<int64_t>(n_groups * 64, 1);
+    PFZ_TRY(pool_alloc(ctx, &pl->meta, n_slots * sizeof(int4)));
+    PFZ_TRY(pool_alloc(ctx, &pl->meta2, n_slots * sizeof(int4)));
+    PFZ_TRY(pool_alloc(ctx, &pl->hist, n_slots * 2 * sizeof(uint4)));
+    if (n_groups > 0) {
+        PackArgs P;
+        P.form[0] = T->chars;
+        P.form[1] = f->form1;
+        P.form[2] = f->form2;
+        P.cw = T->char_width;
+        P.off = T->offsets;
+        P.len1 = f->len1;
+        P.len2 = f->len2;
+        P.ntok = f->ntok;
+        P.ntok_all = f->ntok_all;
+        P.tok_len = f->tok_len;
+        P.tok_id = pl->t_tok_id;
+        P.lut = pl->lut;
+        P.lut_len = pl->lut_len;
+        P.cls = pl->cls;
+        P.space_rank = pl->space_rank;
+        P.space_class = pl->space_class;
+        P.b_orig = pl->b_orig;
+        P.goff = pl->goff;
+        P.tgoff = pl->tgoff;
+        for (int v = 0; v < 3; ++v) P.sym[v] = pl->sym[v];
+        P.tag = pl->tag;
+        P.p_tok_id = pl->tok_id;
+        P.p_tok_len = pl->tok_len;
+        P.meta = pl->meta;
+        P.meta2 = pl->meta2;
+        P.hist = pl->hist;
+        P.n_slots = n_groups * 64;
+        hipLaunchKernelGGL(k7_pack, dim3((unsigned)((n_groups * 64 + 255) / 256)), dim3(256), 0, ctx->stream, P);
+        PFZ_HIP(hipGetLastError());
+    }
+    T->fuzz_plan = pl.release();
+    return PFZ_OK;
+}
+
+// ---- the match kernel -----------------------------------------------------------------------------------------------------
+
+
+struct RowBest {
+    double score;
+    int idx;
+    __device__ void take(double s, int i)
+    {
+        if (s > score || (s == score && i < idx)) {
+            score = s;
+            idx = i;
+        }
+    }
+};
+
+__device__ inline void wave_best(RowBest &b)
 {
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-        const int a = min(max(lo - 64 * w, 0), 64), b = min(max(hi - 64 * w, 0), 64);
-        const uint64_t below_b = b >= 64 ? ~0ull : ((1ull << b) - 1ull), below_a = a >= 64 ? ~0ull : ((1ull << a) - 1ull);
-        m[w] = below_b & ~below_a;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double os = __shfl_xor(b.score, d, 64);
+        const int oi = __shfl_xor(b.idx, d, 64);
+        b.take(os, oi);
     }
+}
+
+__device__ inline bool mode_uses_tokens(int mode) { return mode != kPartialRatio && mode != kPartialTokenSortRatio; }
+
+// 64-bit word-steps a scored pair costs at most (work accounting for the roofline; an estimate from the lengths: one
+// pass over the to-form per LCS, |from| x |to| for a window sweep)
+__device__ inline int work_estimate(const int (&la)[3], const int4 &m, int mode, int W)
+{
+    const int pass = m.x + m.y + m.z;
+    if (mode == kTokenSetRatio || mode == kTokenRatio) return pass * W;
+    return (pass + fz_min(la[0], m.x) * fz_max(la[0], m.x) / 4) * W;
 }
 
 template <int W>
@@ -118,594 +634,547 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *pm = (uint64_t *)smem_raw;               // [symbol][form][word]
-    __shared__ int s_la[3], s_ta;
-    __shared__ int s_tid[32], s_tlen[32];
-    __shared__ uint64_t s_tmask[32][W], s_smask[32][W];
+    __shared__ int s_la[3], s_ta, s_nspace, s_usum;
+    __shared__ int s_tid[kFuzzMaxTokens], s_tlen[kFuzzMaxTokens];
+    __shared__ uint64_t s_tmask[kFuzzMaxTokens * W], s_smask[kFuzzMaxTokens * W];
+    __shared__ int s_cnt[4 * kFuzzHistWords];
+    __shared__ uint32_t s_hist[kFuzzHistWords], s_sig[2];
     __shared__ double red_s[4];
     __shared__ int red_i[4];
-    __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup holds so far (>= 0)
-    // the to-characters of the form a lane is working on, [position][lane] per wave (groups of up to 64 positions):
-    // the window sweeps re-read them |from| times, and a global load per recurrence step is a dependent ~500-cycle
-    // round trip (waves sat in s_waitcnt two thirds of their cycles)
-    __shared__ uint16_t s_sym[4][64][64];
+    __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
+    __shared__ int s_queue[4][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
+    const bool use_tokens = mode_uses_tokens(mode);
 
     for (int p = tid; p < A.n_sym1 * 3 * W; p += 256) pm[p] = 0ull;
+    unsigned long long n_bounded = 0, n_scored = 0, n_steps = 0;
     __syncthreads();
 
     for (int u = blockIdx.x; u < A.n_rows * parts; u += gridDim.x) {
         const int r = u / parts, part = u - r * parts;
         const int row = A.rows[r];
-        // ---- the from-string's tables
+        const int64_t a0 = A.a_off[row];
+        // ---- the from-string's tables, class histogram, tokens
+        if (tid < 4 * kFuzzHistWords) s_cnt[tid] = 0;
+        if (tid == 0) {
+            s_nspace = 0;
+            s_best = 0ull;
+        }
+        __syncthreads();
         for (int v = 0; v < 3; ++v) {
-            const int64_t a0 = A.a_off[v][row];
-            const int m = (int)(A.a_off[v][row + 1] - a0);
+            const int m = v == 0 ? (int)(A.a_off[row + 1] - a0) : (v == 1 ? A.a_len1[row] : A.a_len2[row]);
             if (tid == 0) s_la[v] = m;
             for (int p = tid; p < m; p += 256) {
-                const int sy = A.a_sym[v][a0 + p];
-                if (sy) atomicOr((unsigned long long *)&pm[(sy * 3 + v) * W + (p >> 6)], 1ull << (p & 63));
+                const uint32_t c = load_unit(A.a_form[v], A.a_width, a0 + p);
+                const int sy = c < A.lut_len ? (int)A.lut[c] : 0;
+                if (sy) {
+                    atomicOr((unsigned long long *)&pm[(sy * 3 + v) * W + (p >> 6)], 1ull << (p & 63));
+                    if (v == 0) {
+                        atomicAdd(&s_cnt[A.cls[sy]], 1);
+                        if (sy == A.space_rank) atomicAdd(&s_nspace, 1);
+                    }
+                }
             }
         }
         if (tid == 0) {
-            s_best = 0ull;
-            const int64_t t0 = A.a_tok_off[row];
-            const int ta = (int)(A.a_tok_off[row + 1] - t0);
+            const int64_t tb = tok_base(a0, row);
+            const int ta = A.a_ntok[row];
             s_ta = ta;
             int start = 0;
+            uint64_t sig = 0ull;
             for (int i = 0; i < ta; ++i) {
-                const int len = A.a_tok_len[t0 + i];
-                s_tid[i] = A.a_tok_id[t0 + i];
+                const int len = A.a_tok_len[tb + i];
+                s_tid[i] = A.a_tok_id[tb + i];
                 s_tlen[i] = len;
+                sig |= fz_sig_bit(s_tid[i]);
                 uint64_t tm[W], sm[W];
-                range_mask<W>(tm, start, start + len);
-                range_mask<W>(sm, start + len, i + 1 < ta ? start + len + 1 : start + len);
+                fz_range_mask<W>(tm, start, start + len);
+                fz_range_mask<W>(sm, start + len, i + 1 < ta ? start + len + 1 : start + len);
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    s_tmask[i][w] = tm[w];
-                    s_smask[i][w] = sm[w];
+                    s_tmask[i * W + w] = tm[w];
+                    s_smask[i * W + w] = sm[w];
                 }
                 start += len + 1;
             }
-        }
-        __syncthreads();
-        const int la0 = s_la[0], la1 = s_la[1], la2 = s_la[2], ta = s_ta;
-        const int skip = A.skip_idx ? A.skip_idx[row] : -1;
-        double best_score = -1.0;
-        int best_idx = INT_MAX;
-
-        // WRatio and the partial_* scorers: the groups whose lengths are within a factor 1.5 of the from-string first
-        // -- that is where WRatio's scores above 90 live -- then the others, where whole components can be left out
-        // once the workgroup holds a score they cannot reach (see `cur` below).  The token scorers: one pass.
-        const bool pruning = mode == kWRatio || mode == kPartialRatio || mode >= kPartialTokenSortRatio;
-        const int n_pass = pruning ? 2 : 1;
-        for (int pass = 0; pass < n_pass; ++pass)
-        for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
-            if (pruning) {
-                const int lbmin = __builtin_amdgcn_readfirstlane(A.b_len[0][g * 64]);       // lanes are sorted by length
-                const int lbmax = __builtin_amdgcn_readfirstlane(A.b_gmax[0][g]);
-                const bool near_group = 3 * lbmax > 2 * la0 && 2 * lbmin < 3 * la0;
-                if (near_group != (pass == 0)) continue;
-            }
-            const double cur = __longlong_as_double((long long)*(volatile unsigned long long *)&s_best);
-            const int slot = g * 64 + lane;
-            const int orig = A.b_orig[slot];
-            const int lb0 = A.b_len[0][slot], lb1 = A.b_len[1][slot], lb2 = A.b_len[2][slot], tb = A.b_ntok[slot];
-            uint64_t all[W];
-#pragma unroll
-            for (int w = 0; w < W; ++w) all[w] = ~0ull;
-
-            int staged = -1;            // (per lane: a lane stages and reads only its own column)
-            auto stage = [&](int v, int steps, int64_t off) {
-                if (steps > 64 || staged == v) return;
-#pragma unroll 4
-                for (int pos = 0; pos < steps; ++pos) s_sym[wave][pos][lane] = A.b_sym[v][off + (int64_t)pos * 64];
-                staged = v;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            };
-            auto sym_at = [&](int v, int steps, int64_t off, int pos) -> int {
-                return steps <= 64 ? (int)s_sym[wave][pos][lane] : (int)A.b_sym[v][off + (int64_t)pos * 64];
-            };
-
-            // LCS of the from-form v (restricted to `amask`) and the lane's to-form v; with `rb` only the to-tokens
-            // whose bit is set are fed (form 2), the space after the last of them left out
-            auto lcs_pass = [&](int v, const uint64_t (&amask)[W], bool tagged, uint32_t rb, int last_rb, uint64_t (&V)[W]) {
-#pragma unroll
-                for (int w = 0; w < W; ++w) V[w] = ~0ull;
-                const int steps = __builtin_amdgcn_readfirstlane(A.b_gmax[v][g]);
-                const int64_t off = A.b_goff[v][g] + lane;
-                for (int pos = 0; pos < steps; ++pos) {        // (one pass: straight from global memory, staging would cost more)
-                    int sy = A.b_sym[v][off + (int64_t)pos * 64];
-                    if (tagged) {
-                        const int tag = A.b_tag[off + (int64_t)pos * 64], j = tag & 31;
-                        const bool keep = ((rb >> j) & 1u) && !((tag & 0x80) && j == last_rb);
-                        sy = keep ? sy : 0;
-                    }
-                    bv_step<W>(V, pm + (sy * 3 + v) * W, amask);
-                }
-            };
-
-            // rapidfuzz.fuzz.partial_ratio of the two v-forms
-            auto partial = [&](int v, int la, int lb) -> double {
-                if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
-                int bl = 0, bs = 1;                                     // best window: lcs / (|shorter| + |window|)
-                auto cand = [&](int lcs, int sum) {
-                    if ((int64_t)lcs * bs > (int64_t)bl * sum) {
-                        bl = lcs;
-                        bs = sum;
-                    }
-                };
-                const int steps = __builtin_amdgcn_readfirstlane(A.b_gmax[v][g]);
-                const int64_t off = A.b_goff[v][g] + lane;
-                stage(v, steps, off);
-                uint64_t V[W];
-                if (__any(lb >= la)) {
-                    // the from-form is the shorter (or equal): windows of the to-form starting at s
-                    for (int s = 0; s < steps; ++s) {
-                        const bool on = lb >= la && s < lb;
-                        if (!__any(on)) break;
-                        const int wlen = min(la, lb - s);
-#pragma unroll
-                        for (int w = 0; w < W; ++w) V[w] = ~0ull;
-                        for (int k = 0; k < la; ++k) {
-                            const int pos = s + k;
-                            const int sy = (on && k < wlen && pos < steps) ? sym_at(v, steps, off, pos) : 0;
-                            bv_step<W>(V, pm + (sy * 3 + v) * W, all);
-                            if (s == 0 && on && k + 1 < la) cand(zeros_below<W>(V, la), la + k + 1);       // prefixes
-                        }
-                        if (on) cand(zeros_below<W>(V, la), la + wlen);
-                    }
-                }
-                if (__any(lb <= la)) {
-                    // the from-form is the longer (or equal): windows of the from-form starting at i, one pass each
-                    const bool on = lb <= la;
-                    for (int i = 0; i < la; ++i) {
-                        uint64_t m[W];
-                        range_mask<W>(m, i, la);
-#pragma unroll
-                        for (int w = 0; w < W; ++w) V[w] = ~0ull;
-                        for (int pos = 0; pos < steps; ++pos) {
-                            const int sy = on ? sym_at(v, steps, off, pos) : 0;
-                            bv_step<W>(V, pm + (sy * 3 + v) * W, m);
-                        }
-                        if (on) {
-                            const int wlen = min(lb, la - i);
-                            cand(zeros_below<W>(V, i + wlen) - zeros_below<W>(V, i), lb + wlen);
-                            if (i == 0)
-                                for (int k = 1; k < lb; ++k) cand(zeros_below<W>(V, k), lb + k);          // prefixes
-                        }
-                    }
-                }
-                return ratio_of(bl, bs);
-            };
-
-            // common distinct tokens: bit i of ca (from-tokens), bit j of cb (to-tokens)
-            uint32_t ca = 0, cb = 0;
-            auto intersect = [&]() {
-                const int tmax = __builtin_amdgcn_readfirstlane(A.b_tgmax[g]);
-                const int64_t toff = A.b_tgoff[g] + lane;
-                for (int j = 0; j < tmax; ++j) {
-                    const int idb = j < tb ? A.b_tok_id[toff + (int64_t)j * 64] : -1;
-                    for (int i = 0; i < ta; ++i)
-                        if (s_tid[i] == idb) {
-                            ca |= 1u << i;
-                            cb |= 1u << j;
-                        }
-                }
-            };
-
-            auto token_set = [&]() -> double {
-                if (ta == 0 || tb == 0) return 0.0;
-                const int nc = __popc(ca);
-                if (nc > 0 && (nc == ta || nc == tb)) return 100.0;
-                // lengths of the joined differences and of the joined intersection
-                const uint32_t ra = ~ca & (ta >= 32 ? ~0u : ((1u << ta) - 1u)), rb = ~cb & (tb >= 32 ? ~0u : ((1u << tb) - 1u));
-                int ab_len = __popc(ra) - 1, ba_len = __popc(rb) - 1, sect_len = nc > 0 ? nc - 1 : 0;
-                uint64_t amask[W];
-#pragma unroll
-                for (int w = 0; w < W; ++w) amask[w] = 0ull;
-                const int last_ra = 31 - __clz(ra), last_rb = 31 - __clz(rb);
-                for (int i = 0; i < ta; ++i) {
-                    const bool rem = (ra >> i) & 1u;
-                    ab_len += rem ? s_tlen[i] : 0;
-                    sect_len += rem ? 0 : s_tlen[i];
-#pragma unroll
-                    for (int w = 0; w < W; ++w) amask[w] |= rem ? (s_tmask[i][w] | (i != last_ra ? s_smask[i][w] : 0ull)) : 0ull;
-                }
-                const int tmax = __builtin_amdgcn_readfirstlane(A.b_tgmax[g]);
-                const int64_t toff = A.b_tgoff[g] + lane;
-                for (int j = 0; j < tmax; ++j)
-                    if (j < tb && ((rb >> j) & 1u)) ba_len += A.b_tok_len[toff + (int64_t)j * 64];
-                uint64_t V[W];
-                lcs_pass(2, amask, true, rb, last_rb, V);
-                const int lcs = zeros_below<W>(V, la2);
-                const int sect_sep = sect_len != 0 ? 1 : 0;
-                const int sect_ab_len = sect_len + sect_sep + ab_len, sect_ba_len = sect_len + sect_sep + ba_len;
-                const double result = norm_distance(ab_len + ba_len - 2 * lcs, sect_ab_len + sect_ba_len);
-                if (sect_len == 0) return result;
-                const double r_ab = norm_distance(sect_sep + ab_len, sect_len + sect_ab_len);
-                const double r_ba = norm_distance(sect_sep + ba_len, sect_len + sect_ba_len);
-                return fmax(result, fmax(r_ab, r_ba));
-            };
-            auto token_sort = [&]() -> double {
-                uint64_t V[W];
-                lcs_pass(1, all, false, 0u, 0, V);
-                return ratio_of(zeros_below<W>(V, la1), la1 + lb1);
-            };
-            // partial_ratio, left out (0: a lower bound) when it cannot reach the workgroup's best score: a window has
-            // at most the LCS of the whole strings -- one cheap pass -- and at least that many characters
-            auto partial_pruned = [&](int v, int la, int lb) -> double {
-                if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
-                uint64_t Vv[W];
-                lcs_pass(v, all, false, 0u, 0, Vv);
-                const int l = zeros_below<W>(Vv, la), lm = min(la, lb);
-                const bool want = !(ratio_of(l, lm + l) < cur);
-                double p = 0.0;
-                if (__any(want)) p = partial(v, want ? la : 0, want ? lb : 0);
-                return want ? p : 0.0;
-            };
-            auto partial_token = [&]() -> double {          // partial_token_ratio
-                if (ta == 0 || tb == 0) return 0.0;
-                if (ca) return 100.0;
-                return fmax(partial_pruned(1, la1, lb1), partial_pruned(2, la2, lb2));
-            };
-
-            double score = 0.0;
-            if (mode != kPartialRatio && mode != kPartialTokenSortRatio) intersect();
-            if (mode == kWRatio) {
-                if (la0 != 0 && lb0 != 0) {
-                    uint64_t V[W];
-                    lcs_pass(0, all, false, 0u, 0, V);
-                    double end_ratio = ratio_of(zeros_below<W>(V, la0), la0 + lb0);
-                    const int lmax = max(la0, lb0), lmin = min(la0, lb0);
-                    // (uniformity: lanes of a group have similar lengths, most groups take one branch as a whole)
-                    const bool near = 2 * lmax < 3 * lmin;                  // len_ratio < 1.5
-                    // extractOne keeps the maximum, so a COMPONENT of this pair's score that cannot reach `cur` -- a score
-                    // some valid choice of this from-string already has -- need not be computed: if the pair wins, it wins
-                    // through another component.  Bounds (each through the same floating-point expressions as the value
-                    // it bounds, which are monotone):  token scorers <= 100;  a window of either string has LCS <= the
-                    // LCS of the whole strings (just computed) and at least that many characters, so partial_ratio <=
-                    // ratio_of(lcs, |shorter| + lcs);  the distinct-token form is a subsequence of the sorted-token form.
-                    const int lcs0 = zeros_below<W>(V, la0);
-                    const double scale = lmax < 8 * lmin ? 0.9 : 0.6;       // len_ratio < 8
-                    const bool want_tok = near && !(100.0 * 0.95 < cur);
-                    const bool want_ps = !near && !(ratio_of(lcs0, lmin + lcs0) * scale < cur);
-                    double tok = 0.0, ps = 0.0, pt = 0.0;
-                    if (__any(want_tok)) {
-                        const double t1 = token_sort(), t2 = token_set();     // (no tokens on either side: ratio("", "") = 100, as rapidfuzz)
-                        tok = fmax(t1, t2);
-                    }
-                    if (__any(want_ps)) ps = partial(0, want_ps ? la0 : 0, want_ps ? lb0 : 0);
-                    if (!near && ta != 0 && tb != 0) {
-                        if (ca) pt = 100.0;
-                        else if (!(100.0 * 0.95 * scale < cur)) {
-                            uint64_t V1[W];
-                            lcs_pass(1, all, false, 0u, 0, V1);
-                            const int lcs1 = zeros_below<W>(V1, la1);
-                            const int c1 = min(lcs1, min(la1, lb1)), c2 = min(lcs1, min(la2, lb2));
-                            const bool want1 = !(ratio_of(c1, min(la1, lb1) + c1) * 0.95 * scale < cur);
-                            const bool want2 = !(ratio_of(c2, min(la2, lb2) + c2) * 0.95 * scale < cur);
-                            double p1 = 0.0, p2 = 0.0;
-                            if (__any(want1)) p1 = partial(1, want1 ? la1 : 0, want1 ? lb1 : 0);
-                            if (__any(want2)) p2 = partial(2, want2 ? la2 : 0, want2 ? lb2 : 0);
-                            pt = fmax(want1 ? p1 : 0.0, want2 ? p2 : 0.0);
-                        }
-                    }
-                    if (near)
-                        score = want_tok ? fmax(end_ratio, tok * 0.95) : end_ratio;
-                    else {
-                        end_ratio = fmax(end_ratio, (want_ps ? ps : 0.0) * scale);
-                        score = fmax(end_ratio, pt * 0.95 * scale);
-                    }
-                }
-            }
-            else if (mode == kPartialRatio) score = partial_pruned(0, la0, lb0);
-            else if (mode == kTokenSetRatio) score = token_set();
-            else if (mode == kTokenRatio) score = fmax(token_sort(), token_set());
-            else if (mode == kPartialTokenSortRatio) score = partial_pruned(1, la1, lb1);
-            else if (mode == kPartialTokenSetRatio)
-                score = (ta == 0 || tb == 0) ? 0.0 : (ca ? 100.0 : partial_pruned(2, la2, lb2));
-            else score = partial_token();
-
-            if (orig >= 0 && orig != skip && (score > best_score || (score == best_score && orig < best_idx))) {
-                best_score = score;
-                best_idx = orig;
-            }
-            if (pruning) {                  // publish the wave's best score to the workgroup
-                double wb = fmax(best_score, 0.0);
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) wb = fmax(wb, __shfl_xor(wb, d, 64));
-                if (lane == 0) atomicMax(&s_best, (unsigned long long)__double_as_longlong(wb));
-            }
-        }
-        // first best choice: (score desc, original index asc)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double os = __shfl_xor(best_score, d, 64);
-            const int oi = __shfl_xor(best_idx, d, 64);
-            if (os > best_score || (os == best_score && oi < best_idx)) {
-                best_score = os;
-                best_idx = oi;
-            }
-        }
-        if (lane == 0) {
-            red_s[wave] = best_score;
-            red_i[wave] = best_idx;
+            s_sig[0] = (uint32_t)sig;
+            s_sig[1] = (uint32_t)(sig >> 32);
         }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (red_s[w] > best_score || (red_s[w] == best_score && red_i[w] < best_idx)) {
-                    best_score = red_s[w];
-                    best_idx = red_i[w];
-                }
-            if (parts > 1) {
-                A.part_score[(int64_t)r * parts + part] = best_score;
-                A.part_idx[(int64_t)r * parts + part] = best_idx;
+            const int nt_all = A.a_ntok_all[row];
+            const int extra = (nt_all - 1) - s_nspace;
+            if (extra > 0) s_cnt[A.space_class] += extra;
+            int usum = 0, big = 0;
+            for (int c = 0; c < 4 * kFuzzHistWords; ++c) {
+                usum += s_cnt[c];
+                big |= s_cnt[c] > 255;
             }
-            else {
-                A.out_idx[row] = best_idx == INT_MAX ? -1 : best_idx;
-                A.out_score[row] = best_idx == INT_MAX ? 0.0 : best_score;
+            for (int d = 0; d < kFuzzHistWords; ++d)
+                s_hist[d] = (uint32_t)s_cnt[4 * d] | (uint32_t)s_cnt[4 * d + 1] << 8 | (uint32_t)s_cnt[4 * d + 2] << 16 | (uint32_t)s_cnt[4 * d + 3] << 24;
+            s_usum = big ? -1 : usum;
+        }
+        __syncthreads();
+        FuzzFrom<W> F;
+        F.pm = pm;
+        F.la[0] = s_la[0];
+        F.la[1] = s_la[1];
+        F.la[2] = s_la[2];
+        F.ta = s_ta;
+        F.tid = s_tid;
+        F.tlen = s_tlen;
+        F.tmask = s_tmask;
+        F.smask = s_smask;
+        FuzzSummary sa;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) sa.len[v] = F.la[v];
+        sa.ntok = F.ta;
+#pragma unroll
+        for (int d = 0; d < kFuzzHistWords; ++d) sa.hist[d] = s_hist[d];
+        sa.usum = s_usum;
+        sa.sig = (uint64_t)s_sig[0] | (uint64_t)s_sig[1] << 32;
+        const int skip = A.skip_idx ? A.skip_idx[row] : -1;
+
+        auto cur_now = [&]() { return __longlong_as_double((long long)*(volatile unsigned long long *)&s_best); };
+        auto to_of = [&](int slot, const int4 &m) {
+            const int g = slot >> 6, l = slot & 63;
+            FuzzTo T;
+            const int64_t go = A.b_goff[g] + l, tg = A.b_tgoff[g] + l;
+            T.sym[0] = A.b_sym[0] + go;
+            T.sym[1] = A.b_sym[1] + go;
+            T.sym[2] = A.b_sym[2] + go;
+            T.tag = A.b_tag + go;
+            T.tok_id = A.b_tok_id + tg;
+            T.tok_len = A.b_tok_len + tg;
+            T.stride = 64;
+            T.lb[0] = m.x;
+            T.lb[1] = m.y;
+            T.lb[2] = m.z;
+            T.tb = m.w;
+            return T;
+        };
+        // float32 upper bound of the pair (from-string, slot); valid = a real candidate of this kernel
+        auto bound_of = [&](int slot, float cur32, int4 &m, int &orig, bool &valid) -> float {
+            m = A.b_meta[slot];
+            const int4 m2 = A.b_meta2[slot];
+            orig = m2.w;
+            valid = orig >= 0 && orig != skip && m.w <= kFuzzMaxTokens;
+            FuzzSummary sb;
+            sb.len[0] = m.x;
+            sb.len[1] = m.y;
+            sb.len[2] = m.z;
+            sb.ntok = m.w;
+            const int g = slot >> 6, l = slot & 63;
+            const uint4 h0 = A.b_hist[(g * 2 + 0) * 64 + l], h1 = A.b_hist[(g * 2 + 1) * 64 + l];
+            sb.hist[0] = h0.x;
+            sb.hist[1] = h0.y;
+            sb.hist[2] = h0.z;
+            sb.hist[3] = h0.w;
+            sb.hist[4] = h1.x;
+            sb.hist[5] = h1.y;
+            sb.hist[6] = h1.z;
+            sb.hist[7] = h1.w;
+            sb.usum = m2.z;
+            sb.sig = (uint64_t)(uint32_t)m2.x | (uint64_t)(uint32_t)m2.y << 32;
+            const int uu = fz_common_chars(sa, sb);
+            const bool maybe = use_tokens && (sa.sig & sb.sig) != 0ull;
+            float ub = fz_upper_bound(sa, sb, mode, uu, maybe ? -1 : 0);
+            if (valid && maybe && !(ub + kBoundSlack < cur32)) {
+                // the signatures meet: the exact intersection decides what the token scorers can reach
+                const FuzzTo T = to_of(slot, m);
+                uint32_t ca, cb;
+                fz_intersect<W>(F, T, ca, cb);
+                ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, T, ca, cb, uu) : -1.0f);
             }
+            return ub;
+        };
+        RowBest best = {-1.0, INT_MAX};
+        auto score_slot = [&](int slot, bool active) {
+            double sc = 0.0;
+            int orig = -1;
+            if (active) {
+                const int4 m = A.b_meta[slot];
+                orig = A.b_meta2[slot].w;
+                const FuzzTo T = to_of(slot, m);
+                sc = fz_score<W>(F, T, mode, cur_now());
+                best.take(sc, orig);
+                n_scored += 1;
+                n_steps += (unsigned long long)work_estimate(F.la, m, mode, W);
+            }
+            // publish the wave's best score to the workgroup
+            double wb = active ? fmax(sc, 0.0) : 0.0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) wb = fmax(wb, __shfl_xor(wb, d, 64));
+            if (lane == 0) atomicMax(&s_best, (unsigned long long)__double_as_longlong(wb));
+        };
+
+        // ---- sweep 1: every lane's best-bounded to-string is scored: a real score to prune with
+        float seed_ub = -1.0f;
+        int seed_slot = -1;
+        for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
+            const int slot = g * 64 + lane;
+            int4 m;
+            int orig;
+            bool valid;
+            const float ub = bound_of(slot, 0.0f, m, orig, valid);
+            n_bounded += 1;
+            if (valid && ub > seed_ub) {
+                seed_ub = ub;
+                seed_slot = slot;
+            }
+        }
+        score_slot(seed_slot, seed_slot >= 0);
+        __syncthreads();
+
+        // ---- sweep 2: the pairs whose bound reaches the best score so far, 64 at a time
+        int *queue = s_queue[wave];
+        int q_head = 0, q_tail = 0;             // wave-uniform; entries [q_head, q_tail) of a ring of 128
+        for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
+            const int slot = g * 64 + lane;
+            const float cur32 = (float)cur_now();
+            int4 m;
+            int orig;
+            bool valid;
+            const float ub = bound_of(slot, cur32, m, orig, valid);
+            n_bounded += 1;
+            const bool want = valid && slot != seed_slot && !(ub + kBoundSlack < cur32);
+            const unsigned long long bal = __ballot(want);
+            if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot;
+            q_tail += __popcll(bal);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            while (q_tail - q_head >= 64) {
+                score_slot(queue[(q_head + lane) & 127], true);
+                q_head += 64;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        if (q_tail > q_head) {
+            const bool active = lane < q_tail - q_head;
+            score_slot(active ? queue[(q_head + lane) & 127] : -1, active);
+        }
+
+        // first best choice: (score desc, original index asc)
+        wave_best(best);
+        if (lane == 0) {
+            red_s[wave] = best.score;
+            red_i[wave] = best.idx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) best.take(red_s[w], red_i[w]);
+            const int64_t o = (int64_t)A.row_slot[r] * A.n_parts_total + A.part0 + part;
+            A.part_score[o] = best.score;
+            A.part_idx[o] = best.idx;
         }
         // clear this from-string's table entries
         for (int v = 0; v < 3; ++v) {
-            const int64_t a0 = A.a_off[v][row];
-            const int m = (int)(A.a_off[v][row + 1] - a0);
+            const int m = s_la[v];
             for (int p = tid; p < m; p += 256) {
-                const int sy = A.a_sym[v][a0 + p];
+                const uint32_t c = load_unit(A.a_form[v], A.a_width, a0 + p);
+                const int sy = c < A.lut_len ? (int)A.lut[c] : 0;
 #pragma unroll
                 for (int w = 0; w < W; ++w) pm[(sy * 3 + v) * W + w] = 0ull;
             }
         }
         __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(256) void k7_merge_parts(FuzzArgs A)
-{
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= A.n_rows) return;
-    double bs = -1.0;
-    int bi = INT_MAX;
-    for (int p = 0; p < A.parts; ++p) {
-        const double s = A.part_score[(int64_t)r * A.parts + p];
-        const int i = A.part_idx[(int64_t)r * A.parts + p];
-        if (s > bs || (s == bs && i < bi)) {
-            bs = s;
-            bi = i;
+    if (A.counters) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            n_bounded += __shfl_xor(n_bounded, d, 64);
+            n_scored += __shfl_xor(n_scored, d, 64);
+            n_steps += __shfl_xor(n_steps, d, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&A.counters[0], n_bounded);
+            atomicAdd(&A.counters[1], n_scored);
+            atomicAdd(&A.counters[2], n_steps);
         }
     }
-    const int row = A.rows[r];
-    A.out_idx[row] = bi == INT_MAX ? -1 : bi;
-    A.out_score[row] = bi == INT_MAX ? 0.0 : bs;
 }
 
-namespace {
+// the best of a from-string over all the parts every launch left (same order: score desc, original index asc)
+__global__ __launch_bounds__(256) void k7_merge_parts(const double *__restrict__ part_score, const int32_t *__restrict__ part_idx,
+                                                       int64_t n_rows, int32_t n_parts, int32_t *__restrict__ out_idx,
+                                                       double *__restrict__ out_score)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    RowBest b = {-1.0, INT_MAX};
+    for (int p = 0; p < n_parts; ++p) b.take(part_score[r * n_parts + p], part_idx[r * n_parts + p]);
+    out_idx[r] = b.idx == INT_MAX ? -1 : b.idx;
+    out_score[r] = b.idx == INT_MAX ? 0.0 : b.score;
+}
 
-struct Dev {
-    pfz_ctx *ctx;
-    std::vector<void *> owned;
-    explicit Dev(pfz_ctx *c) : ctx(c) {}
-    ~Dev() { for (void *p : owned) pool_free(p); }
-    template <typename T> int up(const T *src, size_t n, const T **out)
+// (index, float64 score) -> the two-column result buffer the sharded jobs all-gather: idx[r][0] = index, the score's bits in
+// the two value lanes of the row
+__global__ __launch_bounds__(256) void k_best_to_topn(const int32_t *__restrict__ idx, const double *__restrict__ score, int64_t n,
+                                                       int32_t *__restrict__ t_idx, float *__restrict__ t_val)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    t_idx[2 * r] = idx[r];
+    t_idx[2 * r + 1] = -1;
+    ((double *)t_val)[r] = score[r];
+}
+
+struct DevBuf {
+    pfz_ctx *ctx = nullptr;
+    void *p = nullptr;
+    explicit DevBuf(pfz_ctx *c) : ctx(c) {}
+    ~DevBuf() { if (p) pool_free(p); }
+    int alloc(size_t bytes) { return pool_alloc(ctx, &p, bytes > 0 ? bytes : 16); }
+    template <typename T> int upload(const std::vector<T> &v)
     {
-        void *p = nullptr;
-        PFZ_TRY(pool_alloc_raw(ctx, &p, std::max<size_t>(n, 1) * sizeof(T) + 256));
-        owned.push_back(p);
-        if (n) PFZ_TRY(copy_h2d(ctx, p, src, n * sizeof(T)));
-        *out = (const T *)p;
-        return PFZ_OK;
-    }
-    template <typename T> int up(const std::vector<T> &v, const T **out) { return up(v.data(), v.size(), out); }
-    template <typename T> int alloc(size_t n, T **out)
-    {
-        void *p = nullptr;
-        PFZ_TRY(pool_alloc_raw(ctx, &p, std::max<size_t>(n, 1) * sizeof(T)));
-        owned.push_back(p);
-        *out = (T *)p;
+        PFZ_TRY(alloc(v.size() * sizeof(T)));
+        if (!v.empty()) PFZ_TRY(copy_h2d(ctx, p, v.data(), v.size() * sizeof(T)));
         return PFZ_OK;
     }
 };
 
-int check_list(const pfz_fuzz_list *L, const char *what, int32_t n_sym)
+int fuzz_general_launch(pfz_ctx *ctx, FuzzArgs A, const pfz_strings *F, const pfz_strings *T, const std::vector<int32_t> &rows);   // k7_general.hip
+
+// rows [begin, end) of `from` against all of `to`: (first best index, score) into device buffers d_idx / d_score of end - begin entries
+static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c, int32_t scorer, const int32_t *skip_idx, int64_t begin,
+                    int64_t end, int32_t *d_idx, double *d_score, unsigned long long *h_counters)
 {
-    PFZ_REQUIRE(L && L->n >= 0, "pfz_fuzz_extract_one: bad %s list", what);
-    if (L->n == 0) return PFZ_OK;
-    for (int v = 0; v < 3; ++v) {
-        PFZ_REQUIRE(L->sym[v] && L->off[v], "pfz_fuzz_extract_one: %s list, form %d: NULL array", what, v);
-        PFZ_REQUIRE(L->off[v][0] == 0, "pfz_fuzz_extract_one: %s list, form %d: offsets do not start at 0", what, v);
-        for (int64_t i = 0; i < L->n; ++i)
-            PFZ_REQUIRE(L->off[v][i + 1] >= L->off[v][i], "pfz_fuzz_extract_one: %s list, form %d: offsets decrease at %lld", what,
-                        v, (long long)i);
-        for (int64_t p = 0; p < L->off[v][L->n]; ++p)
-            PFZ_REQUIRE(L->sym[v][p] <= n_sym, "pfz_fuzz_extract_one: %s list, form %d: symbol %d at %lld beyond the alphabet of %d",
-                        what, v, (int)L->sym[v][p], (long long)p, n_sym);
+    pfz_strings *F = const_cast<pfz_strings *>(F_c), *T = const_cast<pfz_strings *>(T_c);     // the caches live inside the handles
+    const int64_t n_rows = end - begin, n_to = T->n;
+    if (T->n >= INT_MAX - 64 || F->n >= INT_MAX) {
+        set_error("pfz_fuzz: list too long");
+        return PFZ_ERR_UNSUPPORTED;
     }
-    PFZ_REQUIRE(L->tok_off && L->tok_off[0] == 0, "pfz_fuzz_extract_one: %s list: token offsets", what);
-    for (int64_t i = 0; i < L->n; ++i) {
-        const int64_t nt = L->tok_off[i + 1] - L->tok_off[i];
-        PFZ_REQUIRE(nt >= 0, "pfz_fuzz_extract_one: %s list: token offsets decrease at %lld", what, (long long)i);
-        if (nt > 32) {
-            set_error("pfz_fuzz_extract_one: %s string %lld has %lld distinct tokens; the kernel's token sets hold 32", what,
-                      (long long)i, (long long)nt);
-            return PFZ_ERR_UNSUPPORTED;
+    PFZ_TRY(ensure_forms(ctx, F));
+    if (!T->fuzz_plan) PFZ_TRY(build_plan(ctx, T));
+    const pfz_fuzz_plan *pl = T->fuzz_plan;
+    const pfz_fuzz_forms *ff = F->fuzz_forms;
+
+    // token ids of the from-list in the to-list's table (the same handle: the plan's own)
+    DevBuf d_aid(ctx), d_skip(ctx), d_counters(ctx);
+    const int32_t *a_tok_id = pl->t_tok_id;
+    if (F != T) {
+        PFZ_TRY(d_aid.alloc((size_t)ff->tok_cap * sizeof(int32_t)));
+        if (F->n > 0) {
+            ProfScope ps(ctx, "k7_prepare");
+            hipLaunchKernelGGL(k7_token_ids<false>, dim3((unsigned)((F->n + 127) / 128)), dim3(128), 0, ctx->stream, token_lists(F), F->n,
+                               token_lists(T), T->n, pl->table, pl->table_mask, (int32_t *)d_aid.p);
+            PFZ_HIP(hipGetLastError());
         }
-        int64_t joined = nt > 0 ? nt - 1 : 0;
-        for (int64_t t = L->tok_off[i]; t < L->tok_off[i + 1]; ++t) joined += L->tok_len[t];
-        PFZ_REQUIRE(joined == L->off[2][i + 1] - L->off[2][i],
-                    "pfz_fuzz_extract_one: %s string %lld: form 2 is not its distinct tokens joined by single spaces", what,
-                    (long long)i);
+        a_tok_id = (const int32_t *)d_aid.p;
     }
+    if (skip_idx) {
+        PFZ_TRY(d_skip.alloc((size_t)F->n * sizeof(int32_t)));
+        PFZ_TRY(copy_h2d(ctx, d_skip.p, skip_idx, (size_t)F->n * sizeof(int32_t)));
+    }
+    if (h_counters) {
+        PFZ_TRY(d_counters.alloc(4 * sizeof(unsigned long long)));
+        PFZ_HIP(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    }
+
+    // word classes of the from-strings; beyond 256 characters / 32 distinct tokens / a 60 KiB match table: the general kernel
+    static const int kWords[3] = {1, 2, 4};
+    std::vector<int32_t> cls[4], slot_of[4];
+    const bool force_general = getenv("PFZ_K7_FORCE_GENERAL") != nullptr;
+    for (int64_t i = begin; i < end; ++i) {
+        const int64_t len = F->h_off[(size_t)i + 1] - F->h_off[(size_t)i];
+        int c = len > 256 ? 3 : (len > 128 ? 2 : (len > 64 ? 1 : 0));
+        if (ff->h_ntok[(size_t)i] > kFuzzMaxTokens || force_general) c = 3;
+        if (c < 3 && (size_t)(pl->n_sym + 1) * 3 * kWords[c] * sizeof(uint64_t) > 60 * 1024) c = 3;
+        cls[c].push_back((int32_t)i);
+        slot_of[c].push_back((int32_t)(i - begin));
+    }
+
+    FuzzArgs A{};
+    A.a_form[0] = F->chars;
+    A.a_form[1] = ff->form1;
+    A.a_form[2] = ff->form2;
+    A.a_width = F->char_width;
+    A.a_off = F->offsets;
+    A.a_len1 = ff->len1;
+    A.a_len2 = ff->len2;
+    A.a_ntok = ff->ntok;
+    A.a_ntok_all = ff->ntok_all;
+    A.a_tok_len = ff->tok_len;
+    A.a_tok_id = a_tok_id;
+    A.lut = pl->lut;
+    A.lut_len = pl->lut_len;
+    A.cls = pl->cls;
+    A.space_rank = pl->space_rank;
+    A.space_class = pl->space_class;
+    for (int v = 0; v < 3; ++v) A.b_sym[v] = pl->sym[v];
+    A.b_tag = pl->tag;
+    A.b_goff = pl->goff;
+    A.b_tgoff = pl->tgoff;
+    A.b_tok_id = pl->tok_id;
+    A.b_tok_len = pl->tok_len;
+    A.b_meta = pl->meta;
+    A.b_meta2 = pl->meta2;
+    A.b_hist = pl->hist;
+    A.n_groups = (int32_t)pl->n_groups;
+    A.n_sym1 = pl->n_sym + 1;
+    A.mode = scorer;
+    A.skip_idx = skip_idx ? (const int32_t *)d_skip.p : nullptr;
+    A.counters = h_counters ? (unsigned long long *)d_counters.p : nullptr;
+
+    // how many workgroups share a from-string's to-groups (few from-strings: split, as K4 does), per class; then one slot for
+    // the general kernel's "to-strings with more than 32 tokens" pass and one for its own rows
+    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 4;
+    int32_t parts_of[3] = {1, 1, 1}, max_parts = 1;
+    for (int c = 0; c < 3; ++c) {
+        if (cls[c].empty()) continue;
+        const int64_t n = (int64_t)cls[c].size();
+        const int64_t want = (2 * max_grid + n - 1) / n, cap = std::max<int64_t>(1, pl->n_groups / 4);
+        parts_of[c] = (int32_t)std::max<int64_t>(1, std::min(want, cap));
+        if (const char *e = getenv("PFZ_K7_PARTS")) parts_of[c] = std::max(1, atoi(e));
+        max_parts = std::max(max_parts, parts_of[c]);
+    }
+    const int32_t n_parts_total = max_parts + 1;
+    DevBuf d_ps(ctx), d_pi(ctx);
+    PFZ_TRY(d_ps.alloc((size_t)n_rows * n_parts_total * sizeof(double)));
+    PFZ_TRY(d_pi.alloc((size_t)n_rows * n_parts_total * sizeof(int32_t)));
+    PFZ_HIP(hipMemsetAsync(d_ps.p, 0xff, (size_t)n_rows * n_parts_total * sizeof(double), ctx->stream));      // NaN bits: never taken ...
+    PFZ_HIP(hipMemsetAsync(d_pi.p, 0x7f, (size_t)n_rows * n_parts_total * sizeof(int32_t), ctx->stream));     // ... and a huge index
+    A.n_parts_total = n_parts_total;
+    A.part_score = (double *)d_ps.p;
+    A.part_idx = (int32_t *)d_pi.p;
+
+    DevBuf d_rows[4] = {DevBuf(ctx), DevBuf(ctx), DevBuf(ctx), DevBuf(ctx)}, d_slots[4] = {DevBuf(ctx), DevBuf(ctx), DevBuf(ctx), DevBuf(ctx)};
+    for (int c = 0; c < 3; ++c) {
+        if (cls[c].empty() || n_to == 0) continue;
+        PFZ_TRY(d_rows[c].upload(cls[c]));
+        PFZ_TRY(d_slots[c].upload(slot_of[c]));
+        A.rows = (const int32_t *)d_rows[c].p;
+        A.row_slot = (const int32_t *)d_slots[c].p;
+        A.n_rows = (int32_t)cls[c].size();
+        A.parts = parts_of[c];
+        A.part0 = 0;
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
+        const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t);
+        ProfScope ps(ctx, "k7_fuzz");
+        if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(256), lds, ctx->stream, A);
+        else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, A);
+        else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(256), lds, ctx->stream, A);
+        PFZ_HIP(hipGetLastError());
+    }
+    if (n_to > 0) {
+        // the general kernel: its own from-rows against every to-string, and every OTHER from-row against the to-strings
+        // the kernels above left out (more than 32 distinct tokens)
+        A.parts = 1;
+        A.part0 = max_parts;
+        if (!cls[3].empty()) {
+            PFZ_TRY(d_slots[3].upload(slot_of[3]));
+            A.row_slot = (const int32_t *)d_slots[3].p;
+            A.big_slots = nullptr;
+            A.n_big = 0;
+            ProfScope ps(ctx, "k7_fuzz");
+            PFZ_TRY(fuzz_general_launch(ctx, A, F, T, cls[3]));
+        }
+        if (!pl->big_slots.empty()) {
+            std::vector<int32_t> others, other_slots;
+            for (int c = 0; c < 3; ++c) {
+                others.insert(others.end(), cls[c].begin(), cls[c].end());
+                other_slots.insert(other_slots.end(), slot_of[c].begin(), slot_of[c].end());
+            }
+            if (!others.empty()) {
+                DevBuf d_os(ctx);
+                PFZ_TRY(d_os.upload(other_slots));
+                A.row_slot = (const int32_t *)d_os.p;
+                A.big_slots = pl->d_big_slots;
+                A.n_big = (int32_t)pl->big_slots.size();
+                ProfScope ps(ctx, "k7_fuzz");
+                PFZ_TRY(fuzz_general_launch(ctx, A, F, T, others));
+            }
+        }
+    }
+    {
+        ProfScope ps(ctx, "k7_fuzz");
+        hipLaunchKernelGGL(k7_merge_parts, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)d_ps.p,
+                           (const int32_t *)d_pi.p, n_rows, n_parts_total, d_idx, d_score);
+        PFZ_HIP(hipGetLastError());
+    }
+    if (h_counters) PFZ_TRY(copy_d2h(ctx, h_counters, d_counters.p, 4 * sizeof(unsigned long long)));
     return PFZ_OK;
 }
 
-}  // namespace
+const int32_t *fuzz_forms_tok_pos(const pfz_strings *S) { return S->fuzz_forms ? S->fuzz_forms->tok_pos : nullptr; }
+
+int best_to_topn(pfz_ctx *ctx, const int32_t *d_idx, const double *d_score, int64_t n, pfz_topn *out)
+{
+    if (n == 0) return PFZ_OK;
+    hipLaunchKernelGGL(k_best_to_topn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_idx, d_score, n, out->idx, out->val);
+    PFZ_HIP(hipGetLastError());
+    return PFZ_OK;
+}
+
+static int check_args(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T, int32_t scorer, int64_t begin, int64_t end, const char *who)
+{
+    PFZ_REQUIRE(ctx && F && T, "%s: NULL argument", who);
+    PFZ_REQUIRE(scorer >= kWRatio && scorer <= kPartialTokenRatio, "%s: unknown scorer %d", who, scorer);
+    PFZ_REQUIRE(begin >= 0 && begin <= end && end <= F->n, "%s: row range [%lld,%lld) outside [0,%lld)", who, (long long)begin,
+                (long long)end, (long long)F->n);
+    return PFZ_OK;
+}
 
 }  // namespace pfz
 
 using namespace pfz;
 
-extern "C" int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_fuzz_list *from, const pfz_fuzz_list *to, int32_t n_symbols,
-                                    int32_t scorer, const int32_t *skip_idx, int32_t *out_idx, double *out_score)
+extern "C" {
+
+int pfz_fuzz_extract_one(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings, int32_t scorer,
+                         const int32_t *skip_idx, int64_t from_begin, int64_t from_end, int32_t *out_idx, double *out_score)
 {
-    PFZ_REQUIRE(ctx && from && to && out_idx && out_score, "pfz_fuzz_extract_one: NULL argument");
-    PFZ_REQUIRE(scorer >= kWRatio && scorer <= kPartialTokenRatio, "pfz_fuzz_extract_one: unknown scorer %d", scorer);
-    PFZ_REQUIRE(n_symbols >= 0 && n_symbols < 65535, "pfz_fuzz_extract_one: alphabet of %d symbols", n_symbols);
-    PFZ_TRY(check_list(from, "from", n_symbols));
-    PFZ_TRY(check_list(to, "to", n_symbols));
-    const int64_t n_from = from->n, n_to = to->n;
-    if (n_from == 0) return PFZ_OK;
-    if (n_to == 0) {
-        for (int64_t i = 0; i < n_from; ++i) {
-            out_idx[i] = -1;
-            out_score[i] = 0.0;
-        }
-        return PFZ_OK;
-    }
-    PFZ_REQUIRE(n_to < INT_MAX - 64 && n_from < INT_MAX, "pfz_fuzz_extract_one: lists of more than 2^31 strings");
+    PFZ_TRY(check_args(ctx, from_strings, to_strings, scorer, from_begin, from_end, "pfz_fuzz_extract_one"));
+    PFZ_REQUIRE(out_idx && out_score, "pfz_fuzz_extract_one: NULL output");
+    const int64_t n = from_end - from_begin;
+    if (n == 0) return PFZ_OK;
     PFZ_HIP(hipSetDevice(ctx->device));
-
-    // word classes of the from-strings
-    static const int kWords[3] = {1, 2, 4};
-    std::vector<int32_t> cls[3];
-    for (int64_t i = 0; i < n_from; ++i) {
-        int64_t longest = 0;
-        for (int v = 0; v < 3; ++v) longest = std::max(longest, from->off[v][i + 1] - from->off[v][i]);
-        if (longest > 256) {
-            set_error("pfz_fuzz_extract_one: from-string %lld has %lld characters; the kernel holds 256 (four 64-bit words)",
-                      (long long)i, (long long)longest);
-            return PFZ_ERR_UNSUPPORTED;
-        }
-        cls[longest > 128 ? 2 : longest > 64 ? 1 : 0].push_back((int32_t)i);
-    }
-    for (int c = 0; c < 3; ++c)
-        if (!cls[c].empty() && (size_t)(n_symbols + 1) * 3 * kWords[c] * sizeof(uint64_t) > 60 * 1024) {
-            set_error("pfz_fuzz_extract_one: an alphabet of %d symbols x 3 forms x %d words does not fit the 60 KiB match table",
-                      n_symbols, kWords[c]);
-            return PFZ_ERR_UNSUPPORTED;
-        }
-
-    // ---- to-side: groups of 64 sorted by the length of form 0, everything [position][lane]
-    std::vector<int32_t> order((size_t)n_to);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        return to->off[0][x + 1] - to->off[0][x] < to->off[0][y + 1] - to->off[0][y];
-    });
-    const int64_t n_groups = (n_to + 63) / 64;
-    std::vector<int32_t> b_orig((size_t)n_groups * 64, -1), b_ntok((size_t)n_groups * 64, 0), b_len[3], b_gmax[3], b_tgmax((size_t)n_groups, 0);
-    std::vector<int64_t> b_goff[3], b_tgoff((size_t)n_groups, 0);
-    std::vector<uint16_t> b_sym[3];
-    std::vector<uint8_t> b_tag;
-    for (int v = 0; v < 3; ++v) {
-        b_len[v].assign((size_t)n_groups * 64, 0);
-        b_gmax[v].assign((size_t)n_groups, 0);
-        b_goff[v].assign((size_t)n_groups, 0);
-    }
-    int64_t tok_total = 0;
-    for (int64_t g = 0; g < n_groups; ++g) {
-        for (int l = 0; l < 64 && g * 64 + l < n_to; ++l) {
-            const int32_t o = order[(size_t)(g * 64 + l)];
-            b_orig[(size_t)(g * 64 + l)] = o;
-            for (int v = 0; v < 3; ++v) {
-                const int32_t len = (int32_t)(to->off[v][o + 1] - to->off[v][o]);
-                b_len[v][(size_t)(g * 64 + l)] = len;
-                b_gmax[v][(size_t)g] = std::max(b_gmax[v][(size_t)g], len);
-            }
-            const int32_t nt = (int32_t)(to->tok_off[o + 1] - to->tok_off[o]);
-            b_ntok[(size_t)(g * 64 + l)] = nt;
-            b_tgmax[(size_t)g] = std::max(b_tgmax[(size_t)g], nt);
-        }
-        b_tgoff[(size_t)g] = tok_total;
-        tok_total += (int64_t)b_tgmax[(size_t)g] * 64;
-    }
-    std::vector<int32_t> b_tok_id((size_t)tok_total + 64, -1), b_tok_len((size_t)tok_total + 64, 0);
-    for (int v = 0; v < 3; ++v) {
-        int64_t total = 0;
-        for (int64_t g = 0; g < n_groups; ++g) {
-            b_goff[v][(size_t)g] = total;
-            total += (int64_t)b_gmax[v][(size_t)g] * 64;
-        }
-        b_sym[v].assign((size_t)total + 64, 0);
-        if (v == 2) b_tag.assign((size_t)total + 64, 0);
-    }
-    for (int64_t g = 0; g < n_groups; ++g)
-        for (int l = 0; l < 64 && g * 64 + l < n_to; ++l) {
-            const int32_t o = order[(size_t)(g * 64 + l)];
-            for (int v = 0; v < 3; ++v) {
-                const int64_t s0 = to->off[v][o];
-                const int32_t len = b_len[v][(size_t)(g * 64 + l)];
-                for (int32_t p = 0; p < len; ++p) b_sym[v][(size_t)(b_goff[v][(size_t)g] + (int64_t)p * 64 + l)] = to->sym[v][s0 + p];
-            }
-            const int64_t t0 = to->tok_off[o];
-            const int32_t nt = b_ntok[(size_t)(g * 64 + l)];
-            int32_t pos = 0;
-            for (int32_t j = 0; j < nt; ++j) {
-                const int32_t len = to->tok_len[t0 + j];
-                b_tok_id[(size_t)(b_tgoff[(size_t)g] + (int64_t)j * 64 + l)] = to->tok_id[t0 + j];
-                b_tok_len[(size_t)(b_tgoff[(size_t)g] + (int64_t)j * 64 + l)] = len;
-                for (int32_t p = 0; p < len; ++p) b_tag[(size_t)(b_goff[2][(size_t)g] + (int64_t)(pos + p) * 64 + l)] = (uint8_t)j;
-                if (j + 1 < nt) b_tag[(size_t)(b_goff[2][(size_t)g] + (int64_t)(pos + len) * 64 + l)] = (uint8_t)(j | 0x80);
-                pos += len + 1;
-            }
-        }
-
-    Dev dev(ctx);
-    FuzzArgs A{};
-    for (int v = 0; v < 3; ++v) {
-        PFZ_TRY(dev.up(from->sym[v], (size_t)from->off[v][n_from], &A.a_sym[v]));
-        PFZ_TRY(dev.up(from->off[v], (size_t)n_from + 1, &A.a_off[v]));
-        PFZ_TRY(dev.up(b_sym[v], &A.b_sym[v]));
-        PFZ_TRY(dev.up(b_goff[v], &A.b_goff[v]));
-        PFZ_TRY(dev.up(b_gmax[v], &A.b_gmax[v]));
-        PFZ_TRY(dev.up(b_len[v], &A.b_len[v]));
-    }
-    PFZ_TRY(dev.up(from->tok_id, (size_t)from->tok_off[n_from], &A.a_tok_id));
-    PFZ_TRY(dev.up(from->tok_len, (size_t)from->tok_off[n_from], &A.a_tok_len));
-    PFZ_TRY(dev.up(from->tok_off, (size_t)n_from + 1, &A.a_tok_off));
-    PFZ_TRY(dev.up(b_tag, &A.b_tag));
-    PFZ_TRY(dev.up(b_orig, &A.b_orig));
-    PFZ_TRY(dev.up(b_ntok, &A.b_ntok));
-    PFZ_TRY(dev.up(b_tgoff, &A.b_tgoff));
-    PFZ_TRY(dev.up(b_tgmax, &A.b_tgmax));
-    PFZ_TRY(dev.up(b_tok_id, &A.b_tok_id));
-    PFZ_TRY(dev.up(b_tok_len, &A.b_tok_len));
-    if (skip_idx) PFZ_TRY(dev.up(skip_idx, (size_t)n_from, &A.skip_idx));
-    PFZ_TRY(dev.alloc((size_t)n_from, &A.out_idx));
-    PFZ_TRY(dev.alloc((size_t)n_from, &A.out_score));
-    A.n_groups = (int32_t)n_groups;
-    A.n_sym1 = n_symbols + 1;
-    A.mode = scorer;
-
-    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 4;
-    for (int c = 0; c < 3; ++c) {
-        if (cls[c].empty()) continue;
-        PFZ_TRY(dev.up(cls[c], &A.rows));
-        A.n_rows = (int32_t)cls[c].size();
-        // few from-strings: split every string's to-groups over `parts` workgroups (as K4 does)
-        const int64_t want = (2 * max_grid + A.n_rows - 1) / A.n_rows, cap = std::max<int64_t>(1, n_groups / 4);
-        A.parts = (int32_t)std::max<int64_t>(1, std::min(want, cap));
-        if (const char *e = getenv("PFZ_K7_PARTS")) A.parts = std::max(1, atoi(e));
-        if (A.parts > 1) {
-            PFZ_TRY(dev.alloc((size_t)A.n_rows * (size_t)A.parts, &A.part_score));
-            PFZ_TRY(dev.alloc((size_t)A.n_rows * (size_t)A.parts, &A.part_idx));
-        }
-        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
-        const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t);
-        {
-            ProfScope ps(ctx, "k7_fuzz");
-            if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(256), lds, ctx->stream, A);
-            else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, A);
-            else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(256), lds, ctx->stream, A);
-            PFZ_HIP(hipGetLastError());
-            if (A.parts > 1) {
-                hipLaunchKernelGGL(k7_merge_parts, dim3((unsigned)((A.n_rows + 255) / 256)), dim3(256), 0, ctx->stream, A);
-                PFZ_HIP(hipGetLastError());
-            }
-        }
-    }
-    PFZ_TRY(copy_d2h(ctx, out_idx, A.out_idx, (size_t)n_from * sizeof(int32_t)));
-    PFZ_TRY(copy_d2h(ctx, out_score, A.out_score, (size_t)n_from * sizeof(double)));
+    DevBuf d_idx(ctx), d_score(ctx);
+    PFZ_TRY(d_idx.alloc((size_t)n * sizeof(int32_t)));
+    PFZ_TRY(d_score.alloc((size_t)n * sizeof(double)));
+    PFZ_TRY(fuzz_run(ctx, from_strings, to_strings, scorer, skip_idx, from_begin, from_end, (int32_t *)d_idx.p, (double *)d_score.p, nullptr));
+    PFZ_TRY(copy_d2h(ctx, out_idx, d_idx.p, (size_t)n * sizeof(int32_t)));
+    PFZ_TRY(copy_d2h(ctx, out_score, d_score.p, (size_t)n * sizeof(double)));
     PFZ_HIP(hipStreamSynchronize(ctx->stream));
     return PFZ_OK;
 }
+
+int pfz_fuzz_extract_one_dev(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings, int32_t scorer,
+                             const int32_t *skip_idx, int64_t from_begin, int64_t from_end, pfz_topn *out, uint64_t *work_counters)
+{
+    PFZ_TRY(check_args(ctx, from_strings, to_strings, scorer, from_begin, from_end, "pfz_fuzz_extract_one_dev"));
+    const int64_t n = from_end - from_begin;
+    PFZ_REQUIRE(out && out->ntop == 2 && out->n_rows >= n, "pfz_fuzz_extract_one_dev: the result buffer must have 2 columns and >= %lld rows",
+                (long long)n);
+    if (work_counters) work_counters[0] = work_counters[1] = work_counters[2] = work_counters[3] = 0;
+    if (n == 0) return PFZ_OK;
+    PFZ_HIP(hipSetDevice(ctx->device));
+    DevBuf d_idx(ctx), d_score(ctx);
+    PFZ_TRY(d_idx.alloc((size_t)n * sizeof(int32_t)));
+    PFZ_TRY(d_score.alloc((size_t)n * sizeof(double)));
+    PFZ_TRY(fuzz_run(ctx, from_strings, to_strings, scorer, skip_idx, from_begin, from_end, (int32_t *)d_idx.p, (double *)d_score.p,
+                     (unsigned long long *)work_counters));
+    return best_to_topn(ctx, (const int32_t *)d_idx.p, (const double *)d_score.p, n, out);
+}
+
+int pfz_fuzz_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_symbols, int64_t *n_groups, int64_t *n_tokens,
+                       int64_t *n_general_strings)
+{
+    PFZ_REQUIRE(ctx && to_strings, "pfz_fuzz_plan_info: NULL argument");
+    pfz_strings *T = const_cast<pfz_strings *>(to_strings);
+    if (!T->fuzz_plan) {
+        PFZ_HIP(hipSetDevice(ctx->device));
+        PFZ_TRY(build_plan(ctx, T));
+    }
+    if (n_symbols) *n_symbols = T->fuzz_plan->n_sym;
+    if (n_groups) *n_groups = T->fuzz_plan->n_groups;
+    if (n_tokens) {
+        *n_tokens = 0;
+        for (int32_t t : T->fuzz_forms->h_ntok) *n_tokens += t;
+    }
+    if (n_general_strings) *n_general_strings = (int64_t)T->fuzz_plan->big_slots.size();
+    return PFZ_OK;
+}
+
+}  // extern "C"

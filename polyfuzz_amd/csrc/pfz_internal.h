@@ -115,6 +115,9 @@ struct pfz_strings {
     std::vector<int64_t> h_off;      // n + 1
     // K4's to-side plan (alphabet, length-sorted packed groups), built on first use as a to-list
     struct pfz_indel_plan *indel_plan = nullptr;
+    // K7: the list's token forms (a property of the list alone) and, built on first use as a to-list, its plan
+    struct pfz_fuzz_forms *fuzz_forms = nullptr;
+    struct pfz_fuzz_plan *fuzz_plan = nullptr;
     // n-gram cache of the vectoriser (see k1_vectorize.hip): per-string slot
     // ranges holding first the packed n-gram codes, then (column id, tf) pairs
     uint64_t cache_gen = 0;      // pfz_tfidf::gen the cache was made for (0 = none)
@@ -124,6 +127,8 @@ struct pfz_strings {
 };
 
 void pfz_indel_plan_free(struct pfz_indel_plan *p);   // k4_indel.hip
+void pfz_fuzz_forms_free(struct pfz_fuzz_forms *f);   // k7_fuzz.hip
+void pfz_fuzz_plan_free(struct pfz_fuzz_plan *p);
 
 struct pfz_tfidf {
     pfz_ctx *ctx = nullptr;
@@ -204,6 +209,10 @@ int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n);
 
 // ascending sort of n-gram codes (sort_u64.hip: bitonic network, LDS tiles + streaming passes);
 // `out` must hold sort_codes_capacity(n) keys
+// (first best index, float64 score)[n] -> a two-column result buffer (idx[r][0] = index, the score's bits in the row's two
+// value lanes): what the sharded edit-distance jobs all-gather (k7_fuzz.hip)
+int best_to_topn(pfz_ctx *ctx, const int32_t *d_idx, const double *d_score, int64_t n, pfz_topn *out);
+
 int64_t sort_codes_capacity(int64_t n);
 int sort_codes_u64(pfz_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n);
 

@@ -42,9 +42,12 @@ class EditDistance(BaseMatcher):
         model_id: The name of the particular instance, used when comparing models
         normalize: Whether to min-max normalize the similarity scores (_distance.py:83-86)
 
-    From-strings of up to 1024 characters run in the register-resident word classes (four at a time up to 32
-    characters); longer ones, and alphabets whose match table (distinct code points of the to-list x words) exceeds
-    60 KiB of LDS, take a general -- slower -- kernel with its state in global memory.  There is no CPU fallback.
+    scorer "ratio" (K4): from-strings of up to 1024 characters run in the register-resident word classes (eight / four at
+    a time up to 16 / 32 characters); longer ones, and alphabets whose match table (distinct code points of the to-list x
+    words) exceeds 60 KiB of LDS, take a general -- slower -- kernel with its state in global memory.  The per-pair
+    scorers (K7: WRatio, partial_ratio, the token_set family): from-strings of up to 256 characters and 32 distinct tokens
+    in the LDS kernel, anything beyond (and to-strings beyond 32 distinct tokens) in K7's general kernel, which is slow.
+    Any length and any alphabet is accepted.  There is no CPU fallback.
     """
     def __init__(self,
                  n_jobs: int = 1,
@@ -85,7 +88,7 @@ class EditDistance(BaseMatcher):
         self.last_timings = {"device": (t1 - t0) * 1e3, "frame": (time.perf_counter() - t1) * 1e3}
         return matches
 
-    def _best(self, from_list, to_list, rows=None, reuse_to=False):
+    def _best(self, from_list, to_list, reuse_to=False):
         ctx = _lib.Context.default()
         self_match = to_list is None
         skip = None
@@ -102,23 +105,16 @@ class EditDistance(BaseMatcher):
             names = to_list
         if len(names) - (1 if self_match else 0) <= 0 and len(from_list) > 0:
             raise ValueError("attempt to get argmax of an empty sequence")   # np.argmax([]) in the reference
-        if self._scorer_name != "ratio":      # the other rapidfuzz.fuzz scorers (K4 on transformed strings, or K7)
-            from ._rapidfuzz import best_choice
-            idx, score = best_choice(ctx, self._scorer_name, from_list, names, skip, self_match)
-            if not self_match:
-                self._to_dev, self._to_names = None, names
-            begin, end = (0, len(from_list)) if rows is None else rows
-            return idx[begin:end], score[begin:end], names
-        f_dev = _lib.DeviceStrings.upload(ctx, from_list)
-        if self_match:
-            t_dev = f_dev
-        elif reuse_to and self._to_dev is not None:
-            t_dev = self._to_dev
-        else:
-            t_dev = _lib.DeviceStrings.upload(ctx, names)
-            self._to_dev, self._to_names = t_dev, names
-        begin, end = (0, len(from_list)) if rows is None else rows
-        idx, score = _lib.indel_argmax(ctx, f_dev, t_dev, skip, begin, end)
+        from ._rapidfuzz import best_choice, upload_for
+        name = self._scorer_name              # "ratio": K4; the other rapidfuzz.fuzz scorers: K4 on transformed strings, or K7
+        to_dev = None
+        if not self_match:
+            if reuse_to and self._to_dev is not None:
+                to_dev = self._to_dev
+            else:
+                to_dev = upload_for(ctx, name, names)
+                self._to_dev, self._to_names = to_dev, names
+        idx, score = best_choice(ctx, name, from_list, names, skip, self_match, to_dev=to_dev)
         return idx, score, names
 
     # a matcher is pickled by joblib (reference _distance.py:77, polyfuzz.py:429-457): device handles stay behind

@@ -13,7 +13,8 @@ Scorers, all on the device (names or the rapidfuzz.fuzz functions of those names
   (k7_fuzz.hip: windows by masked match tables and prefix bit counts, token-set differences by token masks).
 rapidfuzz 3.x semantics: no default processor (strings are scored as given).  Any other callable raises
 `NotImplementedError` (there is no CPU path in this package).
-K7's limits (PfzUnsupported): from-strings of at most 256 characters, at most 32 distinct tokens per string.
+Strings of any length and token count are accepted; from-strings beyond 256 characters or 32 distinct tokens (and
+to-strings beyond 32 distinct tokens) take K7's general kernel, which is slow.
 
 Deviation, on purpose: the reference removes the from-string from ONE shared copy of the list
 (`to_list.remove(from_string)`, _rapidfuzz.py:103-104), so with n_jobs=1 the list shrinks as rows are processed
@@ -48,21 +49,28 @@ def _scorer_name(scorer) -> str:
     return getattr(scorer, "__name__", repr(scorer))
 
 
-def best_choice(ctx, name, from_list, names, skip, self_match):
+def _transform(name, strings):
+    """the string every list element is scored as: itself, or (token_sort_ratio) its whitespace tokens sorted and joined"""
+    if name == "token_sort_ratio":           # rapidfuzz: ratio(" ".join(sorted(s1.split())), " ".join(sorted(s2.split())))
+        return [" ".join(sorted(s.split())) for s in strings]
+    return strings
+
+
+def upload_for(ctx, name, strings):
+    """A list resident on the device in the form scorer `name` reads (K4 scorers: one fixed string per element; K7 scorers:
+    the strings themselves -- their token forms are built on the device and cached on the handle)."""
+    return _lib.DeviceStrings.upload(ctx, _transform(name, strings))
+
+
+def best_choice(ctx, name, from_list, names, skip, self_match, to_dev=None):
     """(index of the first best choice int32[n], its score float64[n] on the 0..100 scale) of every from-string under
     the rapidfuzz.fuzz scorer `name`; `names` are the choices (the from-list itself in a self-match, where skip[i] is
-    the choice left out for from-string i)."""
+    the choice left out for from-string i -- still the from-string's own first occurrence in the ORIGINAL list).
+    to_dev: the choices already resident (upload_for), e.g. from the previous call of a fitted matcher."""
+    f_dev = upload_for(ctx, name, from_list)
+    t_dev = f_dev if self_match else (to_dev if to_dev is not None else upload_for(ctx, name, names))
     if name in _lib.FUZZ_SCORERS:
-        return _lib.fuzz_extract_one(ctx, from_list, from_list if self_match else names, name, skip)
-    if name == "token_sort_ratio":
-        # rapidfuzz: ratio(" ".join(sorted(s1.split())), " ".join(sorted(s2.split()))); the choice that is
-        # skipped in a self-match is still the from-string's own first occurrence in the ORIGINAL list
-        scored_from = [" ".join(sorted(s.split())) for s in from_list]
-        scored_to = scored_from if self_match else [" ".join(sorted(s.split())) for s in names]
-    else:
-        scored_from, scored_to = from_list, names
-    f_dev = _lib.DeviceStrings.upload(ctx, scored_from)
-    t_dev = f_dev if self_match else _lib.DeviceStrings.upload(ctx, scored_to)
+        return _lib.fuzz_extract_one(ctx, f_dev, t_dev, name, skip)
     idx, score = _lib.indel_argmax(ctx, f_dev, t_dev, skip)
     if name == "QRatio":
         # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string
@@ -100,15 +108,20 @@ class RapidFuzz(BaseMatcher):
         self.scorer = scorer
         self._scorer_name = name
         self.n_jobs = n_jobs
+        self._to_dev = self._to_names = None     # device copy (+ cached plan) of the last to-list
 
     def match(self,
               from_list: List[str],
               to_list: List[str] = None,
               **kwargs) -> pd.DataFrame:
-        """ Best choice of the to-list for every from-string (reference _rapidfuzz.py:61-113) """
+        """ Best choice of the to-list for every from-string (reference _rapidfuzz.py:61-113).
+
+        `re_train=False` (what PolyFuzz.transform passes, polyfuzz.py:234-240) matches against the to-list of the previous
+        call, whose device copy, token forms and plan are still resident: no upload, no preparation. """
         ctx = _lib.Context.default()
         self_match = to_list is None
-        names = from_list if self_match else to_list
+        reuse = kwargs.get("re_train", True) is False and not self_match and self._to_names is not None
+        names = from_list if self_match else (self._to_names if reuse else to_list)
         n = len(from_list)
         skip = None
         if self_match:
@@ -119,8 +132,19 @@ class RapidFuzz(BaseMatcher):
         if n == 0 or len(names) - (1 if self_match else 0) <= 0:
             idx, score = np.full(n, -1, np.int32), np.zeros(n)             # extractOne over no choices: None
         else:
-            idx, score = best_choice(ctx, self._scorer_name, from_list, names, skip, self_match)
+            if not self_match and not reuse:
+                self._to_dev, self._to_names = upload_for(ctx, self._scorer_name, names), names
+            idx, score = best_choice(ctx, self._scorer_name, from_list, names, skip, self_match,
+                                     to_dev=None if self_match else self._to_dev)
         hit = (idx >= 0) & (score >= self.score_cutoff)                       # extractOne: best score >= score_cutoff
         to_col = gather_column(names, idx, hit)
         sim = np.where(hit, score / 100, 0.0)
         return pd.DataFrame({"From": object_column(from_list), "To": to_col, "Similarity": sim}, copy=False)
+
+    # a matcher is pickled by joblib (reference polyfuzz.py:429-457): device handles stay behind
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in ("_to_dev", "_to_names")}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._to_dev = self._to_names = None

@@ -228,10 +228,12 @@ class BestChoiceJob:
     (first best index, float64 score) blocks are all-gathered, padded to the largest shard.  The float64 scores travel
     as two 32-bit words in the value lanes of a two-column result buffer (the gather moves bytes), so every rank ends with
     the exact scores of all from-strings -- which is also all the reference's global min-max normalisation needs.
-    Both lists (for K4 also the to-side plan) are uploaded once, at construction: a step is device work only."""
+    Both lists are uploaded once, at construction; the to-side plan (K4) / the token forms and the plan (K7) are built on
+    the device on the first step and stay cached on the handles: a step is device work only, its result stays on the
+    device (`result_host` downloads it)."""
 
     def __init__(self, ctx, from_shard, to_list, scorer="ratio", comm=None, skip=None, rows_per_rank=None):
-        from .models._rapidfuzz import _DEVICE_SCORERS, _K4_SCORERS
+        from .models._rapidfuzz import _DEVICE_SCORERS, _K4_SCORERS, upload_for
         if scorer not in _DEVICE_SCORERS:
             raise NotImplementedError(f"scorer {scorer!r} has no kernel")
         self.ctx, self.comm, self.scorer = ctx, comm, scorer
@@ -241,42 +243,66 @@ class BestChoiceJob:
         if self.rows_per_rank < self.n_from:
             raise ValueError("rows_per_rank is smaller than this rank's shard")
         self.k4 = scorer in _K4_SCORERS
-        self.f_dev = self.t_dev = None
-        if self.k4 and scorer != "QRatio":
-            tr = (lambda s: " ".join(sorted(s.split()))) if scorer == "token_sort_ratio" else (lambda s: s)
-            self.f_dev = _lib.DeviceStrings.upload(ctx, [tr(s) for s in self.from_shard])
-            self.t_dev = _lib.DeviceStrings.upload(ctx, [tr(s) for s in to_list])
+        self.f_dev = upload_for(ctx, scorer, self.from_shard)
+        self.t_dev = upload_for(ctx, scorer, to_list)
+        self.local = _lib.DeviceTopN.alloc(ctx, max(self.rows_per_rank, 1), 2)
+        self.local.clear()                     # padding rows stay "no choice" (index -1, score 0.0)
+        self.gathered = None
+        if comm is not None and comm.world > 1:
+            self.gathered = _lib.DeviceTopN.alloc(ctx, max(self.rows_per_rank, 1) * comm.world, 2)
 
     def plan_info(self):
-        """K4's cached to-side plan (alphabet, groups, character steps); {} for the K7 scorers"""
-        return _lib.indel_plan_info(self.ctx, self.t_dev) if self.t_dev is not None else {}
+        """the cached to-side plan: K4's (alphabet, groups, character steps) or K7's (alphabet, groups, tokens)"""
+        return _lib.indel_plan_info(self.ctx, self.t_dev) if self.k4 else _lib.fuzz_plan_info(self.ctx, self.t_dev)
 
-    def step(self):
-        from .models._rapidfuzz import best_choice
-        if self.f_dev is not None:
-            idx, score = _lib.indel_argmax(self.ctx, self.f_dev, self.t_dev, self.skip)
-        else:
-            idx, score = best_choice(self.ctx, self.scorer, self.from_shard, self.to_list, self.skip, False)
-        if self.comm is None or self.comm.world == 1:
-            return idx, score
-        pad = self.rows_per_rank
-        pi = np.full((pad, 2), -1, np.int32)
-        pv = np.zeros((pad, 2), np.float32)
-        pi[:self.n_from, 0] = idx
-        pv[:self.n_from] = np.ascontiguousarray(score, np.float64).view(np.float32).reshape(-1, 2)
-        local = _lib.DeviceTopN.from_host(self.ctx, pi, pv)
-        g_idx, g_val = self.comm.allgather_topn(local).download()
-        return g_idx[:, 0].copy(), np.ascontiguousarray(g_val).view(np.float64).reshape(-1)
+    def step(self, counters=False):
+        work = None
+        if self.n_from and len(self.to_list):
+            if self.k4:
+                _lib.indel_argmax_dev(self.ctx, self.f_dev, self.t_dev, self.local, self.skip)
+            else:
+                work = _lib.fuzz_extract_one_dev(self.ctx, self.f_dev, self.t_dev, self.scorer, self.local, self.skip, counters=counters)
+        if self.gathered is not None:
+            self.comm.allgather_topn(self.local, self.gathered)
+        self.last_work = work
+        return self.gathered if self.gathered is not None else self.local
 
     def result_host(self, result):
         """(index int32[n], score float64[n]) of what step() returned (all ranks' rows, padded, when sharded)"""
-        return result
+        idx, score = _lib.best_from_topn(*result.download())
+        if self.gathered is None:
+            idx, score = idx[:self.n_from], score[:self.n_from]
+        if self.scorer == "QRatio":
+            # QRatio = ratio except that an EMPTY from-string scores 0 against every choice (also the empty one, which
+            # ratio scores 100): its first best is its first choice
+            rows = range(len(idx)) if self.gathered is None else range(self.comm.rank * self.rows_per_rank,
+                                                                       self.comm.rank * self.rows_per_rank + self.n_from)
+            for r, s in zip(rows, self.from_shard):
+                if len(s) == 0:
+                    i = r if self.gathered is None else r - self.comm.rank * self.rows_per_rank
+                    first = next((j for j in range(len(self.to_list)) if not (self.skip is not None and j == self.skip[i])), -1)
+                    idx[r], score[r] = first, 0.0
+        return idx, score
 
     def roofline(self, step_s, peak_tops):
-        return {"kernel": "k7_fuzz" if not self.k4 else "k4_indel", "bound": "int32 VALU issue (+ LDS look-ups)", "achieved": None,
-                "peak": peak_tops, "unit": "Tera int-op/s", "frac": None, "traffic": None,
-                "pairs_per_s_kernel": self.n_from * float(len(self.to_list)) / step_s if step_s > 0 else None,
-                "what": "no work count for this scorer yet"}
+        """K7's work accounting (one more step with the device counters on): every pair costs its upper bound -- 4 x 128-bit
+        loads, 8 v_sad_u8, the float32 bound: priced at 40 integer operations -- and a scored pair its LCS passes /
+        window sweeps -- priced at 10 int32 operations per 64-bit word-step (the recurrence's 5 on both halves), from
+        the kernel's own estimate by the pair's lengths."""
+        if self.k4:
+            return None
+        self.step(counters=True)
+        w = self.last_work or {"pairs_bounded": 0, "pairs_scored": 0, "word_steps_scored": 0}
+        pairs = self.n_from * float(len(self.to_list))
+        ops = 40.0 * w["pairs_bounded"] + 10.0 * w["word_steps_scored"]
+        return {"kernel": "k7_fuzz", "bound": "int32 VALU issue (+ LDS look-ups)", "achieved": ops / step_s / 1e12 if step_s > 0 else None,
+                "peak": peak_tops, "unit": "Tera int-op/s", "frac": ops / step_s / 1e12 / peak_tops if step_s > 0 else None, "traffic": None,
+                "pairs_per_s_kernel": pairs / step_s if step_s > 0 else None, "pairs_bounded": w["pairs_bounded"],
+                "pairs_scored": w["pairs_scored"], "scored_fraction": w["pairs_scored"] / max(pairs, 1.0),
+                "word_steps_scored_estimate": w["word_steps_scored"],
+                "what": "40 int-ops per bounded pair (two sweeps) + 10 per 64-bit word-step of the scored pairs, over the summed "
+                        "k7 kernel time, against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; extractOne keeps only the maximum, so the "
+                        "kernel scores only the pairs whose upper bound reaches the best score found so far"}
 
     @staticmethod
     def unpad(idx, score, sizes, rows_per_rank):

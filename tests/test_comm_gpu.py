@@ -130,10 +130,11 @@ def test_world2_best_choice_job_edit_distance_and_wratio(oracle_mod):
         def rank_fn(r):
             b, e = bounds[r]
             job = pipeline.BestChoiceJob(ctxs[r], fl[b:e], tl, scorer=scorer, comm=comms[r], rows_per_rank=rpr)
-            return pipeline.BestChoiceJob.unpad(*job.step(), sizes, rpr)
+            return pipeline.BestChoiceJob.unpad(*job.result_host(job.step()), sizes, rpr)
         with cf.ThreadPoolExecutor(2) as ex:
             outs = [x.result(timeout=120) for x in [ex.submit(rank_fn, r) for r in range(2)]]
-        single = pipeline.BestChoiceJob(ctxs[0], fl, tl, scorer=scorer).step()
+        job1 = pipeline.BestChoiceJob(ctxs[0], fl, tl, scorer=scorer)
+        single = job1.result_host(job1.step())
         if scorer == "ratio":
             e_idx, e_score = oracle_mod.indel_argmax(fl, tl)
         else:

@@ -84,14 +84,80 @@ def test_two_word_strings_self_match_and_parts(ctx, monkeypatch):
     assert idx[0] == e_idx[0] and score[0] == e_score[0]
 
 
-def test_limits_are_loud(ctx):
+def test_strings_beyond_the_fast_kernel(ctx, oracle_mod, monkeypatch):
+    """No loud limit any more: a 400-character from-string, one of 40 distinct tokens, a to-string of 35 distinct tokens,
+    and -- PFZ_K7_FORCE_GENERAL -- ordinary strings through the general kernel: every scorer, bit for bit."""
     from polyfuzz_amd import _lib
-    with pytest.raises(_lib.PfzUnsupported):
-        _lib.fuzz_extract_one(ctx, ["x" * 257], ["x"], "WRatio")
-    with pytest.raises(_lib.PfzUnsupported):
-        _lib.fuzz_extract_one(ctx, [" ".join(f"t{i}" for i in range(33))], ["x"], "WRatio")
+    fl, tl = _lists(11, 12, 60, long_words=True)
+    rng = np.random.default_rng(5)
+    words = ["alpha", "beta", "gamma", "delta", "of", "the", "inc", "llc", "new", "york", "mets", "braves"]
+    long_from = " ".join(rng.choice(words, size=70))                       # ~ 400 characters, few distinct tokens
+    many_tok = " ".join(f"t{i}" for i in range(40))                        # 40 distinct tokens
+    fl += [long_from[:400], many_tok, "new york mets", ""]
+    tl += [" ".join(f"t{i}" for i in range(3, 38)), long_from[5:300], "york new mets", "t1 t2 t3", ""]
+    assert max(map(len, fl)) > 256 and max(len(set(s.split())) for s in tl) > 32
+    for mode in MODES:
+        idx, score = _lib.fuzz_extract_one(ctx, fl, tl, mode)
+        e_idx, e_score = oracle_mod.fuzz_extract_one(fl, tl, mode)
+        np.testing.assert_array_equal(score, e_score, err_msg=mode)
+        np.testing.assert_array_equal(idx, e_idx, err_msg=mode)
+    monkeypatch.setenv("PFZ_K7_FORCE_GENERAL", "1")
+    fl2, tl2 = _lists(12, 25, 40)
+    first = {}
+    for j, s in enumerate(fl2):
+        first.setdefault(s, j)
+    skip = np.array([first[s] for s in fl2], np.int32)
+    for mode in MODES:
+        idx, score = _lib.fuzz_extract_one(ctx, fl2, tl2, mode)
+        e_idx, e_score = oracle_mod.fuzz_extract_one(fl2, tl2, mode)
+        np.testing.assert_array_equal(score, e_score, err_msg=mode)
+        np.testing.assert_array_equal(idx, e_idx, err_msg=mode)
+    idx, score = _lib.fuzz_extract_one(ctx, fl2, fl2, "WRatio", skip)
+    e_idx, e_score = oracle_mod.fuzz_extract_one(fl2, fl2, "WRatio", skip)
+    np.testing.assert_array_equal(score, e_score)
+    np.testing.assert_array_equal(idx, e_idx)
+    monkeypatch.delenv("PFZ_K7_FORCE_GENERAL")
     idx, score = _lib.fuzz_extract_one(ctx, ["abc"], [], "WRatio")
     assert idx[0] == -1 and score[0] == 0.0
+
+
+def test_prepared_lists_equal_the_python_statement(ctx):
+    """the device-built forms / plan drive the same scores as tests/k7_prep.py's plain-Python statement drives through the
+    CPU build of k7_core.h (tests/test_k7_core_cpu.py): here the end-to-end check is against the oracle on lists with
+    tabs, repeated tokens, non-Latin-1 characters (UTF-32 code units), a to-list without any space"""
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd import _lib
+    fl = ["a\tb  a", "été 　x", "naïve café", "x y z", "  lead and trail  ", "ß", "日本 語", "日本語 日本", "a b a b c"]
+    tl = ["b a", "x　été", "cafe naive", "z y x", "trail lead and", "日本", "語 日本", "c b a", "ss"]
+    for mode in MODES:
+        idx, score = _lib.fuzz_extract_one(ctx, fl, tl, mode)
+        e_idx, e_score = f.extract_one_all(fl, tl, f.SCORERS[mode])
+        np.testing.assert_array_equal(score, np.array(e_score), err_msg=mode)
+        np.testing.assert_array_equal(idx, np.array(e_idx, np.int32), err_msg=mode)
+    nospace = ["abc", "abd", "xyz"]                      # the joining space is a symbol even when the to-list has none
+    idx, score = _lib.fuzz_extract_one(ctx, ["abc xyz", "abd"], nospace, "WRatio")
+    e_idx, e_score = f.extract_one_all(["abc xyz", "abd"], nospace, f.WRatio)
+    assert idx.tolist() == e_idx and score.tolist() == e_score
+
+
+def test_full_size_rows_vs_the_c_oracle(ctx, oracle_mod):
+    """random from-rows of the real 20 000 x 20 000 IMDB title lists (config 3's lists, the RapidFuzz default scorer and two
+    others), the whole to-list as choices: first best choice and float64 score, bit for bit"""
+    import concurrent.futures as cf
+    from polyfuzz_amd import _lib, datasets
+    fl, tl = datasets.c3_lists()
+    f_dev, t_dev = _lib.DeviceStrings.upload(ctx, fl), _lib.DeviceStrings.upload(ctx, tl)
+    rows = np.sort(np.random.default_rng(3).choice(len(fl), 96, replace=False))
+    sample = [fl[i] for i in rows]
+    for mode in ("WRatio", "partial_ratio", "token_set_ratio"):
+        idx, score = _lib.fuzz_extract_one(ctx, f_dev, t_dev, mode)
+        chunks = np.array_split(np.arange(len(sample)), 32)
+        with cf.ThreadPoolExecutor(32) as ex:
+            parts = list(ex.map(lambda c: oracle_mod.fuzz_extract_one([sample[i] for i in c], tl, mode), chunks))
+        e_idx = np.concatenate([p[0] for p in parts])
+        e_score = np.concatenate([p[1] for p in parts])
+        np.testing.assert_array_equal(score[rows], e_score, err_msg=mode)
+        np.testing.assert_array_equal(idx[rows], e_idx, err_msg=mode)
 
 
 def test_four_word_strings_and_editdistance_scorers(ctx):
