@@ -36,6 +36,9 @@
 #ifndef PFZ_HD
 #define PFZ_HD __host__ __device__ inline
 #endif
+#ifndef PFZ_LDS_U16
+#define PFZ_LDS_U16 uint16_t      // the kernel defines it as an LDS-address-space type: LDS and global loads must not be merged into flat ones
+#endif
 
 namespace pfz {
 
@@ -62,7 +65,35 @@ struct FuzzTo {
     const int32_t *tok_id, *tok_len;   // [j * stride]
     int stride;
     int lb[3], tb;
+    // optional scratch column [pos * stage_stride] of kFuzzStage symbols (LDS in the kernel, NULL on the host): a window sweep
+    // re-reads the to-string |from| times, and a global load per recurrence step is a dependent ~500-cycle round trip
+    PFZ_LDS_U16 *stage;
+    int stage_stride;            // 0: there is no column
+    int staged;                  // the form whose symbols the column holds (-1: none)
 };
+
+constexpr int kFuzzStage = 64;
+
+// copy form v into the scratch column (eight loads in flight at a time); longer forms stay in global memory
+PFZ_HD void fz_stage(FuzzTo &T, int v)
+{
+    if (T.stage_stride == 0 || T.staged == v || T.lb[v] > kFuzzStage) return;
+    const int lb = T.lb[v];
+    for (int p0 = 0; p0 < lb; p0 += 8) {
+        uint16_t c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = p0 + q < lb ? T.sym[v][(int64_t)(p0 + q) * T.stride] : (uint16_t)0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (p0 + q < lb) T.stage[(p0 + q) * T.stage_stride] = c[q];
+    }
+    T.staged = v;
+}
+
+PFZ_HD int fz_sym(const FuzzTo &T, int v, int pos)
+{
+    return T.staged == v ? (int)T.stage[pos * T.stage_stride] : (int)T.sym[v][(int64_t)pos * T.stride];
+}
 
 PFZ_HD double fz_ratio_of(int lcs, int lensum)
 {
@@ -146,23 +177,32 @@ PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint
 #pragma unroll
     for (int w = 0; w < W; ++w) V[w] = ~0ull;
     const int lb = T.lb[v];
-    for (int pos = 0; pos < lb; ++pos) {
-        int sy = T.sym[v][(int64_t)pos * T.stride];
-        if (tagged) {
-            const int tag = T.tag[(int64_t)pos * T.stride], j = tag & 31;
-            const bool keep = ((rb >> j) & 1u) && !((tag & 0x80) && j == last_rb);
-            sy = keep ? sy : 0;
+    // eight positions at a time: their symbols (and tags) are requested together, then consumed -- one memory round trip
+    // per eight recurrence steps instead of one per step
+    for (int p0 = 0; p0 < lb; p0 += 8) {
+        int sy[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sy[q] = p0 + q < lb ? fz_sym(T, v, p0 + q) : 0;
+            if (tagged && p0 + q < lb) {
+                const int tag = T.tag[(int64_t)(p0 + q) * T.stride], j = tag & 31;
+                const bool keep = ((rb >> j) & 1u) && !((tag & 0x80) && j == last_rb);
+                sy[q] = keep ? sy[q] : 0;
+            }
         }
-        fz_step<W>(V, F.pm + (sy * 3 + v) * W, amask);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (p0 + q < lb) fz_step<W>(V, F.pm + (sy[q] * 3 + v) * W, amask);
     }
 }
 
 // rapidfuzz.fuzz.partial_ratio of the two v-forms: every window, compared as exact rationals lcs / (|shorter| + |window|)
 template <int W>
-PFZ_HD double fz_partial(const FuzzFrom<W> &F, const FuzzTo &T, int v)
+PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v)
 {
     const int la = F.la[v], lb = T.lb[v];
     if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
+    fz_stage(T, v);
     int bl = 0, bs = 1;
     auto cand = [&](int lcs, int sum) {
         if ((int64_t)lcs * bs > (int64_t)bl * sum) {
@@ -173,8 +213,6 @@ PFZ_HD double fz_partial(const FuzzFrom<W> &F, const FuzzTo &T, int v)
     uint64_t all[W], V[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) all[w] = ~0ull;
-    const uint16_t *sym = T.sym[v];
-    const int64_t st = T.stride;
     if (lb >= la) {
         // the from-form is the shorter (or equal): windows of the to-form starting at s (its prefixes shorter than the
         // from-form fall out of the first window step by step)
@@ -183,7 +221,7 @@ PFZ_HD double fz_partial(const FuzzFrom<W> &F, const FuzzTo &T, int v)
 #pragma unroll
             for (int w = 0; w < W; ++w) V[w] = ~0ull;
             for (int k = 0; k < wlen; ++k) {
-                fz_step<W>(V, F.pm + ((int)sym[(int64_t)(s + k) * st] * 3 + v) * W, all);
+                fz_step<W>(V, F.pm + (fz_sym(T, v, s + k) * 3 + v) * W, all);
                 if (s == 0 && k + 1 < la) cand(fz_zeros_below<W>(V, la), la + k + 1);
             }
             cand(fz_zeros_below<W>(V, la), la + wlen);
@@ -196,7 +234,7 @@ PFZ_HD double fz_partial(const FuzzFrom<W> &F, const FuzzTo &T, int v)
             fz_range_mask<W>(m, i, la);
 #pragma unroll
             for (int w = 0; w < W; ++w) V[w] = ~0ull;
-            for (int pos = 0; pos < lb; ++pos) fz_step<W>(V, F.pm + ((int)sym[(int64_t)pos * st] * 3 + v) * W, m);
+            for (int pos = 0; pos < lb; ++pos) fz_step<W>(V, F.pm + (fz_sym(T, v, pos) * 3 + v) * W, m);
             const int wlen = fz_min(lb, la - i);
             cand(fz_zeros_below<W>(V, i + wlen) - fz_zeros_below<W>(V, i), lb + wlen);
             if (i == 0)
@@ -256,83 +294,110 @@ PFZ_HD double fz_token_set(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t ca, u
     return fz_fmax(result, fz_fmax(r_ab, r_ba));
 }
 
-template <int W>
-PFZ_HD double fz_token_sort(const FuzzFrom<W> &F, const FuzzTo &T)
-{
-    uint64_t all[W], V[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) all[w] = ~0ull;
-    fz_lcs_pass<W>(F, T, 1, all, false, 0u, 0, V);
-    return fz_ratio_of(fz_zeros_below<W>(V, F.la[1]), F.la[1] + T.lb[1]);
-}
-
-// partial_ratio of the v-forms, left out (0: a lower bound) when it cannot reach `cur`: a window has at most the LCS of
-// the whole forms -- one cheap pass -- and at least that many characters
-template <int W>
-PFZ_HD double fz_partial_pruned(const FuzzFrom<W> &F, const FuzzTo &T, int v, double cur)
-{
-    const int la = F.la[v], lb = T.lb[v];
-    if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
-    uint64_t all[W], V[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) all[w] = ~0ull;
-    fz_lcs_pass<W>(F, T, v, all, false, 0u, 0, V);
-    const int l = fz_zeros_below<W>(V, la), lm = fz_min(la, lb);
-    if (fz_ratio_of(l, lm + l) < cur) return 0.0;
-    return fz_partial<W>(F, T, v);
-}
-
 // The score of the pair under `mode`, exact whenever it is >= cur (below cur it may come out lower than the true score,
 // never higher: components that cannot reach cur are left out).
+// Every mode is a combination of three kinds of work -- plain LCS passes of a form (bit v of need_l), the masked
+// token-set pass, window sweeps of a form (bit v of want_p, decided after the passes: a window has at most the LCS of the
+// whole forms and at least that many characters, so ratio_of(lcs, |shorter| + lcs) bounds partial_ratio) -- laid out so
+// that each kind has ONE call site: the kernel inlines one copy of each, whatever the mode.
 template <int W>
-PFZ_HD double fz_score(const FuzzFrom<W> &F, const FuzzTo &T, int mode, double cur)
+PFZ_HD double fz_score(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
 {
     const int la0 = F.la[0], lb0 = T.lb[0], ta = F.ta, tb = T.tb;
+    const bool toks = ta != 0 && tb != 0;
     uint32_t ca = 0u, cb = 0u;
     if (mode != kPartialRatio && mode != kPartialTokenSortRatio) fz_intersect<W>(F, T, ca, cb);
+    bool near = false;
+    double scale = 1.0;
+    int need_l = 0, sweep_of = 0;           // sweep_of: forms a sweep may follow the pass of (staged before the pass)
+    bool need_ts = false;
     if (mode == kWRatio) {
         if (la0 == 0 || lb0 == 0) return 0.0;
-        uint64_t all[W], V[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) all[w] = ~0ull;
-        fz_lcs_pass<W>(F, T, 0, all, false, 0u, 0, V);
-        const int lcs0 = fz_zeros_below<W>(V, la0);
-        double end_ratio = fz_ratio_of(lcs0, la0 + lb0);
         const int lmax = fz_max(la0, lb0), lmin = fz_min(la0, lb0);
-        if (2 * lmax < 3 * lmin) {                                // len_ratio < 1.5
-            if (100.0 * 0.95 < cur) return end_ratio;             // the token scorers are <= 100
-            const double t1 = fz_token_sort<W>(F, T), t2 = fz_token_set<W>(F, T, ca, cb);     // (no tokens on either side: ratio("", "") = 100, as rapidfuzz)
-            return fz_fmax(end_ratio, fz_fmax(t1, t2) * 0.95);
-        }
-        const double scale = lmax < 8 * lmin ? 0.9 : 0.6;       // len_ratio < 8
-        // a window of either string has LCS <= the LCS of the whole strings and at least that many characters
-        if (!(fz_ratio_of(lcs0, lmin + lcs0) * scale < cur)) end_ratio = fz_fmax(end_ratio, fz_partial<W>(F, T, 0) * scale);
-        double pt = 0.0;
-        if (ta != 0 && tb != 0) {
-            if (ca) pt = 100.0;
-            else if (!(100.0 * 0.95 * scale < cur)) {
-                // the distinct-token form is a subsequence of the sorted-token form: one pass bounds both
-                fz_lcs_pass<W>(F, T, 1, all, false, 0u, 0, V);
-                const int lcs1 = fz_zeros_below<W>(V, F.la[1]);
-                const int m1 = fz_min(F.la[1], T.lb[1]), m2 = fz_min(F.la[2], T.lb[2]);
-                const int c1 = fz_min(lcs1, m1), c2 = fz_min(lcs1, m2);
-                double p1 = 0.0, p2 = 0.0;
-                if (!(fz_ratio_of(c1, m1 + c1) * 0.95 * scale < cur)) p1 = fz_partial<W>(F, T, 1);
-                if (!(fz_ratio_of(c2, m2 + c2) * 0.95 * scale < cur)) p2 = fz_partial<W>(F, T, 2);
-                pt = fz_fmax(p1, p2);
+        near = 2 * lmax < 3 * lmin;                               // len_ratio < 1.5
+        scale = lmax < 8 * lmin ? 0.9 : 0.6;                     // len_ratio < 8
+        need_l = 1;
+        if (near) {
+            if (!(100.0 * 0.95 < cur)) {                          // the token scorers are <= 100
+                need_l |= 2;
+                need_ts = true;
             }
         }
-        return fz_fmax(end_ratio, pt * 0.95 * scale);
+        else {
+            sweep_of = 1;
+            // the distinct-token form is a subsequence of the sorted-token form: one pass (form 1) bounds both sweeps
+            if (toks && !ca && !(100.0 * 0.95 * scale < cur)) need_l |= 2, sweep_of |= 2;
+        }
     }
-    if (mode == kPartialRatio) return fz_partial_pruned<W>(F, T, 0, cur);
-    if (mode == kTokenSetRatio) return fz_token_set<W>(F, T, ca, cb);
-    if (mode == kTokenRatio) return fz_fmax(fz_token_sort<W>(F, T), fz_token_set<W>(F, T, ca, cb));
-    if (mode == kPartialTokenSortRatio) return fz_partial_pruned<W>(F, T, 1, cur);
-    if (mode == kPartialTokenSetRatio) return (ta == 0 || tb == 0) ? 0.0 : (ca ? 100.0 : fz_partial_pruned<W>(F, T, 2, cur));
-    // partial_token_ratio
-    if (ta == 0 || tb == 0) return 0.0;
-    if (ca) return 100.0;
-    return fz_fmax(fz_partial_pruned<W>(F, T, 1, cur), fz_partial_pruned<W>(F, T, 2, cur));
+    else if (mode == kPartialRatio) need_l = sweep_of = 1;
+    else if (mode == kTokenSetRatio) need_ts = true;
+    else if (mode == kTokenRatio) need_l = 2, need_ts = true;
+    else if (mode == kPartialTokenSortRatio) need_l = sweep_of = 2;
+    else if (mode == kPartialTokenSetRatio) need_l = sweep_of = (toks && !ca) ? 4 : 0;
+    else need_l = sweep_of = (toks && !ca) ? 6 : 0;
+
+    int lcs[3] = {0, 0, 0};
+    uint64_t all[W], V[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) all[w] = ~0ull;
+    for (int v = 0; v < 3; ++v)
+        if ((need_l >> v) & 1) {
+            if ((sweep_of >> v) & 1) fz_stage(T, v);
+            fz_lcs_pass<W>(F, T, v, all, false, 0u, 0, V);
+            lcs[v] = fz_zeros_below<W>(V, F.la[v]);
+        }
+    const double tset = need_ts ? fz_token_set<W>(F, T, ca, cb) : 0.0;
+
+    // window sweeps: p[v] = partial_ratio of the v-forms, or 0 (a lower bound) where it cannot reach cur / factor
+    double p[3] = {0.0, 0.0, 0.0};
+    int want_p = 0;
+    auto consider = [&](int v, int l, double factor) {           // l: an upper bound of the LCS of any two windows of the v-forms
+        const int la = F.la[v], lb = T.lb[v];
+        if (la == 0 || lb == 0) p[v] = la == 0 && lb == 0 ? 100.0 : 0.0;
+        else {
+            const int lm = fz_min(la, lb), c = fz_min(l, lm);
+            if (!(fz_ratio_of(c, lm + c) * factor < cur)) want_p |= 1 << v;
+        }
+    };
+    if (mode == kWRatio) {
+        if (!near) {
+            consider(0, lcs[0], scale);
+            if (need_l & 2) {
+                consider(1, lcs[1], 0.95 * scale);
+                consider(2, lcs[1], 0.95 * scale);
+            }
+        }
+    }
+    else if (mode == kPartialRatio) consider(0, lcs[0], 1.0);
+    else if (mode == kPartialTokenSortRatio) consider(1, lcs[1], 1.0);
+    else if (mode == kPartialTokenSetRatio) {
+        if (need_l) consider(2, lcs[2], 1.0);
+    }
+    else if (mode == kPartialTokenRatio && need_l) {
+        consider(1, lcs[1], 1.0);
+        consider(2, lcs[2], 1.0);
+    }
+    for (int v = 0; v < 3; ++v)
+        if ((want_p >> v) & 1) p[v] = fz_partial<W>(F, T, v);
+
+    switch (mode) {
+    case kWRatio: {
+        const double end_ratio = fz_ratio_of(lcs[0], la0 + lb0);
+        if (near) {
+            if (!need_ts) return end_ratio;
+            // (no tokens on either side: ratio("", "") = 100, as rapidfuzz)
+            return fz_fmax(end_ratio, fz_fmax(fz_ratio_of(lcs[1], F.la[1] + T.lb[1]), tset) * 0.95);
+        }
+        const double pt = !toks ? 0.0 : (ca ? 100.0 : fz_fmax(p[1], p[2]));
+        return fz_fmax(fz_fmax(end_ratio, p[0] * scale), pt * 0.95 * scale);
+    }
+    case kPartialRatio: return p[0];
+    case kTokenSetRatio: return tset;
+    case kTokenRatio: return fz_fmax(fz_ratio_of(lcs[1], F.la[1] + T.lb[1]), tset);
+    case kPartialTokenSortRatio: return p[1];
+    case kPartialTokenSetRatio: return !toks ? 0.0 : (ca ? 100.0 : p[2]);
+    default: return !toks ? 0.0 : (ca ? 100.0 : fz_fmax(p[1], p[2]));
+    }
 }
 
 // ---- upper bound -------------------------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@
 
 #undef PFZ_HD
 #define PFZ_HD __device__ inline
+#define PFZ_LDS_U16 __attribute__((address_space(3))) uint16_t
 #include "k7_core.h"
 #include "k7_args.h"
 
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
     __shared__ int red_i[4];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
     __shared__ int s_queue[4][128];
+    __shared__ uint16_t s_stage[4][kFuzzStage][64];       // per wave: [position][lane] symbols of the form a lane sweeps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
     const bool use_tokens = mode_uses_tokens(mode);
@@ -736,7 +738,9 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         sa.sig = (uint64_t)s_sig[0] | (uint64_t)s_sig[1] << 32;
         const int skip = A.skip_idx ? A.skip_idx[row] : -1;
 
-        auto cur_now = [&]() { return __longlong_as_double((long long)*(volatile unsigned long long *)&s_best); };
+        auto cur_now = [&]() {
+            return __longlong_as_double((long long)__hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        };
         auto to_of = [&](int slot, const int4 &m) {
             const int g = slot >> 6, l = slot & 63;
             FuzzTo T;
@@ -752,6 +756,9 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             T.lb[1] = m.y;
             T.lb[2] = m.z;
             T.tb = m.w;
+            T.stage = (PFZ_LDS_U16 *)&s_stage[wave][0][lane];
+            T.stage_stride = 64;
+            T.staged = -1;
             return T;
         };
         // float32 upper bound of the pair (from-string, slot); valid = a real candidate of this kernel
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             if (active) {
                 const int4 m = A.b_meta[slot];
                 orig = A.b_meta2[slot].w;
-                const FuzzTo T = to_of(slot, m);
+                FuzzTo T = to_of(slot, m);
                 sc = fz_score<W>(F, T, mode, cur_now());
                 best.take(sc, orig);
                 n_scored += 1;
@@ -809,49 +816,52 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             if (lane == 0) atomicMax(&s_best, (unsigned long long)__double_as_longlong(wb));
         };
 
-        // ---- sweep 1: every lane's best-bounded to-string is scored: a real score to prune with
+        // ---- sweep 1 (phase 0): every lane's best-bounded to-string is scored: a real score to prune with;
+        //      sweep 2 (phase 1): the pairs whose bound reaches the best score so far, 64 at a time.
+        // One loop body serves both, and one more trip past the last group flushes the queue: the scoring code -- by far
+        // the largest part of the kernel -- is inlined exactly once.
         float seed_ub = -1.0f;
         int seed_slot = -1;
-        for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
-            const int slot = g * 64 + lane;
-            int4 m;
-            int orig;
-            bool valid;
-            const float ub = bound_of(slot, 0.0f, m, orig, valid);
-            n_bounded += 1;
-            if (valid && ub > seed_ub) {
-                seed_ub = ub;
-                seed_slot = slot;
-            }
-        }
-        score_slot(seed_slot, seed_slot >= 0);
-        __syncthreads();
-
-        // ---- sweep 2: the pairs whose bound reaches the best score so far, 64 at a time
         int *queue = s_queue[wave];
         int q_head = 0, q_tail = 0;             // wave-uniform; entries [q_head, q_tail) of a ring of 128
-        for (int g = wave + 4 * part; g < A.n_groups; g += 4 * parts) {
-            const int slot = g * 64 + lane;
-            const float cur32 = (float)cur_now();
-            int4 m;
-            int orig;
-            bool valid;
-            const float ub = bound_of(slot, cur32, m, orig, valid);
-            n_bounded += 1;
-            const bool want = valid && slot != seed_slot && !(ub + kBoundSlack < cur32);
-            const unsigned long long bal = __ballot(want);
-            if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot;
-            q_tail += __popcll(bal);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            while (q_tail - q_head >= 64) {
-                score_slot(queue[(q_head + lane) & 127], true);
-                q_head += 64;
+        for (int phase = 0; phase < 2; ++phase) {
+            for (int g = wave + 4 * part;; g += 4 * parts) {
+                const bool last = g >= A.n_groups;
+                bool want = false;
+                int slot = -1;
+                if (!last) {
+                    slot = g * 64 + lane;
+                    const float cur32 = phase ? (float)cur_now() : 0.0f;
+                    int4 m;
+                    int orig;
+                    bool valid;
+                    const float ub = bound_of(slot, cur32, m, orig, valid);
+                    n_bounded += 1;
+                    if (phase == 0) {
+                        if (valid && ub > seed_ub) {
+                            seed_ub = ub;
+                            seed_slot = slot;
+                        }
+                    }
+                    else want = valid && slot != seed_slot && !(ub + kBoundSlack < cur32);
+                }
+                else if (phase == 0) {
+                    slot = seed_slot;
+                    want = seed_slot >= 0;
+                }
+                const unsigned long long bal = __ballot(want);
+                if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot;
+                q_tail += __popcll(bal);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                while (q_tail - q_head >= 64 || (last && q_tail > q_head)) {
+                    const bool active = lane < q_tail - q_head;
+                    score_slot(active ? queue[(q_head + lane) & 127] : -1, active);
+                    q_head += min(64, q_tail - q_head);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                if (last) break;
             }
-        }
-        if (q_tail > q_head) {
-            const bool active = lane < q_tail - q_head;
-            score_slot(active ? queue[(q_head + lane) & 127] : -1, active);
+            if (phase == 0) __syncthreads();        // every wave's seeds are scored: `cur` is what the workgroup knows
         }
 
         // first best choice: (score desc, original index asc)

@@ -355,6 +355,49 @@ static PyObject *fill_objects(PyObject *self, PyObject *args)
     Py_RETURN_NONE;
 }
 
+/* gather_objects(names, idx_addr, n, obj_addr, keep_addr): the To column of the edit-distance matchers -- slot i of a fresh
+ * np.empty(n, object) array gets a new reference to names[idx[i]] (int32 idx), or None when idx[i] is not a row of
+ * `names` or keep[i] (uint8 mask, address 0 = all kept) is zero.  Replaces a numpy fancy-index over an object pool of
+ * the whole to-list (0.7 ms for 20 000 x 20 000 titles, most of what was left of EditDistance.match on the host). */
+static PyObject *gather_objects(PyObject *self, PyObject *args)
+{
+    (void)self;
+    PyObject *src;
+    unsigned long long idx_addr, obj_addr, keep_addr;
+    Py_ssize_t n;
+    if (!PyArg_ParseTuple(args, "OKnKK", &src, &idx_addr, &n, &obj_addr, &keep_addr)) return NULL;
+    PyObject *seq = PySequence_Fast(src, "gather_objects() expects a sequence");
+    if (!seq) return NULL;
+    const Py_ssize_t n_names = PySequence_Fast_GET_SIZE(seq);
+    PyObject **items = PySequence_Fast_ITEMS(seq);
+    PyObject **dst = (PyObject **)(uintptr_t)obj_addr;
+    const int32_t *idx = (const int32_t *)(uintptr_t)idx_addr;
+    const uint8_t *keep = (const uint8_t *)(uintptr_t)keep_addr;
+    Py_ssize_t old_none = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (dst[i] == Py_None) ++old_none;            /* np.empty(n, object) holds n references to None */
+        else if (dst[i] != NULL) {
+            Py_DECREF(seq);
+            PyErr_SetString(PyExc_ValueError, "gather_objects(): the object array must be a fresh np.empty array");
+            return NULL;
+        }
+    }
+    enum { AHEAD = 12 };
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (i + AHEAD < n) {
+            const int32_t jn = idx[i + AHEAD];
+            if (jn >= 0 && jn < n_names) __builtin_prefetch(items[jn], 1, 1);
+        }
+        const int32_t j = idx[i];
+        PyObject *o = (j >= 0 && j < n_names && (!keep || keep[i])) ? items[j] : Py_None;
+        Py_INCREF(o);
+        dst[i] = o;
+    }
+    release_overwritten_none(old_none);
+    Py_DECREF(seq);
+    Py_RETURN_NONE;
+}
+
 /* linkage(from_ids, to_ids, n_strings) -> (cluster: bytes int32[n_strings], order: bytes int32[n_mapped])
  *
  * The order-dependent greedy assignment of reference polyfuzz/linkage.py:28-45 on integer string ids
@@ -419,6 +462,7 @@ done:
 static PyMethodDef methods[] = {
     {"linkage", linkage, METH_VARARGS, "linkage(from_ids, to_ids, n_strings) -> (cluster int32[n], order int32[k]) as bytes"},
     {"pack", pack, METH_VARARGS, "pack(list[str] [, n_threads]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)"},
+    {"gather_objects", gather_objects, METH_VARARGS, "gather_objects(names, idx_addr, n, obj_addr, keep_addr): obj[i] <- names[idx[i]] or None"},
     {"fill_objects", fill_objects, METH_VARARGS, "fill_objects(seq, obj_addr, n): a fresh object array <- new references to seq[i]"},
     {"fill_columns", fill_columns, METH_VARARGS,
      "fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads): the (To, Similarity) column pairs"},

@@ -77,10 +77,12 @@ class EditDistance(BaseMatcher):
         the previous call, whose device copy and K4 plan (alphabet, length-sorted packed groups) are still
         resident: no upload, no preparation. """
         t0 = time.perf_counter()
-        idx, score, names = self._best(from_list, to_list, reuse_to=kwargs.get("re_train", True) is False)
+        pending, names = self._best(from_list, to_list, reuse_to=kwargs.get("re_train", True) is False)
+        from_col = object_column(from_list)          # host work while the device scores
+        idx, score = pending.result()
         t1 = time.perf_counter()
         to_col = gather_column(names, idx)
-        matches = pd.DataFrame({"From": object_column(from_list), "To": to_col, "Similarity": score}, copy=False)
+        matches = pd.DataFrame({"From": from_col, "To": to_col, "Similarity": score}, copy=False)
         if self.normalize:      # global min-max over the best scores, _distance.py:83-86
             matches["Similarity"] = (matches["Similarity"] -
                                      matches["Similarity"].min()) / (matches["Similarity"].max() -
@@ -105,7 +107,7 @@ class EditDistance(BaseMatcher):
             names = to_list
         if len(names) - (1 if self_match else 0) <= 0 and len(from_list) > 0:
             raise ValueError("attempt to get argmax of an empty sequence")   # np.argmax([]) in the reference
-        from ._rapidfuzz import best_choice, upload_for
+        from ._rapidfuzz import best_choice_async, upload_for
         name = self._scorer_name              # "ratio": K4; the other rapidfuzz.fuzz scorers: K4 on transformed strings, or K7
         to_dev = None
         if not self_match:
@@ -114,8 +116,7 @@ class EditDistance(BaseMatcher):
             else:
                 to_dev = upload_for(ctx, name, names)
                 self._to_dev, self._to_names = to_dev, names
-        idx, score = best_choice(ctx, name, from_list, names, skip, self_match, to_dev=to_dev)
-        return idx, score, names
+        return best_choice_async(ctx, name, from_list, names, skip, self_match, to_dev=to_dev), names
 
     # a matcher is pickled by joblib (reference _distance.py:77, polyfuzz.py:429-457): device handles stay behind
     def __getstate__(self):

@@ -62,23 +62,48 @@ def upload_for(ctx, name, strings):
     return _lib.DeviceStrings.upload(ctx, _transform(name, strings))
 
 
-def best_choice(ctx, name, from_list, names, skip, self_match, to_dev=None):
-    """(index of the first best choice int32[n], its score float64[n] on the 0..100 scale) of every from-string under
-    the rapidfuzz.fuzz scorer `name`; `names` are the choices (the from-list itself in a self-match, where skip[i] is
-    the choice left out for from-string i -- still the from-string's own first occurrence in the ORIGINAL list).
-    to_dev: the choices already resident (upload_for), e.g. from the previous call of a fitted matcher."""
+class _PendingBest:
+    """an enqueued best-choice pass: `result()` waits for the device and returns (index int32[n], score float64[n])"""
+
+    def __init__(self, out, n, fix=None):
+        self.out, self.n, self.fix = out, n, fix
+
+    def result(self):
+        idx, score = _lib.best_from_topn(*self.out.download())
+        idx, score = idx[:self.n], score[:self.n]
+        if self.fix is not None:
+            self.fix(idx, score)
+        return idx, score
+
+
+def best_choice_async(ctx, name, from_list, names, skip, self_match, to_dev=None):
+    """Enqueue the best-choice pass of every from-string under the rapidfuzz.fuzz scorer `name` and return at once (the
+    caller builds its From column while the device works); `names` are the choices (the from-list itself in a
+    self-match, where skip[i] is the choice left out for from-string i -- still the from-string's own first occurrence
+    in the ORIGINAL list).  to_dev: the choices already resident (upload_for), e.g. from the previous call of a fitted
+    matcher."""
+    n = len(from_list)
     f_dev = upload_for(ctx, name, from_list)
     t_dev = f_dev if self_match else (to_dev if to_dev is not None else upload_for(ctx, name, names))
+    out = _lib.DeviceTopN.alloc(ctx, max(n, 1), 2)
+    fix = None
     if name in _lib.FUZZ_SCORERS:
-        return _lib.fuzz_extract_one(ctx, f_dev, t_dev, name, skip)
-    idx, score = _lib.indel_argmax(ctx, f_dev, t_dev, skip)
-    if name == "QRatio":
-        # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string
-        # scores 0 against every choice, so its first best is simply its first choice
-        for i in [i for i, s in enumerate(from_list) if len(s) == 0]:
-            first_choice = next((j for j in range(len(names)) if not (skip is not None and j == skip[i])), -1)
-            idx[i], score[i] = first_choice, 0.0
-    return idx, score
+        _lib.fuzz_extract_one_dev(ctx, f_dev, t_dev, name, out, skip)
+    else:
+        _lib.indel_argmax_dev(ctx, f_dev, t_dev, out, skip)
+        if name == "QRatio":
+            def fix(idx, score):
+                # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string
+                # scores 0 against every choice, so its first best is simply its first choice
+                for i in [i for i, s in enumerate(from_list) if len(s) == 0]:
+                    first_choice = next((j for j in range(len(names)) if not (skip is not None and j == skip[i])), -1)
+                    idx[i], score[i] = first_choice, 0.0
+    return _PendingBest(out, n, fix)
+
+
+def best_choice(ctx, name, from_list, names, skip, self_match, to_dev=None):
+    """(index of the first best choice int32[n], its score float64[n] on the 0..100 scale) of every from-string"""
+    return best_choice_async(ctx, name, from_list, names, skip, self_match, to_dev).result()
 
 
 class RapidFuzz(BaseMatcher):
@@ -129,17 +154,21 @@ class RapidFuzz(BaseMatcher):
             for j, s in enumerate(names):
                 first.setdefault(s, j)
             skip = np.fromiter((first[s] for s in from_list), np.int32, n)
+        from_col = None
         if n == 0 or len(names) - (1 if self_match else 0) <= 0:
             idx, score = np.full(n, -1, np.int32), np.zeros(n)             # extractOne over no choices: None
+            from_col = object_column(from_list)
         else:
             if not self_match and not reuse:
                 self._to_dev, self._to_names = upload_for(ctx, self._scorer_name, names), names
-            idx, score = best_choice(ctx, self._scorer_name, from_list, names, skip, self_match,
-                                     to_dev=None if self_match else self._to_dev)
+            pending = best_choice_async(ctx, self._scorer_name, from_list, names, skip, self_match,
+                                        to_dev=None if self_match else self._to_dev)
+            from_col = object_column(from_list)                              # (host work while the device scores)
+            idx, score = pending.result()
         hit = (idx >= 0) & (score >= self.score_cutoff)                       # extractOne: best score >= score_cutoff
         to_col = gather_column(names, idx, hit)
         sim = np.where(hit, score / 100, 0.0)
-        return pd.DataFrame({"From": object_column(from_list), "To": to_col, "Similarity": sim}, copy=False)
+        return pd.DataFrame({"From": from_col, "To": to_col, "Similarity": sim}, copy=False)
 
     # a matcher is pickled by joblib (reference polyfuzz.py:429-457): device handles stay behind
     def __getstate__(self):

@@ -40,7 +40,14 @@ def object_column(strings) -> np.ndarray:
 
 
 def gather_column(names, idx, keep=None) -> np.ndarray:
-    """object column of names[idx[i]] (None where `keep[i]` is false or idx[i] < 0): one fancy-index instead of a Python loop"""
+    """object column of names[idx[i]] (None where `keep[i]` is false or idx[i] < 0): one pass of the CPython helper
+    (prefetched gathers of the names), or -- without it -- one fancy-index over an object pool"""
+    if _lib._pack is not None and isinstance(names, (list, tuple)) and hasattr(_lib._pack, "gather_objects"):
+        j = np.ascontiguousarray(idx, np.int32)
+        out = np.empty(len(j), dtype=object)
+        k = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        _lib._pack.gather_objects(names, j.ctypes.data, len(j), out.ctypes.data, 0 if k is None else k.ctypes.data)
+        return out
     pool = np.empty(len(names) + 1, dtype=object)
     pool[:len(names)] = object_column(names)
     pool[len(names)] = None

@@ -255,16 +255,14 @@ class BestChoiceJob:
         """the cached to-side plan: K4's (alphabet, groups, character steps) or K7's (alphabet, groups, tokens)"""
         return _lib.indel_plan_info(self.ctx, self.t_dev) if self.k4 else _lib.fuzz_plan_info(self.ctx, self.t_dev)
 
-    def step(self, counters=False):
-        work = None
+    def step(self):
         if self.n_from and len(self.to_list):
             if self.k4:
                 _lib.indel_argmax_dev(self.ctx, self.f_dev, self.t_dev, self.local, self.skip)
             else:
-                work = _lib.fuzz_extract_one_dev(self.ctx, self.f_dev, self.t_dev, self.scorer, self.local, self.skip, counters=counters)
+                _lib.fuzz_extract_one_dev(self.ctx, self.f_dev, self.t_dev, self.scorer, self.local, self.skip)
         if self.gathered is not None:
             self.comm.allgather_topn(self.local, self.gathered)
-        self.last_work = work
         return self.gathered if self.gathered is not None else self.local
 
     def result_host(self, result):
@@ -291,8 +289,10 @@ class BestChoiceJob:
         the kernel's own estimate by the pair's lengths."""
         if self.k4:
             return None
-        self.step(counters=True)
-        w = self.last_work or {"pairs_bounded": 0, "pairs_scored": 0, "word_steps_scored": 0}
+        # (this rank's shard only, no exchange: the other ranks are not here)
+        w = _lib.fuzz_extract_one_dev(self.ctx, self.f_dev, self.t_dev, self.scorer, self.local, self.skip, counters=True) \
+            if self.n_from and len(self.to_list) else None
+        w = w or {"pairs_bounded": 0, "pairs_scored": 0, "word_steps_scored": 0}
         pairs = self.n_from * float(len(self.to_list))
         ops = 40.0 * w["pairs_bounded"] + 10.0 * w["word_steps_scored"]
         return {"kernel": "k7_fuzz", "bound": "int32 VALU issue (+ LDS look-ups)", "achieved": ops / step_s / 1e12 if step_s > 0 else None,

@@ -83,6 +83,9 @@ static void run(int n_sym, const List &A, const List &B, int mode, const double 
             T.tok_id = B.tok_id + B.tok_off[j];
             T.tok_len = B.tok_len + B.tok_off[j];
             T.stride = 1;
+            T.stage = nullptr;
+            T.stage_stride = 0;
+            T.staged = -1;
             T.tb = sb.ntok = (int)(B.tok_off[j + 1] - B.tok_off[j]);
             for (int t = 0; t < T.tb; ++t) sb.sig |= fz_sig_bit(T.tok_id[t]);
             memcpy(sb.hist, B.hist + (size_t)j * kFuzzHistWords, sizeof(sb.hist));

@@ -1,0 +1,9 @@
+#!/bin/bash
+# K7 iteration on the GPU box: its parity tests, then timings.  usage: bash tools/r3_k7.sh <tag> [names]
+tag=${1:-k7}
+mkdir -p gpurun_out
+timeout 500 python -m pytest tests/test_fuzz_gpu.py tests/test_comm_gpu.py tests/test_facade_flow_gpu.py -m gpu -q -x --timeout 200 > gpurun_out/${tag}_tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/${tag}_tests.log
+tail -12 gpurun_out/${tag}_tests.log
+timeout 300 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio,partial_token_ratio $2 > gpurun_out/${tag}_time.log 2>&1
+cat gpurun_out/${tag}_time.log | tail -12

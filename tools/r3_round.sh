@@ -3,10 +3,10 @@
 # usage (on the GPU box, from the repo root): bash tools/r3_round.sh <tag> [extra pytest args]
 tag=${1:-r3}; shift
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q -x "$@" > gpurun_out/${tag}_tests.log 2>&1
+timeout 600 python -m pytest tests -m gpu -q -x --timeout 240 "$@" > gpurun_out/${tag}_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/${tag}_tests.log
 tail -15 gpurun_out/${tag}_tests.log
-timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench rc=$?"
 grep -v -E "^\s" gpurun_out/${tag}_bench.err | tail -c 1500
 python - <<PY
