@@ -18,12 +18,11 @@ struct FuzzArgs {
     int32_t space_rank, space_class;
     const int32_t *rows;         // from-rows of this launch
     int32_t n_rows;
-    // to side (the plan)
-    const uint16_t *b_sym[3];
+    // to side (the plan): per-string records + per-slot summaries
+    const uint16_t *b_sym;
     const uint8_t *b_tag;
-    const int64_t *b_goff, *b_tgoff;
     const int32_t *b_tok_id, *b_tok_len;
-    const int4 *b_meta, *b_meta2;
+    const int4 *b_meta, *b_meta2, *b_meta3, *b_meta4;
     const uint4 *b_hist;
     const int32_t *big_slots;    // general kernel: only these to-slots (n_big > 0), else all
     int32_t n_big;
@@ -35,6 +34,10 @@ struct FuzzArgs {
     double *part_score;
     int32_t *part_idx;
     unsigned long long *counters;    // [0] pairs bounded, [1] pairs scored, [2] 64-bit word-steps of the scored pairs (or NULL)
+    // tuning aids (PFZ_K7_ROW_STATS / PFZ_K7_EXP; never set in production): per from-row {pairs scored, clock ticks}, experiment
+    unsigned long long *row_stats;
+    int32_t exp;                     // 1: bound only, score nothing (results wrong)
+    int32_t *next_unit;              // dynamic distribution of the (row, part) units over the workgroups
 };
 
 }  // namespace pfz

@@ -58,14 +58,14 @@ template <int W> struct FuzzFrom {
     const uint64_t *smask;       // [ta][W] position of the space after token i (empty for the last token)
 };
 
-// one to-string: element pos of form v is sym[v][pos * stride]
+// one to-string, every array its own contiguous record: on the device the records are 16-byte aligned and padded to
+// whole 8-symbol (8-tag, 4-token) chunks, so that a lane fetches 8 symbols with ONE 128-bit load
 struct FuzzTo {
-    const uint16_t *sym[3];
+    const uint16_t *sym[3];      // symbols of form v
     const uint8_t *tag;          // form 2: token number (5 bits) | 0x80 for the space that follows that token
-    const int32_t *tok_id, *tok_len;   // [j * stride]
-    int stride;
+    const int32_t *tok_id, *tok_len;   // distinct tokens, in the order of form 2
     int lb[3], tb;
-    // optional scratch column [pos * stage_stride] of kFuzzStage symbols (LDS in the kernel, NULL on the host): a window sweep
+    // optional scratch column [pos * stage_stride] of kFuzzStage symbols (LDS in the kernel, none on the host): a window sweep
     // re-reads the to-string |from| times, and a global load per recurrence step is a dependent ~500-cycle round trip
     PFZ_LDS_U16 *stage;
     int stage_stride;            // 0: there is no column
@@ -74,25 +74,49 @@ struct FuzzTo {
 
 constexpr int kFuzzStage = 64;
 
-// copy form v into the scratch column (eight loads in flight at a time); longer forms stay in global memory
+// eight consecutive symbols / tags (the device records are aligned and padded for it; the host reads them one by one)
+PFZ_HD void fz_load8(const uint16_t *p, int n, int (&c)[8])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = *(const uint4 *)p;
+    c[0] = (int)(v.x & 0xffffu), c[1] = (int)(v.x >> 16), c[2] = (int)(v.y & 0xffffu), c[3] = (int)(v.y >> 16);
+    c[4] = (int)(v.z & 0xffffu), c[5] = (int)(v.z >> 16), c[6] = (int)(v.w & 0xffffu), c[7] = (int)(v.w >> 16);
+    (void)n;
+#else
+    for (int q = 0; q < 8; ++q) c[q] = q < n ? (int)p[q] : 0;
+#endif
+}
+
+PFZ_HD void fz_load8(const uint8_t *p, int n, int (&c)[8])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint2 v = *(const uint2 *)p;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = (int)((v.x >> (8 * q)) & 0xffu), c[4 + q] = (int)((v.y >> (8 * q)) & 0xffu);
+    (void)n;
+#else
+    for (int q = 0; q < 8; ++q) c[q] = q < n ? (int)p[q] : 0;
+#endif
+}
+
+// copy form v into the scratch column; longer forms stay in global memory
 PFZ_HD void fz_stage(FuzzTo &T, int v)
 {
     if (T.stage_stride == 0 || T.staged == v || T.lb[v] > kFuzzStage) return;
     const int lb = T.lb[v];
     for (int p0 = 0; p0 < lb; p0 += 8) {
-        uint16_t c[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) c[q] = p0 + q < lb ? T.sym[v][(int64_t)(p0 + q) * T.stride] : (uint16_t)0;
+        int c[8];
+        fz_load8(T.sym[v] + p0, lb - p0, c);
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (p0 + q < lb) T.stage[(p0 + q) * T.stage_stride] = c[q];
+            if (p0 + q < lb) T.stage[(p0 + q) * T.stage_stride] = (uint16_t)c[q];
     }
     T.staged = v;
 }
 
 PFZ_HD int fz_sym(const FuzzTo &T, int v, int pos)
 {
-    return T.staged == v ? (int)T.stage[pos * T.stage_stride] : (int)T.sym[v][(int64_t)pos * T.stride];
+    return T.staged == v ? (int)T.stage[pos * T.stage_stride] : (int)T.sym[v][pos];
 }
 
 PFZ_HD double fz_ratio_of(int lcs, int lensum)
@@ -177,16 +201,16 @@ PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint
 #pragma unroll
     for (int w = 0; w < W; ++w) V[w] = ~0ull;
     const int lb = T.lb[v];
-    // eight positions at a time: their symbols (and tags) are requested together, then consumed -- one memory round trip
-    // per eight recurrence steps instead of one per step
+    // eight positions at a time: one 128-bit load of symbols (one 64-bit load of tags), then eight recurrence steps
     for (int p0 = 0; p0 < lb; p0 += 8) {
-        int sy[8];
+        int sy[8], tg[8];
+        fz_load8(T.sym[v] + p0, lb - p0, sy);
+        if (tagged) {
+            fz_load8(T.tag + p0, lb - p0, tg);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            sy[q] = p0 + q < lb ? fz_sym(T, v, p0 + q) : 0;
-            if (tagged && p0 + q < lb) {
-                const int tag = T.tag[(int64_t)(p0 + q) * T.stride], j = tag & 31;
-                const bool keep = ((rb >> j) & 1u) && !((tag & 0x80) && j == last_rb);
+            for (int q = 0; q < 8; ++q) {
+                const int j = tg[q] & 31;
+                const bool keep = ((rb >> j) & 1u) && !((tg[q] & 0x80) && j == last_rb);
                 sy[q] = keep ? sy[q] : 0;
             }
         }
@@ -250,7 +274,7 @@ PFZ_HD void fz_intersect(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t &ca, ui
 {
     ca = cb = 0u;
     for (int j = 0; j < T.tb; ++j) {
-        const int idb = T.tok_id[(int64_t)j * T.stride];
+        const int idb = T.tok_id[j];
         for (int i = 0; i < F.ta; ++i)
             if (F.tid[i] == idb) {
                 ca |= 1u << i;
@@ -281,7 +305,7 @@ PFZ_HD double fz_token_set(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t ca, u
         for (int w = 0; w < W; ++w) amask[w] |= rem ? (F.tmask[i * W + w] | (i != last_ra ? F.smask[i * W + w] : 0ull)) : 0ull;
     }
     for (int j = 0; j < tb; ++j)
-        if ((rb >> j) & 1u) ba_len += T.tok_len[(int64_t)j * T.stride];
+        if ((rb >> j) & 1u) ba_len += T.tok_len[j];
     uint64_t V[W];
     fz_lcs_pass<W>(F, T, 2, amask, true, rb, last_rb, V);
     const int lcs = fz_zeros_below<W>(V, F.la[2]);
@@ -457,7 +481,7 @@ PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t 
         sect_chars += rem ? 0 : F.tlen[i];
     }
     for (int j = 0; j < tb; ++j)
-        if ((rb >> j) & 1u) ba_len += T.tok_len[(int64_t)j * T.stride];
+        if ((rb >> j) & 1u) ba_len += T.tok_len[j];
     const int sect_len = sect_chars + (nc > 0 ? nc - 1 : 0), sect_sep = sect_len != 0 ? 1 : 0;
     const int sect_ab_len = sect_len + sect_sep + ab_len, sect_ba_len = sect_len + sect_sep + ba_len;
     const int m = fz_min(fz_min(ab_len, ba_len), fz_max(u - sect_chars, 0));

@@ -99,21 +99,21 @@ struct pfz_fuzz_plan {
     int32_t *t_tok_id = nullptr;         // [tok_cap of the to-list's forms] id of every distinct token (its table representative)
     int64_t n_groups = 0;
     int32_t *b_orig = nullptr;           // [n_groups * 64] original index, -1 = padding lane
-    int64_t *goff = nullptr;             // [n_groups] element offset of the group in sym[v] / tag (capacity: longest string x 64)
-    int64_t *tgoff = nullptr;            // [n_groups] element offset in tok_id / tok_len
-    uint16_t *sym[3] = {nullptr, nullptr, nullptr};
-    uint8_t *tag = nullptr;
-    int32_t *tok_id = nullptr, *tok_len = nullptr;
+    // every to-string's record, contiguous and 16-byte aligned (a lane fetches 8 symbols / 8 tags / 4 tokens per load):
+    uint16_t *sym = nullptr;             // forms 0, 1, 2 at meta3.x + v * meta3.w, each padded to meta3.w = pad8(len0) symbols
+    uint8_t *tag = nullptr;              // form 2's tags at meta3.y (padded to 16)
+    int32_t *tok_id = nullptr, *tok_len = nullptr;    // distinct tokens at meta3.z (padded to 4)
     int4 *meta = nullptr;                // [n_groups * 64] {len0, len1, len2, distinct tokens}
     int4 *meta2 = nullptr;               // [n_groups * 64] {signature lo, hi, histogram sum (-1: none), original index}
+    int4 *meta3 = nullptr;               // [n_groups * 64] {symbol offset, tag offset, token offset, padded form length}
+    int4 *meta4 = nullptr;               // [n_groups * 64] ids of the first four distinct tokens (-1: none)
     uint4 *hist = nullptr;               // [n_groups][2][64]
     std::vector<int32_t> big_slots;      // to-strings with more than 32 distinct tokens (scored by the general kernel)
     int32_t *d_big_slots = nullptr;
     ~pfz_fuzz_plan()
     {
-        for (void *p : {(void *)lut, (void *)cls, (void *)table, (void *)t_tok_id, (void *)b_orig, (void *)goff, (void *)tgoff, (void *)sym[0],
-                        (void *)sym[1], (void *)sym[2], (void *)tag, (void *)tok_id, (void *)tok_len, (void *)meta, (void *)meta2, (void *)hist,
-                        (void *)d_big_slots})
+        for (void *p : {(void *)lut, (void *)cls, (void *)table, (void *)t_tok_id, (void *)b_orig, (void *)sym, (void *)tag, (void *)tok_id,
+                        (void *)tok_len, (void *)meta, (void *)meta2, (void *)meta3, (void *)meta4, (void *)hist, (void *)d_big_slots})
             if (p) pfz::pool_free(p);
     }
 };
@@ -350,16 +350,17 @@ struct PackArgs {
     const uint8_t *cls;
     int32_t space_rank, space_class;
     const int32_t *b_orig;
-    const int64_t *goff, *tgoff;
-    uint16_t *sym[3];
+    const int4 *meta3;
+    uint16_t *sym;
     uint8_t *tag;
     int32_t *p_tok_id, *p_tok_len;
-    int4 *meta, *meta2;
+    int4 *meta, *meta2, *meta4;
     uint4 *hist;
     int64_t n_slots;
 };
 
-// slot (group g, lane l) = to-string b_orig[slot]: everything the match kernel reads of it, [position][lane]
+// slot (group g, lane l) = to-string b_orig[slot]: everything the match kernel reads of it -- its record (symbols of the
+// three forms, tags, tokens) and its summary (lengths, class histogram, token signature, first token ids)
 __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
 {
     const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -373,27 +374,32 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
     if (j < 0) {
         A.meta[slot] = make_int4(0, 0, 0, 0);
         A.meta2[slot] = make_int4(0, 0, 0, -1);
+        A.meta4[slot] = make_int4(-1, -1, -1, -1);
         A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
         A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
+    const int4 rec = A.meta3[slot];
     const int64_t o = A.off[j];
     const int len[3] = {(int)(A.off[j + 1] - o), A.len1[j], A.len2[j]};
     const int nt = A.ntok[j], nt_all = A.ntok_all[j];
     const bool with_hist = len[0] + (nt_all > 0 ? nt_all - 1 : 0) <= 255;      // no class counter can pass 255
     int n_space = 0, usum = 0;
     for (int v = 0; v < 3; ++v) {
-        uint16_t *dst = A.sym[v] + A.goff[g] + lane;
-        for (int p = 0; p < len[v]; ++p) {
-            const uint32_t c = load_unit(A.form[v], A.cw, o + p);
-            const int sy = c < A.lut_len ? (int)A.lut[c] : 0;
-            dst[(int64_t)p * 64] = (uint16_t)sy;
-            if (v == 0 && with_hist && sy) {
-                const int cl = A.cls[sy];
-                hw[cl >> 2] += 1u << (8 * (cl & 3));
-                ++usum;
-                n_space += sy == A.space_rank;
+        uint16_t *dst = A.sym + rec.x + (int64_t)v * rec.w;
+        for (int p = 0; p < rec.w; ++p) {
+            int sy = 0;
+            if (p < len[v]) {
+                const uint32_t c = load_unit(A.form[v], A.cw, o + p);
+                sy = c < A.lut_len ? (int)A.lut[c] : 0;
+                if (v == 0 && with_hist && sy) {
+                    const int cl = A.cls[sy];
+                    hw[cl >> 2] += 1u << (8 * (cl & 3));
+                    ++usum;
+                    n_space += sy == A.space_rank;
+                }
             }
+            dst[p] = (uint16_t)sy;                 // (the padding of the record is zero: symbol 0 matches nothing)
         }
     }
     if (with_hist) {
@@ -405,21 +411,24 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
     }
     // distinct tokens: ids, lengths, and the tag of every character of form 2
     const int64_t tb = tok_base(o, j);
-    uint8_t *tg = A.tag + A.goff[g] + lane;
-    int32_t *pid = A.p_tok_id + A.tgoff[g] + lane, *pln = A.p_tok_len + A.tgoff[g] + lane;
+    uint8_t *tg = A.tag + rec.y;
+    int32_t *pid = A.p_tok_id + rec.z, *pln = A.p_tok_len + rec.z;
     uint64_t sig = 0ull;
+    int first[4] = {-1, -1, -1, -1};
     int pos = 0;
     for (int t = 0; t < nt; ++t) {
         const int32_t id = A.tok_id[tb + t], l = A.tok_len[tb + t];
-        pid[(int64_t)t * 64] = id;
-        pln[(int64_t)t * 64] = l;
+        pid[t] = id;
+        pln[t] = l;
+        if (t < 4) first[t] = id;
         sig |= fz_sig_bit(id);
-        for (int q = 0; q < l; ++q) tg[(int64_t)(pos + q) * 64] = (uint8_t)(t & 31);
-        if (t + 1 < nt) tg[(int64_t)(pos + l) * 64] = (uint8_t)((t & 31) | 0x80);
+        for (int q = 0; q < l; ++q) tg[pos + q] = (uint8_t)(t & 31);
+        if (t + 1 < nt) tg[pos + l] = (uint8_t)((t & 31) | 0x80);
         pos += l + 1;
     }
     A.meta[slot] = make_int4(len[0], len[1], len[2], nt);
     A.meta2[slot] = make_int4((int)(uint32_t)sig, (int)(uint32_t)(sig >> 32), with_hist ? usum : -1, j);
+    A.meta4[slot] = make_int4(first[0], first[1], first[2], first[3]);
     A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
     A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
 }
@@ -529,34 +538,39 @@ static int build_plan(pfz_ctx *ctx, pfz_strings *T)
     for (size_t l = 1; l < start.size(); ++l) start[l] += start[l - 1];
     const int64_t n_groups = (n_to + 63) / 64;
     std::vector<int32_t> b_orig((size_t)n_groups * 64, -1);
-    std::vector<int64_t> goff((size_t)n_groups), tgoff((size_t)n_groups);
     for (int64_t j = 0; j < n_to; ++j) {      // ascending j inside one length: a stable sort
         const int64_t len = T->h_off[(size_t)j + 1] - T->h_off[(size_t)j];
         b_orig[(size_t)start[(size_t)len]++] = (int32_t)j;
     }
-    int64_t total = 0, ttotal = 0;
-    for (int64_t g = 0; g < n_groups; ++g) {
-        const int32_t last = b_orig[(size_t)(std::min<int64_t>(n_to, (g + 1) * 64) - 1)];     // sorted: the group's longest string
-        const int64_t gmax = T->h_off[(size_t)last + 1] - T->h_off[(size_t)last];
-        goff[(size_t)g] = total;
-        tgoff[(size_t)g] = ttotal;
-        total += gmax * 64;                   // (no form is longer than the string; a string has at most (len + 1) / 2 tokens)
-        ttotal += ((gmax + 1) / 2) * 64;
+    // record offsets: no form is longer than the string, a string of len characters has at most (len + 1) / 2 tokens
+    const size_t n_slots = (size_t)std::max<int64_t>(n_groups * 64, 1);
+    std::vector<int4> meta3(n_slots, make_int4(0, 0, 0, 8));
+    int64_t total = 0, tag_total = 0, ttotal = 0;
+    for (int64_t sl = 0; sl < n_groups * 64; ++sl) {
+        const int32_t j = b_orig[(size_t)sl];
+        const int64_t len = j >= 0 ? T->h_off[(size_t)j + 1] - T->h_off[(size_t)j] : 0;
+        const int64_t cap8 = std::max<int64_t>(8, (len + 7) & ~(int64_t)7);
+        if (total + 3 * cap8 >= INT_MAX || tag_total + cap8 + 16 >= INT_MAX) {
+            set_error("pfz_fuzz: a to-list of %lld code units exceeds the 2^31-symbol plan", (long long)T->n_units);
+            return PFZ_ERR_UNSUPPORTED;
+        }
+        meta3[(size_t)sl] = make_int4((int)total, (int)tag_total, (int)ttotal, (int)cap8);
+        total += 3 * cap8;
+        tag_total += (cap8 + 15) & ~(int64_t)15;
+        ttotal += std::max<int64_t>(4, ((len + 1) / 2 + 3) & ~(int64_t)3);
+        if (j >= 0 && f->h_ntok[(size_t)j] > kFuzzMaxTokens) pl->big_slots.push_back((int32_t)sl);
     }
-    for (int64_t s = 0; s < n_groups * 64; ++s)
-        if (b_orig[(size_t)s] >= 0 && f->h_ntok[(size_t)b_orig[(size_t)s]] > kFuzzMaxTokens) pl->big_slots.push_back((int32_t)s);
     pl->n_groups = n_groups;
     PFZ_TRY(up(ctx, &pl->b_orig, b_orig));
-    PFZ_TRY(up(ctx, &pl->goff, goff));
-    PFZ_TRY(up(ctx, &pl->tgoff, tgoff));
+    PFZ_TRY(up(ctx, &pl->meta3, meta3));
     PFZ_TRY(up(ctx, &pl->d_big_slots, pl->big_slots));
-    for (int v = 0; v < 3; ++v) PFZ_TRY(pool_alloc(ctx, &pl->sym[v], (size_t)(total + 64) * sizeof(uint16_t)));
-    PFZ_TRY(pool_alloc(ctx, &pl->tag, (size_t)(total + 64)));
+    PFZ_TRY(pool_alloc(ctx, &pl->sym, (size_t)(total + 64) * sizeof(uint16_t)));
+    PFZ_TRY(pool_alloc(ctx, &pl->tag, (size_t)(tag_total + 64)));
     PFZ_TRY(pool_alloc(ctx, &pl->tok_id, (size_t)(ttotal + 64) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &pl->tok_len, (size_t)(ttotal + 64) * sizeof(int32_t)));
-    const size_t n_slots = (size_t)std::max<int64_t>(n_groups * 64, 1);
     PFZ_TRY(pool_alloc(ctx, &pl->meta, n_slots * sizeof(int4)));
     PFZ_TRY(pool_alloc(ctx, &pl->meta2, n_slots * sizeof(int4)));
+    PFZ_TRY(pool_alloc(ctx, &pl->meta4, n_slots * sizeof(int4)));
     PFZ_TRY(pool_alloc(ctx, &pl->hist, n_slots * 2 * sizeof(uint4)));
     if (n_groups > 0) {
         PackArgs P;
@@ -577,14 +591,14 @@ static int build_plan(pfz_ctx *ctx, pfz_strings *T)
         P.space_rank = pl->space_rank;
         P.space_class = pl->space_class;
         P.b_orig = pl->b_orig;
-        P.goff = pl->goff;
-        P.tgoff = pl->tgoff;
-        for (int v = 0; v < 3; ++v) P.sym[v] = pl->sym[v];
+        P.meta3 = pl->meta3;
+        P.sym = pl->sym;
         P.tag = pl->tag;
         P.p_tok_id = pl->tok_id;
         P.p_tok_len = pl->tok_len;
         P.meta = pl->meta;
         P.meta2 = pl->meta2;
+        P.meta4 = pl->meta4;
         P.hist = pl->hist;
         P.n_slots = n_groups * 64;
         hipLaunchKernelGGL(k7_pack, dim3((unsigned)((n_groups * 64 + 255) / 256)), dim3(256), 0, ctx->stream, P);
@@ -653,7 +667,16 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
     unsigned long long n_bounded = 0, n_scored = 0, n_steps = 0;
     __syncthreads();
 
-    for (int u = blockIdx.x; u < A.n_rows * parts; u += gridDim.x) {
+    __shared__ int s_unit;
+    for (;;) {
+        // the from-strings differ by orders of magnitude in how many pairs survive their bound: units are handed out one at
+        // a time (an atomic counter) instead of by a fixed stride, so no workgroup is left with a run of heavy ones
+        if (tid == 0) s_unit = atomicAdd(A.next_unit, 1);
+        __syncthreads();
+        const int u = s_unit;
+        if (u >= A.n_rows * parts) break;
+        const long long t_begin = A.row_stats ? wall_clock64() : 0;
+        const unsigned long long scored_before = n_scored;
         const int r = u / parts, part = u - r * parts;
         const int row = A.rows[r];
         const int64_t a0 = A.a_off[row];
@@ -742,16 +765,14 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             return __longlong_as_double((long long)__hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         };
         auto to_of = [&](int slot, const int4 &m) {
-            const int g = slot >> 6, l = slot & 63;
+            const int4 rec = A.b_meta3[slot];
             FuzzTo T;
-            const int64_t go = A.b_goff[g] + l, tg = A.b_tgoff[g] + l;
-            T.sym[0] = A.b_sym[0] + go;
-            T.sym[1] = A.b_sym[1] + go;
-            T.sym[2] = A.b_sym[2] + go;
-            T.tag = A.b_tag + go;
-            T.tok_id = A.b_tok_id + tg;
-            T.tok_len = A.b_tok_len + tg;
-            T.stride = 64;
+            T.sym[0] = A.b_sym + rec.x;
+            T.sym[1] = T.sym[0] + rec.w;
+            T.sym[2] = T.sym[1] + rec.w;
+            T.tag = A.b_tag + rec.y;
+            T.tok_id = A.b_tok_id + rec.z;
+            T.tok_len = A.b_tok_len + rec.z;
             T.lb[0] = m.x;
             T.lb[1] = m.y;
             T.lb[2] = m.z;
@@ -761,38 +782,71 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             T.staged = -1;
             return T;
         };
-        // float32 upper bound of the pair (from-string, slot); valid = a real candidate of this kernel
-        auto bound_of = [&](int slot, float cur32, int4 &m, int &orig, bool &valid) -> float {
-            m = A.b_meta[slot];
-            const int4 m2 = A.b_meta2[slot];
-            orig = m2.w;
-            valid = orig >= 0 && orig != skip && m.w <= kFuzzMaxTokens;
+        // what a sweep reads of one to-string: five 128-bit loads, all issued one group ahead of their use
+        struct Meta {
+            int4 m, m2, m4;
+            uint4 h0, h1;
+        };
+        auto load_meta = [&](int g) {
+            const int slot = g * 64 + lane;
+            Meta x;
+            x.m = A.b_meta[slot];
+            x.m2 = A.b_meta2[slot];
+            x.m4 = A.b_meta4[slot];
+            x.h0 = A.b_hist[(g * 2 + 0) * 64 + lane];
+            x.h1 = A.b_hist[(g * 2 + 1) * 64 + lane];
+            return x;
+        };
+        // float32 upper bound of the pair (from-string, slot); valid = a real candidate of this kernel.  When the token
+        // signatures meet, the exact intersection is taken from registers (to-strings of up to four distinct tokens);
+        // refine (sweep 2): also what needs the string's record -- more tokens, token_set_ratio's length arithmetic
+        auto bound_of = [&](int slot, const Meta &x, float cur32, bool refine, bool &valid) -> float {
+            const int4 m = x.m, m2 = x.m2;
+            valid = m2.w >= 0 && m2.w != skip && m.w <= kFuzzMaxTokens;
             FuzzSummary sb;
             sb.len[0] = m.x;
             sb.len[1] = m.y;
             sb.len[2] = m.z;
             sb.ntok = m.w;
-            const int g = slot >> 6, l = slot & 63;
-            const uint4 h0 = A.b_hist[(g * 2 + 0) * 64 + l], h1 = A.b_hist[(g * 2 + 1) * 64 + l];
-            sb.hist[0] = h0.x;
-            sb.hist[1] = h0.y;
-            sb.hist[2] = h0.z;
-            sb.hist[3] = h0.w;
-            sb.hist[4] = h1.x;
-            sb.hist[5] = h1.y;
-            sb.hist[6] = h1.z;
-            sb.hist[7] = h1.w;
+            sb.hist[0] = x.h0.x;
+            sb.hist[1] = x.h0.y;
+            sb.hist[2] = x.h0.z;
+            sb.hist[3] = x.h0.w;
+            sb.hist[4] = x.h1.x;
+            sb.hist[5] = x.h1.y;
+            sb.hist[6] = x.h1.z;
+            sb.hist[7] = x.h1.w;
             sb.usum = m2.z;
             sb.sig = (uint64_t)(uint32_t)m2.x | (uint64_t)(uint32_t)m2.y << 32;
             const int uu = fz_common_chars(sa, sb);
             const bool maybe = use_tokens && (sa.sig & sb.sig) != 0ull;
             float ub = fz_upper_bound(sa, sb, mode, uu, maybe ? -1 : 0);
             if (valid && maybe && !(ub + kBoundSlack < cur32)) {
-                // the signatures meet: the exact intersection decides what the token scorers can reach
-                const FuzzTo T = to_of(slot, m);
-                uint32_t ca, cb;
-                fz_intersect<W>(F, T, ca, cb);
-                ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, T, ca, cb, uu) : -1.0f);
+                // the signatures meet: the exact intersection decides what the token scorers can reach.  Up to four
+                // distinct tokens on the to-side (nearly every string) it is decided from registers
+                uint32_t ca = 0u, cb = 0u;
+                if (m.w <= 4) {
+                    const int idb[4] = {x.m4.x, x.m4.y, x.m4.z, x.m4.w};
+                    for (int i = 0; i < F.ta; ++i) {
+                        const int ida = s_tid[i];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (idb[j] == ida) {          // (absent to-tokens are -1, unknown from-tokens <= -2)
+                                ca |= 1u << i;
+                                cb |= 1u << j;
+                            }
+                    }
+                    ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, -1.0f);
+                    if (refine && ca && !(ub + kBoundSlack < cur32)) {
+                        const FuzzTo T = to_of(slot, m);
+                        ub = fz_upper_bound(sa, sb, mode, uu, 1, fz_token_set_bound<W>(F, T, ca, cb, uu));
+                    }
+                }
+                else if (refine) {
+                    const FuzzTo T = to_of(slot, m);
+                    fz_intersect<W>(F, T, ca, cb);
+                    ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, T, ca, cb, uu) : -1.0f);
+                }
             }
             return ub;
         };
@@ -800,7 +854,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         auto score_slot = [&](int slot, bool active) {
             double sc = 0.0;
             int orig = -1;
-            if (active) {
+            if (active && A.exp != 1) {
                 const int4 m = A.b_meta[slot];
                 orig = A.b_meta2[slot].w;
                 FuzzTo T = to_of(slot, m);
@@ -824,18 +878,20 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         int seed_slot = -1;
         int *queue = s_queue[wave];
         int q_head = 0, q_tail = 0;             // wave-uniform; entries [q_head, q_tail) of a ring of 128
+        const int g_step = 4 * parts, g_first = wave + 4 * part;
         for (int phase = 0; phase < 2; ++phase) {
-            for (int g = wave + 4 * part;; g += 4 * parts) {
+            Meta nxt = load_meta(min(g_first, A.n_groups - 1));
+            for (int g = g_first;; g += g_step) {
                 const bool last = g >= A.n_groups;
                 bool want = false;
                 int slot = -1;
                 if (!last) {
+                    const Meta x = nxt;
+                    nxt = load_meta(min(g + g_step, A.n_groups - 1));         // (the last trips re-read a group: harmless)
                     slot = g * 64 + lane;
                     const float cur32 = phase ? (float)cur_now() : 0.0f;
-                    int4 m;
-                    int orig;
                     bool valid;
-                    const float ub = bound_of(slot, cur32, m, orig, valid);
+                    const float ub = bound_of(slot, x, cur32, phase != 0, valid);
                     n_bounded += 1;
                     if (phase == 0) {
                         if (valid && ub > seed_ub) {
@@ -876,6 +932,13 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             const int64_t o = (int64_t)A.row_slot[r] * A.n_parts_total + A.part0 + part;
             A.part_score[o] = best.score;
             A.part_idx[o] = best.idx;
+        }
+        if (A.row_stats) {
+            unsigned long long ns = n_scored - scored_before;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) ns += __shfl_xor(ns, d, 64);
+            if (lane == 0) atomicAdd(&A.row_stats[2 * (int64_t)A.row_slot[r]], ns);
+            if (tid == 0) atomicAdd(&A.row_stats[2 * (int64_t)A.row_slot[r] + 1], (unsigned long long)(wall_clock64() - t_begin));
         }
         // clear this from-string's table entries
         for (int v = 0; v < 3; ++v) {
@@ -1012,14 +1075,14 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     A.cls = pl->cls;
     A.space_rank = pl->space_rank;
     A.space_class = pl->space_class;
-    for (int v = 0; v < 3; ++v) A.b_sym[v] = pl->sym[v];
+    A.b_sym = pl->sym;
     A.b_tag = pl->tag;
-    A.b_goff = pl->goff;
-    A.b_tgoff = pl->tgoff;
     A.b_tok_id = pl->tok_id;
     A.b_tok_len = pl->tok_len;
     A.b_meta = pl->meta;
     A.b_meta2 = pl->meta2;
+    A.b_meta3 = pl->meta3;
+    A.b_meta4 = pl->meta4;
     A.b_hist = pl->hist;
     A.n_groups = (int32_t)pl->n_groups;
     A.n_sym1 = pl->n_sym + 1;
@@ -1050,6 +1113,16 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     A.part_idx = (int32_t *)d_pi.p;
 
     DevBuf d_rows[4] = {DevBuf(ctx), DevBuf(ctx), DevBuf(ctx), DevBuf(ctx)}, d_slots[4] = {DevBuf(ctx), DevBuf(ctx), DevBuf(ctx), DevBuf(ctx)};
+    DevBuf d_next(ctx), d_stats(ctx);
+    PFZ_TRY(d_next.alloc(4 * sizeof(int32_t)));
+    PFZ_HIP(hipMemsetAsync(d_next.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    const char *stats_path = getenv("PFZ_K7_ROW_STATS");
+    if (stats_path) {
+        PFZ_TRY(d_stats.alloc((size_t)n_rows * 2 * sizeof(unsigned long long)));
+        PFZ_HIP(hipMemsetAsync(d_stats.p, 0, (size_t)n_rows * 2 * sizeof(unsigned long long), ctx->stream));
+        A.row_stats = (unsigned long long *)d_stats.p;
+    }
+    if (const char *e = getenv("PFZ_K7_EXP")) A.exp = atoi(e);
     for (int c = 0; c < 3; ++c) {
         if (cls[c].empty() || n_to == 0) continue;
         PFZ_TRY(d_rows[c].upload(cls[c]));
@@ -1059,6 +1132,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.n_rows = (int32_t)cls[c].size();
         A.parts = parts_of[c];
         A.part0 = 0;
+        A.next_unit = (int32_t *)d_next.p + c;
         const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
         const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t);
         ProfScope ps(ctx, "k7_fuzz");
@@ -1104,6 +1178,14 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         PFZ_HIP(hipGetLastError());
     }
     if (h_counters) PFZ_TRY(copy_d2h(ctx, h_counters, d_counters.p, 4 * sizeof(unsigned long long)));
+    if (stats_path) {
+        std::vector<unsigned long long> st((size_t)n_rows * 2);
+        PFZ_TRY(copy_d2h(ctx, st.data(), d_stats.p, st.size() * sizeof(unsigned long long)));
+        if (FILE *fp = fopen(stats_path, "wb")) {
+            fwrite(st.data(), sizeof(unsigned long long), st.size(), fp);
+            fclose(fp);
+        }
+    }
     return PFZ_OK;
 }
 

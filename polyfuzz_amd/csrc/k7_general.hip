@@ -26,7 +26,7 @@ __device__ inline uint32_t g_load_unit(const void *p, int width, int64_t i)
 
 
 // a string the DP walks: a form of the from-string (code units mapped through the alphabet) or of the lane's to-string
-// (symbol ranks, [position][lane]), optionally only the tokens whose flag byte is zero, joined by single spaces
+// (symbol ranks, its record of the plan), optionally only the tokens whose flag byte is zero, joined by single spaces
 struct Seq {
     // from-form: chars != NULL; to-form: sym != NULL
     const void *chars;
@@ -38,7 +38,7 @@ struct Seq {
     int len;
     __device__ int at(int p) const
     {
-        if (sym) return (int)sym[(int64_t)p * 64];
+        if (sym) return (int)sym[p];
         const uint32_t c = g_load_unit(chars, width, base + p);
         return c < lut_len ? (int)lut[c] : -1 - (int)c;      // a from-character outside the to-alphabet matches nothing of the to-side
     }
@@ -171,12 +171,11 @@ __global__ __launch_bounds__(256) void k7_general_kernel(FuzzArgs A, GeneralScra
             const int4 m = A.b_meta[slot];
             const int orig = A.b_meta2[slot].w;
             if (orig < 0 || orig == skip) continue;
-            const int g = slot >> 6, l = slot & 63;
-            const int64_t go = A.b_goff[g] + l, tg = A.b_tgoff[g] + l;
+            const int4 rec = A.b_meta3[slot];
             const int lb[3] = {m.x, m.y, m.z}, tb = m.w;
             Seq fb[3];
-            for (int v = 0; v < 3; ++v) fb[v] = Seq{nullptr, 0, 0, nullptr, 0, A.b_sym[v] + go, lb[v]};
-            const int32_t *b_id = A.b_tok_id + tg, *b_len = A.b_tok_len + tg;
+            for (int v = 0; v < 3; ++v) fb[v] = Seq{nullptr, 0, 0, nullptr, 0, A.b_sym + rec.x + (int64_t)v * rec.w, lb[v]};
+            const int32_t *b_id = A.b_tok_id + rec.z, *b_len = A.b_tok_len + rec.z;
 
             // the joined differences of the distinct-token sets (and what token_set_ratio needs of the intersection)
             int nc = 0, sect_len = 0;
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(256) void k7_general_kernel(FuzzArgs A, GeneralScra
                 for (int i = 0; i < ta; ++i) {
                     const int id = A.a_tok_id[atb + i], len = A.a_tok_len[atb + i], pos = a_tok_pos[atb + i];
                     bool common = false;
-                    for (int j = 0; j < tb && !common; ++j) common = b_id[(int64_t)j * 64] == id;
+                    for (int j = 0; j < tb && !common; ++j) common = b_id[j] == id;
                     if (common) {
                         sect_len += len + (nc ? 1 : 0);
                         ++nc;
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(256) void k7_general_kernel(FuzzArgs A, GeneralScra
                 int nb = 0, posb = 0;
                 first = 1;
                 for (int j = 0; j < tb; ++j) {
-                    const int id = b_id[(int64_t)j * 64], len = b_len[(int64_t)j * 64];
+                    const int id = b_id[j], len = b_len[j];
                     bool common = false;
                     for (int i = 0; i < ta && !common; ++i) common = A.a_tok_id[atb + i] == id;
                     if (!common) {

@@ -82,7 +82,6 @@ static void run(int n_sym, const List &A, const List &B, int mode, const double 
             T.tag = B.tag + B.off[2][j];
             T.tok_id = B.tok_id + B.tok_off[j];
             T.tok_len = B.tok_len + B.tok_off[j];
-            T.stride = 1;
             T.stage = nullptr;
             T.stage_stride = 0;
             T.staged = -1;

@@ -1,0 +1,37 @@
+"""Where K7's time goes, row by row (PFZ_K7_ROW_STATS): pairs scored and clock ticks of every from-title of config 3's lists,
+against its length / tokens; and the kernel with scoring switched off (PFZ_K7_EXP=1: the two bounding sweeps alone)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import polyfuzz_amd
+from polyfuzz_amd import _lib, datasets
+ctx = polyfuzz_amd.Context.default()
+fl, tl = datasets.c3_lists()
+mode = sys.argv[1] if len(sys.argv) > 1 else "WRatio"
+f_dev, t_dev = _lib.DeviceStrings.upload(ctx, fl), _lib.DeviceStrings.upload(ctx, tl)
+out = _lib.DeviceTopN.alloc(ctx, len(fl), 2)
+def run(label, reps=3):
+    _lib.fuzz_extract_one_dev(ctx, f_dev, t_dev, mode, out); ctx.sync()
+    ctx.prof_enable(True); ctx.prof_reset()
+    for _ in range(reps): _lib.fuzz_extract_one_dev(ctx, f_dev, t_dev, mode, out)
+    ctx.sync(); k_ms, _ = ctx.prof_get("k7_fuzz"); ctx.prof_enable(False)
+    print(f"{label}: k7_fuzz {k_ms / reps:.2f} ms")
+run("as shipped")
+os.environ["PFZ_K7_EXP"] = "1"; run("bounds only (no scoring)"); del os.environ["PFZ_K7_EXP"]
+path = "/tmp/k7_stats.bin"
+os.environ["PFZ_K7_ROW_STATS"] = path
+_lib.fuzz_extract_one_dev(ctx, f_dev, t_dev, mode, out); ctx.sync()
+del os.environ["PFZ_K7_ROW_STATS"]
+st = np.fromfile(path, np.uint64).reshape(-1, 2).astype(np.float64)
+scored, ticks = st[:, 0], st[:, 1]
+L = np.array([len(s) for s in fl]); T = np.array([len(set(s.split())) for s in fl])
+idx, score = _lib.best_from_topn(*out.download())
+print("ticks per row: pct", np.percentile(ticks, [1, 25, 50, 75, 90, 99, 100]).round(0), "sum", ticks.sum(), "(100 MHz clock: 1 tick = 10 ns)")
+print("scored per row: pct", np.percentile(scored, [1, 25, 50, 75, 90, 99, 100]).round(0))
+for lo, hi in ((0, 4), (5, 8), (9, 12), (13, 16), (17, 24), (25, 32), (33, 64), (65, 999)):
+    m = (L >= lo) & (L <= hi)
+    if m.any():
+        print(f"len {lo:3d}-{hi:3d}: rows {m.sum():6d}  scored/row {scored[m].mean():9.0f}  us/row {ticks[m].mean() / 100:9.1f}  share of time {ticks[m].sum() / ticks.sum():.3f}  mean best {score[m].mean():.1f}")
+order = np.argsort(-ticks)[:12]
+for i in order: print(f"  {ticks[i] / 100:9.1f} us  scored {scored[i]:7.0f}  best {score[i]:.1f}  {fl[i]!r}")
+print("corr(ticks, scored)", np.corrcoef(ticks, scored)[0, 1])
