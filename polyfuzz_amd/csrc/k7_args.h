@@ -38,6 +38,14 @@ struct FuzzArgs {
     unsigned long long *row_stats;
     int32_t exp;                     // 1: bound only, score nothing (results wrong)
     int32_t *next_unit;              // dynamic distribution of the (row, part) units over the workgroups
+    // hand-over of heavy rows: a wave that has scored many batches of one from-string and still has most of the to-groups
+    // ahead appends {row position r, next group, group step, 0} (+ the best score found so far) to cont_list and goes
+    // on to the next row; a second launch (cont_mode = 1) spreads every such remainder over cont_parts waves, each starting
+    // from that score.  Exact: the remainder is the same set of pairs, bounded against a score that is really attained.
+    int4 *cont_list;
+    unsigned long long *cont_cur;
+    int32_t *n_cont;
+    int32_t cont_cap, cont_mode, cont_parts, cont_part0, hand_batches, hand_min_groups;
 };
 
 }  // namespace pfz

@@ -461,27 +461,33 @@ PFZ_HD int fz_common_chars(const FuzzSummary &a, const FuzzSummary &b)
     return (a.usum + b.usum - sad) >> 1;
 }
 
-PFZ_HD float fz_r32(int lcs, int lensum) { return lensum > 0 ? 200.0f * (float)lcs / (float)lensum : 100.0f; }
-
-// token_set_ratio's bound once the common tokens are known (ca / cb as fz_intersect leaves them): the two "sect" ratios
-// are length arithmetic -- exact -- and the LCS of the joined differences is at most the shorter difference and at most
-// u minus the characters of the common tokens (they sit in both histograms and in neither difference)
-template <int W>
-PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t ca, uint32_t cb, int u)
+// 200 lcs / lensum with the hardware reciprocal (1 ulp; the caller's slack is five orders of magnitude wider): a correctly
+// rounded float division is ten instructions, and the bound of one pair holds up to seven of them
+PFZ_HD float fz_r32(int lcs, int lensum)
 {
-    const int ta = F.ta, tb = T.tb;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return lensum > 0 ? 200.0f * (float)lcs * __builtin_amdgcn_rcpf((float)lensum) : 100.0f;
+#else
+    return lensum > 0 ? 200.0f * (float)lcs / (float)lensum : 100.0f;
+#endif
+}
+
+// token_set_ratio's bound once the common tokens of the from-string are known (bit i of ca; lb2 / tb: the to-string's
+// form-2 length and distinct tokens): the two "sect" ratios are length arithmetic -- exact -- and the LCS of the joined
+// differences is at most the shorter difference and at most u minus the characters of the common tokens (they sit in both
+// histograms and in neither difference).  Only from-side token lengths are needed: a form 2 is its tokens joined by
+// single spaces, so the to-side difference is what is left of its length.
+template <int W>
+PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, uint32_t ca, int lb2, int tb, int u)
+{
+    const int ta = F.ta;
     if (ta == 0 || tb == 0) return 0.0f;
     const int nc = fz_popc32(ca);
     if (nc > 0 && (nc == ta || nc == tb)) return 100.0f;
-    const uint32_t ra = ~ca & (ta >= 32 ? ~0u : ((1u << ta) - 1u)), rb = ~cb & (tb >= 32 ? ~0u : ((1u << tb) - 1u));
-    int ab_len = fz_popc32(ra) - 1, ba_len = fz_popc32(rb) - 1, sect_chars = 0;
-    for (int i = 0; i < ta; ++i) {
-        const bool rem = (ra >> i) & 1u;
-        ab_len += rem ? F.tlen[i] : 0;
-        sect_chars += rem ? 0 : F.tlen[i];
-    }
-    for (int j = 0; j < tb; ++j)
-        if ((rb >> j) & 1u) ba_len += T.tok_len[j];
+    int sect_chars = 0;
+    for (int i = 0; i < ta; ++i) sect_chars += ((ca >> i) & 1u) ? F.tlen[i] : 0;
+    // joined length of k tokens with c characters in total: c + k - 1
+    const int ab_len = (F.la[2] - (ta - 1) - sect_chars) + (ta - nc) - 1, ba_len = (lb2 - (tb - 1) - sect_chars) + (tb - nc) - 1;
     const int sect_len = sect_chars + (nc > 0 ? nc - 1 : 0), sect_sep = sect_len != 0 ? 1 : 0;
     const int sect_ab_len = sect_len + sect_sep + ab_len, sect_ba_len = sect_len + sect_sep + ba_len;
     const int m = fz_min(fz_min(ab_len, ba_len), fz_max(u - sect_chars, 0));

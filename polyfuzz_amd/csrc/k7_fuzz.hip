@@ -45,7 +45,12 @@
 
 namespace pfz {
 
-constexpr float kBoundSlack = 0.05f;      // a pair is dismissed only when bound + slack < cur (float32 bound, float64 scores)
+// One from-string per WAVE (a one-wave workgroup): what a from-string costs on top of its pairs -- the bounding sweeps, a
+// batch of seeds, a last partial batch -- is paid per wave that works on it, and four waves sharing one from-string paid
+// it four times over (20 000 x 20 000 titles: 47 -> ... ms).  More waves per workgroup = fewer from-strings in flight.
+constexpr int kK7Waves = 1, kK7Threads = 64 * kK7Waves;
+constexpr float kBoundSlack = 0.05f;
+constexpr int kHandBatches = 12, kHandMinGroups = 16, kContParts = 16;      // heavy-row hand-over (see FuzzArgs::cont_list)      // a pair is dismissed only when bound + slack < cur (float32 bound, float64 scores)
 
 __device__ inline uint32_t load_unit(const void *p, int width, int64_t i)
 {
@@ -645,7 +650,7 @@ __device__ inline int work_estimate(const int (&la)[3], const int4 &m, int mode,
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
+__global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *pm = (uint64_t *)smem_raw;               // [symbol][form][word]
@@ -654,16 +659,16 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
     __shared__ uint64_t s_tmask[kFuzzMaxTokens * W], s_smask[kFuzzMaxTokens * W];
     __shared__ int s_cnt[4 * kFuzzHistWords];
     __shared__ uint32_t s_hist[kFuzzHistWords], s_sig[2];
-    __shared__ double red_s[4];
-    __shared__ int red_i[4];
+    __shared__ double red_s[kK7Waves];
+    __shared__ int red_i[kK7Waves];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
-    __shared__ int s_queue[4][128];
-    __shared__ uint16_t s_stage[4][kFuzzStage][64];       // per wave: [position][lane] symbols of the form a lane sweeps
+    __shared__ int s_queue[kK7Waves][128];
+    __shared__ uint16_t s_stage[kK7Waves][kFuzzStage][64];       // per wave: [position][lane] symbols of the form a lane sweeps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
     const bool use_tokens = mode_uses_tokens(mode);
 
-    for (int p = tid; p < A.n_sym1 * 3 * W; p += 256) pm[p] = 0ull;
+    for (int p = tid; p < A.n_sym1 * 3 * W; p += kK7Threads) pm[p] = 0ull;
     unsigned long long n_bounded = 0, n_scored = 0, n_steps = 0;
     __syncthreads();
 
@@ -674,23 +679,40 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         if (tid == 0) s_unit = atomicAdd(A.next_unit, 1);
         __syncthreads();
         const int u = s_unit;
-        if (u >= A.n_rows * parts) break;
+        const bool is_cont = A.cont_mode != 0;
+        if (u >= (is_cont ? min(*A.n_cont, A.cont_cap) * A.cont_parts : A.n_rows * parts)) break;
         const long long t_begin = A.row_stats ? wall_clock64() : 0;
         const unsigned long long scored_before = n_scored;
-        const int r = u / parts, part = u - r * parts;
+        int r, part, g_first, g_step;
+        unsigned long long cur0 = 0ull;
+        if (!is_cont) {
+            r = u / parts;
+            part = u - r * parts;
+            g_first = wave + kK7Waves * part;
+            g_step = kK7Waves * parts;
+        }
+        else {                       // the remainder of a heavy row: its groups g_next, g_next + step, ... dealt to cont_parts units
+            const int c = u / A.cont_parts;
+            part = u - c * A.cont_parts;
+            const int4 rec = A.cont_list[c];
+            r = rec.x;
+            g_first = rec.y + (wave + kK7Waves * part) * rec.z;
+            g_step = rec.z * kK7Waves * A.cont_parts;
+            cur0 = A.cont_cur[c];
+        }
         const int row = A.rows[r];
         const int64_t a0 = A.a_off[row];
         // ---- the from-string's tables, class histogram, tokens
         if (tid < 4 * kFuzzHistWords) s_cnt[tid] = 0;
         if (tid == 0) {
             s_nspace = 0;
-            s_best = 0ull;
+            s_best = cur0;
         }
         __syncthreads();
         for (int v = 0; v < 3; ++v) {
             const int m = v == 0 ? (int)(A.a_off[row + 1] - a0) : (v == 1 ? A.a_len1[row] : A.a_len2[row]);
             if (tid == 0) s_la[v] = m;
-            for (int p = tid; p < m; p += 256) {
+            for (int p = tid; p < m; p += kK7Threads) {
                 const uint32_t c = load_unit(A.a_form[v], A.a_width, a0 + p);
                 const int sy = c < A.lut_len ? (int)A.lut[c] : 0;
                 if (sy) {
@@ -797,17 +819,16 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             x.h1 = A.b_hist[(g * 2 + 1) * 64 + lane];
             return x;
         };
-        // float32 upper bound of the pair (from-string, slot); valid = a real candidate of this kernel.  When the token
-        // signatures meet, the exact intersection is taken from registers (to-strings of up to four distinct tokens);
-        // refine (sweep 2): also what needs the string's record -- more tokens, token_set_ratio's length arithmetic
-        auto bound_of = [&](int slot, const Meta &x, float cur32, bool refine, bool &valid) -> float {
-            const int4 m = x.m, m2 = x.m2;
-            valid = m2.w >= 0 && m2.w != skip && m.w <= kFuzzMaxTokens;
+        // float32 upper bound of the pair (from-string, to-string x) FROM REGISTERS ONLY; valid = a real candidate of this
+        // kernel.  When the token signatures meet, the exact intersection is taken from the first four token ids (nearly
+        // every to-string has no more); `coarse` = the signatures meet but the string has more tokens: the bound assumes
+        // the best, and the pair is looked at again -- with its record -- when it is popped from the queue.
+        auto summary_of = [&](const Meta &x) {
             FuzzSummary sb;
-            sb.len[0] = m.x;
-            sb.len[1] = m.y;
-            sb.len[2] = m.z;
-            sb.ntok = m.w;
+            sb.len[0] = x.m.x;
+            sb.len[1] = x.m.y;
+            sb.len[2] = x.m.z;
+            sb.ntok = x.m.w;
             sb.hist[0] = x.h0.x;
             sb.hist[1] = x.h0.y;
             sb.hist[2] = x.h0.z;
@@ -816,52 +837,65 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
             sb.hist[5] = x.h1.y;
             sb.hist[6] = x.h1.z;
             sb.hist[7] = x.h1.w;
-            sb.usum = m2.z;
-            sb.sig = (uint64_t)(uint32_t)m2.x | (uint64_t)(uint32_t)m2.y << 32;
+            sb.usum = x.m2.z;
+            sb.sig = (uint64_t)(uint32_t)x.m2.x | (uint64_t)(uint32_t)x.m2.y << 32;
+            return sb;
+        };
+        auto bound_of = [&](const Meta &x, float cur32, bool &valid, bool &coarse) -> float {
+            const int4 m = x.m;
+            valid = x.m2.w >= 0 && x.m2.w != skip && m.w <= kFuzzMaxTokens;
+            coarse = false;
+            const FuzzSummary sb = summary_of(x);
             const int uu = fz_common_chars(sa, sb);
             const bool maybe = use_tokens && (sa.sig & sb.sig) != 0ull;
             float ub = fz_upper_bound(sa, sb, mode, uu, maybe ? -1 : 0);
             if (valid && maybe && !(ub + kBoundSlack < cur32)) {
-                // the signatures meet: the exact intersection decides what the token scorers can reach.  Up to four
-                // distinct tokens on the to-side (nearly every string) it is decided from registers
-                uint32_t ca = 0u, cb = 0u;
                 if (m.w <= 4) {
+                    uint32_t ca = 0u;
                     const int idb[4] = {x.m4.x, x.m4.y, x.m4.z, x.m4.w};
                     for (int i = 0; i < F.ta; ++i) {
-                        const int ida = s_tid[i];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (idb[j] == ida) {          // (absent to-tokens are -1, unknown from-tokens <= -2)
-                                ca |= 1u << i;
-                                cb |= 1u << j;
-                            }
+                        const int ida = s_tid[i];          // (absent to-tokens are -1, unknown from-tokens <= -2)
+                        ca |= (uint32_t)((idb[0] == ida) | (idb[1] == ida) | (idb[2] == ida) | (idb[3] == ida)) << i;
                     }
-                    ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, -1.0f);
-                    if (refine && ca && !(ub + kBoundSlack < cur32)) {
-                        const FuzzTo T = to_of(slot, m);
-                        ub = fz_upper_bound(sa, sb, mode, uu, 1, fz_token_set_bound<W>(F, T, ca, cb, uu));
-                    }
+                    ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, ca, m.z, m.w, uu) : -1.0f);
                 }
-                else if (refine) {
-                    const FuzzTo T = to_of(slot, m);
-                    fz_intersect<W>(F, T, ca, cb);
-                    ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, T, ca, cb, uu) : -1.0f);
-                }
+                else coarse = true;
             }
             return ub;
         };
         RowBest best = {-1.0, INT_MAX};
-        auto score_slot = [&](int slot, bool active) {
+        // a popped queue entry: bit 31 = the pair's bound was coarse -- it is bounded again with the exact token
+        // intersection first (64 lanes at a time: one memory round trip for all of them), then scored if it still can win
+        auto score_slot = [&](int entry, bool active) {
             double sc = 0.0;
             int orig = -1;
             if (active && A.exp != 1) {
+                const int slot = entry & 0x7fffffff;
                 const int4 m = A.b_meta[slot];
                 orig = A.b_meta2[slot].w;
                 FuzzTo T = to_of(slot, m);
-                sc = fz_score<W>(F, T, mode, cur_now());
-                best.take(sc, orig);
-                n_scored += 1;
-                n_steps += (unsigned long long)work_estimate(F.la, m, mode, W);
+                bool go = true;
+                const double cur = cur_now();
+                if (entry < 0) {
+                    Meta x;
+                    x.m = m;
+                    x.m2 = A.b_meta2[slot];
+                    x.m4 = make_int4(-1, -1, -1, -1);
+                    x.h0 = A.b_hist[((slot >> 6) * 2 + 0) * 64 + (slot & 63)];
+                    x.h1 = A.b_hist[((slot >> 6) * 2 + 1) * 64 + (slot & 63)];
+                    const FuzzSummary sb = summary_of(x);
+                    const int uu = fz_common_chars(sa, sb);
+                    uint32_t ca, cb;
+                    fz_intersect<W>(F, T, ca, cb);
+                    const float ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, ca, m.z, m.w, uu) : -1.0f);
+                    go = !(ub + kBoundSlack < (float)cur);
+                }
+                if (go) {
+                    sc = fz_score<W>(F, T, mode, cur);
+                    best.take(sc, orig);
+                    n_scored += 1;
+                    n_steps += (unsigned long long)work_estimate(F.la, m, mode, W);
+                }
             }
             // publish the wave's best score to the workgroup
             double wb = active ? fmax(sc, 0.0) : 0.0;
@@ -878,11 +912,12 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         int seed_slot = -1;
         int *queue = s_queue[wave];
         int q_head = 0, q_tail = 0;             // wave-uniform; entries [q_head, q_tail) of a ring of 128
-        const int g_step = 4 * parts, g_first = wave + 4 * part;
-        for (int phase = 0; phase < 2; ++phase) {
+        int batches = 0;
+        bool handed = false;
+        for (int phase = is_cont ? 1 : 0; phase < 2; ++phase) {
             Meta nxt = load_meta(min(g_first, A.n_groups - 1));
             for (int g = g_first;; g += g_step) {
-                const bool last = g >= A.n_groups;
+                const bool last = g >= A.n_groups || handed;
                 bool want = false;
                 int slot = -1;
                 if (!last) {
@@ -890,16 +925,19 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                     nxt = load_meta(min(g + g_step, A.n_groups - 1));         // (the last trips re-read a group: harmless)
                     slot = g * 64 + lane;
                     const float cur32 = phase ? (float)cur_now() : 0.0f;
-                    bool valid;
-                    const float ub = bound_of(slot, x, cur32, phase != 0, valid);
+                    bool valid, coarse;
+                    const float ub = bound_of(x, cur32, valid, coarse);
                     n_bounded += 1;
                     if (phase == 0) {
-                        if (valid && ub > seed_ub) {
+                        if (valid && !coarse && ub > seed_ub) {       // (a coarse bound says little: not a seed)
                             seed_ub = ub;
                             seed_slot = slot;
                         }
                     }
-                    else want = valid && slot != seed_slot && !(ub + kBoundSlack < cur32);
+                    else {
+                        want = valid && slot != seed_slot && !(ub + kBoundSlack < cur32);
+                        slot |= coarse ? (int)0x80000000 : 0;
+                    }
                 }
                 else if (phase == 0) {
                     slot = seed_slot;
@@ -913,9 +951,23 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
                     const bool active = lane < q_tail - q_head;
                     score_slot(active ? queue[(q_head + lane) & 127] : -1, active);
                     q_head += min(64, q_tail - q_head);
+                    ++batches;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
                 if (last) break;
+                if (phase == 1 && !is_cont && A.cont_list && batches >= A.hand_batches && A.n_groups - g > A.hand_min_groups * g_step) {
+                    // a heavy row: leave the rest of its groups to several waves (they start from the best score so far)
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(A.n_cont, 1);
+                    at = __builtin_amdgcn_readfirstlane(at);
+                    if (at < A.cont_cap) {
+                        if (lane == 0) {
+                            A.cont_list[at] = make_int4(r, g + g_step, g_step, 0);
+                            A.cont_cur[at] = __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        handed = true;           // (the next trip flushes the queue and ends the loop)
+                    }
+                }
             }
             if (phase == 0) __syncthreads();        // every wave's seeds are scored: `cur` is what the workgroup knows
         }
@@ -928,8 +980,8 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w) best.take(red_s[w], red_i[w]);
-            const int64_t o = (int64_t)A.row_slot[r] * A.n_parts_total + A.part0 + part;
+            for (int w = 1; w < kK7Waves; ++w) best.take(red_s[w], red_i[w]);
+            const int64_t o = (int64_t)A.row_slot[r] * A.n_parts_total + (is_cont ? A.cont_part0 : A.part0) + part;
             A.part_score[o] = best.score;
             A.part_idx[o] = best.idx;
         }
@@ -943,7 +995,7 @@ __global__ __launch_bounds__(256) void k7_fuzz_kernel(FuzzArgs A)
         // clear this from-string's table entries
         for (int v = 0; v < 3; ++v) {
             const int m = s_la[v];
-            for (int p = tid; p < m; p += 256) {
+            for (int p = tid; p < m; p += kK7Threads) {
                 const uint32_t c = load_unit(A.a_form[v], A.a_width, a0 + p);
                 const int sy = c < A.lut_len ? (int)A.lut[c] : 0;
 #pragma unroll
@@ -1092,17 +1144,17 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
 
     // how many workgroups share a from-string's to-groups (few from-strings: split, as K4 does), per class; then one slot for
     // the general kernel's "to-strings with more than 32 tokens" pass and one for its own rows
-    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 4;
+    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * (16 / kK7Waves);      // (persistent workgroups: units are handed out)
     int32_t parts_of[3] = {1, 1, 1}, max_parts = 1;
     for (int c = 0; c < 3; ++c) {
         if (cls[c].empty()) continue;
         const int64_t n = (int64_t)cls[c].size();
-        const int64_t want = (2 * max_grid + n - 1) / n, cap = std::max<int64_t>(1, pl->n_groups / 4);
+        const int64_t want = (2 * max_grid + n - 1) / n, cap = std::max<int64_t>(1, pl->n_groups / (4 * kK7Waves));
         parts_of[c] = (int32_t)std::max<int64_t>(1, std::min(want, cap));
         if (const char *e = getenv("PFZ_K7_PARTS")) parts_of[c] = std::max(1, atoi(e));
         max_parts = std::max(max_parts, parts_of[c]);
     }
-    const int32_t n_parts_total = max_parts + 1;
+    const int32_t n_parts_total = max_parts + 1 + kContParts;
     DevBuf d_ps(ctx), d_pi(ctx);
     PFZ_TRY(d_ps.alloc((size_t)n_rows * n_parts_total * sizeof(double)));
     PFZ_TRY(d_pi.alloc((size_t)n_rows * n_parts_total * sizeof(int32_t)));
@@ -1113,9 +1165,13 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     A.part_idx = (int32_t *)d_pi.p;
 
     DevBuf d_rows[4] = {DevBuf(ctx), DevBuf(ctx), DevBuf(ctx), DevBuf(ctx)}, d_slots[4] = {DevBuf(ctx), DevBuf(ctx), DevBuf(ctx), DevBuf(ctx)};
-    DevBuf d_next(ctx), d_stats(ctx);
-    PFZ_TRY(d_next.alloc(4 * sizeof(int32_t)));
-    PFZ_HIP(hipMemsetAsync(d_next.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    DevBuf d_next(ctx), d_stats(ctx), d_cont(ctx), d_cont_cur(ctx);
+    PFZ_TRY(d_next.alloc(16 * sizeof(int32_t)));          // [0..2] unit counters, [4..6] continuation unit counters, [8..10] continuation counts
+    PFZ_HIP(hipMemsetAsync(d_next.p, 0, 16 * sizeof(int32_t), ctx->stream));
+    const int32_t cont_cap = (int32_t)std::min<int64_t>(n_rows, 1 << 20);
+    PFZ_TRY(d_cont.alloc((size_t)cont_cap * 3 * sizeof(int4)));
+    PFZ_TRY(d_cont_cur.alloc((size_t)cont_cap * 3 * sizeof(unsigned long long)));
+    const bool hand_over = !getenv("PFZ_K7_NO_HANDOVER");
     const char *stats_path = getenv("PFZ_K7_ROW_STATS");
     if (stats_path) {
         PFZ_TRY(d_stats.alloc((size_t)n_rows * 2 * sizeof(unsigned long long)));
@@ -1132,15 +1188,30 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.n_rows = (int32_t)cls[c].size();
         A.parts = parts_of[c];
         A.part0 = 0;
-        A.next_unit = (int32_t *)d_next.p + c;
-        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
         const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t);
+        A.cont_list = hand_over ? (int4 *)d_cont.p + (size_t)c * cont_cap : nullptr;
+        A.cont_cur = (unsigned long long *)d_cont_cur.p + (size_t)c * cont_cap;
+        A.n_cont = (int32_t *)d_next.p + 8 + c;
+        A.cont_cap = cont_cap;
+        A.cont_parts = kContParts;
+        A.hand_batches = kHandBatches;
+        A.hand_min_groups = kHandMinGroups;
+        if (const char *e = getenv("PFZ_K7_HAND_BATCHES")) A.hand_batches = atoi(e), A.hand_min_groups = 0;      // tests: hand over early
+        A.cont_part0 = max_parts + 1;
         ProfScope ps(ctx, "k7_fuzz");
-        if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(256), lds, ctx->stream, A);
-        else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, A);
-        else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(256), lds, ctx->stream, A);
-        PFZ_HIP(hipGetLastError());
+        // the rows, then the remainders of the heavy ones (as many as the first launch hands over: it reads the count)
+        for (int pass = 0; pass < (hand_over ? 2 : 1); ++pass) {
+            A.cont_mode = pass;
+            A.next_unit = (int32_t *)d_next.p + (pass ? 4 : 0) + c;
+            const unsigned grid = (unsigned)(pass ? max_grid : std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid));
+            if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, ctx->stream, A);
+            else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, ctx->stream, A);
+            else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, ctx->stream, A);
+            PFZ_HIP(hipGetLastError());
+        }
     }
+    A.cont_list = nullptr;
+    A.cont_mode = 0;
     if (n_to > 0) {
         // the general kernel: its own from-rows against every to-string, and every OTHER from-row against the to-strings
         // the kernels above left out (more than 32 distinct tokens)

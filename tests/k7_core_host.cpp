@@ -97,7 +97,7 @@ static void run(int n_sym, const List &A, const List &B, int mode, const double 
             if (maybe) {
                 uint32_t ca, cb;
                 fz_intersect<W>(F, T, ca, cb);
-                const float ub2 = fz_upper_bound(sa, sb, mode, u, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, T, ca, cb, u) : -1.0f);
+                const float ub2 = fz_upper_bound(sa, sb, mode, u, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, ca, T.lb[2], T.tb, u) : -1.0f);
                 if (ub2 > ub + 1e-3f) ub = -1000.0f;      // the refined bound must never exceed the coarse one (flagged for the test)
                 else ub = ub2;
             }

@@ -121,6 +121,21 @@ def test_strings_beyond_the_fast_kernel(ctx, oracle_mod, monkeypatch):
     assert idx[0] == -1 and score[0] == 0.0
 
 
+def test_heavy_row_hand_over(ctx, oracle_mod, monkeypatch):
+    """PFZ_K7_HAND_BATCHES=1: every from-string that scores a second batch leaves the rest of its to-groups to the
+    continuation launch (16 units starting from the score reached) -- same answers, bit for bit"""
+    from polyfuzz_amd import _lib, datasets
+    fl, tl = datasets.c3_lists(3000)
+    fl = fl[:150]
+    monkeypatch.setenv("PFZ_K7_HAND_BATCHES", "1")
+    t_dev = _lib.DeviceStrings.upload(ctx, tl)
+    for mode in ("WRatio", "partial_ratio", "token_ratio"):
+        idx, score = _lib.fuzz_extract_one(ctx, fl, t_dev, mode)
+        e_idx, e_score = oracle_mod.fuzz_extract_one(fl, tl, mode)
+        np.testing.assert_array_equal(score, e_score, err_msg=mode)
+        np.testing.assert_array_equal(idx, e_idx, err_msg=mode)
+
+
 def test_prepared_lists_equal_the_python_statement(ctx):
     """the device-built forms / plan drive the same scores as tests/k7_prep.py's plain-Python statement drives through the
     CPU build of k7_core.h (tests/test_k7_core_cpu.py): here the end-to-end check is against the oracle on lists with
