@@ -47,10 +47,10 @@ namespace pfz {
 
 // One from-string per WAVE (a one-wave workgroup): what a from-string costs on top of its pairs -- the bounding sweeps, a
 // batch of seeds, a last partial batch -- is paid per wave that works on it, and four waves sharing one from-string paid
-// it four times over (20 000 x 20 000 titles: 47 -> ... ms).  More waves per workgroup = fewer from-strings in flight.
+// it four times over (the 100 000-name self-match: 0.79 -> 0.49 s).  More waves per workgroup = fewer from-strings in flight.
 constexpr int kK7Waves = 1, kK7Threads = 64 * kK7Waves;
 constexpr float kBoundSlack = 0.05f;
-constexpr int kHandBatches = 12, kHandMinGroups = 16, kContParts = 16;      // heavy-row hand-over (see FuzzArgs::cont_list)      // a pair is dismissed only when bound + slack < cur (float32 bound, float64 scores)
+constexpr int kHandBatches = 32, kHandMinGroups = 16, kContParts = 8;      // heavy-row hand-over (see FuzzArgs::cont_list)      // a pair is dismissed only when bound + slack < cur (float32 bound, float64 scores)
 
 __device__ inline uint32_t load_unit(const void *p, int width, int64_t i)
 {
@@ -1154,7 +1154,11 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         if (const char *e = getenv("PFZ_K7_PARTS")) parts_of[c] = std::max(1, atoi(e));
         max_parts = std::max(max_parts, parts_of[c]);
     }
-    const int32_t n_parts_total = max_parts + 1 + kContParts;
+    int32_t hand_batches = kHandBatches, hand_min_groups = kHandMinGroups, cont_parts = kContParts;
+    if (const char *e = getenv("PFZ_K7_HAND")) sscanf(e, "%d,%d,%d", &hand_batches, &hand_min_groups, &cont_parts);      // tuning
+    if (const char *e = getenv("PFZ_K7_HAND_BATCHES")) hand_batches = atoi(e), hand_min_groups = 0;      // tests: hand over early
+    cont_parts = std::max(1, std::min(cont_parts, 64));
+    const int32_t n_parts_total = max_parts + 1 + cont_parts;
     DevBuf d_ps(ctx), d_pi(ctx);
     PFZ_TRY(d_ps.alloc((size_t)n_rows * n_parts_total * sizeof(double)));
     PFZ_TRY(d_pi.alloc((size_t)n_rows * n_parts_total * sizeof(int32_t)));
@@ -1189,18 +1193,20 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.parts = parts_of[c];
         A.part0 = 0;
         const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t);
-        A.cont_list = hand_over ? (int4 *)d_cont.p + (size_t)c * cont_cap : nullptr;
+        // (only where a row is ONE unit: a row already split over several units would hand over several remainders, and they
+        // would share the continuation's result slots)
+        const bool hand = hand_over && A.parts == 1 && kK7Waves == 1;
+        A.cont_list = hand ? (int4 *)d_cont.p + (size_t)c * cont_cap : nullptr;
         A.cont_cur = (unsigned long long *)d_cont_cur.p + (size_t)c * cont_cap;
         A.n_cont = (int32_t *)d_next.p + 8 + c;
         A.cont_cap = cont_cap;
-        A.cont_parts = kContParts;
-        A.hand_batches = kHandBatches;
-        A.hand_min_groups = kHandMinGroups;
-        if (const char *e = getenv("PFZ_K7_HAND_BATCHES")) A.hand_batches = atoi(e), A.hand_min_groups = 0;      // tests: hand over early
+        A.cont_parts = cont_parts;
+        A.hand_batches = hand_batches;
+        A.hand_min_groups = hand_min_groups;
         A.cont_part0 = max_parts + 1;
         ProfScope ps(ctx, "k7_fuzz");
         // the rows, then the remainders of the heavy ones (as many as the first launch hands over: it reads the count)
-        for (int pass = 0; pass < (hand_over ? 2 : 1); ++pass) {
+        for (int pass = 0; pass < (hand ? 2 : 1); ++pass) {
             A.cont_mode = pass;
             A.next_unit = (int32_t *)d_next.p + (pass ? 4 : 0) + c;
             const unsigned grid = (unsigned)(pass ? max_grid : std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid));

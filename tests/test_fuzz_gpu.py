@@ -128,6 +128,7 @@ def test_heavy_row_hand_over(ctx, oracle_mod, monkeypatch):
     fl, tl = datasets.c3_lists(3000)
     fl = fl[:150]
     monkeypatch.setenv("PFZ_K7_HAND_BATCHES", "1")
+    monkeypatch.setenv("PFZ_K7_PARTS", "1")          # (few from-strings would be split over several units: no hand-over there)
     t_dev = _lib.DeviceStrings.upload(ctx, tl)
     for mode in ("WRatio", "partial_ratio", "token_ratio"):
         idx, score = _lib.fuzz_extract_one(ctx, fl, t_dev, mode)
