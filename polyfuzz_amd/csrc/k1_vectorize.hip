@@ -773,6 +773,61 @@ static int build_sorted_vocab(pfz_ctx *ctx, pfz_tfidf *v, pfz_strings *const lis
     return PFZ_OK;
 }
 
+// Sorted-vocabulary mode across ranks: every rank holds the distinct codes of ITS lists; the vocabulary is their union.
+// The ranks' arrays differ in length, so the lengths are all-gathered first, the arrays padded with all-ones keys to the
+// longest, all-gathered, sorted as one array (the padding sorts to the end and is cut off) and made distinct again --
+// every rank ends with the same vcodes a single-GPU fit on the concatenated lists would build.
+static int merge_sorted_vocab(pfz_ctx *ctx, pfz_comm *comm, pfz_tfidf *v)
+{
+    const int world = comm_world(comm);
+    struct Tmp {
+        void *p = nullptr;
+        ~Tmp() { if (p) pool_free(p); }
+    } sizes, send, gathered, sorted, flags;
+    PFZ_TRY(pool_alloc(ctx, &sizes.p, (size_t)(world + 1) * sizeof(int64_t)));
+    const int64_t mine = v->vocab;
+    PFZ_TRY(copy_h2d(ctx, (int64_t *)sizes.p + world, &mine, sizeof(int64_t)));
+    PFZ_TRY(comm_allgather_bytes(comm, (int64_t *)sizes.p + world, sizes.p, sizeof(int64_t)));
+    std::vector<int64_t> h((size_t)world);
+    PFZ_TRY(copy_d2h(ctx, h.data(), sizes.p, (size_t)world * sizeof(int64_t)));
+    int64_t longest = 0, total = 0;
+    for (int64_t x : h) {
+        longest = std::max(longest, x);
+        total += x;
+    }
+    Tmp old_codes;                        // this rank's own codes: released when the merge is enqueued
+    old_codes.p = v->vcodes;
+    v->vcodes = nullptr;
+    v->vocab = 0;
+    if (total == 0) return PFZ_OK;
+    if ((int64_t)world * longest >= ((int64_t)1 << 31) - 2) {
+        set_error("pfz_tfidf_fit_sharded: %lld distinct n-grams per rank exceed the int32 layout of the sorted-vocabulary path",
+                  (long long)longest);
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    const int64_t padded = (int64_t)world * longest;
+    PFZ_TRY(pool_alloc(ctx, &send.p, (size_t)longest * sizeof(uint64_t)));
+    PFZ_HIP(hipMemsetAsync(send.p, 0xff, (size_t)longest * sizeof(uint64_t), ctx->stream));
+    if (mine > 0) PFZ_HIP(hipMemcpyAsync(send.p, old_codes.p, (size_t)mine * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    PFZ_TRY(pool_alloc(ctx, &gathered.p, (size_t)padded * sizeof(uint64_t)));
+    PFZ_TRY(comm_allgather_bytes(comm, send.p, gathered.p, (size_t)longest * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &sorted.p, (size_t)sort_codes_capacity(padded) * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &flags.p, (size_t)(total + 1) * sizeof(int32_t)));
+    PFZ_TRY(sort_codes_u64(ctx, (const uint64_t *)gathered.p, (uint64_t *)sorted.p, padded));
+    // (the first `total` keys are the real ones: a real all-ones code would be among them, the padding behind)
+    hipLaunchKernelGGL(k_flag_heads, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const uint64_t *)sorted.p, total,
+                       (int32_t *)flags.p);
+    PFZ_TRY(exclusive_scan_i32(ctx, (int32_t *)flags.p, total));
+    int32_t n_distinct = 0;
+    PFZ_TRY(copy_d2h(ctx, &n_distinct, (int32_t *)flags.p + total, sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &v->vcodes, (size_t)n_distinct * sizeof(uint64_t)));
+    hipLaunchKernelGGL(k_scatter_heads, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const uint64_t *)sorted.p, total,
+                       (const int32_t *)flags.p, v->vcodes);
+    PFZ_HIP(hipGetLastError());
+    v->vocab = n_distinct;
+    return PFZ_OK;
+}
+
 static int alloc_vocab_space(pfz_ctx *ctx, pfz_tfidf *v)
 {
     const int64_t n_bits = std::max<int64_t>((int64_t)1 << v->code_bits, 256);
@@ -972,20 +1027,17 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         PFZ_TRY(set_alphabet(ctx, v, cps));
     }
     const bool sorted_vocab = v->code_bits > kBitmapMaxBits;
-    if (sorted_vocab && world > 1) {
-        set_error("pfz_tfidf_fit_sharded: %d-bit n-gram codes use the sorted-vocabulary path, which is single-GPU", v->code_bits);
-        return PFZ_ERR_UNSUPPORTED;
-    }
     if (sorted_vocab) {
         for (pfz_strings *s : lists)
             if (s) PFZ_TRY(run_extract(ctx, v, s, false));
         PFZ_TRY(build_sorted_vocab(ctx, v, lists));
+        if (world > 1) PFZ_TRY(merge_sorted_vocab(ctx, comm, v));      // vocabulary = union of the ranks' distinct codes
     } else {
         PFZ_TRY(alloc_vocab_space(ctx, v));
         for (pfz_strings *s : lists)
             if (s) PFZ_TRY(run_extract(ctx, v, s, true));
     }
-    if (world > 1) {   // vocabulary = union of the ranks' n-gram sets
+    if (world > 1 && !sorted_vocab) {   // vocabulary = union of the ranks' n-gram sets
         const int64_t n_words = v->n_groups * 8;
         if (v->code_bits > 30) {
             set_error("pfz_tfidf_fit_sharded: %d-bit n-gram codes: the bitmap all-gather is limited to 30 bits", v->code_bits);

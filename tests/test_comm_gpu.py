@@ -77,6 +77,34 @@ def test_world2_local_transport_sharded_job(oracle_mod, clean):
         c.free()
 
 
+def test_world2_sharded_fit_of_wide_ngram_codes(oracle_mod):
+    """n_gram_range=(3, 6) -- the range the reference's own test uses (tests/test_polyfuzz.py:111) -- gives 36-bit codes
+    of cleaned text: the sorted-vocabulary path.  Its sharded fit (all-gather of the ranks' distinct codes, one sort,
+    distinct again) must build the vectoriser of the single-context fit; so must (6, 10): 60-bit codes."""
+    import polyfuzz_amd
+    from polyfuzz_amd import _lib, pipeline, synth
+    fl, tl = synth.company_names(203, 31), synth.company_names(180, 32)
+    ctxs = [polyfuzz_amd.Context(0), polyfuzz_amd.Context(0)]
+    comms = _lib.Comm.local_group(ctxs)
+    for rng in ((3, 6), (6, 10)):
+        res = pipeline.run_sharded_job(ctxs, comms, fl, tl, top_n=3, min_similarity=0.0, n_gram_range=rng)
+        single = pipeline.TfidfMatchJob(ctxs[0], fl, tl, top_n=3, min_similarity=0.0, n_gram_range=rng)
+        s_idx, s_val = single.step().download()
+        assert single.vec.info()["code_bits"] > 32
+        for (idx, val), job in res:
+            assert job.vec.info() == single.vec.info()
+            np.testing.assert_array_equal(job.vec.export()[0], single.vec.export()[0])      # the n-grams themselves
+            np.testing.assert_array_equal(job.vec.export()[1], single.vec.export()[1])      # idf
+            np.testing.assert_array_equal(idx, s_idx)
+            np.testing.assert_array_equal(val, s_val)
+        a3, b3, n_col = single.host_matrices()
+        e_idx, e_val = oracle_mod.cossim_topn(a3, b3, n_col, 3, 0.0)
+        assert np.abs(s_val - e_val).max() <= 1e-5
+    del res
+    for c in comms:
+        c.free()
+
+
 @pytest.mark.parametrize("self_match", [False, True])
 def test_world2_to_side_sharding_and_merge(oracle_mod, self_match):
     """The north-star's variant: the TO-list sharded over two ranks (uneven: 257 = 129 + 128), every rank matches all
