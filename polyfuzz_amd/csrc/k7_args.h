@@ -38,6 +38,9 @@ struct FuzzArgs {
     unsigned long long *row_stats;
     int32_t exp;                     // 1: bound only, score nothing (results wrong)
     int32_t *next_unit;              // dynamic distribution of the (row, part) units over the workgroups
+    // sweep 1 leaves every pair's bound here (one byte: the bound rounded UP in steps of 1 / 1.27, bit 7 = coarse; 0 = not a
+    // candidate), [workgroup][group][lane]; sweep 2 reads it back instead of computing the bound again.  NULL: recompute.
+    uint8_t *ub_cache;
     // hand-over of heavy rows: a wave that has scored many batches of one from-string and still has most of the to-groups
     // ahead appends {row position r, next group, group step, 0} (+ the best score found so far) to cont_list and goes
     // on to the next row; a second launch (cont_mode = 1) spreads every such remainder over cont_parts waves, each starting

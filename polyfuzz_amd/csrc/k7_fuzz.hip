@@ -914,13 +914,28 @@ __global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
         int q_head = 0, q_tail = 0;             // wave-uniform; entries [q_head, q_tail) of a ring of 128
         int batches = 0;
         bool handed = false;
+        uint8_t *ubc = (A.ub_cache && !is_cont) ? A.ub_cache + (int64_t)blockIdx.x * A.n_groups * 64 + lane : nullptr;
         for (int phase = is_cont ? 1 : 0; phase < 2; ++phase) {
-            Meta nxt = load_meta(min(g_first, A.n_groups - 1));
+            const bool cached = phase == 1 && ubc != nullptr;
+            Meta nxt;
+            int nxt_q = 0;
+            if (cached) nxt_q = ubc[(int64_t)min(g_first, A.n_groups - 1) * 64];
+            else nxt = load_meta(min(g_first, A.n_groups - 1));
             for (int g = g_first;; g += g_step) {
                 const bool last = g >= A.n_groups || handed;
                 bool want = false;
                 int slot = -1;
-                if (!last) {
+                if (!last && cached) {
+                    // sweep 2 from the byte sweep 1 left: bound (rounded up) against the best score so far
+                    const int q = nxt_q;
+                    nxt_q = ubc[(int64_t)min(g + g_step, A.n_groups - 1) * 64];
+                    slot = g * 64 + lane;
+                    const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;
+                    n_bounded += 1;
+                    want = (q & 127) != 0 && slot != seed_slot && !((float)(q & 127) < thr);
+                    slot |= (q & 128) ? (int)0x80000000 : 0;
+                }
+                else if (!last) {
                     const Meta x = nxt;
                     nxt = load_meta(min(g + g_step, A.n_groups - 1));         // (the last trips re-read a group: harmless)
                     slot = g * 64 + lane;
@@ -933,6 +948,7 @@ __global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
                             seed_ub = ub;
                             seed_slot = slot;
                         }
+                        if (ubc) ubc[(int64_t)g * 64] = valid ? (uint8_t)(min(127, (int)(fmaxf(ub, 0.0f) * 1.27f) + 1) | (coarse ? 128 : 0)) : (uint8_t)0;
                     }
                     else {
                         want = valid && slot != seed_slot && !(ub + kBoundSlack < cur32);
@@ -1176,6 +1192,12 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     PFZ_TRY(d_cont.alloc((size_t)cont_cap * 3 * sizeof(int4)));
     PFZ_TRY(d_cont_cur.alloc((size_t)cont_cap * 3 * sizeof(unsigned long long)));
     const bool hand_over = !getenv("PFZ_K7_NO_HANDOVER");
+    DevBuf d_ubc(ctx);
+    const size_t ubc_bytes = (size_t)max_grid * (size_t)pl->n_groups * 64;
+    if (ubc_bytes <= ((size_t)1 << 30) && !getenv("PFZ_K7_NO_UB_CACHE")) {      // (beyond 1 GiB: sweep 2 computes the bounds again)
+        PFZ_TRY(d_ubc.alloc(ubc_bytes));
+        A.ub_cache = (uint8_t *)d_ubc.p;
+    }
     const char *stats_path = getenv("PFZ_K7_ROW_STATS");
     if (stats_path) {
         PFZ_TRY(d_stats.alloc((size_t)n_rows * 2 * sizeof(unsigned long long)));
