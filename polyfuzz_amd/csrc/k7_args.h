@@ -42,13 +42,15 @@ struct FuzzArgs {
     // candidate), [workgroup][group][lane]; sweep 2 reads it back instead of computing the bound again.  NULL: recompute.
     uint8_t *ub_cache;
     // hand-over of heavy rows: a wave that has scored many batches of one from-string and still has most of the to-groups
-    // ahead appends {row position r, next group, group step, 0} (+ the best score found so far) to cont_list and goes
-    // on to the next row; a second launch (cont_mode = 1) spreads every such remainder over cont_parts waves, each starting
-    // from that score.  Exact: the remainder is the same set of pairs, bounded against a score that is really attained.
+    // ahead appends {row position r, next group, group step, ready flag} (+ the best score found so far) to cont_list and
+    // goes on to the next row; the units after the last row are those remainders, each spread over cont_parts waves that
+    // start from that score -- taken by whichever wave runs out of rows first, while others are still on theirs (a wave
+    // waits for a record only as long as rows are unfinished: rows_done counts them).  Exact: a remainder is the same set
+    // of pairs, bounded against a score that is really attained.
     int4 *cont_list;
     unsigned long long *cont_cur;
-    int32_t *n_cont;
-    int32_t cont_cap, cont_mode, cont_parts, cont_part0, hand_batches, hand_min_groups;
+    int32_t *n_cont, *rows_done;
+    int32_t cont_cap, cont_parts, cont_part0, hand_batches, hand_min_groups;
 };
 
 }  // namespace pfz

@@ -672,15 +672,16 @@ __global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
     unsigned long long n_bounded = 0, n_scored = 0, n_steps = 0;
     __syncthreads();
 
-    __shared__ int s_unit;
+    __shared__ int s_unit, s_cont[4];
+    __shared__ unsigned long long s_cont_cur;
     for (;;) {
         // the from-strings differ by orders of magnitude in how many pairs survive their bound: units are handed out one at
         // a time (an atomic counter) instead of by a fixed stride, so no workgroup is left with a run of heavy ones
         if (tid == 0) s_unit = atomicAdd(A.next_unit, 1);
         __syncthreads();
         const int u = s_unit;
-        const bool is_cont = A.cont_mode != 0;
-        if (u >= (is_cont ? min(*A.n_cont, A.cont_cap) * A.cont_parts : A.n_rows * parts)) break;
+        const int n_primary = A.n_rows * parts;
+        const bool is_cont = u >= n_primary;
         const long long t_begin = A.row_stats ? wall_clock64() : 0;
         const unsigned long long scored_before = n_scored;
         int r, part, g_first, g_step;
@@ -691,14 +692,45 @@ __global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
             g_first = wave + kK7Waves * part;
             g_step = kK7Waves * parts;
         }
-        else {                       // the remainder of a heavy row: its groups g_next, g_next + step, ... dealt to cont_parts units
-            const int c = u / A.cont_parts;
-            part = u - c * A.cont_parts;
-            const int4 rec = A.cont_list[c];
-            r = rec.x;
-            g_first = rec.y + (wave + kK7Waves * part) * rec.z;
-            g_step = rec.z * kK7Waves * A.cont_parts;
-            cur0 = A.cont_cur[c];
+        else {
+            // the remainder of a heavy row: its groups g_next, g_next + step, ... dealt to cont_parts units.  Its record may
+            // not be there yet (its row is still being worked on), or never come (all rows finished: the list is final)
+            if (!A.cont_list) break;
+            const int c = (u - n_primary) / A.cont_parts;
+            part = (u - n_primary) - c * A.cont_parts;
+            if (tid == 0) {
+                // (relaxed polls with long sleeps: an acquire per poll would invalidate the caches the working waves live on)
+                int ok;
+                for (;;) {
+                    if (c < min(__hip_atomic_load(A.n_cont, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), A.cont_cap)) {
+                        ok = 1;
+                        break;
+                    }
+                    if (__hip_atomic_load(A.rows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_primary) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        ok = c < min(__hip_atomic_load(A.n_cont, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), A.cont_cap);
+                        break;
+                    }
+                    for (int z = 0; z < 16; ++z) __builtin_amdgcn_s_sleep(127);
+                }
+                if (ok) {
+                    while (__hip_atomic_load(&A.cont_list[c].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(64);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                s_cont[0] = ok;
+                if (ok) {
+                    s_cont[1] = __hip_atomic_load(&A.cont_list[c].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_cont[2] = __hip_atomic_load(&A.cont_list[c].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_cont[3] = __hip_atomic_load(&A.cont_list[c].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_cont_cur = __hip_atomic_load(&A.cont_cur[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            if (!s_cont[0]) break;
+            r = s_cont[1];
+            g_first = s_cont[2] + (wave + kK7Waves * part) * s_cont[3];
+            g_step = s_cont[3] * kK7Waves * A.cont_parts;
+            cur0 = s_cont_cur;
         }
         const int row = A.rows[r];
         const int64_t a0 = A.a_off[row];
@@ -978,8 +1010,12 @@ __global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
                     at = __builtin_amdgcn_readfirstlane(at);
                     if (at < A.cont_cap) {
                         if (lane == 0) {
-                            A.cont_list[at] = make_int4(r, g + g_step, g_step, 0);
-                            A.cont_cur[at] = __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(&A.cont_list[at].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&A.cont_list[at].y, g + g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&A.cont_list[at].z, g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&A.cont_cur[at], __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&A.cont_list[at].w, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // ready
                         }
                         handed = true;           // (the next trip flushes the queue and ends the loop)
                     }
@@ -1000,6 +1036,8 @@ __global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
             const int64_t o = (int64_t)A.row_slot[r] * A.n_parts_total + (is_cont ? A.cont_part0 : A.part0) + part;
             A.part_score[o] = best.score;
             A.part_idx[o] = best.idx;
+            // (after a possible hand-over of this row: when every row is counted, the list of remainders is final)
+            if (!is_cont && A.cont_list) __hip_atomic_fetch_add(A.rows_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (A.row_stats) {
             unsigned long long ns = n_scored - scored_before;
@@ -1205,7 +1243,11 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.row_stats = (unsigned long long *)d_stats.p;
     }
     if (const char *e = getenv("PFZ_K7_EXP")) A.exp = atoi(e);
-    for (int c = 0; c < 3; ++c) {
+    const bool side = !cls[0].empty() && (!cls[1].empty() || !cls[2].empty()) && !getenv("PFZ_K7_NO_SIDE_STREAM");
+    bool used_side = false;
+    if (side) PFZ_TRY(ensure_side_stream(ctx));
+    ProfScope ps_all(ctx, "k7_fuzz");
+    for (int c = 2; c >= 0; --c) {       // (the side-stream launches first: the persistent waves of class 0 would keep them out)
         if (cls[c].empty() || n_to == 0) continue;
         PFZ_TRY(d_rows[c].upload(cls[c]));
         PFZ_TRY(d_slots[c].upload(slot_of[c]));
@@ -1226,20 +1268,29 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.hand_batches = hand_batches;
         A.hand_min_groups = hand_min_groups;
         A.cont_part0 = max_parts + 1;
-        ProfScope ps(ctx, "k7_fuzz");
-        // the rows, then the remainders of the heavy ones (as many as the first launch hands over: it reads the count)
-        for (int pass = 0; pass < (hand ? 2 : 1); ++pass) {
-            A.cont_mode = pass;
-            A.next_unit = (int32_t *)d_next.p + (pass ? 4 : 0) + c;
-            const unsigned grid = (unsigned)(pass ? max_grid : std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid));
-            if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, ctx->stream, A);
-            else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, ctx->stream, A);
-            else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, ctx->stream, A);
-            PFZ_HIP(hipGetLastError());
+        A.rows_done = (int32_t *)d_next.p + 4 + c;
+        A.next_unit = (int32_t *)d_next.p + c;
+        if (hand) PFZ_HIP(hipMemsetAsync(A.cont_list, 0, (size_t)cont_cap * sizeof(int4), ctx->stream));
+        // the classes of long from-strings (few rows, every one split over many units) run beside the first on the side stream
+        hipStream_t st = ctx->stream;
+        if (c > 0 && side) {
+            PFZ_HIP(hipEventRecord(ctx->side_events[0], ctx->stream));      // (inputs, counters and the cleared lists are ready)
+            PFZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->side_events[0], 0));
+            st = ctx->stream2;
+            used_side = true;
         }
+        // persistent one-wave workgroups: the rows, then -- in the same launch -- the remainders of the heavy ones
+        const unsigned grid = (unsigned)(hand ? max_grid : std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid));
+        if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, st, A);
+        else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, st, A);
+        else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, st, A);
+        PFZ_HIP(hipGetLastError());
+    }
+    if (used_side) {
+        PFZ_HIP(hipEventRecord(ctx->side_events[1], ctx->stream2));
+        PFZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_events[1], 0));
     }
     A.cont_list = nullptr;
-    A.cont_mode = 0;
     if (n_to > 0) {
         // the general kernel: its own from-rows against every to-string, and every OTHER from-row against the to-strings
         // the kernels above left out (more than 32 distinct tokens)
@@ -1250,7 +1301,6 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
             A.row_slot = (const int32_t *)d_slots[3].p;
             A.big_slots = nullptr;
             A.n_big = 0;
-            ProfScope ps(ctx, "k7_fuzz");
             PFZ_TRY(fuzz_general_launch(ctx, A, F, T, cls[3]));
         }
         if (!pl->big_slots.empty()) {
@@ -1265,13 +1315,11 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
                 A.row_slot = (const int32_t *)d_os.p;
                 A.big_slots = pl->d_big_slots;
                 A.n_big = (int32_t)pl->big_slots.size();
-                ProfScope ps(ctx, "k7_fuzz");
-                PFZ_TRY(fuzz_general_launch(ctx, A, F, T, others));
+                    PFZ_TRY(fuzz_general_launch(ctx, A, F, T, others));
             }
         }
     }
     {
-        ProfScope ps(ctx, "k7_fuzz");
         hipLaunchKernelGGL(k7_merge_parts, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)d_ps.p,
                            (const int32_t *)d_pi.p, n_rows, n_parts_total, d_idx, d_score);
         PFZ_HIP(hipGetLastError());

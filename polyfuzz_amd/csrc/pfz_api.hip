@@ -66,6 +66,15 @@ static int stage_take(pfz_ctx *ctx, size_t bytes, char **out)
     return PFZ_OK;
 }
 
+int ensure_side_stream(pfz_ctx *ctx)
+{
+    if (!ctx->stream2) {
+        PFZ_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (hipEvent_t &ev : ctx->side_events) PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    return PFZ_OK;
+}
+
 int copy_h2d(pfz_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return PFZ_OK;

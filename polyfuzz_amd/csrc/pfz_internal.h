@@ -167,6 +167,8 @@ template <typename T, void (*Free)(T *)> struct Owner {
 };
 
 int ensure_scratch(pfz_ctx *ctx, size_t bytes);
+// the context's side stream (ctx->stream2) and its four events (ctx->side_events), created on first use
+int ensure_side_stream(pfz_ctx *ctx);
 // Host <-> device copies of caller-owned (pageable) buffers through the context's pinned staging buffer.
 // Handing a pageable pointer to hipMemcpy makes the runtime register those pages with the GPU driver; when
 // the caller later frees the buffer (a numpy array, a Python bytes object) the unmap evicts and restores the
