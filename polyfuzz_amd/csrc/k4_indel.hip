@@ -684,14 +684,13 @@ static int build_plan(pfz_ctx *ctx, const pfz_strings *T, pfz_indel_plan **out)
 }
 
 template <typename WORD, int W>
-static int launch_class(pfz_ctx *ctx, const IndelArgs &A, int idb, unsigned grid)
+static int launch_class(pfz_ctx *ctx, const IndelArgs &A, int idb, unsigned grid, hipStream_t st)
 {
     const size_t lds = (size_t)A.n_sym1 * W * sizeof(WORD);
-    ProfScope ps(ctx, "k4_indel");
     if (idb == 8)
-        hipLaunchKernelGGL((k4_indel_kernel<WORD, W, 8>), dim3(grid), dim3(256), lds, ctx->stream, A);
+        hipLaunchKernelGGL((k4_indel_kernel<WORD, W, 8>), dim3(grid), dim3(256), lds, st, A);
     else
-        hipLaunchKernelGGL((k4_indel_kernel<WORD, W, 16>), dim3(grid), dim3(256), lds, ctx->stream, A);
+        hipLaunchKernelGGL((k4_indel_kernel<WORD, W, 16>), dim3(grid), dim3(256), lds, st, A);
     PFZ_HIP(hipGetLastError());
     return PFZ_OK;
 }
@@ -777,8 +776,6 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
     const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 8;
     A.parts = 1;
     A.partial = nullptr;
-    DevBuf d_partial;
-    d_partial.ctx = ctx;
     // A class with few rows (the 33 IMDB titles beyond 64 characters ran as 33 workgroups for 178 us) or a unit count
     // that is a small non-integer multiple of the chip's workgroup slots (5000 quads on 2048 slots: the third round is
     // 44 % full) splits every unit's to-groups over `parts` workgroups: >= 4 rounds of work units, each part at least
@@ -789,40 +786,59 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         if (const char *e = getenv("PFZ_K4_PARTS")) parts = std::max(1, atoi(e));      // tests, A/B timing
         return (int32_t)parts;
     };
-    auto merge = [&]() -> int {
+    auto merge = [&](hipStream_t st) -> int {
         if (A.parts <= 1) return PFZ_OK;
-        hipLaunchKernelGGL(k4_merge_parts, dim3((unsigned)((A.n_rows + 255) / 256)), dim3(256), 0, ctx->stream, A);
+        hipLaunchKernelGGL(k4_merge_parts, dim3((unsigned)((A.n_rows + 255) / 256)), dim3(256), 0, st, A);
         PFZ_HIP(hipGetLastError());
         return PFZ_OK;
     };
-    size_t partial_cap = 0;
-    auto ensure_partial = [&]() -> int {          // room for this launch's (row, part) records
-        const size_t need = A.parts > 1 ? (size_t)A.n_rows * (size_t)A.parts * 3 * sizeof(int32_t) : 0;
-        if (need > partial_cap) {
-            if (d_partial.p) pool_free(d_partial.p);     // (stream order keeps it alive for the kernels already queued)
-            d_partial.p = nullptr;
-            PFZ_TRY(d_partial.alloc(need));
-            partial_cap = need;
-        }
-        A.partial = (int32_t *)d_partial.p;
+    // every launch has its own (row, part) records: the classes run on two streams
+    DevBuf d_part[8];
+    int n_part = 0;
+    auto ensure_partial = [&]() -> int {
+        A.partial = nullptr;
+        if (A.parts <= 1) return PFZ_OK;
+        DevBuf &b = d_part[n_part++];
+        b.ctx = ctx;
+        PFZ_TRY(b.alloc((size_t)A.n_rows * (size_t)A.parts * 3 * sizeof(int32_t)));
+        A.partial = (int32_t *)b.p;
         return PFZ_OK;
     };
+    // PFZ_K4_SIDE_STREAM=1: the classes of longer from-strings (few rows each: 5 % of the IMDB titles, a fifth of the kernel
+    // time) on the side stream, beside the two big launches of class 0.  Measured on 20k x 20k titles: the kernels overlap
+    // (1.02 -> 0.97 ms), but the two cross-stream dependencies cost 0.4 ms of host / queue time per call (step 1.06 -> 1.45 ms):
+    // off by default.  (K7 uses the same scheme where the overlapped launch is 7 ms long.)
+    bool any_long = false;
+    for (int c = 1; c < 6; ++c) any_long = any_long || !cls[c].empty();
+    const bool side = any_long && !cls[0].empty() && getenv("PFZ_K4_SIDE_STREAM") != nullptr;
+    if (side) PFZ_TRY(ensure_side_stream(ctx));
+    // the row lists of all classes first (the side stream starts from an event recorded behind these copies); class 0:
+    // several short from-strings per workgroup pass (PFZ_K4_NO_QUAD=1: the one-string kernel, tests) -- eight of <= 16
+    // characters, four of 17 .. 32 (PFZ_K4_NO_OCTO=1: four of <= 32)
+    const bool quad = !cls[0].empty() && !out_matrix && (size_t)A.n_sym1 * sizeof(uint4) <= 60 * 1024 && T->max_len < (1 << 24) - 64 &&
+                      !getenv("PFZ_K4_NO_QUAD");
+    std::vector<int32_t> rows8, rows4;
+    if (quad) {
+        for (int32_t i : cls[0])
+            (F->h_off[(size_t)i + 1] - F->h_off[(size_t)i] <= 16 && !getenv("PFZ_K4_NO_OCTO") ? rows8 : rows4).push_back(i);
+        std::copy(rows4.begin(), rows4.end(), std::copy(rows8.begin(), rows8.end(), cls[0].begin()));
+    }
     for (int c = 0; c < 6; ++c) {
         if (cls[c].empty()) continue;
         PFZ_TRY(d_rows[c].alloc(cls[c].size() * sizeof(int32_t)));
         PFZ_TRY(copy_h2d(ctx, d_rows[c].p, cls[c].data(), cls[c].size() * sizeof(int32_t)));
+    }
+    ProfScope ps_all(ctx, "k4_indel");
+    if (side) {
+        PFZ_HIP(hipEventRecord(ctx->side_events[0], ctx->stream));      // (the inputs are ready)
+        PFZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->side_events[0], 0));
+    }
+    for (int c = 5; c >= 0; --c) {
+        if (cls[c].empty()) continue;
+        hipStream_t st = (c > 0 && side) ? ctx->stream2 : ctx->stream;
         A.rows = (const int32_t *)d_rows[c].p;
         A.n_rows = (int32_t)cls[c].size();
-        if (c == 0 && !out_matrix && (size_t)A.n_sym1 * sizeof(uint4) <= 60 * 1024 && T->max_len < (1 << 24) - 64 &&
-            !getenv("PFZ_K4_NO_QUAD")) {
-            // several short from-strings per workgroup pass (PFZ_K4_NO_QUAD=1: the one-string kernel, tests):
-            // eight of <= 16 characters, four of 17 .. 32 (PFZ_K4_NO_OCTO=1: four of <= 32)
-            std::vector<int32_t> rows8, rows4;
-            for (int32_t i : cls[0])
-                (F->h_off[(size_t)i + 1] - F->h_off[(size_t)i] <= 16 && !getenv("PFZ_K4_NO_OCTO") ? rows8 : rows4).push_back(i);
-            std::copy(rows4.begin(), rows4.end(), std::copy(rows8.begin(), rows8.end(), cls[0].begin()));
-            PFZ_TRY(copy_h2d(ctx, d_rows[0].p, cls[0].data(), cls[0].size() * sizeof(int32_t)));
-            ProfScope ps(ctx, "k4_indel");
+        if (c == 0 && quad) {
             const size_t lds = (size_t)A.n_sym1 * sizeof(uint4);
             for (int pass = 0; pass < 2; ++pass) {
                 const int ns = pass == 0 ? 8 : 4;
@@ -833,12 +849,12 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
                 A.parts = split(n_units);
                 PFZ_TRY(ensure_partial());
                 const dim3 qgrid((unsigned)std::min<int64_t>(n_units * A.parts, max_grid));
-                if (pl->idb == 8 && ns == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8, 8>), qgrid, dim3(256), lds, ctx->stream, A);
-                else if (pl->idb == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8, 4>), qgrid, dim3(256), lds, ctx->stream, A);
-                else if (ns == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<16, 8>), qgrid, dim3(256), lds, ctx->stream, A);
-                else hipLaunchKernelGGL((k4_indel_quad_kernel<16, 4>), qgrid, dim3(256), lds, ctx->stream, A);
+                if (pl->idb == 8 && ns == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8, 8>), qgrid, dim3(256), lds, st, A);
+                else if (pl->idb == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<8, 4>), qgrid, dim3(256), lds, st, A);
+                else if (ns == 8) hipLaunchKernelGGL((k4_indel_quad_kernel<16, 8>), qgrid, dim3(256), lds, st, A);
+                else hipLaunchKernelGGL((k4_indel_quad_kernel<16, 4>), qgrid, dim3(256), lds, st, A);
                 PFZ_HIP(hipGetLastError());
-                PFZ_TRY(merge());
+                PFZ_TRY(merge(st));
             }
             continue;
         }
@@ -846,17 +862,18 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         PFZ_TRY(ensure_partial());
         const unsigned grid = (unsigned)std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid);
         switch (c) {
-        case 0: PFZ_TRY((launch_class<uint32_t, 1>(ctx, A, pl->idb, grid))); break;
-        case 1: PFZ_TRY((launch_class<uint64_t, 1>(ctx, A, pl->idb, grid))); break;
-        case 2: PFZ_TRY((launch_class<uint64_t, 2>(ctx, A, pl->idb, grid))); break;
-        case 3: PFZ_TRY((launch_class<uint64_t, 4>(ctx, A, pl->idb, grid))); break;
-        case 4: PFZ_TRY((launch_class<uint64_t, 8>(ctx, A, pl->idb, grid))); break;
-        default: PFZ_TRY((launch_class<uint64_t, 16>(ctx, A, pl->idb, grid))); break;
+        case 0: PFZ_TRY((launch_class<uint32_t, 1>(ctx, A, pl->idb, grid, st))); break;
+        case 1: PFZ_TRY((launch_class<uint64_t, 1>(ctx, A, pl->idb, grid, st))); break;
+        case 2: PFZ_TRY((launch_class<uint64_t, 2>(ctx, A, pl->idb, grid, st))); break;
+        case 3: PFZ_TRY((launch_class<uint64_t, 4>(ctx, A, pl->idb, grid, st))); break;
+        case 4: PFZ_TRY((launch_class<uint64_t, 8>(ctx, A, pl->idb, grid, st))); break;
+        default: PFZ_TRY((launch_class<uint64_t, 16>(ctx, A, pl->idb, grid, st))); break;
         }
-        {
-            ProfScope ps(ctx, "k4_indel");
-            PFZ_TRY(merge());
-        }
+        PFZ_TRY(merge(st));
+    }
+    if (side) {
+        PFZ_HIP(hipEventRecord(ctx->side_events[1], ctx->stream2));
+        PFZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_events[1], 0));
     }
     A.parts = 1;
     if (!cls[6].empty()) {
@@ -879,7 +896,6 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
         PFZ_TRY(copy_h2d(ctx, d_rows[6].p, cls[6].data(), cls[6].size() * sizeof(int32_t)));
         A.rows = (const int32_t *)d_rows[6].p;
         A.n_rows = (int32_t)cls[6].size();
-        ProfScope ps(ctx, "k4_indel");
         if (pl->idb == 8)
             hipLaunchKernelGGL((k4_indel_general_kernel<8>), dim3((unsigned)gridg), dim3(256), 0, ctx->stream, A, W,
                                (uint64_t *)d_pm.p, (uint64_t *)d_v.p);
