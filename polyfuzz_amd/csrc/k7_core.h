@@ -220,6 +220,24 @@ PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint
     }
 }
 
+// four recurrence steps on positions pos0 .. pos0 + 3 of the to-form (positions from `end` on feed symbol 0, whose table
+// entry is empty: a step that changes nothing): the four symbols, then the four table entries, are requested together --
+// two LDS round trips per four steps instead of two per step
+template <int W>
+PFZ_HD void fz_steps4(uint64_t (&V)[W], const FuzzFrom<W> &F, const FuzzTo &T, int v, int pos0, int end, const uint64_t (&mask)[W])
+{
+    int sy[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sy[q] = pos0 + q < end ? fz_sym(T, v, pos0 + q) : 0;
+    uint64_t pmv[4][W];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int w = 0; w < W; ++w) pmv[q][w] = F.pm[(sy[q] * 3 + v) * W + w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fz_step<W>(V, pmv[q], mask);
+}
+
 // rapidfuzz.fuzz.partial_ratio of the two v-forms: every window, compared as exact rationals lcs / (|shorter| + |window|)
 template <int W>
 PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v)
@@ -244,10 +262,13 @@ PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v)
             const int wlen = fz_min(la, lb - s);
 #pragma unroll
             for (int w = 0; w < W; ++w) V[w] = ~0ull;
-            for (int k = 0; k < wlen; ++k) {
-                fz_step<W>(V, F.pm + (fz_sym(T, v, s + k) * 3 + v) * W, all);
-                if (s == 0 && k + 1 < la) cand(fz_zeros_below<W>(V, la), la + k + 1);
-            }
+            if (s == 0)
+                for (int k = 0; k < wlen; ++k) {
+                    fz_step<W>(V, F.pm + (fz_sym(T, v, k) * 3 + v) * W, all);
+                    if (k + 1 < la) cand(fz_zeros_below<W>(V, la), la + k + 1);
+                }
+            else
+                for (int k = 0; k < wlen; k += 4) fz_steps4<W>(V, F, T, v, s + k, s + wlen, all);
             cand(fz_zeros_below<W>(V, la), la + wlen);
         }
     }
@@ -258,7 +279,7 @@ PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v)
             fz_range_mask<W>(m, i, la);
 #pragma unroll
             for (int w = 0; w < W; ++w) V[w] = ~0ull;
-            for (int pos = 0; pos < lb; ++pos) fz_step<W>(V, F.pm + (fz_sym(T, v, pos) * 3 + v) * W, m);
+            for (int pos = 0; pos < lb; pos += 4) fz_steps4<W>(V, F, T, v, pos, lb, m);
             const int wlen = fz_min(lb, la - i);
             cand(fz_zeros_below<W>(V, i + wlen) - fz_zeros_below<W>(V, i), lb + wlen);
             if (i == 0)

@@ -650,7 +650,7 @@ __device__ inline int work_estimate(const int (&la)[3], const int4 &m, int mode,
 }
 
 template <int W>
-__global__ __launch_bounds__(kK7Threads) void k7_fuzz_kernel(FuzzArgs A)
+__global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *pm = (uint64_t *)smem_raw;               // [symbol][form][word]
@@ -1279,11 +1279,14 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
             st = ctx->stream2;
             used_side = true;
         }
+        // (the bound cache is indexed by workgroup: only one of two launches that run side by side may use it)
+        FuzzArgs L = A;
+        if (st != ctx->stream) L.ub_cache = nullptr;
         // persistent one-wave workgroups: the rows, then -- in the same launch -- the remainders of the heavy ones
         const unsigned grid = (unsigned)(hand ? max_grid : std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid));
-        if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, st, A);
-        else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, st, A);
-        else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, st, A);
+        if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, st, L);
+        else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, st, L);
+        else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, st, L);
         PFZ_HIP(hipGetLastError());
     }
     if (used_side) {

@@ -176,6 +176,36 @@ def test_full_size_rows_vs_the_c_oracle(ctx, oracle_mod):
         np.testing.assert_array_equal(idx[rows], e_idx, err_msg=mode)
 
 
+def test_names_self_match_rows_vs_the_c_oracle(ctx, oracle_mod):
+    """RapidFuzz().match(names): all 100 000 company names against themselves under WRatio (every word class at once, the
+    long-string classes on the side stream, heavy rows handed over) -- two runs identical, and 64 random rows equal to the
+    oracle's answer over the whole list (own first occurrence skipped), bit for bit"""
+    import concurrent.futures as cf
+    from polyfuzz_amd import _lib, datasets
+    names = datasets.load_company_names()
+    first = {}
+    for j, s in enumerate(names):
+        first.setdefault(s, j)
+    skip = np.fromiter((first[s] for s in names), np.int32, len(names))
+    dev = _lib.DeviceStrings.upload(ctx, names)
+    idx, score = _lib.fuzz_extract_one(ctx, dev, dev, "WRatio", skip)
+    idx2, score2 = _lib.fuzz_extract_one(ctx, dev, dev, "WRatio", skip)
+    np.testing.assert_array_equal(idx, idx2)
+    np.testing.assert_array_equal(score, score2)
+    rng = np.random.default_rng(8)
+    long_rows = np.array([i for i, s in enumerate(names) if len(s) > 64][:8], np.int64)
+    rows = np.unique(np.concatenate([rng.choice(len(names), 56, replace=False), long_rows]))
+
+    def one(i):
+        return oracle_mod.fuzz_extract_one(names, names, "WRatio", skip=skip, rows=(int(i), int(i) + 1))
+    with cf.ThreadPoolExecutor(32) as ex:
+        parts = list(ex.map(one, rows))
+    e_idx = np.concatenate([p[0] for p in parts])
+    e_score = np.concatenate([p[1] for p in parts])
+    np.testing.assert_array_equal(score[rows], e_score)
+    np.testing.assert_array_equal(idx[rows], e_idx)
+
+
 def test_four_word_strings_and_editdistance_scorers(ctx):
     """From-strings of 129 .. 256 characters (four 64-bit words: the longest company names have 145) against the
     oracle; EditDistance(scorer=...) takes the same scorers (the reference maps any scorer over all pairs,
