@@ -36,6 +36,7 @@ struct FuzzArgs {
     unsigned long long *counters;    // [0] pairs bounded, [1] pairs scored, [2] 64-bit word-steps of the scored pairs (or NULL)
     // tuning aids (PFZ_K7_ROW_STATS / PFZ_K7_EXP; never set in production): per from-row {pairs scored, clock ticks}, experiment
     unsigned long long *row_stats;
+    unsigned long long *phase_ticks;         // profiling only (PFZ_K7_ROW_STATS): shader-clock ticks of all waves by phase [8]
     int32_t exp;                     // 1: bound only, score nothing (results wrong)
     int32_t *next_unit;              // dynamic distribution of the (row, part) units over the workgroups
     // sweep 1 leaves every pair's bound here (one byte: the bound rounded UP in steps of 1 / 1.27, bit 7 = coarse; 0 = not a

@@ -238,9 +238,13 @@ PFZ_HD void fz_steps4(uint64_t (&V)[W], const FuzzFrom<W> &F, const FuzzTo &T, i
     for (int q = 0; q < 4; ++q) fz_step<W>(V, pmv[q], mask);
 }
 
-// rapidfuzz.fuzz.partial_ratio of the two v-forms: every window, compared as exact rationals lcs / (|shorter| + |window|)
+// rapidfuzz.fuzz.partial_ratio of the two v-forms: the best window, compared as exact rationals lcs / (|shorter| + |window|).
+// `floor`: ratios below it do not matter to the caller (0: all do); the result is exact whenever it is >= floor.
+// Not every window is swept: moving a window by d positions brings in at most d new characters, so its LCS grows by at most
+// d -- after a window with LCS l, the next windows that can neither beat the best ratio so far nor reach `floor` are
+// stepped over (integer arithmetic on l + d; a typical far-from-matching pair sweeps one window in |shorter| / 2).
 template <int W>
-PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v)
+PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v, double floor)
 {
     const int la = F.la[v], lb = T.lb[v];
     if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
@@ -252,13 +256,16 @@ PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v)
             bs = sum;
         }
     };
+    const double fl = floor - 1e-7;        // (ratios are (1 - d / s) * 100 in doubles: a margin far above their rounding)
+    // could a window with at most `lcs` matches and length sum `sum` still matter?
+    auto worth = [&](int lcs, int sum) { return (int64_t)lcs * bs > (int64_t)bl * sum && !(200.0 * (double)lcs < fl * (double)sum); };
     uint64_t all[W], V[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) all[w] = ~0ull;
     if (lb >= la) {
         // the from-form is the shorter (or equal): windows of the to-form starting at s (its prefixes shorter than the
         // from-form fall out of the first window step by step)
-        for (int s = 0; s < lb; ++s) {
+        for (int s = 0; s < lb;) {
             const int wlen = fz_min(la, lb - s);
 #pragma unroll
             for (int w = 0; w < W; ++w) V[w] = ~0ull;
@@ -269,21 +276,37 @@ PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v)
                 }
             else
                 for (int k = 0; k < wlen; k += 4) fz_steps4<W>(V, F, T, v, s + k, s + wlen, all);
-            cand(fz_zeros_below<W>(V, la), la + wlen);
+            const int l = fz_zeros_below<W>(V, la);
+            cand(l, la + wlen);
+            int d = 1;
+            while (s + d < lb) {
+                const int wl = fz_min(la, lb - s - d);
+                if (worth(fz_min(l + d, wl), la + wl)) break;
+                ++d;
+            }
+            s += d;
         }
     }
     if (lb <= la) {
         // the from-form is the longer (or equal): windows of the from-form starting at i, one pass over the to-form each
-        for (int i = 0; i < la; ++i) {
+        for (int i = 0; i < la;) {
             uint64_t m[W];
             fz_range_mask<W>(m, i, la);
 #pragma unroll
             for (int w = 0; w < W; ++w) V[w] = ~0ull;
             for (int pos = 0; pos < lb; pos += 4) fz_steps4<W>(V, F, T, v, pos, lb, m);
             const int wlen = fz_min(lb, la - i);
-            cand(fz_zeros_below<W>(V, i + wlen) - fz_zeros_below<W>(V, i), lb + wlen);
+            const int l = fz_zeros_below<W>(V, i + wlen) - fz_zeros_below<W>(V, i);
+            cand(l, lb + wlen);
             if (i == 0)
                 for (int k = 1; k < lb; ++k) cand(fz_zeros_below<W>(V, k), lb + k);          // prefixes
+            int d = 1;
+            while (i + d < la) {
+                const int wl = fz_min(lb, la - i - d);
+                if (worth(fz_min(l + d, wl), lb + wl)) break;
+                ++d;
+            }
+            i += d;
         }
     }
     return fz_ratio_of(bl, bs);
@@ -394,36 +417,37 @@ PFZ_HD double fz_score(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
     const double tset = need_ts ? fz_token_set<W>(F, T, ca, cb) : 0.0;
 
     // window sweeps: p[v] = partial_ratio of the v-forms, or 0 (a lower bound) where it cannot reach cur / factor
-    double p[3] = {0.0, 0.0, 0.0};
+    double p[3] = {0.0, 0.0, 0.0}, pfac[3] = {1.0, 1.0, 1.0};
     int want_p = 0;
-    auto consider = [&](int v, int l, double factor) {           // l: an upper bound of the LCS of any two windows of the v-forms
+    // (f1, f2: the factors the caller's formula multiplies p[v] by, in its order -- the test below must round as it does)
+    auto consider = [&](int v, int l, double f1, double f2) {    // l: an upper bound of the LCS of any two windows of the v-forms
         const int la = F.la[v], lb = T.lb[v];
         if (la == 0 || lb == 0) p[v] = la == 0 && lb == 0 ? 100.0 : 0.0;
         else {
             const int lm = fz_min(la, lb), c = fz_min(l, lm);
-            if (!(fz_ratio_of(c, lm + c) * factor < cur)) want_p |= 1 << v;
+            if (!(fz_ratio_of(c, lm + c) * f1 * f2 < cur)) want_p |= 1 << v, pfac[v] = f1 * f2;
         }
     };
     if (mode == kWRatio) {
         if (!near) {
-            consider(0, lcs[0], scale);
+            consider(0, lcs[0], scale, 1.0);
             if (need_l & 2) {
-                consider(1, lcs[1], 0.95 * scale);
-                consider(2, lcs[1], 0.95 * scale);
+                consider(1, lcs[1], 0.95, scale);
+                consider(2, lcs[1], 0.95, scale);
             }
         }
     }
-    else if (mode == kPartialRatio) consider(0, lcs[0], 1.0);
-    else if (mode == kPartialTokenSortRatio) consider(1, lcs[1], 1.0);
+    else if (mode == kPartialRatio) consider(0, lcs[0], 1.0, 1.0);
+    else if (mode == kPartialTokenSortRatio) consider(1, lcs[1], 1.0, 1.0);
     else if (mode == kPartialTokenSetRatio) {
-        if (need_l) consider(2, lcs[2], 1.0);
+        if (need_l) consider(2, lcs[2], 1.0, 1.0);
     }
     else if (mode == kPartialTokenRatio && need_l) {
-        consider(1, lcs[1], 1.0);
-        consider(2, lcs[2], 1.0);
+        consider(1, lcs[1], 1.0, 1.0);
+        consider(2, lcs[2], 1.0, 1.0);
     }
     for (int v = 0; v < 3; ++v)
-        if ((want_p >> v) & 1) p[v] = fz_partial<W>(F, T, v);
+        if ((want_p >> v) & 1) p[v] = fz_partial<W>(F, T, v, cur / pfac[v]);
 
     switch (mode) {
     case kWRatio: {
@@ -498,26 +522,32 @@ PFZ_HD float fz_r32(int lcs, int lensum)
 // differences is at most the shorter difference and at most u minus the characters of the common tokens (they sit in both
 // histograms and in neither difference).  Only from-side token lengths are needed: a form 2 is its tokens joined by
 // single spaces, so the to-side difference is what is left of its length.
-template <int W>
-PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, uint32_t ca, int lb2, int tb, int u)
+// (nc common tokens with sect_chars characters between them; la2 / ta, lb2 / tb: form-2 length and distinct tokens of
+// the two strings.  Selects only: the sweep runs it for all 64 lanes.)
+PFZ_HD float fz_token_set_bound_n(int la2, int ta, int lb2, int tb, int u, int nc, int sect_chars)
 {
-    const int ta = F.ta;
-    if (ta == 0 || tb == 0) return 0.0f;
-    const int nc = fz_popc32(ca);
-    if (nc > 0 && (nc == ta || nc == tb)) return 100.0f;
-    int sect_chars = 0;
-    for (int i = 0; i < ta; ++i) sect_chars += ((ca >> i) & 1u) ? F.tlen[i] : 0;
     // joined length of k tokens with c characters in total: c + k - 1
-    const int ab_len = (F.la[2] - (ta - 1) - sect_chars) + (ta - nc) - 1, ba_len = (lb2 - (tb - 1) - sect_chars) + (tb - nc) - 1;
+    const int ab_len = (la2 - (ta - 1) - sect_chars) + (ta - nc) - 1, ba_len = (lb2 - (tb - 1) - sect_chars) + (tb - nc) - 1;
     const int sect_len = sect_chars + (nc > 0 ? nc - 1 : 0), sect_sep = sect_len != 0 ? 1 : 0;
     const int sect_ab_len = sect_len + sect_sep + ab_len, sect_ba_len = sect_len + sect_sep + ba_len;
     const int m = fz_min(fz_min(ab_len, ba_len), fz_max(u - sect_chars, 0));
-    const float total = (float)(sect_ab_len + sect_ba_len);
-    const float result = total > 0.0f ? 100.0f - 100.0f * (float)(ab_len + ba_len - 2 * m) / total : 100.0f;
-    if (sect_len == 0) return result;
-    const float r_ab = 100.0f - 100.0f * (float)(sect_sep + ab_len) / (float)(sect_len + sect_ab_len);
-    const float r_ba = 100.0f - 100.0f * (float)(sect_sep + ba_len) / (float)(sect_len + sect_ba_len);
-    return fmaxf(result, fmaxf(r_ab, r_ba));
+    // (100 - 100 d / s = 100 (s - d) / s: the same expression shape as fz_r32, hardware reciprocal included)
+    const int total = sect_ab_len + sect_ba_len;
+    const float result = total > 0 ? 0.5f * fz_r32(total - (ab_len + ba_len - 2 * m), total) : 100.0f;
+    const float r_ab = 0.5f * fz_r32(sect_len + sect_ab_len - (sect_sep + ab_len), sect_len + sect_ab_len);
+    const float r_ba = 0.5f * fz_r32(sect_len + sect_ba_len - (sect_sep + ba_len), sect_len + sect_ba_len);
+    const float sect_best = r_ab > r_ba ? r_ab : r_ba;
+    const float r = sect_len == 0 ? result : (result > sect_best ? result : sect_best);
+    const float full = (nc > 0 && (nc == ta || nc == tb)) ? 100.0f : r;       // one token set inside the other
+    return (ta == 0 || tb == 0) ? 0.0f : full;
+}
+
+template <int W>
+PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, uint32_t ca, int lb2, int tb, int u)
+{
+    int sect_chars = 0;
+    for (int i = 0; i < F.ta; ++i) sect_chars += ((ca >> i) & 1u) ? F.tlen[i] : 0;
+    return fz_token_set_bound_n(F.la[2], F.ta, lb2, tb, u, fz_popc32(ca), sect_chars);
 }
 
 // An upper bound of fz_score(F, T, mode, .) -- of the TRUE score -- from the two summaries alone.  `common` says what is
@@ -526,32 +556,46 @@ PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, uint32_t ca, int lb2, int 
 // bound + 0.05 < cur).
 PFZ_HD float fz_upper_bound(const FuzzSummary &a, const FuzzSummary &b, int mode, int u, int common, float tset = -1.0f)
 {
-    auto lcs_ub = [&](int v) { return fz_min(u, fz_min(a.len[v], b.len[v])); };
-    auto ratio_ub = [&](int v) { return fz_r32(lcs_ub(v), a.len[v] + b.len[v]); };
+    // (written with selects, not branches: the lanes of a wave take every path of this function between them)
+    auto fmx = [](float x, float y) { return x > y ? x : y; };
+    auto ratio_ub = [&](int v) { return fz_r32(fz_min(u, fz_min(a.len[v], b.len[v])), a.len[v] + b.len[v]); };
     auto partial_ub = [&](int v) -> float {
-        if (a.len[v] == 0 || b.len[v] == 0) return a.len[v] == 0 && b.len[v] == 0 ? 100.0f : 0.0f;
-        const int m = lcs_ub(v);
-        return fz_r32(m, fz_min(a.len[v], b.len[v]) + m);      // a window has at most m matches and at least m characters
+        const int mn = fz_min(a.len[v], b.len[v]), m = fz_min(u, mn);
+        const float r = fz_r32(m, mn + m);                       // a window has at most m matches and at least m characters
+        return mn != 0 ? r : ((a.len[v] | b.len[v]) == 0 ? 100.0f : 0.0f);
     };
     const bool toks = a.ntok != 0 && b.ntok != 0;
     // token_set_ratio: 100 is possible as soon as there may be a common token; without one it is the (other
     // normalisation of the) ratio of the distinct-token forms
-    auto token_set_ub = [&]() -> float { return !toks ? 0.0f : (common != 0 ? (tset >= 0.0f ? tset : 100.0f) : ratio_ub(2)); };
-    auto ptoken_ub = [&]() -> float { return !toks ? 0.0f : (common != 0 ? 100.0f : fmaxf(partial_ub(1), partial_ub(2))); };
+    auto token_set_ub = [&]() -> float {
+        const float with_common = tset >= 0.0f ? tset : 100.0f, t = common != 0 ? with_common : ratio_ub(2);
+        return toks ? t : 0.0f;
+    };
+    auto ptoken_ub = [&]() -> float {
+        const float t = common != 0 ? 100.0f : fmx(partial_ub(1), partial_ub(2));
+        return toks ? t : 0.0f;
+    };
     switch (mode) {
     case kWRatio: {
         const int la = a.len[0], lb = b.len[0];
-        if (la == 0 || lb == 0) return 0.0f;
         const int lmax = fz_max(la, lb), lmin = fz_min(la, lb);
-        if (2 * lmax < 3 * lmin) return fmaxf(ratio_ub(0), 0.95f * fmaxf(ratio_ub(1), token_set_ub()));
-        const float scale = lmax < 8 * lmin ? 0.9f : 0.6f;
-        return fmaxf(ratio_ub(0), fmaxf(scale * partial_ub(0), 0.95f * scale * ptoken_ub()));
+        const float r0 = ratio_ub(0);
+        float ub;
+        if (2 * lmax < 3 * lmin) ub = fmx(r0, 0.95f * fmx(ratio_ub(1), token_set_ub()));       // (groups are sorted by length: mostly one side per wave)
+        else {
+            const float scale = lmax < 8 * lmin ? 0.9f : 0.6f;
+            ub = fmx(r0, fmx(scale * partial_ub(0), 0.95f * scale * ptoken_ub()));
+        }
+        return lmin != 0 ? ub : 0.0f;
     }
     case kPartialRatio: return partial_ub(0);
     case kTokenSetRatio: return token_set_ub();
-    case kTokenRatio: return fmaxf(ratio_ub(1), token_set_ub());
+    case kTokenRatio: return fmx(ratio_ub(1), token_set_ub());
     case kPartialTokenSortRatio: return partial_ub(1);
-    case kPartialTokenSetRatio: return !toks ? 0.0f : (common != 0 ? 100.0f : partial_ub(2));
+    case kPartialTokenSetRatio: {
+        const float t = common != 0 ? 100.0f : partial_ub(2);
+        return toks ? t : 0.0f;
+    }
     default: return ptoken_ub();
     }
 }

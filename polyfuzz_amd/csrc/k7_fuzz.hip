@@ -674,6 +674,18 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
 
     __shared__ int s_unit, s_cont[4];
     __shared__ unsigned long long s_cont_cur;
+    // profiling only: where the waves' time goes -- 0 set-up of a from-string, 1 / 2 the two bounding sweeps, 3 scoring,
+    // 4 the end of a unit (merge, table clean-up, next unit), 5 waiting for a continuation record
+    __shared__ unsigned long long s_ticks[8];
+    if (tid < 8) s_ticks[tid] = 0ull;
+    long long t_last = A.phase_ticks ? clock64() : 0;
+    auto tick = [&](int k) {
+        if (A.phase_ticks) {
+            const long long now = clock64();
+            if (tid == 0) s_ticks[k] += (unsigned long long)(now - t_last);
+            t_last = now;
+        }
+    };
     for (;;) {
         // the from-strings differ by orders of magnitude in how many pairs survive their bound: units are handed out one at
         // a time (an atomic counter) instead of by a fixed stride, so no workgroup is left with a run of heavy ones
@@ -682,6 +694,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
         const int u = s_unit;
         const int n_primary = A.n_rows * parts;
         const bool is_cont = u >= n_primary;
+        tick(4);
         const long long t_begin = A.row_stats ? wall_clock64() : 0;
         const unsigned long long scored_before = n_scored;
         int r, part, g_first, g_step;
@@ -726,6 +739,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                 }
             }
             __syncthreads();
+            tick(5);
             if (!s_cont[0]) break;
             r = s_cont[1];
             g_first = s_cont[2] + (wave + kK7Waves * part) * s_cont[3];
@@ -873,29 +887,29 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
             sb.sig = (uint64_t)(uint32_t)x.m2.x | (uint64_t)(uint32_t)x.m2.y << 32;
             return sb;
         };
-        auto bound_of = [&](const Meta &x, float cur32, bool &valid, bool &coarse) -> float {
+        auto bound_of = [&](const Meta &x, bool &valid, bool &coarse) -> float {
             const int4 m = x.m;
             valid = x.m2.w >= 0 && x.m2.w != skip && m.w <= kFuzzMaxTokens;
-            coarse = false;
             const FuzzSummary sb = summary_of(x);
             const int uu = fz_common_chars(sa, sb);
             const bool maybe = use_tokens && (sa.sig & sb.sig) != 0ull;
-            float ub = fz_upper_bound(sa, sb, mode, uu, maybe ? -1 : 0);
-            if (valid && maybe && !(ub + kBoundSlack < cur32)) {
-                if (m.w <= 4) {
-                    uint32_t ca = 0u;
-                    const int idb[4] = {x.m4.x, x.m4.y, x.m4.z, x.m4.w};
-                    for (int i = 0; i < F.ta; ++i) {
-                        const int ida = s_tid[i];          // (absent to-tokens are -1, unknown from-tokens <= -2)
-                        ca |= (uint32_t)((idb[0] == ida) | (idb[1] == ida) | (idb[2] == ida) | (idb[3] == ida)) << i;
-                    }
-                    ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, ca, m.z, m.w, uu) : -1.0f);
+            coarse = maybe && m.w > 4;
+            // the common tokens: every lane compares its (up to four) to-token ids with the from-string's, which sit in
+            // scalar registers -- one pass, no branch (disjoint signatures simply find nothing)
+            int nc = 0, sect_chars = 0;
+            if (use_tokens)
+                for (int i = 0; i < F.ta; ++i) {
+                    const int ida = __builtin_amdgcn_readfirstlane(s_tid[i]);          // (absent to-tokens are -1, unknown from-tokens <= -2)
+                    const int len = __builtin_amdgcn_readfirstlane(s_tlen[i]);
+                    const bool hit = (x.m4.x == ida) | (x.m4.y == ida) | (x.m4.z == ida) | (x.m4.w == ida);
+                    nc += hit ? 1 : 0;
+                    sect_chars += hit ? len : 0;
                 }
-                else coarse = true;
-            }
-            return ub;
+            const float tset = nc != 0 ? fz_token_set_bound_n(F.la[2], F.ta, m.z, m.w, uu, nc, sect_chars) : -1.0f;
+            return fz_upper_bound(sa, sb, mode, uu, coarse ? -1 : (nc != 0 ? 1 : 0), coarse ? -1.0f : tset);
         };
         RowBest best = {-1.0, INT_MAX};
+        tick(0);
         // a popped queue entry: bit 31 = the pair's bound was coarse -- it is bounded again with the exact token
         // intersection first (64 lanes at a time: one memory round trip for all of them), then scored if it still can win
         auto score_slot = [&](int entry, bool active) {
@@ -973,7 +987,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                     slot = g * 64 + lane;
                     const float cur32 = phase ? (float)cur_now() : 0.0f;
                     bool valid, coarse;
-                    const float ub = bound_of(x, cur32, valid, coarse);
+                    const float ub = bound_of(x, valid, coarse);
                     n_bounded += 1;
                     if (phase == 0) {
                         if (valid && !coarse && ub > seed_ub) {       // (a coarse bound says little: not a seed)
@@ -995,12 +1009,14 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                 if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot;
                 q_tail += __popcll(bal);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                tick(1 + phase);
                 while (q_tail - q_head >= 64 || (last && q_tail > q_head)) {
                     const bool active = lane < q_tail - q_head;
                     score_slot(active ? queue[(q_head + lane) & 127] : -1, active);
                     q_head += min(64, q_tail - q_head);
                     ++batches;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    tick(3);
                 }
                 if (last) break;
                 if (phase == 1 && !is_cont && A.cont_list && batches >= A.hand_batches && A.n_groups - g > A.hand_min_groups * g_step) {
@@ -1057,6 +1073,10 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
             }
         }
         __syncthreads();
+    }
+    if (A.phase_ticks) {
+        __syncthreads();
+        if (tid < 8) atomicAdd(&A.phase_ticks[tid], s_ticks[tid]);
     }
     if (A.counters) {
 #pragma unroll
@@ -1238,9 +1258,11 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     }
     const char *stats_path = getenv("PFZ_K7_ROW_STATS");
     if (stats_path) {
-        PFZ_TRY(d_stats.alloc((size_t)n_rows * 2 * sizeof(unsigned long long)));
-        PFZ_HIP(hipMemsetAsync(d_stats.p, 0, (size_t)n_rows * 2 * sizeof(unsigned long long), ctx->stream));
+        // (two per row, then eight phase timers: see the kernel)
+        PFZ_TRY(d_stats.alloc(((size_t)n_rows * 2 + 8) * sizeof(unsigned long long)));
+        PFZ_HIP(hipMemsetAsync(d_stats.p, 0, ((size_t)n_rows * 2 + 8) * sizeof(unsigned long long), ctx->stream));
         A.row_stats = (unsigned long long *)d_stats.p;
+        A.phase_ticks = A.row_stats + (size_t)n_rows * 2;
     }
     if (const char *e = getenv("PFZ_K7_EXP")) A.exp = atoi(e);
     const bool side = !cls[0].empty() && (!cls[1].empty() || !cls[2].empty()) && !getenv("PFZ_K7_NO_SIDE_STREAM");
@@ -1329,7 +1351,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     }
     if (h_counters) PFZ_TRY(copy_d2h(ctx, h_counters, d_counters.p, 4 * sizeof(unsigned long long)));
     if (stats_path) {
-        std::vector<unsigned long long> st((size_t)n_rows * 2);
+        std::vector<unsigned long long> st((size_t)n_rows * 2 + 8);
         PFZ_TRY(copy_d2h(ctx, st.data(), d_stats.p, st.size() * sizeof(unsigned long long)));
         if (FILE *fp = fopen(stats_path, "wb")) {
             fwrite(st.data(), sizeof(unsigned long long), st.size(), fp);

@@ -96,6 +96,13 @@ def test_score_and_bound_vs_oracle(host, oracle_mod, mode, W, seed, long_words):
     reach = truth >= cur[:, None]
     np.testing.assert_array_equal(score2[reach], truth[reach])
     assert (score2 <= truth).all()
+    # ... and a running best that IS a score of the row (ties count: extractOne keeps the first of equal scores): the row's
+    # best, and its 10th best -- the window sweeps step over windows that cannot reach it, equality must survive
+    for cur in (truth.max(axis=1), np.sort(truth, axis=1)[:, -10]):
+        score3, _ = run_pairs(host, W, alpha, A, B, mode, cur)
+        reach = truth >= cur[:, None]
+        np.testing.assert_array_equal(score3[reach], truth[reach])
+        assert (score3 <= truth).all()
 
 
 def test_bound_is_useful(host, oracle_mod):

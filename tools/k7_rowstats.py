@@ -22,7 +22,11 @@ path = "/tmp/k7_stats.bin"
 os.environ["PFZ_K7_ROW_STATS"] = path
 _lib.fuzz_extract_one_dev(ctx, f_dev, t_dev, mode, out); ctx.sync()
 del os.environ["PFZ_K7_ROW_STATS"]
-st = np.fromfile(path, np.uint64).reshape(-1, 2).astype(np.float64)
+raw = np.fromfile(path, np.uint64)
+phase = raw[-8:].astype(np.float64)
+st = raw[:-8].reshape(-1, 2).astype(np.float64)
+names = ["set-up of a from-string", "sweep 1 (bounds, seeds)", "sweep 2 (cached bounds)", "scoring batches", "end of unit / next unit", "waiting for a continuation"]
+print("wave time by phase (shader clock, all waves):", " | ".join(f"{n} {phase[i] / phase.sum():.3f}" for i, n in enumerate(names)), f"| total {phase.sum():.3e} ticks")
 scored, ticks = st[:, 0], st[:, 1]
 L = np.array([len(s) for s in fl]); T = np.array([len(set(s.split())) for s in fl])
 idx, score = _lib.best_from_topn(*out.download())
