@@ -49,9 +49,23 @@ constexpr int kFuzzMaxTokens = 32;     // distinct tokens per string in the regi
 constexpr int kFuzzHistWords = 8;      // character classes: 8 dwords x 4 one-byte counters
 
 // one from-string: match tables of its three forms, its distinct tokens
+// three of a kind, one per form.  Read [v] with v known only at run time is a chain of selects -- NOT an indexed array:
+// the compiler moves an indexed register array to scratch memory, and with it every later access to the struct around it
+template <typename X>
+struct Fz3 {
+    X a0, a1, a2;
+    PFZ_HD X operator[](int v) const { return v == 0 ? a0 : (v == 1 ? a1 : a2); }
+    PFZ_HD void set(int v, X x)
+    {
+        a0 = v == 0 ? x : a0;
+        a1 = v == 1 ? x : a1;
+        a2 = v == 2 ? x : a2;
+    }
+};
+
 template <int W> struct FuzzFrom {
     const uint64_t *pm;          // [symbol][form][W]; symbol 0 (padding / not in the to-alphabet) is all zero
-    int la[3];                   // form lengths
+    Fz3<int> la;                 // form lengths
     int ta;                      // distinct tokens (<= kFuzzMaxTokens)
     const int32_t *tid, *tlen;   // [ta]
     const uint64_t *tmask;       // [ta][W] positions of token i in form 2
@@ -61,16 +75,27 @@ template <int W> struct FuzzFrom {
 // one to-string, every array its own contiguous record: on the device the records are 16-byte aligned and padded to
 // whole 8-symbol (8-tag, 4-token) chunks, so that a lane fetches 8 symbols with ONE 128-bit load
 struct FuzzTo {
-    const uint16_t *sym[3];      // symbols of form v
+    Fz3<const uint16_t *> sym;   // symbols of form v
     const uint8_t *tag;          // form 2: token number (5 bits) | 0x80 for the space that follows that token
     const int32_t *tok_id, *tok_len;   // distinct tokens, in the order of form 2
-    int lb[3], tb;
+    Fz3<int> lb;
+    int tb;
     // optional scratch column [pos * stage_stride] of kFuzzStage symbols (LDS in the kernel, none on the host): a window sweep
     // re-reads the to-string |from| times, and a global load per recurrence step is a dependent ~500-cycle round trip
     PFZ_LDS_U16 *stage;
     int stage_stride;            // 0: there is no column
     int staged;                  // the form whose symbols the column holds (-1: none)
+    int n_windows;               // (statistics) windows fz_partial swept for this pair
+#ifdef PFZ_K7_PROFILE
+    long long t0;                // (profiling build: tools/build_variant.sh -DPFZ_K7_PROFILE) clock at the last FZ_TICK
+    unsigned int tk[6];          // ticks of this lane by sub-phase of scoring
+#endif
 };
+
+// FZ_TICK(T, k): the time since the last tick goes to sub-phase k (profiling build of the kernel only)
+#ifndef FZ_TICK
+#define FZ_TICK(T, k)
+#endif
 
 constexpr int kFuzzStage = 64;
 
@@ -102,8 +127,8 @@ PFZ_HD void fz_load8(const uint8_t *p, int n, int (&c)[8])
 // copy form v into the scratch column; longer forms stay in global memory
 PFZ_HD void fz_stage(FuzzTo &T, int v)
 {
-    if (T.stage_stride == 0 || T.staged == v || T.lb[v] > kFuzzStage) return;
     const int lb = T.lb[v];
+    if (T.stage_stride == 0 || T.staged == v || lb > kFuzzStage) return;
     for (int p0 = 0; p0 < lb; p0 += 8) {
         int c[8];
         fz_load8(T.sym[v] + p0, lb - p0, c);
@@ -201,10 +226,11 @@ PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint
 #pragma unroll
     for (int w = 0; w < W; ++w) V[w] = ~0ull;
     const int lb = T.lb[v];
+    const uint16_t *sym = T.sym[v];
     // eight positions at a time: one 128-bit load of symbols (one 64-bit load of tags), then eight recurrence steps
     for (int p0 = 0; p0 < lb; p0 += 8) {
         int sy[8], tg[8];
-        fz_load8(T.sym[v] + p0, lb - p0, sy);
+        fz_load8(sym + p0, lb - p0, sy);
         if (tagged) {
             fz_load8(T.tag + p0, lb - p0, tg);
 #pragma unroll
@@ -238,78 +264,155 @@ PFZ_HD void fz_steps4(uint64_t (&V)[W], const FuzzFrom<W> &F, const FuzzTo &T, i
     for (int q = 0; q < 4; ++q) fz_step<W>(V, pmv[q], mask);
 }
 
-// rapidfuzz.fuzz.partial_ratio of the two v-forms: the best window, compared as exact rationals lcs / (|shorter| + |window|).
-// `floor`: ratios below it do not matter to the caller (0: all do); the result is exact whenever it is >= floor.
+// ---- window sweeps (rapidfuzz.fuzz.partial_ratio of two v-forms) -----------------------------------------------------------
+// The windows of a pair, numbered: with the from-form the shorter (or equal) -- windows of the to-form starting at
+// s = 0 .. lb - 1 (its prefixes shorter than the from-form fall out of the first window step by step); with the from-form
+// the longer (or equal) -- windows of the from-form starting at i = 0 .. la - 1, one pass over the to-form each (the
+// prefixes of the from-form fall out of the first pass).  Equal lengths: both families, the first then the second.
+// The best window is found as an exact rational lcs / (|shorter| + |window|).
+//
 // Not every window is swept: moving a window by d positions brings in at most d new characters, so its LCS grows by at most
-// d -- after a window with LCS l, the next windows that can neither beat the best ratio so far nor reach `floor` are
-// stepped over (integer arithmetic on l + d; a typical far-from-matching pair sweeps one window in |shorter| / 2).
+// d -- after a window with LCS l, the next windows that can neither beat the best ratio so far nor reach what the caller
+// cares for are stepped over (integer arithmetic on l + d; a typical far-from-matching pair sweeps one window in
+// |shorter| / 2).  The windows of a pair can be shared out ([w, w_end) below): every share is swept on its own, the best
+// of the shares is the best of the pair.
+PFZ_HD int fz_n_windows(int la, int lb) { return (lb >= la ? lb : 0) + (lb <= la ? la : 0); }
+
+#ifndef FZ_ANY
+#define FZ_ANY(x) (x)          // (the kernel: any lane of the wave -- a cheap way round code few lanes need)
+#endif
+
+struct FuzzSweep {
+    int v, la, lb;         // the forms (both non-empty)
+    int w, w_end;          // the next window, the end of this share
+    int bl, bs;            // the best candidate so far: lcs, length sum
+    const uint16_t *sym;   // the to-form's symbols; or, when stage_stride != 0, its copy in the scratch column
+    PFZ_LDS_U16 *stage;
+    int stage_stride;
+};
+
+// copy a to-form of at most kFuzzStage symbols into the scratch column (a window sweep re-reads it |from| times)
+PFZ_HD void fz_stage_form(const uint16_t *sym, int lb, PFZ_LDS_U16 *stage, int stride)
+{
+    for (int p0 = 0; p0 < lb; p0 += 8) {
+        int c[8];
+        fz_load8(sym + p0, lb - p0, c);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (p0 + q < lb) stage[(p0 + q) * stride] = (uint16_t)c[q];
+    }
+}
+
+// (sym / stage: see FuzzSweep; stage_stride 0 = read the symbols where they are)
+PFZ_HD void fz_sweep_begin(FuzzSweep &S, int v, int la, int lb, int w, int w_end, const uint16_t *sym, PFZ_LDS_U16 *stage,
+                           int stage_stride)
+{
+    S.v = v;
+    S.la = la;
+    S.lb = lb;
+    S.w = w;
+    S.w_end = w_end;
+    S.bl = 0;
+    S.bs = 1;
+    S.sym = sym;
+    S.stage = stage;
+    S.stage_stride = stage_stride;
+}
+
+PFZ_HD int fz_sweep_sym(const FuzzSweep &S, int pos) { return S.stage_stride != 0 ? (int)S.stage[pos * S.stage_stride] : (int)S.sym[pos]; }
+
+// sweeps window S.w and moves S.w to the next window that can matter; true: the share is done.  A window matters when it
+// can beat the best so far AND reach `thr` after the factor f the caller's formula multiplies partial_ratio by
+// (200 lcs f / sum >= thr; thr is the caller's floor minus a margin far above the rounding of these products).
+template <int W>
+PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double thr)
+{
+    const int la = S.la, lb = S.lb, v = S.v;
+    const int n_first = lb >= la ? lb : 0;
+    const bool of_to = S.w < n_first;                           // a window of the to-form (else: of the from-form)
+    const int idx = of_to ? S.w : S.w - n_first;
+    const int lm = fz_min(la, lb), ll = fz_max(la, lb);
+    const int wlen = fz_min(lm, ll - idx);
+    const int t0 = of_to ? idx : 0, t1 = of_to ? idx + wlen : lb;       // to-positions fed
+    const int c_lo = of_to ? 0 : idx, c_hi = of_to ? la : idx + wlen;   // from-positions allowed (from c_lo on) and counted
+    int bl = S.bl, bs = S.bs;
+    auto cand = [&](int lcs, int sum) {
+        if (lcs * bs > bl * sum) {          // (lengths <= 256 W... <= 1024: the products fit an int)
+            bl = lcs;
+            bs = sum;
+        }
+    };
+    auto worth = [&](int lcs, int sum) { return lcs * bs > bl * sum && !(200.0 * (double)lcs * f < thr * (double)sum); };
+    uint64_t m[W], V[W];
+    fz_range_mask<W>(m, c_lo, la);
+#pragma unroll
+    for (int w = 0; w < W; ++w) V[w] = ~0ull;
+    const bool prefixes = of_to && idx == 0;
+    for (int k = t0; k < t1; k += 4) {
+        int sy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sy[q] = k + q < t1 ? fz_sweep_sym(S, k + q) : 0;
+        uint64_t pmv[4][W];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int w = 0; w < W; ++w) pmv[q][w] = F.pm[(sy[q] * 3 + v) * W + w];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fz_step<W>(V, pmv[q], m);
+            // a prefix of the to-form, k + q + 1 characters long (shorter than the from-form): only the long ones can matter
+            const int fed = k + q + 1;
+            const bool look = prefixes && fed < la && fed <= t1 && worth(fed, la + fed);
+            if (FZ_ANY(look))
+                if (look) cand(fz_zeros_below<W>(V, la), la + fed);
+        }
+    }
+    const int l = fz_zeros_below<W>(V, c_hi) - fz_zeros_below<W>(V, c_lo);
+    cand(l, lm + wlen);
+    if (!of_to && idx == 0)
+        for (int k = 1; k < lb; ++k) cand(fz_zeros_below<W>(V, k), lb + k);          // prefixes of the from-form
+    int d = 1;
+    while (idx + d < ll) {
+        const int wl = fz_min(lm, ll - idx - d);
+        if (worth(fz_min(l + d, wl), lm + wl)) break;
+        ++d;
+    }
+    S.bl = bl;
+    S.bs = bs;
+    S.w += d;              // (stops at the end of its family: the other family starts with a window of its own)
+    return S.w >= S.w_end;
+}
+
+// partial_ratio of the two v-forms, every window in one share.  `floor`: ratios below it do not matter to the caller
+// (0: all do); the result is exact whenever it is >= floor.
 template <int W>
 PFZ_HD double fz_partial(const FuzzFrom<W> &F, FuzzTo &T, int v, double floor)
 {
     const int la = F.la[v], lb = T.lb[v];
     if (la == 0 || lb == 0) return la == 0 && lb == 0 ? 100.0 : 0.0;
     fz_stage(T, v);
-    int bl = 0, bs = 1;
-    auto cand = [&](int lcs, int sum) {
-        if ((int64_t)lcs * bs > (int64_t)bl * sum) {
-            bl = lcs;
-            bs = sum;
-        }
-    };
-    const double fl = floor - 1e-7;        // (ratios are (1 - d / s) * 100 in doubles: a margin far above their rounding)
-    // could a window with at most `lcs` matches and length sum `sum` still matter?
-    auto worth = [&](int lcs, int sum) { return (int64_t)lcs * bs > (int64_t)bl * sum && !(200.0 * (double)lcs < fl * (double)sum); };
-    uint64_t all[W], V[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) all[w] = ~0ull;
-    if (lb >= la) {
-        // the from-form is the shorter (or equal): windows of the to-form starting at s (its prefixes shorter than the
-        // from-form fall out of the first window step by step)
-        for (int s = 0; s < lb;) {
-            const int wlen = fz_min(la, lb - s);
-#pragma unroll
-            for (int w = 0; w < W; ++w) V[w] = ~0ull;
-            if (s == 0)
-                for (int k = 0; k < wlen; ++k) {
-                    fz_step<W>(V, F.pm + (fz_sym(T, v, k) * 3 + v) * W, all);
-                    if (k + 1 < la) cand(fz_zeros_below<W>(V, la), la + k + 1);
-                }
-            else
-                for (int k = 0; k < wlen; k += 4) fz_steps4<W>(V, F, T, v, s + k, s + wlen, all);
-            const int l = fz_zeros_below<W>(V, la);
-            cand(l, la + wlen);
-            int d = 1;
-            while (s + d < lb) {
-                const int wl = fz_min(la, lb - s - d);
-                if (worth(fz_min(l + d, wl), la + wl)) break;
-                ++d;
-            }
-            s += d;
-        }
-    }
-    if (lb <= la) {
-        // the from-form is the longer (or equal): windows of the from-form starting at i, one pass over the to-form each
-        for (int i = 0; i < la;) {
-            uint64_t m[W];
-            fz_range_mask<W>(m, i, la);
-#pragma unroll
-            for (int w = 0; w < W; ++w) V[w] = ~0ull;
-            for (int pos = 0; pos < lb; pos += 4) fz_steps4<W>(V, F, T, v, pos, lb, m);
-            const int wlen = fz_min(lb, la - i);
-            const int l = fz_zeros_below<W>(V, i + wlen) - fz_zeros_below<W>(V, i);
-            cand(l, lb + wlen);
-            if (i == 0)
-                for (int k = 1; k < lb; ++k) cand(fz_zeros_below<W>(V, k), lb + k);          // prefixes
-            int d = 1;
-            while (i + d < la) {
-                const int wl = fz_min(lb, la - i - d);
-                if (worth(fz_min(l + d, wl), lb + wl)) break;
-                ++d;
-            }
-            i += d;
-        }
-    }
-    return fz_ratio_of(bl, bs);
+    FuzzSweep S;
+    const bool staged = T.staged == v;
+    fz_sweep_begin(S, v, la, lb, 0, fz_n_windows(la, lb), T.sym[v], T.stage, staged ? T.stage_stride : 0);
+    while (!fz_sweep_window<W>(S, F, 1.0, floor - 1e-7)) T.n_windows += 1;
+    T.n_windows += 1;
+    return fz_ratio_of(S.bl, S.bs);
+}
+
+// what a swept partial_ratio p of the v-forms contributes to the pair's score under `mode` -- the factors in the order
+// fz_score's formulas apply them -- and (fz_sweep_factor) their product, for fz_sweep_window's test
+PFZ_HD double fz_sweep_score(int mode, int v, int la0, int lb0, double p)
+{
+    if (mode != kWRatio) return p;
+    const double scale = fz_max(la0, lb0) < 8 * fz_min(la0, lb0) ? 0.9 : 0.6;
+    return v == 0 ? p * scale : p * 0.95 * scale;
+}
+
+PFZ_HD double fz_sweep_factor(int mode, int v, int la0, int lb0)
+{
+    if (mode != kWRatio) return 1.0;
+    const double scale = fz_max(la0, lb0) < 8 * fz_min(la0, lb0) ? 0.9 : 0.6;
+    return v == 0 ? scale : 0.95 * scale;
 }
 
 // common distinct tokens: bit i of ca (from-tokens), bit j of cb (to-tokens)
@@ -368,9 +471,12 @@ PFZ_HD double fz_token_set(const FuzzFrom<W> &F, const FuzzTo &T, uint32_t ca, u
 // token-set pass, window sweeps of a form (bit v of want_p, decided after the passes: a window has at most the LCS of the
 // whole forms and at least that many characters, so ratio_of(lcs, |shorter| + lcs) bounds partial_ratio) -- laid out so
 // that each kind has ONE call site: the kernel inlines one copy of each, whatever the mode.
-template <int W>
-PFZ_HD double fz_score(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
+// DEFER: the window sweeps are left to the caller -- *want gets the forms to sweep (bit v), the returned score is that of
+// the other components (the pair's score is the maximum of it and fz_sweep_score() of every swept form).
+template <int W, bool DEFER = false>
+PFZ_HD double fz_score(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur, int *want = nullptr)
 {
+    if (DEFER) *want = 0;
     const int la0 = F.la[0], lb0 = T.lb[0], ta = F.ta, tb = T.tb;
     const bool toks = ta != 0 && tb != 0;
     uint32_t ca = 0u, cb = 0u;
@@ -404,28 +510,34 @@ PFZ_HD double fz_score(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
     else if (mode == kPartialTokenSetRatio) need_l = sweep_of = (toks && !ca) ? 4 : 0;
     else need_l = sweep_of = (toks && !ca) ? 6 : 0;
 
-    int lcs[3] = {0, 0, 0};
+    Fz3<int> lcs = {0, 0, 0};
     uint64_t all[W], V[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) all[w] = ~0ull;
+    FZ_TICK(T, 0);
     for (int v = 0; v < 3; ++v)
         if ((need_l >> v) & 1) {
             if ((sweep_of >> v) & 1) fz_stage(T, v);
             fz_lcs_pass<W>(F, T, v, all, false, 0u, 0, V);
-            lcs[v] = fz_zeros_below<W>(V, F.la[v]);
+            lcs.set(v, fz_zeros_below<W>(V, F.la[v]));
         }
+    FZ_TICK(T, 1);
     const double tset = need_ts ? fz_token_set<W>(F, T, ca, cb) : 0.0;
+    FZ_TICK(T, 2);
 
     // window sweeps: p[v] = partial_ratio of the v-forms, or 0 (a lower bound) where it cannot reach cur / factor
-    double p[3] = {0.0, 0.0, 0.0}, pfac[3] = {1.0, 1.0, 1.0};
+    Fz3<double> p = {0.0, 0.0, 0.0}, pfac = {1.0, 1.0, 1.0};
     int want_p = 0;
     // (f1, f2: the factors the caller's formula multiplies p[v] by, in its order -- the test below must round as it does)
     auto consider = [&](int v, int l, double f1, double f2) {    // l: an upper bound of the LCS of any two windows of the v-forms
         const int la = F.la[v], lb = T.lb[v];
-        if (la == 0 || lb == 0) p[v] = la == 0 && lb == 0 ? 100.0 : 0.0;
+        if (la == 0 || lb == 0) p.set(v, la == 0 && lb == 0 ? 100.0 : 0.0);
         else {
             const int lm = fz_min(la, lb), c = fz_min(l, lm);
-            if (!(fz_ratio_of(c, lm + c) * f1 * f2 < cur)) want_p |= 1 << v, pfac[v] = f1 * f2;
+            if (!(fz_ratio_of(c, lm + c) * f1 * f2 < cur)) {
+                want_p |= 1 << v;
+                if (!DEFER) pfac.set(v, f1 * f2);
+            }
         }
     };
     if (mode == kWRatio) {
@@ -446,8 +558,11 @@ PFZ_HD double fz_score(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
         consider(1, lcs[1], 1.0, 1.0);
         consider(2, lcs[2], 1.0, 1.0);
     }
-    for (int v = 0; v < 3; ++v)
-        if ((want_p >> v) & 1) p[v] = fz_partial<W>(F, T, v, cur / pfac[v]);
+    if (DEFER) *want = want_p;
+    else
+        for (int v = 0; v < 3; ++v)
+            if ((want_p >> v) & 1) p.set(v, fz_partial<W>(F, T, v, cur / pfac[v]));
+    FZ_TICK(T, 3);
 
     switch (mode) {
     case kWRatio: {

@@ -40,6 +40,15 @@
 #undef PFZ_HD
 #define PFZ_HD __device__ inline
 #define PFZ_LDS_U16 __attribute__((address_space(3))) uint16_t
+#ifdef PFZ_K7_PROFILE
+#define FZ_TICK(T, k)                                                 \
+    do {                                                              \
+        const long long now_ = clock64();                             \
+        (T).tk[k] += (unsigned int)(now_ - (T).t0);                   \
+        (T).t0 = now_;                                                \
+    } while (0)
+#endif
+#define FZ_ANY(x) (__ballot(x) != 0ull)
 #include "k7_core.h"
 #include "k7_args.h"
 
@@ -50,6 +59,8 @@ namespace pfz {
 // it four times over (the 100 000-name self-match: 0.79 -> 0.49 s).  More waves per workgroup = fewer from-strings in flight.
 constexpr int kK7Waves = 1, kK7Threads = 64 * kK7Waves;
 constexpr float kBoundSlack = 0.05f;
+// log2 of the windows per run of a window sweep: 16, more for long forms -- at most 8 runs (forms are <= 256 symbols here)
+__device__ inline int sweep_share_log2(int n_windows) { return n_windows <= 128 ? 4 : (n_windows <= 256 ? 5 : (n_windows <= 512 ? 6 : 7)); }
 constexpr int kHandBatches = 32, kHandMinGroups = 16, kContParts = 8;      // heavy-row hand-over (see FuzzArgs::cont_list)      // a pair is dismissed only when bound + slack < cur (float32 bound, float64 scores)
 
 __device__ inline uint32_t load_unit(const void *p, int width, int64_t i)
@@ -542,6 +553,10 @@ static int build_plan(pfz_ctx *ctx, pfz_strings *T)
     for (int64_t j = 0; j < n_to; ++j) start[(size_t)(T->h_off[(size_t)j + 1] - T->h_off[(size_t)j]) + 1]++;
     for (size_t l = 1; l < start.size(); ++l) start[l] += start[l - 1];
     const int64_t n_groups = (n_to + 63) / 64;
+    if (n_groups * 64 > ((int64_t)1 << 26)) {      // (the kernel's window-sweep items hold a to-slot in 26 bits)
+        set_error("pfz_fuzz: a to-list of %lld strings exceeds the 2^26-string plan", (long long)n_to);
+        return PFZ_ERR_UNSUPPORTED;
+    }
     std::vector<int32_t> b_orig((size_t)n_groups * 64, -1);
     for (int64_t j = 0; j < n_to; ++j) {      // ascending j inside one length: a stable sort
         const int64_t len = T->h_off[(size_t)j + 1] - T->h_off[(size_t)j];
@@ -642,7 +657,7 @@ __device__ inline bool mode_uses_tokens(int mode) { return mode != kPartialRatio
 
 // 64-bit word-steps a scored pair costs at most (work accounting for the roofline; an estimate from the lengths: one
 // pass over the to-form per LCS, |from| x |to| for a window sweep)
-__device__ inline int work_estimate(const int (&la)[3], const int4 &m, int mode, int W)
+__device__ inline int work_estimate(const Fz3<int> &la, const int4 &m, int mode, int W)
 {
     const int pass = m.x + m.y + m.z;
     if (mode == kTokenSetRatio || mode == kTokenRatio) return pass * W;
@@ -663,6 +678,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
     __shared__ int red_i[kK7Waves];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
     __shared__ int s_queue[kK7Waves][128];
+    __shared__ int s_sweeps[kK7Waves][128];       // runs of windows waiting for a lane (see sweep_rounds)
     __shared__ uint16_t s_stage[kK7Waves][kFuzzStage][64];       // per wave: [position][lane] symbols of the form a lane sweeps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
@@ -676,8 +692,8 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
     __shared__ unsigned long long s_cont_cur;
     // profiling only: where the waves' time goes -- 0 set-up of a from-string, 1 / 2 the two bounding sweeps, 3 scoring,
     // 4 the end of a unit (merge, table clean-up, next unit), 5 waiting for a continuation record
-    __shared__ unsigned long long s_ticks[8];
-    if (tid < 8) s_ticks[tid] = 0ull;
+    __shared__ unsigned long long s_ticks[24];
+    if (tid < 24) s_ticks[tid] = 0ull;
     long long t_last = A.phase_ticks ? clock64() : 0;
     auto tick = [&](int k) {
         if (A.phase_ticks) {
@@ -811,9 +827,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
         __syncthreads();
         FuzzFrom<W> F;
         F.pm = pm;
-        F.la[0] = s_la[0];
-        F.la[1] = s_la[1];
-        F.la[2] = s_la[2];
+        F.la = {s_la[0], s_la[1], s_la[2]};
         F.ta = s_ta;
         F.tid = s_tid;
         F.tlen = s_tlen;
@@ -835,19 +849,16 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
         auto to_of = [&](int slot, const int4 &m) {
             const int4 rec = A.b_meta3[slot];
             FuzzTo T;
-            T.sym[0] = A.b_sym + rec.x;
-            T.sym[1] = T.sym[0] + rec.w;
-            T.sym[2] = T.sym[1] + rec.w;
+            T.sym = {A.b_sym + rec.x, A.b_sym + rec.x + rec.w, A.b_sym + rec.x + 2 * rec.w};
             T.tag = A.b_tag + rec.y;
             T.tok_id = A.b_tok_id + rec.z;
             T.tok_len = A.b_tok_len + rec.z;
-            T.lb[0] = m.x;
-            T.lb[1] = m.y;
-            T.lb[2] = m.z;
+            T.lb = {m.x, m.y, m.z};
             T.tb = m.w;
             T.stage = (PFZ_LDS_U16 *)&s_stage[wave][0][lane];
-            T.stage_stride = 64;
+            T.stage_stride = 0;          // (the scratch column belongs to the window sweeps: sweep_rounds)
             T.staged = -1;
+            T.n_windows = 0;
             return T;
         };
         // what a sweep reads of one to-string: five 128-bit loads, all issued one group ahead of their use
@@ -910,11 +921,82 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
         };
         RowBest best = {-1.0, INT_MAX};
         tick(0);
-        // a popped queue entry: bit 31 = the pair's bound was coarse -- it is bounded again with the exact token
-        // intersection first (64 lanes at a time: one memory round trip for all of them), then scored if it still can win
-        auto score_slot = [&](int entry, bool active) {
+        // ---- window sweeps.  Few of the scored pairs need them, those that do need many times the work of the others,
+        // and how many windows a pair sweeps is anybody's guess: swept inside the scoring batches, one lane in ten would
+        // work and the wave would wait for the slowest.  So scoring only ASKS for sweeps: the windows of a form are shared
+        // out in runs of kSweepShare, every run an item of a ring; a lane takes an item, sweeps one window per round of the
+        // wave, and takes the next item when its run is done -- rounds are held only while all 64 lanes have a run (or at
+        // the end of a sweep of the to-list), a lane's unfinished run waits in its registers in between.
+        int sw_item = -1;                       // this lane's run (-1: none): slot | form << 26 | run << 28
+        // (what a run keeps between rounds, packed: lb | lb0 << 16, w | w_end << 16, bl | bs << 16 -- lengths <= 256 W)
+        int sw_len = 0, sw_win = 0, sw_best = 1 << 16;
+        int *sweeps = s_sweeps[wave];
+        int sq_head = 0, sq_tail = 0;
+        auto sweep_rounds = [&](bool flush) {
+            for (;;) {
+                const unsigned long long idle = __ballot(sw_item < 0);
+                const int n_take = min((int)__popcll(idle), sq_tail - sq_head);
+                const int n_busy = 64 - (int)__popcll(idle) + n_take;
+                if (n_busy == 0 || (!flush && n_busy < 64)) break;
+                PFZ_LDS_U16 *column = (PFZ_LDS_U16 *)&s_stage[wave][0][lane];
+                if (sw_item < 0) {
+                    const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    if (rank < n_take) {
+                        sw_item = sweeps[(sq_head + rank) & 127];
+                        const int slot = sw_item & 0x3ffffff, v = (sw_item >> 26) & 3, run = sw_item >> 28;
+                        const int4 m = A.b_meta[slot];
+                        const int la = F.la[v], lb = v == 0 ? m.x : (v == 1 ? m.y : m.z);
+                        sw_len = lb | m.x << 16;
+                        const int n_win = fz_n_windows(la, lb), sh = sweep_share_log2(n_win);
+                        sw_win = (run << sh) | min((run + 1) << sh, n_win) << 16;
+                        sw_best = 1 << 16;
+                        if (lb <= kFuzzStage) {
+                            const int4 rec = A.b_meta3[slot];
+                            fz_stage_form(A.b_sym + rec.x + (int64_t)v * rec.w, lb, column, 64);
+                        }
+                    }
+                }
+                sq_head += n_take;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (sw_item >= 0) {
+                    const int slot = sw_item & 0x3ffffff, v = (sw_item >> 26) & 3;
+                    const int lb = sw_len & 0xffff, lb0 = sw_len >> 16;
+                    const bool staged = lb <= kFuzzStage;
+                    const uint16_t *sym = A.b_sym;
+                    if (!staged) {                       // (a long to-form: read where it is)
+                        const int4 rec = A.b_meta3[slot];
+                        sym += rec.x + (int64_t)v * rec.w;
+                    }
+                    FuzzSweep SW;
+                    fz_sweep_begin(SW, v, F.la[v], lb, sw_win & 0xffff, sw_win >> 16, sym, column,
+                                   staged ? 64 : 0);
+                    SW.bl = sw_best & 0xffff;
+                    SW.bs = sw_best >> 16;
+                    const bool done = fz_sweep_window<W>(SW, F, fz_sweep_factor(mode, v, F.la[0], lb0), cur_now() - 1e-6);
+                    sw_win = SW.w | SW.w_end << 16;
+                    sw_best = SW.bl | SW.bs << 16;
+                    if (done) {
+                        const double sc = fz_sweep_score(mode, v, F.la[0], lb0, fz_ratio_of(SW.bl, SW.bs));
+                        best.take(sc, A.b_meta2[slot].w);
+                        if (sc > 0.0) atomicMax(&s_best, (unsigned long long)__double_as_longlong(sc));
+                        sw_item = -1;
+                    }
+                }
+                if (A.phase_ticks && lane == 0) {
+                    s_ticks[12] += n_busy;           // windows swept
+                    s_ticks[13] += 64;               // ... and what the wave paid for
+                }
+            }
+        };
+        auto score_slot = [&](int entry, bool active, bool flush) {
             double sc = 0.0;
-            int orig = -1;
+            int orig = -1, want_p = 0, slot_of = 0;
+            int4 lens = make_int4(0, 0, 0, 0);
+            bool did_score = false;
+#ifdef PFZ_K7_PROFILE
+            unsigned int sub[6] = {0, 0, 0, 0, 0, 0};
+            const long long t_pop = clock64();
+#endif
             if (active && A.exp != 1) {
                 const int slot = entry & 0x7fffffff;
                 const int4 m = A.b_meta[slot];
@@ -936,11 +1018,45 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                     const float ub = fz_upper_bound(sa, sb, mode, uu, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, ca, m.z, m.w, uu) : -1.0f);
                     go = !(ub + kBoundSlack < (float)cur);
                 }
+#ifdef PFZ_K7_PROFILE
+                T.t0 = t_pop;
+                for (int k = 0; k < 6; ++k) T.tk[k] = 0;
+                FZ_TICK(T, 4);                          // the pair's metadata, the refined bound of a coarse entry
+#endif
                 if (go) {
-                    sc = fz_score<W>(F, T, mode, cur);
+                    sc = fz_score<W, true>(F, T, mode, cur, &want_p);
+                    slot_of = slot;
+                    lens = m;
+#ifdef PFZ_K7_PROFILE
+                    FZ_TICK(T, 5);                      // (what follows the sweeps)
+#endif
+                    did_score = true;
                     best.take(sc, orig);
                     n_scored += 1;
                     n_steps += (unsigned long long)work_estimate(F.la, m, mode, W);
+                }
+#ifdef PFZ_K7_PROFILE
+                for (int k = 0; k < 6; ++k) sub[k] = T.tk[k];
+#endif
+            }
+            if (A.phase_ticks) {
+                // 8 batches, 9 lanes with a pair, 10 lanes scored, 11 lanes that swept windows, 12 windows swept,
+                // 13 64 x the most windows any lane swept (what the wave paid for)
+                const int n_act = __popcll(__ballot(active)), n_go = __popcll(__ballot(did_score)), n_sw = __popcll(__ballot(want_p != 0));
+#ifdef PFZ_K7_PROFILE
+                // 16..21: the slowest lane's ticks by sub-phase -- tokens / set-up, LCS passes, token-set pass, window
+                // sweeps, metadata + refined bound, the rest
+                for (int k = 0; k < 6; ++k) {
+                    unsigned int v = sub[k];
+                    for (int d = 32; d >= 1; d >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, d, 64));
+                    if (lane == 0) s_ticks[16 + k] += v;
+                }
+#endif
+                if (lane == 0) {
+                    s_ticks[8] += 1;
+                    s_ticks[9] += n_act;
+                    s_ticks[10] += n_go;
+                    s_ticks[11] += n_sw;
                 }
             }
             // publish the wave's best score to the workgroup
@@ -948,96 +1064,114 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) wb = fmax(wb, __shfl_xor(wb, d, 64));
             if (lane == 0) atomicMax(&s_best, (unsigned long long)__double_as_longlong(wb));
+            tick(3);
+            // the sweeps this batch asks for: one item per run of windows (it-th item of the lane: forms in order)
+            auto runs_of = [&](int bit, int la, int lb) {
+                const int n_win = fz_n_windows(la, lb), sh = sweep_share_log2(n_win);
+                return (want_p & bit) ? (n_win + (1 << sh) - 1) >> sh : 0;
+            };
+            const int runs0 = runs_of(1, F.la[0], lens.x), runs1 = runs_of(2, F.la[1], lens.y), runs2 = runs_of(4, F.la[2], lens.z);
+            for (int it = 0;; ++it) {
+                const bool has = it < runs0 + runs1 + runs2;
+                const unsigned long long bal = __ballot(has);
+                if (has) {
+                    const int v = it < runs0 ? 0 : (it < runs0 + runs1 ? 1 : 2);
+                    const int run = it - (v == 0 ? 0 : (v == 1 ? runs0 : runs0 + runs1));
+                    sweeps[(sq_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot_of | v << 26 | run << 28;
+                }
+                sq_tail += __popcll(bal);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                sweep_rounds(flush && bal == 0ull);
+                if (bal == 0ull) break;
+            }
+            tick(6);
         };
 
-        // ---- sweep 1 (phase 0): every lane's best-bounded to-string is scored: a real score to prune with;
-        //      sweep 2 (phase 1): the pairs whose bound reaches the best score so far, 64 at a time.
-        // One loop body serves both, and one more trip past the last group flushes the queue: the scoring code -- by far
-        // the largest part of the kernel -- is inlined exactly once.
+        // ---- sweep 1: the bound of every pair of this unit's groups, left as a byte per pair in the workgroup's stretch of
+        //      the bound cache (rounded up; bit 7: coarse), and every lane's best-bounded to-string: its seed.  Nothing but
+        //      bounds in this loop.
         float seed_ub = -1.0f;
         int seed_slot = -1;
+        uint8_t *ubc = A.ub_cache + (int64_t)blockIdx.x * A.n_groups * 64 + lane;
+        {
+            Meta nxt = load_meta(min(g_first, A.n_groups - 1));
+            for (int g = g_first; g < A.n_groups; g += g_step) {
+                const Meta x = nxt;
+                nxt = load_meta(min(g + g_step, A.n_groups - 1));         // (the last trip re-reads a group: harmless)
+                bool valid, coarse;
+                const float ub = bound_of(x, valid, coarse);
+                n_bounded += 1;
+                if (!is_cont && valid && !coarse && ub > seed_ub) {       // (a coarse bound says little: not a seed)
+                    seed_ub = ub;
+                    seed_slot = g * 64 + lane;
+                }
+                ubc[(int64_t)g * 64] = valid ? (uint8_t)(min(127, (int)(fmaxf(ub, 0.0f) * 1.27f) + 1) | (coarse ? 128 : 0)) : (uint8_t)0;
+            }
+        }
+        tick(1);
+        // ---- sweep 2: the seeds are scored -- a real score to prune with (a continuation unit starts from its row's) --
+        //      then the pairs whose byte reaches the best score so far, 64 at a time; one more trip past the last group
+        //      empties the queue and finishes the window sweeps.  The scoring code -- by far the largest part of the
+        //      kernel -- is inlined exactly once.
         int *queue = s_queue[wave];
         int q_head = 0, q_tail = 0;             // wave-uniform; entries [q_head, q_tail) of a ring of 128
         int batches = 0;
-        bool handed = false;
-        uint8_t *ubc = (A.ub_cache && !is_cont) ? A.ub_cache + (int64_t)blockIdx.x * A.n_groups * 64 + lane : nullptr;
-        for (int phase = is_cont ? 1 : 0; phase < 2; ++phase) {
-            const bool cached = phase == 1 && ubc != nullptr;
-            Meta nxt;
-            int nxt_q = 0;
-            if (cached) nxt_q = ubc[(int64_t)min(g_first, A.n_groups - 1) * 64];
-            else nxt = load_meta(min(g_first, A.n_groups - 1));
-            for (int g = g_first;; g += g_step) {
-                const bool last = g >= A.n_groups || handed;
-                bool want = false;
-                int slot = -1;
-                if (!last && cached) {
-                    // sweep 2 from the byte sweep 1 left: bound (rounded up) against the best score so far
-                    const int q = nxt_q;
-                    nxt_q = ubc[(int64_t)min(g + g_step, A.n_groups - 1) * 64];
-                    slot = g * 64 + lane;
-                    const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;
-                    n_bounded += 1;
-                    want = (q & 127) != 0 && slot != seed_slot && !((float)(q & 127) < thr);
-                    slot |= (q & 128) ? (int)0x80000000 : 0;
-                }
-                else if (!last) {
-                    const Meta x = nxt;
-                    nxt = load_meta(min(g + g_step, A.n_groups - 1));         // (the last trips re-read a group: harmless)
-                    slot = g * 64 + lane;
-                    const float cur32 = phase ? (float)cur_now() : 0.0f;
-                    bool valid, coarse;
-                    const float ub = bound_of(x, valid, coarse);
-                    n_bounded += 1;
-                    if (phase == 0) {
-                        if (valid && !coarse && ub > seed_ub) {       // (a coarse bound says little: not a seed)
-                            seed_ub = ub;
-                            seed_slot = slot;
-                        }
-                        if (ubc) ubc[(int64_t)g * 64] = valid ? (uint8_t)(min(127, (int)(fmaxf(ub, 0.0f) * 1.27f) + 1) | (coarse ? 128 : 0)) : (uint8_t)0;
-                    }
-                    else {
-                        want = valid && slot != seed_slot && !(ub + kBoundSlack < cur32);
-                        slot |= coarse ? (int)0x80000000 : 0;
-                    }
-                }
-                else if (phase == 0) {
-                    slot = seed_slot;
-                    want = seed_slot >= 0;
-                }
-                const unsigned long long bal = __ballot(want);
-                if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot;
-                q_tail += __popcll(bal);
+        bool handed = false, swept_out = false;
+        int nxt_q = ubc[(int64_t)min(g_first, A.n_groups - 1) * 64];
+        for (int g = g_first, trip = 0;; ++trip) {
+            const bool seeds = trip == 0 && !is_cont;
+            const bool last = !seeds && (g >= A.n_groups || handed);
+            bool want = false;
+            int slot = -1;
+            if (seeds) {
+                slot = seed_slot;
+                want = seed_slot >= 0;
+            }
+            else if (!last) {
+                const int q = nxt_q;
+                nxt_q = ubc[(int64_t)min(g + g_step, A.n_groups - 1) * 64];
+                slot = g * 64 + lane;
+                const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;
+                n_bounded += 1;
+                want = (q & 127) != 0 && slot != seed_slot && !((float)(q & 127) < thr);
+                slot |= (q & 128) ? (int)0x80000000 : 0;
+            }
+            const unsigned long long bal = __ballot(want);
+            if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot;
+            q_tail += __popcll(bal);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            tick(2);
+            const bool drain = last || seeds;
+            // (a last call, with or without pairs, finishes the window sweeps under way)
+            while (q_tail - q_head >= 64 || (drain && (q_tail > q_head || (last && !swept_out)))) {
+                const bool active = lane < q_tail - q_head;
+                const bool flush = drain && q_tail - q_head <= 64;
+                score_slot(active ? queue[(q_head + lane) & 127] : -1, active, flush);
+                swept_out = flush;
+                q_head += min(64, q_tail - q_head);
+                ++batches;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                tick(1 + phase);
-                while (q_tail - q_head >= 64 || (last && q_tail > q_head)) {
-                    const bool active = lane < q_tail - q_head;
-                    score_slot(active ? queue[(q_head + lane) & 127] : -1, active);
-                    q_head += min(64, q_tail - q_head);
-                    ++batches;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    tick(3);
-                }
-                if (last) break;
-                if (phase == 1 && !is_cont && A.cont_list && batches >= A.hand_batches && A.n_groups - g > A.hand_min_groups * g_step) {
-                    // a heavy row: leave the rest of its groups to several waves (they start from the best score so far)
-                    int at = 0;
-                    if (lane == 0) at = atomicAdd(A.n_cont, 1);
-                    at = __builtin_amdgcn_readfirstlane(at);
-                    if (at < A.cont_cap) {
-                        if (lane == 0) {
-                            __hip_atomic_store(&A.cont_list[at].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&A.cont_list[at].y, g + g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&A.cont_list[at].z, g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&A.cont_cur[at], __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&A.cont_list[at].w, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // ready
-                        }
-                        handed = true;           // (the next trip flushes the queue and ends the loop)
+            }
+            if (last) break;
+            if (seeds) continue;
+            if (!is_cont && A.cont_list && batches >= A.hand_batches && A.n_groups - g > A.hand_min_groups * g_step) {
+                // a heavy row: leave the rest of its groups to several waves (they start from the best score so far)
+                int at = 0;
+                if (lane == 0) at = atomicAdd(A.n_cont, 1);
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (at < A.cont_cap) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&A.cont_list[at].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&A.cont_list[at].y, g + g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&A.cont_list[at].z, g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&A.cont_cur[at], __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&A.cont_list[at].w, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // ready
                     }
+                    handed = true;           // (the next trip empties the queue and ends the loop)
                 }
             }
-            if (phase == 0) __syncthreads();        // every wave's seeds are scored: `cur` is what the workgroup knows
+            g += g_step;
         }
 
         // first best choice: (score desc, original index asc)
@@ -1076,7 +1210,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
     }
     if (A.phase_ticks) {
         __syncthreads();
-        if (tid < 8) atomicAdd(&A.phase_ticks[tid], s_ticks[tid]);
+        if (tid < 24) atomicAdd(&A.phase_ticks[tid], s_ticks[tid]);
     }
     if (A.counters) {
 #pragma unroll
@@ -1249,18 +1383,23 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     const int32_t cont_cap = (int32_t)std::min<int64_t>(n_rows, 1 << 20);
     PFZ_TRY(d_cont.alloc((size_t)cont_cap * 3 * sizeof(int4)));
     PFZ_TRY(d_cont_cur.alloc((size_t)cont_cap * 3 * sizeof(unsigned long long)));
+    // the bound cache: a byte per (workgroup, to-slot), a stretch of its own for every launch (they may run side by side).
+    // Few enough persistent workgroups that it stays within 16 GiB (4096 of them up to four million to-strings)
+    const int64_t grid_cap = std::max<int64_t>(64, std::min<int64_t>(max_grid, ((int64_t)16 << 30) / (3 * std::max<int64_t>(pl->n_groups, 1) * 64)));
+    auto grid_of = [&](int c, bool hand) { return hand ? grid_cap : std::min<int64_t>((int64_t)cls[c].size() * parts_of[c], grid_cap); };
     const bool hand_over = !getenv("PFZ_K7_NO_HANDOVER");
     DevBuf d_ubc(ctx);
-    const size_t ubc_bytes = (size_t)max_grid * (size_t)pl->n_groups * 64;
-    if (ubc_bytes <= ((size_t)1 << 30) && !getenv("PFZ_K7_NO_UB_CACHE")) {      // (beyond 1 GiB: sweep 2 computes the bounds again)
-        PFZ_TRY(d_ubc.alloc(ubc_bytes));
-        A.ub_cache = (uint8_t *)d_ubc.p;
+    int64_t ubc_at[3] = {0, 0, 0}, ubc_slots = 0;
+    for (int c = 0; c < 3; ++c) {
+        ubc_at[c] = ubc_slots;
+        if (!cls[c].empty()) ubc_slots += grid_of(c, hand_over && parts_of[c] == 1 && kK7Waves == 1) * pl->n_groups * 64;
     }
+    PFZ_TRY(d_ubc.alloc((size_t)std::max<int64_t>(ubc_slots, 64)));
     const char *stats_path = getenv("PFZ_K7_ROW_STATS");
     if (stats_path) {
         // (two per row, then eight phase timers: see the kernel)
-        PFZ_TRY(d_stats.alloc(((size_t)n_rows * 2 + 8) * sizeof(unsigned long long)));
-        PFZ_HIP(hipMemsetAsync(d_stats.p, 0, ((size_t)n_rows * 2 + 8) * sizeof(unsigned long long), ctx->stream));
+        PFZ_TRY(d_stats.alloc(((size_t)n_rows * 2 + 24) * sizeof(unsigned long long)));
+        PFZ_HIP(hipMemsetAsync(d_stats.p, 0, ((size_t)n_rows * 2 + 24) * sizeof(unsigned long long), ctx->stream));
         A.row_stats = (unsigned long long *)d_stats.p;
         A.phase_ticks = A.row_stats + (size_t)n_rows * 2;
     }
@@ -1301,11 +1440,10 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
             st = ctx->stream2;
             used_side = true;
         }
-        // (the bound cache is indexed by workgroup: only one of two launches that run side by side may use it)
         FuzzArgs L = A;
-        if (st != ctx->stream) L.ub_cache = nullptr;
+        L.ub_cache = (uint8_t *)d_ubc.p + ubc_at[c];
         // persistent one-wave workgroups: the rows, then -- in the same launch -- the remainders of the heavy ones
-        const unsigned grid = (unsigned)(hand ? max_grid : std::min<int64_t>((int64_t)A.n_rows * A.parts, max_grid));
+        const unsigned grid = (unsigned)grid_of(c, hand);
         if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, st, L);
         else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, st, L);
         else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, st, L);
@@ -1351,7 +1489,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     }
     if (h_counters) PFZ_TRY(copy_d2h(ctx, h_counters, d_counters.p, 4 * sizeof(unsigned long long)));
     if (stats_path) {
-        std::vector<unsigned long long> st((size_t)n_rows * 2 + 8);
+        std::vector<unsigned long long> st((size_t)n_rows * 2 + 24);
         PFZ_TRY(copy_d2h(ctx, st.data(), d_stats.p, st.size() * sizeof(unsigned long long)));
         if (FILE *fp = fopen(stats_path, "wb")) {
             fwrite(st.data(), sizeof(unsigned long long), st.size(), fp);

@@ -16,6 +16,32 @@
 
 using namespace pfz;
 
+// 0: fz_score sweeps its windows itself; > 0: the kernel's way -- the sweeps deferred, every form's windows shared out in
+// runs of this many, each run swept on its own, the pair's score the maximum of the parts
+static int g_share = 0;
+extern "C" void k7_host_set_share(int share) { g_share = share; }
+
+template <int W>
+static double score_pair(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
+{
+    if (g_share <= 0) return fz_score<W>(F, T, mode, cur);
+    int want = 0;
+    double sc = fz_score<W, true>(F, T, mode, cur, &want);
+    for (int v = 0; v < 3; ++v) {
+        if (!((want >> v) & 1)) continue;
+        const int n_win = fz_n_windows(F.la[v], T.lb[v]);
+        const double f = fz_sweep_factor(mode, v, F.la[0], T.lb[0]);
+        for (int w0 = 0; w0 < n_win; w0 += g_share) {
+            FuzzSweep S;
+            fz_sweep_begin(S, v, F.la[v], T.lb[v], w0, w0 + g_share < n_win ? w0 + g_share : n_win, T.sym[v], nullptr, 0);
+            while (!fz_sweep_window<W>(S, F, f, cur - 1e-6)) {}
+            const double part = fz_sweep_score(mode, v, F.la[0], T.lb[0], fz_ratio_of(S.bl, S.bs));
+            if (part > sc) sc = part;
+        }
+    }
+    return sc;
+}
+
 struct List {
     int64_t n;
     const uint16_t *sym[3];
@@ -36,7 +62,7 @@ static void run(int n_sym, const List &A, const List &B, int mode, const double 
         FuzzFrom<W> F;
         for (int v = 0; v < 3; ++v) {
             const int64_t a0 = A.off[v][i];
-            F.la[v] = (int)(A.off[v][i + 1] - a0);
+            F.la.set(v, (int)(A.off[v][i + 1] - a0));
             for (int p = 0; p < F.la[v]; ++p) {
                 const int sy = A.sym[v][a0 + p];
                 if (sy) pm[((size_t)sy * 3 + v) * W + (p >> 6)] |= 1ull << (p & 63);
@@ -76,8 +102,8 @@ static void run(int n_sym, const List &A, const List &B, int mode, const double 
             FuzzSummary sb;
             sb.sig = 0;
             for (int v = 0; v < 3; ++v) {
-                T.sym[v] = B.sym[v] + B.off[v][j];
-                T.lb[v] = sb.len[v] = (int)(B.off[v][j + 1] - B.off[v][j]);
+                T.sym.set(v, B.sym[v] + B.off[v][j]);
+                T.lb.set(v, sb.len[v] = (int)(B.off[v][j + 1] - B.off[v][j]));
             }
             T.tag = B.tag + B.off[2][j];
             T.tok_id = B.tok_id + B.tok_off[j];
@@ -85,11 +111,12 @@ static void run(int n_sym, const List &A, const List &B, int mode, const double 
             T.stage = nullptr;
             T.stage_stride = 0;
             T.staged = -1;
+            T.n_windows = 0;
             T.tb = sb.ntok = (int)(B.tok_off[j + 1] - B.tok_off[j]);
             for (int t = 0; t < T.tb; ++t) sb.sig |= fz_sig_bit(T.tok_id[t]);
             memcpy(sb.hist, B.hist + (size_t)j * kFuzzHistWords, sizeof(sb.hist));
             sb.usum = B.usum[j];
-            out_score[i * B.n + j] = fz_score<W>(F, T, mode, cur[i]);
+            out_score[i * B.n + j] = score_pair<W>(F, T, mode, cur[i]);
             // the sweep's two-step bound: signatures first, the exact intersection only when they meet
             const int u = fz_common_chars(sa, sb);
             const bool maybe = (sa.sig & sb.sig) != 0;

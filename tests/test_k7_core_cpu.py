@@ -33,7 +33,8 @@ def host():
     return lib
 
 
-def run_pairs(lib, W, alpha, A, B, mode, cur):
+def run_pairs(lib, W, alpha, A, B, mode, cur, share=0):
+    lib.k7_host_set_share(share)
     out = np.empty((A["n"], B["n"]), np.float64)
     ub = np.empty((A["n"], B["n"]), np.float32)
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
@@ -103,6 +104,15 @@ def test_score_and_bound_vs_oracle(host, oracle_mod, mode, W, seed, long_words):
         reach = truth >= cur[:, None]
         np.testing.assert_array_equal(score3[reach], truth[reach])
         assert (score3 <= truth).all()
+    # the kernel's way: window sweeps deferred and shared out in runs of windows, each run on its own
+    for share in (5, 16 * W):
+        score4, _ = run_pairs(host, W, alpha, A, B, mode, np.zeros(len(fl)), share)
+        np.testing.assert_array_equal(score4, truth)
+        for cur in (truth.max(axis=1), np.quantile(truth, 0.8, axis=1)):
+            score5, _ = run_pairs(host, W, alpha, A, B, mode, cur, share)
+            reach = truth >= cur[:, None]
+            np.testing.assert_array_equal(score5[reach], truth[reach])
+            assert (score5 <= truth).all()
 
 
 def test_bound_is_useful(host, oracle_mod):

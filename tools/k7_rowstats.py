@@ -23,10 +23,18 @@ os.environ["PFZ_K7_ROW_STATS"] = path
 _lib.fuzz_extract_one_dev(ctx, f_dev, t_dev, mode, out); ctx.sync()
 del os.environ["PFZ_K7_ROW_STATS"]
 raw = np.fromfile(path, np.uint64)
-phase = raw[-8:].astype(np.float64)
-st = raw[:-8].reshape(-1, 2).astype(np.float64)
-names = ["set-up of a from-string", "sweep 1 (bounds, seeds)", "sweep 2 (cached bounds)", "scoring batches", "end of unit / next unit", "waiting for a continuation"]
+ext = raw[-24:].astype(np.float64)
+phase = ext[:7]
+st = raw[:-24].reshape(-1, 2).astype(np.float64)
+names = ["set-up of a from-string", "sweep 1 (bounds, seeds)", "sweep 2 (cached bounds)", "scoring batches", "end of unit / next unit", "waiting for a continuation", "window sweeps"]
 print("wave time by phase (shader clock, all waves):", " | ".join(f"{n} {phase[i] / phase.sum():.3f}" for i, n in enumerate(names)), f"| total {phase.sum():.3e} ticks")
+b, act, go, sw, win, paid = ext[8:14]
+if ext[16:22].sum() > 0:          # (a -DPFZ_K7_PROFILE build)
+    sub = ext[16:22]
+    print("scoring, slowest lane of each batch by sub-phase (share of the scoring ticks", f"{sub.sum() / phase[3]:.2f}):",
+          " | ".join(f"{n} {x / sub.sum():.3f}" for n, x in zip(["tokens/set-up", "LCS passes", "token-set pass", "window sweeps", "metadata + refined bound", "rest"], sub)))
+print(f"scoring batches {b:.0f}: lanes with a pair {act / (64 * b):.3f}, scored {go / (64 * b):.3f}, swept windows {sw / (64 * b):.3f}; windows per sweeping lane {win / max(sw, 1):.2f}, "
+      f"windows the waves paid for / windows swept {paid / max(win, 1):.2f}")
 scored, ticks = st[:, 0], st[:, 1]
 L = np.array([len(s) for s in fl]); T = np.array([len(set(s.split())) for s in fl])
 idx, score = _lib.best_from_topn(*out.download())
