@@ -39,6 +39,9 @@
 #ifndef PFZ_LDS_U16
 #define PFZ_LDS_U16 uint16_t      // the kernel defines it as an LDS-address-space type: LDS and global loads must not be merged into flat ones
 #endif
+#ifndef PFZ_LDS_U8
+#define PFZ_LDS_U8 uint8_t
+#endif
 
 namespace pfz {
 
@@ -288,25 +291,30 @@ struct FuzzSweep {
     int bl, bs;            // the best candidate so far: lcs, length sum
     const uint16_t *sym;   // the to-form's symbols; or, when stage_stride != 0, its copy in the scratch column
     PFZ_LDS_U16 *stage;
-    int stage_stride;
+    int stage_stride;      // (in elements)
+    bool narrow;           // the column holds bytes (an alphabet of at most 255 symbols: half the scratch memory)
 };
 
 // copy a to-form of at most kFuzzStage symbols into the scratch column (a window sweep re-reads it |from| times)
-PFZ_HD void fz_stage_form(const uint16_t *sym, int lb, PFZ_LDS_U16 *stage, int stride)
+PFZ_HD void fz_stage_form(const uint16_t *sym, int lb, PFZ_LDS_U16 *stage, int stride, bool narrow)
 {
     for (int p0 = 0; p0 < lb; p0 += 8) {
         int c[8];
         fz_load8(sym + p0, lb - p0, c);
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (p0 + q < lb) stage[(p0 + q) * stride] = (uint16_t)c[q];
+            if (p0 + q < lb) {
+                if (narrow) ((PFZ_LDS_U8 *)stage)[(p0 + q) * stride] = (uint8_t)c[q];
+                else stage[(p0 + q) * stride] = (uint16_t)c[q];
+            }
     }
 }
 
 // (sym / stage: see FuzzSweep; stage_stride 0 = read the symbols where they are)
 PFZ_HD void fz_sweep_begin(FuzzSweep &S, int v, int la, int lb, int w, int w_end, const uint16_t *sym, PFZ_LDS_U16 *stage,
-                           int stage_stride)
+                           int stage_stride, bool narrow = false)
 {
+    S.narrow = narrow;
     S.v = v;
     S.la = la;
     S.lb = lb;
@@ -319,7 +327,11 @@ PFZ_HD void fz_sweep_begin(FuzzSweep &S, int v, int la, int lb, int w, int w_end
     S.stage_stride = stage_stride;
 }
 
-PFZ_HD int fz_sweep_sym(const FuzzSweep &S, int pos) { return S.stage_stride != 0 ? (int)S.stage[pos * S.stage_stride] : (int)S.sym[pos]; }
+PFZ_HD int fz_sweep_sym(const FuzzSweep &S, int pos)
+{
+    if (S.stage_stride == 0) return (int)S.sym[pos];
+    return S.narrow ? (int)((PFZ_LDS_U8 *)S.stage)[pos * S.stage_stride] : (int)S.stage[pos * S.stage_stride];
+}
 
 // sweeps window S.w and moves S.w to the next window that can matter; true: the share is done.  A window matters when it
 // can beat the best so far AND reach `thr` after the factor f the caller's formula multiplies partial_ratio by

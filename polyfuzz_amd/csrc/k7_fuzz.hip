@@ -40,6 +40,7 @@
 #undef PFZ_HD
 #define PFZ_HD __device__ inline
 #define PFZ_LDS_U16 __attribute__((address_space(3))) uint16_t
+#define PFZ_LDS_U8 __attribute__((address_space(3))) uint8_t
 #ifdef PFZ_K7_PROFILE
 #define FZ_TICK(T, k)                                                 \
     do {                                                              \
@@ -60,8 +61,17 @@ namespace pfz {
 constexpr int kK7Waves = 1, kK7Threads = 64 * kK7Waves;
 constexpr float kBoundSlack = 0.05f;
 // log2 of the windows per run of a window sweep: 16, more for long forms -- at most 8 runs (forms are <= 256 symbols here)
-__device__ inline int sweep_share_log2(int n_windows) { return n_windows <= 128 ? 4 : (n_windows <= 256 ? 5 : (n_windows <= 512 ? 6 : 7)); }
-constexpr int kHandBatches = 32, kHandMinGroups = 16, kContParts = 8;      // heavy-row hand-over (see FuzzArgs::cont_list)      // a pair is dismissed only when bound + slack < cur (float32 bound, float64 scores)
+#ifndef PFZ_K7_SHARE_LOG2
+#define PFZ_K7_SHARE_LOG2 5
+#endif
+__device__ inline int sweep_share_log2(int n_windows)
+{
+    constexpr int k = PFZ_K7_SHARE_LOG2;
+    return n_windows <= (8 << k) ? k : (n_windows <= (16 << k) ? k + 1 : (n_windows <= (32 << k) ? k + 2 : k + 3));
+}
+// heavy-row hand-over (see FuzzArgs::cont_list): a row that has scored kHandBatches batches and still has kHandMinGroups
+// groups to go leaves them to continuation units -- as many (up to kContParts) as leave each about kHandBatches batches
+constexpr int kHandBatches = 64, kHandMinGroups = 16, kContParts = 64;
 
 __device__ inline uint32_t load_unit(const void *p, int width, int64_t i)
 {
@@ -665,10 +675,15 @@ __device__ inline int work_estimate(const Fz3<int> &la, const int4 &m, int mode,
 }
 
 template <int W>
-__global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
+__global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_fuzz_kernel(FuzzArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint64_t *pm = (uint64_t *)smem_raw;               // [symbol][form][word]
+    // dynamic part: the from-string's match table [symbol][form][word]; the scratch columns of the window sweeps
+    // [position][lane], bytes when the alphabet has at most 255 symbols; (profiling) the phase timers
+    uint64_t *pm = (uint64_t *)smem_raw;
+    const bool narrow = A.n_sym1 <= 256;
+    unsigned char *s_stage = smem_raw + (size_t)A.n_sym1 * 3 * W * sizeof(uint64_t);
+    unsigned long long *s_ticks = (unsigned long long *)(s_stage + (size_t)kK7Waves * kFuzzStage * 64 * (narrow ? 1 : 2));
     __shared__ int s_la[3], s_ta, s_nspace, s_usum;
     __shared__ int s_tid[kFuzzMaxTokens], s_tlen[kFuzzMaxTokens];
     __shared__ uint64_t s_tmask[kFuzzMaxTokens * W], s_smask[kFuzzMaxTokens * W];
@@ -678,22 +693,18 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
     __shared__ int red_i[kK7Waves];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
     __shared__ int s_queue[kK7Waves][128];
-    __shared__ int s_sweeps[kK7Waves][128];       // runs of windows waiting for a lane (see sweep_rounds)
-    __shared__ uint16_t s_stage[kK7Waves][kFuzzStage][64];       // per wave: [position][lane] symbols of the form a lane sweeps
+    __shared__ int s_sweeps[kK7Waves][64];        // runs of windows waiting for a lane (see sweep_rounds)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
     const bool use_tokens = mode_uses_tokens(mode);
 
     for (int p = tid; p < A.n_sym1 * 3 * W; p += kK7Threads) pm[p] = 0ull;
-    unsigned long long n_bounded = 0, n_scored = 0, n_steps = 0;
     __syncthreads();
 
     __shared__ int s_unit, s_cont[4];
-    __shared__ unsigned long long s_cont_cur;
     // profiling only: where the waves' time goes -- 0 set-up of a from-string, 1 / 2 the two bounding sweeps, 3 scoring,
     // 4 the end of a unit (merge, table clean-up, next unit), 5 waiting for a continuation record
-    __shared__ unsigned long long s_ticks[24];
-    if (tid < 24) s_ticks[tid] = 0ull;
+    if (A.phase_ticks && tid < 24) s_ticks[tid] = 0ull;
     long long t_last = A.phase_ticks ? clock64() : 0;
     auto tick = [&](int k) {
         if (A.phase_ticks) {
@@ -712,8 +723,8 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
         const bool is_cont = u >= n_primary;
         tick(4);
         const long long t_begin = A.row_stats ? wall_clock64() : 0;
-        const unsigned long long scored_before = n_scored;
-        int r, part, g_first, g_step;
+        unsigned int n_bounded = 0, n_scored = 0, n_steps = 0;        // (work counters of this unit, per lane)
+        int r, part, g_first, g_step, cont_rec = -1;
         unsigned long long cur0 = 0ull;
         if (!is_cont) {
             r = u / parts;
@@ -722,11 +733,11 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
             g_step = kK7Waves * parts;
         }
         else {
-            // the remainder of a heavy row: its groups g_next, g_next + step, ... dealt to cont_parts units.  Its record may
-            // not be there yet (its row is still being worked on), or never come (all rows finished: the list is final)
+            // a share of a heavy row: the row's hand-over left one record per continuation unit {row, first group, step, units
+            // | part << 8 (-1: void)}; unit numbers are dealt in the order the records were claimed.  The record may not be
+            // there yet (its row is still being worked on), or never come (all rows finished: the list is final)
             if (!A.cont_list) break;
-            const int c = (u - n_primary) / A.cont_parts;
-            part = (u - n_primary) - c * A.cont_parts;
+            const int c = u - n_primary;
             if (tid == 0) {
                 // (relaxed polls with long sleeps: an acquire per poll would invalidate the caches the working waves live on)
                 int ok;
@@ -746,21 +757,23 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                     while (__hip_atomic_load(&A.cont_list[c].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(64);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
-                s_cont[0] = ok;
+                s_cont[0] = ok ? __hip_atomic_load(&A.cont_list[c].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 if (ok) {
                     s_cont[1] = __hip_atomic_load(&A.cont_list[c].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_cont[2] = __hip_atomic_load(&A.cont_list[c].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_cont[3] = __hip_atomic_load(&A.cont_list[c].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_cont_cur = __hip_atomic_load(&A.cont_cur[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             __syncthreads();
             tick(5);
             if (!s_cont[0]) break;
+            if (s_cont[0] < 0) continue;           // (a void record: its row could not hand over)
+            part = s_cont[0] >> 8;
             r = s_cont[1];
-            g_first = s_cont[2] + (wave + kK7Waves * part) * s_cont[3];
-            g_step = s_cont[3] * kK7Waves * A.cont_parts;
-            cur0 = s_cont_cur;
+            g_first = s_cont[2];
+            g_step = s_cont[3];
+            cont_rec = c - part;                   // (the row's first record: where its units share their best score)
+            cur0 = __hip_atomic_load(&A.cont_cur[cont_rec], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const int row = A.rows[r];
         const int64_t a0 = A.a_off[row];
@@ -855,8 +868,8 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
             T.tok_len = A.b_tok_len + rec.z;
             T.lb = {m.x, m.y, m.z};
             T.tb = m.w;
-            T.stage = (PFZ_LDS_U16 *)&s_stage[wave][0][lane];
-            T.stage_stride = 0;          // (the scratch column belongs to the window sweeps: sweep_rounds)
+            T.stage = nullptr;
+            T.stage_stride = 0;          // (the scratch columns belong to the window sweeps: sweep_rounds)
             T.staged = -1;
             T.n_windows = 0;
             return T;
@@ -937,12 +950,14 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                 const unsigned long long idle = __ballot(sw_item < 0);
                 const int n_take = min((int)__popcll(idle), sq_tail - sq_head);
                 const int n_busy = 64 - (int)__popcll(idle) + n_take;
-                if (n_busy == 0 || (!flush && n_busy < 64)) break;
-                PFZ_LDS_U16 *column = (PFZ_LDS_U16 *)&s_stage[wave][0][lane];
+                // (the lane's column: [position][lane] elements of 1 or 2 bytes)
+                PFZ_LDS_U16 *column = (PFZ_LDS_U16 *)(s_stage + (size_t)wave * kFuzzStage * 64 * (narrow ? 1 : 2) + lane * (narrow ? 1 : 2));
+                // every waiting run is taken whenever the lanes are not all busy (the ring holds 64): a round is held only
+                // when all of them are, or at the end
                 if (sw_item < 0) {
                     const int rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (rank < n_take) {
-                        sw_item = sweeps[(sq_head + rank) & 127];
+                        sw_item = sweeps[(sq_head + rank) & 63];
                         const int slot = sw_item & 0x3ffffff, v = (sw_item >> 26) & 3, run = sw_item >> 28;
                         const int4 m = A.b_meta[slot];
                         const int la = F.la[v], lb = v == 0 ? m.x : (v == 1 ? m.y : m.z);
@@ -952,12 +967,13 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                         sw_best = 1 << 16;
                         if (lb <= kFuzzStage) {
                             const int4 rec = A.b_meta3[slot];
-                            fz_stage_form(A.b_sym + rec.x + (int64_t)v * rec.w, lb, column, 64);
+                            fz_stage_form(A.b_sym + rec.x + (int64_t)v * rec.w, lb, column, 64, narrow);
                         }
                     }
                 }
                 sq_head += n_take;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (n_busy == 0 || (!flush && n_busy < 64)) break;
                 if (sw_item >= 0) {
                     const int slot = sw_item & 0x3ffffff, v = (sw_item >> 26) & 3;
                     const int lb = sw_len & 0xffff, lb0 = sw_len >> 16;
@@ -968,8 +984,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                         sym += rec.x + (int64_t)v * rec.w;
                     }
                     FuzzSweep SW;
-                    fz_sweep_begin(SW, v, F.la[v], lb, sw_win & 0xffff, sw_win >> 16, sym, column,
-                                   staged ? 64 : 0);
+                    fz_sweep_begin(SW, v, F.la[v], lb, sw_win & 0xffff, sw_win >> 16, sym, column, staged ? 64 : 0, narrow);
                     SW.bl = sw_best & 0xffff;
                     SW.bs = sw_best >> 16;
                     const bool done = fz_sweep_window<W>(SW, F, fz_sweep_factor(mode, v, F.la[0], lb0), cur_now() - 1e-6);
@@ -1033,7 +1048,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                     did_score = true;
                     best.take(sc, orig);
                     n_scored += 1;
-                    n_steps += (unsigned long long)work_estimate(F.la, m, mode, W);
+                    n_steps += (unsigned int)work_estimate(F.la, m, mode, W);
                 }
 #ifdef PFZ_K7_PROFILE
                 for (int k = 0; k < 6; ++k) sub[k] = T.tk[k];
@@ -1063,7 +1078,15 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
             double wb = active ? fmax(sc, 0.0) : 0.0;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) wb = fmax(wb, __shfl_xor(wb, d, 64));
-            if (lane == 0) atomicMax(&s_best, (unsigned long long)__double_as_longlong(wb));
+            if (lane == 0) {
+                atomicMax(&s_best, (unsigned long long)__double_as_longlong(wb));
+                if (cont_rec >= 0) {
+                    // the units of a record tell each other: the best score any of them has found prunes for all
+                    const unsigned long long mine = __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned long long theirs = atomicMax(&A.cont_cur[cont_rec], mine);
+                    if (theirs > mine) atomicMax(&s_best, theirs);
+                }
+            }
             tick(3);
             // the sweeps this batch asks for: one item per run of windows (it-th item of the lane: forms in order)
             auto runs_of = [&](int bit, int la, int lb) {
@@ -1077,7 +1100,7 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                 if (has) {
                     const int v = it < runs0 ? 0 : (it < runs0 + runs1 ? 1 : 2);
                     const int run = it - (v == 0 ? 0 : (v == 1 ? runs0 : runs0 + runs1));
-                    sweeps[(sq_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot_of | v << 26 | run << 28;
+                    sweeps[(sq_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 63] = slot_of | v << 26 | run << 28;
                 }
                 sq_tail += __popcll(bal);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1153,25 +1176,40 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             if (last) break;
-            if (seeds) continue;
-            if (!is_cont && A.cont_list && batches >= A.hand_batches && A.n_groups - g > A.hand_min_groups * g_step) {
-                // a heavy row: leave the rest of its groups to several waves (they start from the best score so far)
-                int at = 0;
-                if (lane == 0) at = atomicAdd(A.n_cont, 1);
-                at = __builtin_amdgcn_readfirstlane(at);
-                if (at < A.cont_cap) {
-                    if (lane == 0) {
-                        __hip_atomic_store(&A.cont_list[at].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&A.cont_list[at].y, g + g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&A.cont_list[at].z, g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&A.cont_cur[at], __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&A.cont_list[at].w, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // ready
-                    }
-                    handed = true;           // (the next trip empties the queue and ends the loop)
-                }
+            if (!seeds) {
+                g += g_step;
+                continue;
             }
-            g += g_step;
+            // The seeds are scored: the pairs whose bound reaches the best of them are (at most) what is left to score -- one
+            // quick pass over the bytes counts them.  A heavy row -- more than hand_batches batches of them -- is left to
+            // several waves: as many continuation units as give each about half that (up to cont_parts), all of its groups
+            // dealt among them, starting from the seeds' best
+            if (!A.cont_list || A.n_groups - g <= A.hand_min_groups * g_step) continue;
+            int survivors = 0;
+            {
+                const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;
+                for (int gg = g; gg < A.n_groups; gg += g_step) survivors += !((float)(ubc[(int64_t)gg * 64] & 127) < thr) ? 1 : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) survivors += __shfl_xor(survivors, d, 64);
+            }
+            if (survivors > 64 * A.hand_batches) {
+                const int units = min(A.cont_parts, max(2, (2 * survivors + 64 * A.hand_batches - 1) / (64 * A.hand_batches)));
+                int at = 0;
+                if (lane == 0) at = atomicAdd(A.n_cont, units);
+                at = __builtin_amdgcn_readfirstlane(at);
+                const bool fits = at + units <= A.cont_cap;
+                if (fits && lane == 0)
+                    __hip_atomic_store(&A.cont_cur[at], __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane < units && at + lane < A.cont_cap) {          // one record per unit (void ones when the list is full)
+                    __hip_atomic_store(&A.cont_list[at + lane].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&A.cont_list[at + lane].y, g + lane * g_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&A.cont_list[at + lane].z, g_step * units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&A.cont_list[at + lane].w, fits ? (units | lane << 8) : -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                handed = fits;           // (the next trip finishes the seeds' window sweeps and ends the loop)
+            }
         }
 
         // first best choice: (score desc, original index asc)
@@ -1190,11 +1228,31 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
             if (!is_cont && A.cont_list) __hip_atomic_fetch_add(A.rows_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (A.row_stats) {
-            unsigned long long ns = n_scored - scored_before;
+            unsigned int ns = n_scored;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) ns += __shfl_xor(ns, d, 64);
-            if (lane == 0) atomicAdd(&A.row_stats[2 * (int64_t)A.row_slot[r]], ns);
-            if (tid == 0) atomicAdd(&A.row_stats[2 * (int64_t)A.row_slot[r] + 1], (unsigned long long)(wall_clock64() - t_begin));
+            if (lane == 0) atomicAdd(&A.row_stats[2 * (int64_t)A.row_slot[r]], (unsigned long long)ns);
+            if (tid == 0) {
+                const long long t_end = wall_clock64();
+                atomicAdd(&A.row_stats[2 * (int64_t)A.row_slot[r] + 1], (unsigned long long)(t_end - t_begin));
+                // (after the timers: when the row's first unit began -- kept as 2^62 minus the time --, when its last ended)
+                atomicMax(&A.phase_ticks[24 + 2 * (int64_t)A.row_slot[r]], (1ull << 62) - (unsigned long long)t_begin);
+                atomicMax(&A.phase_ticks[24 + 2 * (int64_t)A.row_slot[r] + 1], (unsigned long long)t_end);
+            }
+        }
+        if (A.counters) {
+            unsigned long long nb = n_bounded, nsc = n_scored, nst = n_steps;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                nb += __shfl_xor(nb, d, 64);
+                nsc += __shfl_xor(nsc, d, 64);
+                nst += __shfl_xor(nst, d, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(&A.counters[0], nb);
+                atomicAdd(&A.counters[1], nsc);
+                atomicAdd(&A.counters[2], nst);
+            }
         }
         // clear this from-string's table entries
         for (int v = 0; v < 3; ++v) {
@@ -1211,19 +1269,6 @@ __global__ __launch_bounds__(kK7Threads, 3) void k7_fuzz_kernel(FuzzArgs A)
     if (A.phase_ticks) {
         __syncthreads();
         if (tid < 24) atomicAdd(&A.phase_ticks[tid], s_ticks[tid]);
-    }
-    if (A.counters) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            n_bounded += __shfl_xor(n_bounded, d, 64);
-            n_scored += __shfl_xor(n_scored, d, 64);
-            n_steps += __shfl_xor(n_steps, d, 64);
-        }
-        if (lane == 0) {
-            atomicAdd(&A.counters[0], n_bounded);
-            atomicAdd(&A.counters[1], n_scored);
-            atomicAdd(&A.counters[2], n_steps);
-        }
     }
 }
 
@@ -1317,6 +1362,23 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         cls[c].push_back((int32_t)i);
         slot_of[c].push_back((int32_t)(i - begin));
     }
+    // the units are handed out in this order: the long from-strings -- many more of their pairs survive the bound -- first,
+    // so that none of them starts when the others are about to finish (a counting sort by length: O(n))
+    for (int c = 0; c < 3; ++c) {
+        const size_t n = cls[c].size();
+        if (n < 2) continue;
+        std::vector<int32_t> start(258, 0), rows(n), slots(n);
+        auto len_of = [&](int32_t i) { return (int)(F->h_off[(size_t)i + 1] - F->h_off[(size_t)i]); };
+        for (size_t k = 0; k < n; ++k) start[(size_t)(256 - len_of(cls[c][k])) + 1]++;
+        for (size_t l = 1; l < start.size(); ++l) start[l] += start[l - 1];
+        for (size_t k = 0; k < n; ++k) {
+            const size_t at = (size_t)start[(size_t)(256 - len_of(cls[c][k]))]++;
+            rows[at] = cls[c][k];
+            slots[at] = slot_of[c][k];
+        }
+        cls[c].swap(rows);
+        slot_of[c].swap(slots);
+    }
 
     FuzzArgs A{};
     A.a_form[0] = F->chars;
@@ -1380,7 +1442,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     DevBuf d_next(ctx), d_stats(ctx), d_cont(ctx), d_cont_cur(ctx);
     PFZ_TRY(d_next.alloc(16 * sizeof(int32_t)));          // [0..2] unit counters, [4..6] continuation unit counters, [8..10] continuation counts
     PFZ_HIP(hipMemsetAsync(d_next.p, 0, 16 * sizeof(int32_t), ctx->stream));
-    const int32_t cont_cap = (int32_t)std::min<int64_t>(n_rows, 1 << 20);
+    const int32_t cont_cap = (int32_t)std::min<int64_t>(4 * n_rows + 64, 1 << 22);      // (continuation units of one launch, at most)
     PFZ_TRY(d_cont.alloc((size_t)cont_cap * 3 * sizeof(int4)));
     PFZ_TRY(d_cont_cur.alloc((size_t)cont_cap * 3 * sizeof(unsigned long long)));
     // the bound cache: a byte per (workgroup, to-slot), a stretch of its own for every launch (they may run side by side).
@@ -1398,8 +1460,8 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     const char *stats_path = getenv("PFZ_K7_ROW_STATS");
     if (stats_path) {
         // (two per row, then eight phase timers: see the kernel)
-        PFZ_TRY(d_stats.alloc(((size_t)n_rows * 2 + 24) * sizeof(unsigned long long)));
-        PFZ_HIP(hipMemsetAsync(d_stats.p, 0, ((size_t)n_rows * 2 + 24) * sizeof(unsigned long long), ctx->stream));
+        PFZ_TRY(d_stats.alloc(((size_t)n_rows * 4 + 24) * sizeof(unsigned long long)));
+        PFZ_HIP(hipMemsetAsync(d_stats.p, 0, ((size_t)n_rows * 4 + 24) * sizeof(unsigned long long), ctx->stream));
         A.row_stats = (unsigned long long *)d_stats.p;
         A.phase_ticks = A.row_stats + (size_t)n_rows * 2;
     }
@@ -1417,7 +1479,9 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.n_rows = (int32_t)cls[c].size();
         A.parts = parts_of[c];
         A.part0 = 0;
-        const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t);
+        // (the match table, the scratch columns -- bytes for a small alphabet --, the timers when asked for: see the kernel)
+        const size_t lds = (size_t)A.n_sym1 * 3 * (size_t)kWords[c] * sizeof(uint64_t) +
+                           (size_t)kK7Waves * kFuzzStage * 64 * (A.n_sym1 <= 256 ? 1 : 2) + (A.phase_ticks ? 24 * sizeof(unsigned long long) : 0);
         // (only where a row is ONE unit: a row already split over several units would hand over several remainders, and they
         // would share the continuation's result slots)
         const bool hand = hand_over && A.parts == 1 && kK7Waves == 1;
@@ -1426,7 +1490,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.n_cont = (int32_t *)d_next.p + 8 + c;
         A.cont_cap = cont_cap;
         A.cont_parts = cont_parts;
-        A.hand_batches = hand_batches;
+        A.hand_batches = std::max(1, hand_batches);
         A.hand_min_groups = hand_min_groups;
         A.cont_part0 = max_parts + 1;
         A.rows_done = (int32_t *)d_next.p + 4 + c;
@@ -1444,6 +1508,13 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         L.ub_cache = (uint8_t *)d_ubc.p + ubc_at[c];
         // persistent one-wave workgroups: the rows, then -- in the same launch -- the remainders of the heavy ones
         const unsigned grid = (unsigned)grid_of(c, hand);
+        if (getenv("PFZ_K7_DEBUG")) {
+            int occ = -1;
+            if (c == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k7_fuzz_kernel<1>, kK7Threads, lds);
+            else if (c == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k7_fuzz_kernel<2>, kK7Threads, lds);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k7_fuzz_kernel<4>, kK7Threads, lds);
+            fprintf(stderr, "k7 class %d: rows %d parts %d grid %u dynamic LDS %zu B, workgroups per CU %d\n", c, A.n_rows, A.parts, grid, lds, occ);
+        }
         if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, st, L);
         else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, st, L);
         else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, st, L);
@@ -1489,7 +1560,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     }
     if (h_counters) PFZ_TRY(copy_d2h(ctx, h_counters, d_counters.p, 4 * sizeof(unsigned long long)));
     if (stats_path) {
-        std::vector<unsigned long long> st((size_t)n_rows * 2 + 24);
+        std::vector<unsigned long long> st((size_t)n_rows * 4 + 24);
         PFZ_TRY(copy_d2h(ctx, st.data(), d_stats.p, st.size() * sizeof(unsigned long long)));
         if (FILE *fp = fopen(stats_path, "wb")) {
             fwrite(st.data(), sizeof(unsigned long long), st.size(), fp);

@@ -14,6 +14,7 @@
 #undef PFZ_HD
 #define PFZ_HD __device__ inline
 #define PFZ_LDS_U16 __attribute__((address_space(3))) uint16_t
+#define PFZ_LDS_U8 __attribute__((address_space(3))) uint8_t
 #include "k7_core.h"
 #include "k7_args.h"
 

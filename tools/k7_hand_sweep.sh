@@ -1,3 +1,7 @@
-for h in "12,16,16" "24,16,8" "32,16,8" "48,16,8" "32,8,16" "64,16,16" "9999,16,8"; do
-  echo "== PFZ_K7_HAND=$h"; PFZ_K7_HAND=$h timeout 100 python tools/k7_time.py 20000 WRatio,token_ratio,partial_ratio 2>&1 | grep -E "^(WRatio|token_ratio|partial_ratio)" | cut -c1-110
-done
+#!/bin/bash
+# hand-over tuning on one box: PFZ_K7_HAND=<batches of surviving pairs that make a row heavy>,<min groups>,<most continuation units>
+lib=${1:-polyfuzz_amd/libpolyfuzz_hip.so}
+mkdir -p gpurun_out
+for h in 16,16,64 32,16,64 48,16,64 64,16,64 96,16,64 128,16,64 64,16,16 32,16,16 1000000,16,8; do
+  echo "HAND=$h: $(PFZ_K7_HAND=$h POLYFUZZ_HIP_LIB=$lib timeout 100 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio 2>&1 | grep '20000 x' | sed 's/k7_prepare.*//' | sed 's/step.*k7_fuzz//' | tr '\n' ' ')"
+done 2>&1 | tee gpurun_out/k7_hand_sweep.log

@@ -23,9 +23,16 @@ os.environ["PFZ_K7_ROW_STATS"] = path
 _lib.fuzz_extract_one_dev(ctx, f_dev, t_dev, mode, out); ctx.sync()
 del os.environ["PFZ_K7_ROW_STATS"]
 raw = np.fromfile(path, np.uint64)
-ext = raw[-24:].astype(np.float64)
+n = (len(raw) - 24) // 4
+ext = raw[2 * n:2 * n + 24].astype(np.float64)
 phase = ext[:7]
-st = raw[:-24].reshape(-1, 2).astype(np.float64)
+st = raw[:2 * n].reshape(-1, 2).astype(np.float64)
+span = raw[2 * n + 24:].reshape(-1, 2)
+t0 = ((1 << 62) - span[:, 0].astype(np.int64)).astype(np.float64); t1 = span[:, 1].astype(np.float64)
+k0 = t0.min(); t0 = (t0 - k0) / 100.0; t1 = (t1 - k0) / 100.0           # microseconds since the first unit began (100 MHz clock)
+print(f"timeline: last row ends at {t1.max():.0f} us; rows still running at 50/60/70/80/90/95 % of that:",
+      [int(((t0 <= f * t1.max()) & (t1 > f * t1.max())).sum()) for f in (0.5, 0.6, 0.7, 0.8, 0.9, 0.95)])
+late = np.argsort(-t1)[:10]
 names = ["set-up of a from-string", "sweep 1 (bounds, seeds)", "sweep 2 (cached bounds)", "scoring batches", "end of unit / next unit", "waiting for a continuation", "window sweeps"]
 print("wave time by phase (shader clock, all waves):", " | ".join(f"{n} {phase[i] / phase.sum():.3f}" for i, n in enumerate(names)), f"| total {phase.sum():.3e} ticks")
 b, act, go, sw, win, paid = ext[8:14]
@@ -46,4 +53,6 @@ for lo, hi in ((0, 4), (5, 8), (9, 12), (13, 16), (17, 24), (25, 32), (33, 64), 
         print(f"len {lo:3d}-{hi:3d}: rows {m.sum():6d}  scored/row {scored[m].mean():9.0f}  us/row {ticks[m].mean() / 100:9.1f}  share of time {ticks[m].sum() / ticks.sum():.3f}  mean best {score[m].mean():.1f}")
 order = np.argsort(-ticks)[:12]
 for i in order: print(f"  {ticks[i] / 100:9.1f} us  scored {scored[i]:7.0f}  best {score[i]:.1f}  {fl[i]!r}")
+print("the rows that end last:")
+for i in late: print(f"  began {t0[i]:8.0f} us  ended {t1[i]:8.0f} us  scored {st[i, 0]:7.0f}  len {len(fl[i]):3d}  {fl[i]!r}")
 print("corr(ticks, scored)", np.corrcoef(ticks, scored)[0, 1])
