@@ -1133,42 +1133,52 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         }
         tick(1);
         // ---- sweep 2: the seeds are scored -- a real score to prune with (a continuation unit starts from its row's) --
-        //      then the pairs whose byte reaches the best score so far, 64 at a time; one more trip past the last group
-        //      empties the queue and finishes the window sweeps.  The scoring code -- by far the largest part of the
-        //      kernel -- is inlined exactly once.
+        //      then the pairs whose byte reaches the best score so far, 64 at a time.  Two loops inside one: a tight one that
+        //      walks the bytes until 64 pairs wait in the queue (nothing but a load, a compare and a push), and around it the
+        //      ONE place where pairs are scored -- that code, by far the largest part of the kernel, is inlined exactly once;
+        //      its last call empties the queue and finishes the window sweeps.
         int *queue = s_queue[wave];
         int q_head = 0, q_tail = 0;             // wave-uniform; entries [q_head, q_tail) of a ring of 128
         int batches = 0;
-        bool handed = false, swept_out = false;
-        int nxt_q = ubc[(int64_t)min(g_first, A.n_groups - 1) * 64];
-        for (int g = g_first, trip = 0;; ++trip) {
-            const bool seeds = trip == 0 && !is_cont;
-            const bool last = !seeds && (g >= A.n_groups || handed);
-            bool want = false;
-            int slot = -1;
-            if (seeds) {
-                slot = seed_slot;
-                want = seed_slot >= 0;
-            }
-            else if (!last) {
-                const int q = nxt_q;
-                nxt_q = ubc[(int64_t)min(g + g_step, A.n_groups - 1) * 64];
-                slot = g * 64 + lane;
-                const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;
-                n_bounded += 1;
-                want = (q & 127) != 0 && slot != seed_slot && !((float)(q & 127) < thr);
-                slot |= (q & 128) ? (int)0x80000000 : 0;
-            }
-            const unsigned long long bal = __ballot(want);
-            if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot;
-            q_tail += __popcll(bal);
+        bool swept_out = false;
+        bool drain = !is_cont;                  // (the seeds: scored before anything else)
+        if (drain) {
+            const unsigned long long bal = __ballot(seed_slot >= 0);
+            if (seed_slot >= 0) queue[__popcll(bal & ((1ull << lane) - 1ull))] = seed_slot;
+            q_tail = __popcll(bal);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        for (int g = g_first;;) {
+            if (!drain && g < A.n_groups) {
+                const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;       // (the best score moves only where pairs are scored)
+                do {
+                    // four groups' bytes in flight at a time (a group is no more than a compare and a push: one load's
+                    // latency per group would be all there is to it); when the queue fills up in between, the rest are
+                    // read again later
+                    int q4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q4[k] = ubc[(int64_t)min(g + k * g_step, A.n_groups - 1) * 64];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (g < A.n_groups && q_tail - q_head < 64) {
+                            const int q = q4[k], slot = g * 64 + lane;
+                            const bool want = (q & 127) != 0 && slot != seed_slot && !((float)(q & 127) < thr);
+                            const unsigned long long bal = __ballot(want);
+                            if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot | ((q & 128) ? (int)0x80000000 : 0);
+                            q_tail += __popcll(bal);
+                            n_bounded += 1;
+                            g += g_step;
+                        }
+                    }
+                } while (g < A.n_groups && q_tail - q_head < 64);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
             tick(2);
-            const bool drain = last || seeds;
+            const bool last = !drain && g >= A.n_groups;
             // (a last call, with or without pairs, finishes the window sweeps under way)
-            while (q_tail - q_head >= 64 || (drain && (q_tail > q_head || (last && !swept_out)))) {
+            while (q_tail - q_head >= 64 || ((drain || last) && (q_tail > q_head || (last && !swept_out)))) {
                 const bool active = lane < q_tail - q_head;
-                const bool flush = drain && q_tail - q_head <= 64;
+                const bool flush = (drain || last) && q_tail - q_head <= 64;
                 score_slot(active ? queue[(q_head + lane) & 127] : -1, active, flush);
                 swept_out = flush;
                 q_head += min(64, q_tail - q_head);
@@ -1176,10 +1186,8 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             if (last) break;
-            if (!seeds) {
-                g += g_step;
-                continue;
-            }
+            if (!drain) continue;
+            drain = false;
             // The seeds are scored: the pairs whose bound reaches the best of them are (at most) what is left to score -- one
             // quick pass over the bytes counts them.  A heavy row -- more than hand_batches batches of them -- is left to
             // several waves: as many continuation units as give each about half that (up to cont_parts), all of its groups
@@ -1208,7 +1216,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     __hip_atomic_store(&A.cont_list[at + lane].z, g_step * units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&A.cont_list[at + lane].w, fits ? (units | lane << 8) : -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                handed = fits;           // (the next trip finishes the seeds' window sweeps and ends the loop)
+                if (fits) g = A.n_groups;           // (the next trip finds nothing to walk: it finishes the seeds' window sweeps and ends the loop)
             }
         }
 
