@@ -383,12 +383,31 @@ PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double
     cand(l, lm + wlen);
     if (!of_to && idx == 0)
         for (int k = 1; k < lb; ++k) cand(fz_zeros_below<W>(V, k), lb + k);          // prefixes of the from-form
+    // the next window that can matter.  Whole windows (starts up to ll - lm) all need the same LCS: the step over them is
+    // one subtraction; the shrinking windows at the end are tried one by one
     int d = 1;
-    while (idx + d < ll) {
-        const int wl = fz_min(lm, ll - idx - d);
-        if (worth(fz_min(l + d, wl), lm + wl)) break;
-        ++d;
+    const int last_whole = ll - lm;
+    if (idx < last_whole) {
+        const int sum = 2 * lm;
+        int need = bl * sum / bs + 1;                        // ... to beat the best so far
+#if defined(__HIP_DEVICE_COMPILE__)
+        int reach = (int)((float)thr * (float)sum * __builtin_amdgcn_rcpf(200.0f * (float)f)) - 1;      // ... to reach thr, nearly:
+#else
+        int reach = (int)((float)thr * (float)sum / (200.0f * (float)f)) - 1;
+#endif
+        reach = fz_max(reach, 0);
+        while (200.0 * (double)reach * f < thr * (double)sum) ++reach;       // ... exactly (a step or two)
+        need = fz_max(need, reach);
+        // (a whole window holds at most lm matches: beyond that none of them matters; else on to the first that may, or to
+        // the first of the shrinking windows)
+        d = need > lm ? last_whole + 1 - idx : fz_min(fz_max(need - l, 1), last_whole + 1 - idx);
     }
+    if (idx + d > last_whole)
+        while (idx + d < ll) {
+            const int wl = fz_min(lm, ll - idx - d);
+            if (worth(fz_min(l + d, wl), lm + wl)) break;
+            ++d;
+        }
     S.bl = bl;
     S.bs = bs;
     S.w += d;              // (stops at the end of its family: the other family starts with a window of its own)

@@ -62,7 +62,7 @@ constexpr int kK7Waves = 1, kK7Threads = 64 * kK7Waves;
 constexpr float kBoundSlack = 0.05f;
 // log2 of the windows per run of a window sweep: 16, more for long forms -- at most 8 runs (forms are <= 256 symbols here)
 #ifndef PFZ_K7_SHARE_LOG2
-#define PFZ_K7_SHARE_LOG2 5
+#define PFZ_K7_SHARE_LOG2 6
 #endif
 __device__ inline int sweep_share_log2(int n_windows)
 {
