@@ -13,6 +13,7 @@ echo "bench rc=$?"
 tail -c 600 gpurun_out/${tag}_bench.err
 timeout 300 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio,partial_token_ratio names > gpurun_out/${tag}_k7.log 2>&1
 timeout 200 bash tools/k7_trace.sh >> gpurun_out/${tag}_k7.log 2>&1
+timeout 200 python tools/k7_rowstats.py WRatio 2>&1 | grep -E "as shipped|wave time|timeline|scoring batches|began" >> gpurun_out/${tag}_k7.log
 timeout 900 bash tools/profile_bench.sh gpurun_out/${tag}_profile > gpurun_out/${tag}_profile.log 2>&1
 python - <<PY
 import json
