@@ -281,3 +281,39 @@ def test_reference_rapidfuzz_test_scenarios(ctx):
         assert model.type == "EditDistance" and isinstance(matches, pd.DataFrame) and len(matches) == 6
         assert list(matches.columns) == ["From", "To", "Similarity"]
         assert check(matches.Similarity.mean())
+
+
+@pytest.mark.parametrize("n_chars", [230, 600])
+def test_alphabet_size_and_the_scratch_columns(ctx, oracle_mod, n_chars):
+    """The window sweeps stage a to-form in an LDS column of BYTES when the to-list's alphabet has at most 255 symbols, of
+    16-bit ranks beyond: lists over 230 and over 600 distinct characters (CJK range, plus the ASCII words), every scorer
+    that sweeps windows and the token scorers, bit for bit -- with from-strings much shorter and much longer than the
+    to-strings, so that both families of windows run."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(n_chars)
+    glyphs = [chr(0x4E00 + k) for k in range(n_chars)]
+
+    def mk(n, lo, hi):
+        out = []
+        for _ in range(n):
+            words = []
+            for _ in range(int(rng.integers(1, 5))):
+                words.append("".join(rng.choice(glyphs, size=int(rng.integers(lo, hi)))))
+            out.append(" ".join(words))
+        return out
+    tl = mk(400, 2, 9) + mk(60, 1, 3)
+    # from-strings built from pieces of to-strings (so that scores are high and windows matter), shorter and longer
+    fl = []
+    for _ in range(60):
+        t = tl[int(rng.integers(0, len(tl)))]
+        a, b = sorted(int(x) for x in rng.integers(0, len(t) + 1, size=2))
+        piece = t[a:b] or t[:3]
+        fl.append(piece if rng.random() < 0.5 else piece + " " + tl[int(rng.integers(0, len(tl)))] + " " + "".join(rng.choice(glyphs, size=6)))
+    fl += mk(20, 2, 9) + ["", glyphs[0]]
+    info_symbols = len(set("".join(tl)))
+    assert (info_symbols <= 255) == (n_chars == 230), info_symbols
+    for mode in ("WRatio", "partial_ratio", "partial_token_ratio", "token_ratio"):
+        idx, score = _lib.fuzz_extract_one(ctx, fl, tl, mode)
+        e_idx, e_score = oracle_mod.fuzz_extract_one(fl, tl, mode)
+        np.testing.assert_array_equal(score, e_score, err_msg=mode)
+        np.testing.assert_array_equal(idx, e_idx, err_msg=mode)
