@@ -42,6 +42,8 @@ struct FuzzArgs {
     // sweep 1 leaves every pair's bound here (one byte: the bound rounded UP in steps of 1 / 1.27, bit 7 = coarse; 0 = not a
     // candidate), [workgroup][group][lane]; sweep 2 reads it back instead of computing the bound again.  NULL: recompute.
     uint8_t *ub_cache;
+    int32_t *region_next, *cont_region;      // spare stretches of the cache taken so far; per hand-over: the stretch with the row's bytes (-1: none)
+    int32_t n_regions;                       // stretches of this launch: one per workgroup, then the spare ones
     // hand-over of heavy rows: a wave that has scored many batches of one from-string and still has most of the to-groups
     // ahead appends {row position r, next group, group step, ready flag} (+ the best score found so far) to cont_list and
     // goes on to the next row; the units after the last row are those remainders, each spread over cont_parts waves that

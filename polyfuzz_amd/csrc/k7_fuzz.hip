@@ -713,6 +713,9 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
             t_last = now;
         }
     };
+    // the workgroup's stretch of the bound cache: its own, until a row it hands over takes that stretch along (the row's
+    // continuation units walk the bytes sweep 1 left there) and the workgroup moves on to a spare one
+    int my_region = blockIdx.x;
     for (;;) {
         // the from-strings differ by orders of magnitude in how many pairs survive their bound: units are handed out one at
         // a time (an atomic counter) instead of by a fixed stride, so no workgroup is left with a run of heavy ones
@@ -1115,8 +1118,9 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         //      bounds in this loop.
         float seed_ub = -1.0f;
         int seed_slot = -1;
-        uint8_t *ubc = A.ub_cache + (int64_t)blockIdx.x * A.n_groups * 64 + lane;
-        {
+        const int row_region = is_cont ? __builtin_amdgcn_readfirstlane(A.cont_region[cont_rec]) : -1;      // (a continuation unit: its row's bytes)
+        uint8_t *ubc = A.ub_cache + (int64_t)(row_region >= 0 ? row_region : my_region) * A.n_groups * 64 + lane;
+        if (row_region < 0) {
             Meta nxt = load_meta(min(g_first, A.n_groups - 1));
             for (int g = g_first; g < A.n_groups; g += g_step) {
                 const Meta x = nxt;
@@ -1206,9 +1210,20 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                 if (lane == 0) at = atomicAdd(A.n_cont, units);
                 at = __builtin_amdgcn_readfirstlane(at);
                 const bool fits = at + units <= A.cont_cap;
-                if (fits && lane == 0)
-                    __hip_atomic_store(&A.cont_cur[at], __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                if (fits) {
+                    // the row's bytes go with it when there is a spare stretch for this workgroup to go on with (else the
+                    // units bound their shares again)
+                    int spare = 0;
+                    if (lane == 0) spare = atomicAdd(A.region_next, 1);
+                    spare = (int)gridDim.x + __builtin_amdgcn_readfirstlane(spare);
+                    const bool moved = spare < A.n_regions;
+                    if (lane == 0) {
+                        __hip_atomic_store(&A.cont_region[at], moved ? my_region : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&A.cont_cur[at], __hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (moved) my_region = spare;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (lane < units && at + lane < A.cont_cap) {          // one record per unit (void ones when the list is full)
                     __hip_atomic_store(&A.cont_list[at + lane].x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1458,13 +1473,21 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     const int64_t grid_cap = std::max<int64_t>(64, std::min<int64_t>(max_grid, ((int64_t)16 << 30) / (3 * std::max<int64_t>(pl->n_groups, 1) * 64)));
     auto grid_of = [&](int c, bool hand) { return hand ? grid_cap : std::min<int64_t>((int64_t)cls[c].size() * parts_of[c], grid_cap); };
     const bool hand_over = !getenv("PFZ_K7_NO_HANDOVER");
-    DevBuf d_ubc(ctx);
-    int64_t ubc_at[3] = {0, 0, 0}, ubc_slots = 0;
+    // (a launch that hands rows over has spare stretches: a handed-over row keeps the one its bytes are in -- one per row at
+    // most, fewer when that would not fit: its continuation units then bound their shares again)
+    DevBuf d_ubc(ctx), d_cont_region(ctx);
+    int64_t ubc_at[3] = {0, 0, 0}, ubc_regions[3] = {0, 0, 0}, ubc_slots = 0;
+    const int64_t region_bytes = std::max<int64_t>(pl->n_groups, 1) * 64;
     for (int c = 0; c < 3; ++c) {
         ubc_at[c] = ubc_slots;
-        if (!cls[c].empty()) ubc_slots += grid_of(c, hand_over && parts_of[c] == 1 && kK7Waves == 1) * pl->n_groups * 64;
+        if (cls[c].empty()) continue;
+        const bool hand = hand_over && parts_of[c] == 1 && kK7Waves == 1;
+        const int64_t spare = hand ? std::max<int64_t>(0, std::min<int64_t>((int64_t)cls[c].size(), ((int64_t)8 << 30) / region_bytes - grid_of(c, hand))) : 0;
+        ubc_regions[c] = grid_of(c, hand) + spare;
+        ubc_slots += ubc_regions[c] * region_bytes;
     }
     PFZ_TRY(d_ubc.alloc((size_t)std::max<int64_t>(ubc_slots, 64)));
+    PFZ_TRY(d_cont_region.alloc((size_t)cont_cap * 3 * sizeof(int32_t)));
     const char *stats_path = getenv("PFZ_K7_ROW_STATS");
     if (stats_path) {
         // (two per row, then eight phase timers: see the kernel)
@@ -1514,6 +1537,9 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         }
         FuzzArgs L = A;
         L.ub_cache = (uint8_t *)d_ubc.p + ubc_at[c];
+        L.n_regions = (int32_t)std::min<int64_t>(ubc_regions[c], INT32_MAX);
+        L.region_next = (int32_t *)d_next.p + 12 + c;
+        L.cont_region = (int32_t *)d_cont_region.p + (size_t)c * cont_cap;
         // persistent one-wave workgroups: the rows, then -- in the same launch -- the remainders of the heavy ones
         const unsigned grid = (unsigned)grid_of(c, hand);
         if (getenv("PFZ_K7_DEBUG")) {

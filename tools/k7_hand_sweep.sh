@@ -2,6 +2,6 @@
 # hand-over tuning on one box: PFZ_K7_HAND=<batches of surviving pairs that make a row heavy>,<min groups>,<most continuation units>
 lib=${1:-polyfuzz_amd/libpolyfuzz_hip.so}
 mkdir -p gpurun_out
-for h in 32,16,64 48,16,64 64,16,64 96,16,64 128,16,64 192,16,64 64,16,16 1000000,16,8; do
-  echo "HAND=$h: $(PFZ_K7_HAND=$h POLYFUZZ_HIP_LIB=$lib timeout 100 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio 2>&1 | grep '20000 x' | sed 's/k7_prepare.*//' | sed 's/step.*k7_fuzz//' | tr '\n' ' ')"
+for h in 16,16,64 24,16,64 32,16,64 48,16,64 64,16,64 96,16,64 32,16,16 1000000,16,8; do
+  echo "HAND=$h: $(PFZ_K7_HAND=$h POLYFUZZ_HIP_LIB=$lib timeout 100 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio 2>&1 | grep '20000 x' | sed 's/k7_prepare.*//' | sed 's/step.*k7_fuzz//' | sed 's/20000 x 20000: //' | tr '\n' ' ')"
 done 2>&1 | tee gpurun_out/k7_hand_sweep.log
