@@ -1473,8 +1473,8 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     const int64_t grid_cap = std::max<int64_t>(64, std::min<int64_t>(max_grid, ((int64_t)16 << 30) / (3 * std::max<int64_t>(pl->n_groups, 1) * 64)));
     auto grid_of = [&](int c, bool hand) { return hand ? grid_cap : std::min<int64_t>((int64_t)cls[c].size() * parts_of[c], grid_cap); };
     const bool hand_over = !getenv("PFZ_K7_NO_HANDOVER");
-    // (a launch that hands rows over has spare stretches: a handed-over row keeps the one its bytes are in -- one per row at
-    // most, fewer when that would not fit: its continuation units then bound their shares again)
+    // (a launch that hands rows over has spare stretches: a handed-over row keeps the one its bytes are in; when they run out,
+    // the continuation units of the rows handed over after that bound their shares again)
     DevBuf d_ubc(ctx), d_cont_region(ctx);
     int64_t ubc_at[3] = {0, 0, 0}, ubc_regions[3] = {0, 0, 0}, ubc_slots = 0;
     const int64_t region_bytes = std::max<int64_t>(pl->n_groups, 1) * 64;
@@ -1482,7 +1482,8 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         ubc_at[c] = ubc_slots;
         if (cls[c].empty()) continue;
         const bool hand = hand_over && parts_of[c] == 1 && kK7Waves == 1;
-        const int64_t spare = hand ? std::max<int64_t>(0, std::min<int64_t>((int64_t)cls[c].size(), ((int64_t)8 << 30) / region_bytes - grid_of(c, hand))) : 0;
+        // (half the rows at most are ever heavy; 2 GiB of spare stretches at most)
+        const int64_t spare = hand ? std::min<int64_t>((int64_t)cls[c].size() / 2 + 64, ((int64_t)2 << 30) / region_bytes) : 0;
         ubc_regions[c] = grid_of(c, hand) + spare;
         ubc_slots += ubc_regions[c] * region_bytes;
     }
