@@ -36,20 +36,23 @@ struct FuzzArgs {
     unsigned long long *counters;    // [0] pairs bounded, [1] pairs scored, [2] 64-bit word-steps of the scored pairs (or NULL)
     // tuning aids (PFZ_K7_ROW_STATS / PFZ_K7_EXP; never set in production): per from-row {pairs scored, clock ticks}, experiment
     unsigned long long *row_stats;
-    unsigned long long *phase_ticks;         // profiling only (PFZ_K7_ROW_STATS): shader-clock ticks of all waves by phase [8]
+    unsigned long long *phase_ticks;         // profiling only (PFZ_K7_ROW_STATS): [24] shader-clock ticks of all waves by phase and batch statistics, then per row {2^62 - first start, last end} (100 MHz clock)
     int32_t exp;                     // 1: bound only, score nothing (results wrong)
     int32_t *next_unit;              // dynamic distribution of the (row, part) units over the workgroups
     // sweep 1 leaves every pair's bound here (one byte: the bound rounded UP in steps of 1 / 1.27, bit 7 = coarse; 0 = not a
-    // candidate), [workgroup][group][lane]; sweep 2 reads it back instead of computing the bound again.  NULL: recompute.
+    // candidate), [stretch][group][lane]; sweep 2 walks the bytes.  A stretch per workgroup of the launch, then spare ones:
+    // a row that is handed over keeps the stretch its bytes are in, and its workgroup goes on with a spare one
     uint8_t *ub_cache;
-    int32_t *region_next, *cont_region;      // spare stretches of the cache taken so far; per hand-over: the stretch with the row's bytes (-1: none)
+    int32_t *region_next, *cont_region;      // spare stretches taken so far; per hand-over (at its first record): the row's stretch (-1: none)
     int32_t n_regions;                       // stretches of this launch: one per workgroup, then the spare ones
-    // hand-over of heavy rows: a wave that has scored many batches of one from-string and still has most of the to-groups
-    // ahead appends {row position r, next group, group step, ready flag} (+ the best score found so far) to cont_list and
-    // goes on to the next row; the units after the last row are those remainders, each spread over cont_parts waves that
-    // start from that score -- taken by whichever wave runs out of rows first, while others are still on theirs (a wave
-    // waits for a record only as long as rows are unfinished: rows_done counts them).  Exact: a remainder is the same set
-    // of pairs, bounded against a score that is really attained.
+    // hand-over of heavy rows: once its seeds are scored, a wave counts the bytes that reach their best score; a row with
+    // more than hand_batches batches of them (and hand_min_groups groups) is dealt to continuation units -- one record
+    // {row position r, first group, group step, units | part << 8 (-1: void)} per unit, claimed together from n_cont,
+    // cont_cur / cont_region at the first of them: the best score of the row so far (the units raise it as they go) and
+    // the stretch with its bytes -- and the wave goes on to the next row.  The units after the last row are those shares,
+    // taken by whichever wave runs out of rows first, while others are still on theirs (a wave waits for a record only as
+    // long as rows are unfinished: rows_done counts them).  Exact: the shares are the same set of pairs, bounded against a
+    // score that is really attained.
     int4 *cont_list;
     unsigned long long *cont_cur;
     int32_t *n_cont, *rows_done;

@@ -16,17 +16,24 @@
 //    lengths, class histogram, token signature (k7_pack);
 //  * per call: the from-list's token ids by look-up in the plan's table, then the match kernel.
 //
-// The match kernel (k7_fuzz_kernel<W>): a workgroup holds ONE from-string -- the bit-parallel match tables of its three
-// forms in LDS (W 64-bit words per form) -- and process.extractOne keeps only the maximum, so almost every pair can be
+// The match kernel (k7_fuzz_kernel<W>): persistent one-wave workgroups (16 per CU for W = 1) take units -- a from-string,
+// or a share of one -- from an atomic counter; the wave holds the bit-parallel match tables of the from-string's three
+// forms in LDS (W 64-bit words per form).  process.extractOne keeps only the maximum, so almost every pair can be
 // dismissed without scoring it:
 //    sweep 1  every lane walks its to-strings computing only the UPPER BOUND of the pair's score (lengths, common
-//             character classes by v_sad_u8, token signatures) and remembers its best-bounded one; those 256 pairs are
-//             scored exactly: the best of them is `cur`, a score some valid choice really has;
-//    sweep 2  every to-string again: a pair whose bound (+ slack) is below `cur` cannot be the answer, nor tie with it;
-//             the survivors are compacted (ballot) into a per-wave queue and scored 64 at a time, one pair per lane,
-//             each raising `cur` for everybody.
+//             character classes by v_sad_u8, token signatures and the first four token ids), leaves it as a byte in the
+//             workgroup's stretch of the bound cache, and remembers its best-bounded one: those 64 SEEDS are scored
+//             exactly -- the best of them is `cur`, a score some valid choice really has;
+//    sweep 2  a tight loop over the bytes: a pair whose bound (+ slack) is below `cur` cannot be the answer, nor tie with
+//             it; the survivors are compacted (ballot) into a queue and scored 64 at a time, one pair per lane, each
+//             raising `cur`;
+//    window sweeps (partial_ratio and what builds on it) are not part of a pair's scoring: the pair asks for them, runs
+//             of windows are handed to lanes of their own (sweep_rounds);
+//    heavy rows -- known from a count of the bytes that reach the seeds' best -- are dealt to continuation units, which
+//             other workgroups take when the rows run out (FuzzArgs::cont_list).
 // Pruned pairs are strictly worse than the final best, so the first-best rule (score desc, original index asc) over the
-// scored pairs is the exact answer.  On the 20 000 x 20 000 IMDB title lists fewer than 1 % of the pairs are scored.
+// scored pairs is the exact answer.  On the 20 000 x 20 000 IMDB title lists 6 % of the pairs are scored (WRatio).
+// How it got here, with the measurements: DESIGN.md, "K7".
 //
 // From-strings beyond 256 characters or 32 distinct tokens (and to-strings beyond 32 distinct tokens, for every
 // from-string) take k7_general_kernel: the same scorers with any number of words and tokens, all state in global
