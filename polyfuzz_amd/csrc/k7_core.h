@@ -142,11 +142,6 @@ PFZ_HD void fz_stage(FuzzTo &T, int v)
     T.staged = v;
 }
 
-PFZ_HD int fz_sym(const FuzzTo &T, int v, int pos)
-{
-    return T.staged == v ? (int)T.stage[pos * T.stage_stride] : (int)T.sym[v][pos];
-}
-
 PFZ_HD double fz_ratio_of(int lcs, int lensum)
 {
     const int dist = lensum - 2 * lcs;
@@ -247,24 +242,6 @@ PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint
         for (int q = 0; q < 8; ++q)
             if (p0 + q < lb) fz_step<W>(V, F.pm + (sy[q] * 3 + v) * W, amask);
     }
-}
-
-// four recurrence steps on positions pos0 .. pos0 + 3 of the to-form (positions from `end` on feed symbol 0, whose table
-// entry is empty: a step that changes nothing): the four symbols, then the four table entries, are requested together --
-// two LDS round trips per four steps instead of two per step
-template <int W>
-PFZ_HD void fz_steps4(uint64_t (&V)[W], const FuzzFrom<W> &F, const FuzzTo &T, int v, int pos0, int end, const uint64_t (&mask)[W])
-{
-    int sy[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sy[q] = pos0 + q < end ? fz_sym(T, v, pos0 + q) : 0;
-    uint64_t pmv[4][W];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int w = 0; w < W; ++w) pmv[q][w] = F.pm[(sy[q] * 3 + v) * W + w];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) fz_step<W>(V, pmv[q], mask);
 }
 
 // ---- window sweeps (rapidfuzz.fuzz.partial_ratio of two v-forms) -----------------------------------------------------------
