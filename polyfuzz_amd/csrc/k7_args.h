@@ -57,6 +57,7 @@ struct FuzzArgs {
     unsigned long long *cont_cur;
     int32_t *n_cont, *rows_done;
     int32_t cont_cap, cont_parts, cont_part0, hand_batches, hand_min_groups;
+    int32_t hand_short_len, hand_short_batches;      // from-strings this short are heavy from fewer batches on (their pairs sweep windows)
 };
 
 }  // namespace pfz

@@ -79,6 +79,8 @@ __device__ inline int sweep_share_log2(int n_windows)
 // heavy-row hand-over (see FuzzArgs::cont_list): a row that has scored kHandBatches batches and still has kHandMinGroups
 // groups to go leaves them to continuation units -- as many (up to kContParts) as leave each about kHandBatches batches
 constexpr int kHandBatches = 64, kHandMinGroups = 16, kContParts = 64;
+constexpr int kHandShortLen = 6, kHandShortBatches = 24;      // ... a from-string of up to 6 characters from 24 batches on
+static bool mode_sweeps_windows(int mode) { return mode != kTokenSetRatio && mode != kTokenRatio; }
 
 __device__ inline uint32_t load_unit(const void *p, int width, int64_t i)
 {
@@ -1211,8 +1213,11 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) survivors += __shfl_xor(survivors, d, 64);
             }
-            if (survivors > 64 * A.hand_batches) {
-                const int units = min(A.cont_parts, max(2, (2 * survivors + 64 * A.hand_batches - 1) / (64 * A.hand_batches)));
+            // (a short from-string is heavy from fewer batches on: under WRatio and the partial scorers nearly every pair of
+            // it sweeps windows -- the rows that END a launch are five-letter words with 50 batches)
+            const int heavy = F.la[0] <= A.hand_short_len ? A.hand_short_batches : A.hand_batches;
+            if (survivors > 64 * heavy) {
+                const int units = min(A.cont_parts, max(2, (2 * survivors + 64 * heavy - 1) / (64 * heavy)));
                 int at = 0;
                 if (lane == 0) at = atomicAdd(A.n_cont, units);
                 at = __builtin_amdgcn_readfirstlane(at);
@@ -1455,7 +1460,8 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         max_parts = std::max(max_parts, parts_of[c]);
     }
     int32_t hand_batches = kHandBatches, hand_min_groups = kHandMinGroups, cont_parts = kContParts;
-    if (const char *e = getenv("PFZ_K7_HAND")) sscanf(e, "%d,%d,%d", &hand_batches, &hand_min_groups, &cont_parts);      // tuning
+    int32_t short_len = kHandShortLen, short_batches = kHandShortBatches;
+    if (const char *e = getenv("PFZ_K7_HAND")) sscanf(e, "%d,%d,%d,%d,%d", &hand_batches, &hand_min_groups, &cont_parts, &short_len, &short_batches);      // tuning
     if (const char *e = getenv("PFZ_K7_HAND_BATCHES")) hand_batches = atoi(e), hand_min_groups = 0;      // tests: hand over early
     cont_parts = std::max(1, std::min(cont_parts, 64));
     const int32_t n_parts_total = max_parts + 1 + cont_parts;
@@ -1530,6 +1536,8 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.cont_cap = cont_cap;
         A.cont_parts = cont_parts;
         A.hand_batches = std::max(1, hand_batches);
+        A.hand_short_len = mode_sweeps_windows(scorer) ? short_len : 0;
+        A.hand_short_batches = std::max(1, std::min(short_batches, A.hand_batches));
         A.hand_min_groups = hand_min_groups;
         A.cont_part0 = max_parts + 1;
         A.rows_done = (int32_t *)d_next.p + 4 + c;
