@@ -127,3 +127,29 @@ def test_bound_is_useful(host, oracle_mod):
     assert (ub + SLACK >= truth).all()
     kept = (ub + SLACK >= truth.max(axis=1)[:, None]).mean()
     assert kept < 0.15, kept
+
+
+@pytest.mark.parametrize("W", [1, 2])
+def test_window_sweeps_on_a_three_letter_alphabet(host, oracle_mod, W):
+    """partial_ratio where windows matter most: strings over {a, b, c} (high LCS everywhere, ties everywhere), all length
+    combinations from 1 to 20 (to 70 for two words) -- both window families, equal lengths (both at once), prefixes and
+    shrinking suffix windows -- swept in one piece and in shares of 3, 7 and 16 windows, with no floor, with the row's
+    best score and with its median as the running best: exact wherever the true score reaches it, never above it."""
+    rng = np.random.default_rng(17 + W)
+    hi = 20 if W == 1 else 70
+    mk = lambda n: ["".join(rng.choice(list("abc"), size=int(rng.integers(1, hi + 1)))) for _ in range(n)]
+    fl, tl = mk(45), mk(120)
+    fl += ["a", "abcabcabcabc", "c" * 9]
+    tl += ["a", "b", "abc" * 6, "cab" * 5 + "a", "c" * 9, "c" * 10]
+    alpha = k7_prep.Alphabet(tl)
+    A, B = k7_prep.prepare(fl, alpha, False), k7_prep.prepare(tl, alpha, True)
+    for mode in ("partial_ratio", "WRatio"):
+        truth = oracle_mod.fuzz_matrix(fl, tl, mode)
+        for share in (0, 3, 7, 16):
+            score, _ = run_pairs(host, W, alpha, A, B, mode, np.zeros(len(fl)), share)
+            np.testing.assert_array_equal(score, truth, err_msg=f"{mode} share {share}")
+            for cur in (truth.max(axis=1), np.median(truth, axis=1)):
+                s2, _ = run_pairs(host, W, alpha, A, B, mode, cur, share)
+                reach = truth >= cur[:, None]
+                np.testing.assert_array_equal(s2[reach], truth[reach], err_msg=f"{mode} share {share}")
+                assert (s2 <= truth).all()
