@@ -702,7 +702,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
     __shared__ int red_i[kK7Waves];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
     __shared__ int s_queue[kK7Waves][128];
-    __shared__ int s_sweeps[kK7Waves][64];        // runs of windows waiting for a lane (see sweep_rounds)
+    __shared__ int s_sweeps[kK7Waves][3][64];     // runs of windows waiting for a lane (see sweep_rounds): item, lengths, symbols
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
     const bool use_tokens = mode_uses_tokens(mode);
@@ -954,8 +954,8 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         // the end of a sweep of the to-list), a lane's unfinished run waits in its registers in between.
         int sw_item = -1;                       // this lane's run (-1: none): slot | form << 26 | run << 28
         // (what a run keeps between rounds, packed: lb | lb0 << 16, w | w_end << 16, bl | bs << 16 -- lengths <= 256 W)
-        int sw_len = 0, sw_win = 0, sw_best = 1 << 16;
-        int *sweeps = s_sweeps[wave];
+        int sw_len = 0, sw_sym = 0, sw_win = 0, sw_best = 1 << 16;      // (sw_sym: where the form's symbols are, from b_sym)
+        int (*sweeps)[64] = s_sweeps[wave];
         int sq_head = 0, sq_tail = 0;
         auto sweep_rounds = [&](bool flush) {
             for (;;) {
@@ -969,18 +969,17 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                 if (sw_item < 0) {
                     const int rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (rank < n_take) {
-                        sw_item = sweeps[(sq_head + rank) & 63];
-                        const int slot = sw_item & 0x3ffffff, v = (sw_item >> 26) & 3, run = sw_item >> 28;
-                        const int4 m = A.b_meta[slot];
-                        const int la = F.la[v], lb = v == 0 ? m.x : (v == 1 ? m.y : m.z);
-                        sw_len = lb | m.x << 16;
-                        const int n_win = fz_n_windows(la, lb), sh = sweep_share_log2(n_win);
+                        // (the pair's scoring lane left lengths and the form's place beside the item: the lane goes to memory
+                        // once, for the symbols)
+                        const int at = (sq_head + rank) & 63;
+                        sw_item = sweeps[0][at];
+                        sw_len = sweeps[1][at];
+                        sw_sym = sweeps[2][at];
+                        const int v = (sw_item >> 26) & 3, run = sw_item >> 28, lb = sw_len & 0xffff;
+                        const int n_win = fz_n_windows(F.la[v], lb), sh = sweep_share_log2(n_win);
                         sw_win = (run << sh) | min((run + 1) << sh, n_win) << 16;
                         sw_best = 1 << 16;
-                        if (lb <= kFuzzStage) {
-                            const int4 rec = A.b_meta3[slot];
-                            fz_stage_form(A.b_sym + rec.x + (int64_t)v * rec.w, lb, column, 64, narrow);
-                        }
+                        if (lb <= kFuzzStage) fz_stage_form(A.b_sym + sw_sym, lb, column, 64, narrow);
                     }
                 }
                 sq_head += n_take;
@@ -990,11 +989,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     const int slot = sw_item & 0x3ffffff, v = (sw_item >> 26) & 3;
                     const int lb = sw_len & 0xffff, lb0 = sw_len >> 16;
                     const bool staged = lb <= kFuzzStage;
-                    const uint16_t *sym = A.b_sym;
-                    if (!staged) {                       // (a long to-form: read where it is)
-                        const int4 rec = A.b_meta3[slot];
-                        sym += rec.x + (int64_t)v * rec.w;
-                    }
+                    const uint16_t *sym = A.b_sym + sw_sym;      // (a long to-form is read where it is)
                     FuzzSweep SW;
                     fz_sweep_begin(SW, v, F.la[v], lb, sw_win & 0xffff, sw_win >> 16, sym, column, staged ? 64 : 0, narrow);
                     SW.bl = sw_best & 0xffff;
@@ -1017,7 +1012,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         };
         auto score_slot = [&](int entry, bool active, bool flush) {
             double sc = 0.0;
-            int orig = -1, want_p = 0, slot_of = 0;
+            int orig = -1, want_p = 0, slot_of = 0, sym_at = 0, sym_step = 0;
             int4 lens = make_int4(0, 0, 0, 0);
             bool did_score = false;
 #ifdef PFZ_K7_PROFILE
@@ -1054,6 +1049,8 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     sc = fz_score<W, true>(F, T, mode, cur, &want_p);
                     slot_of = slot;
                     lens = m;
+                    sym_at = (int)(T.sym[0] - A.b_sym);
+                    sym_step = (int)(T.sym[1] - T.sym[0]);
 #ifdef PFZ_K7_PROFILE
                     FZ_TICK(T, 5);                      // (what follows the sweeps)
 #endif
@@ -1112,7 +1109,10 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                 if (has) {
                     const int v = it < runs0 ? 0 : (it < runs0 + runs1 ? 1 : 2);
                     const int run = it - (v == 0 ? 0 : (v == 1 ? runs0 : runs0 + runs1));
-                    sweeps[(sq_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 63] = slot_of | v << 26 | run << 28;
+                    const int at = (sq_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 63;
+                    sweeps[0][at] = slot_of | v << 26 | run << 28;
+                    sweeps[1][at] = (v == 0 ? lens.x : (v == 1 ? lens.y : lens.z)) | lens.x << 16;
+                    sweeps[2][at] = sym_at + v * sym_step;
                 }
                 sq_tail += __popcll(bal);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
