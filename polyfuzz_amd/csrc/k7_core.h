@@ -629,6 +629,24 @@ PFZ_HD int fz_common_chars(const FuzzSummary &a, const FuzzSummary &b)
     return (a.usum + b.usum - sad) >> 1;
 }
 
+// Symbol presence (NOT YET IN THE KERNEL: measured on the CPU, tests/test_k7_core_cpu.py::test_symbol_presence_bound -- a third
+// fewer pairs reach a row's best score on config 3's titles; the device side needs 32 B more per to-string summary).
+// pres: one bit per symbol rank (mod 256), the space left out -- joined forms gain and lose spaces.  Folding ranks onto
+// shared bits only merges symbols: a bit absent on the other side still means every symbol on it is absent there.
+constexpr int kFuzzPresWords = 8;
+PFZ_HD void fz_presence_miss(const uint32_t *pa, const uint32_t *pb, int &miss_a, int &miss_b)
+{
+    int na = 0, nb = 0, common = 0;
+#pragma unroll
+    for (int w = 0; w < kFuzzPresWords; ++w) {
+        na += fz_popc32(pa[w]);
+        nb += fz_popc32(pb[w]);
+        common += fz_popc32(pa[w] & pb[w]);
+    }
+    miss_a = na - common;
+    miss_b = nb - common;
+}
+
 // 200 lcs / lensum with the hardware reciprocal (1 ulp; the caller's slack is five orders of magnitude wider): a correctly
 // rounded float division is ten instructions, and the bound of one pair holds up to seven of them
 PFZ_HD float fz_r32(int lcs, int lensum)
@@ -647,13 +665,15 @@ PFZ_HD float fz_r32(int lcs, int lensum)
 // single spaces, so the to-side difference is what is left of its length.
 // (nc common tokens with sect_chars characters between them; la2 / ta, lb2 / tb: form-2 length and distinct tokens of
 // the two strings.  Selects only: the sweep runs it for all 64 lanes.)
-PFZ_HD float fz_token_set_bound_n(int la2, int ta, int lb2, int tb, int u, int nc, int sect_chars)
+// (miss_a / miss_b: distinct symbols of the one string that the other lacks -- see fz_presence_miss; they all sit in the
+// token differences: a common token has every symbol on both sides)
+PFZ_HD float fz_token_set_bound_n(int la2, int ta, int lb2, int tb, int u, int nc, int sect_chars, int miss_a = 0, int miss_b = 0)
 {
     // joined length of k tokens with c characters in total: c + k - 1
     const int ab_len = (la2 - (ta - 1) - sect_chars) + (ta - nc) - 1, ba_len = (lb2 - (tb - 1) - sect_chars) + (tb - nc) - 1;
     const int sect_len = sect_chars + (nc > 0 ? nc - 1 : 0), sect_sep = sect_len != 0 ? 1 : 0;
     const int sect_ab_len = sect_len + sect_sep + ab_len, sect_ba_len = sect_len + sect_sep + ba_len;
-    const int m = fz_min(fz_min(ab_len, ba_len), fz_max(u - sect_chars, 0));
+    const int m = fz_min(fz_min(ab_len - miss_a, ba_len - miss_b), fz_max(u - sect_chars, 0));
     // (100 - 100 d / s = 100 (s - d) / s: the same expression shape as fz_r32, hardware reciprocal included)
     const int total = sect_ab_len + sect_ba_len;
     const float result = total > 0 ? 0.5f * fz_r32(total - (ab_len + ba_len - 2 * m), total) : 100.0f;
@@ -666,24 +686,32 @@ PFZ_HD float fz_token_set_bound_n(int la2, int ta, int lb2, int tb, int u, int n
 }
 
 template <int W>
-PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, uint32_t ca, int lb2, int tb, int u)
+PFZ_HD float fz_token_set_bound(const FuzzFrom<W> &F, uint32_t ca, int lb2, int tb, int u, int miss_a = 0, int miss_b = 0)
 {
     int sect_chars = 0;
     for (int i = 0; i < F.ta; ++i) sect_chars += ((ca >> i) & 1u) ? F.tlen[i] : 0;
-    return fz_token_set_bound_n(F.la[2], F.ta, lb2, tb, u, fz_popc32(ca), sect_chars);
+    return fz_token_set_bound_n(F.la[2], F.ta, lb2, tb, u, fz_popc32(ca), sect_chars, miss_a, miss_b);
 }
 
 // An upper bound of fz_score(F, T, mode, .) -- of the TRUE score -- from the two summaries alone.  `common` says what is
 // known about common tokens: -1 unknown (the signatures intersect; assume the best), 0 none, 1 some -- then `tset` is
 // fz_token_set_bound (pass a negative value to assume 100).  float32: the caller keeps a slack (prune only when
 // bound + 0.05 < cur).
-PFZ_HD float fz_upper_bound(const FuzzSummary &a, const FuzzSummary &b, int mode, int u, int common, float tset = -1.0f)
+//
+// miss_a / miss_b (fz_presence_miss; 0 = not known): distinct non-space symbols of the one string that the other lacks.
+// Every form of a string holds every one of its symbols at least once, and a position holding a symbol the other string
+// lacks matches nothing: LCS(form of a, anything of b) <= |form of a| - miss_a, and the same with the roles swapped; a
+// window sweep aligns the WHOLE shorter form, so its misses count (equal lengths: both families run, the smaller counts).
+PFZ_HD float fz_upper_bound(const FuzzSummary &a, const FuzzSummary &b, int mode, int u, int common, float tset = -1.0f, int miss_a = 0,
+                            int miss_b = 0)
 {
     // (written with selects, not branches: the lanes of a wave take every path of this function between them)
     auto fmx = [](float x, float y) { return x > y ? x : y; };
-    auto ratio_ub = [&](int v) { return fz_r32(fz_min(u, fz_min(a.len[v], b.len[v])), a.len[v] + b.len[v]); };
+    auto ratio_ub = [&](int v) { return fz_r32(fz_min(u, fz_min(a.len[v] - miss_a, b.len[v] - miss_b)), a.len[v] + b.len[v]); };
     auto partial_ub = [&](int v) -> float {
-        const int mn = fz_min(a.len[v], b.len[v]), m = fz_min(u, mn);
+        const int la = a.len[v], lb = b.len[v];
+        const int miss = la < lb ? miss_a : (lb < la ? miss_b : fz_min(miss_a, miss_b));
+        const int mn = fz_min(la, lb), m = fz_min(u, mn - miss);
         const float r = fz_r32(m, mn + m);                       // a window has at most m matches and at least m characters
         return mn != 0 ? r : ((a.len[v] | b.len[v]) == 0 ? 100.0f : 0.0f);
     };

@@ -21,6 +21,10 @@ using namespace pfz;
 static int g_share = 0;
 extern "C" void k7_host_set_share(int share) { g_share = share; }
 
+// symbol-presence masks of the two lists ([n][kFuzzPresWords]; NULL: the bound as the kernel computes it today)
+static const uint32_t *g_pres_a = nullptr, *g_pres_b = nullptr;
+extern "C" void k7_host_set_presence(const uint32_t *a, const uint32_t *b) { g_pres_a = a, g_pres_b = b; }
+
 template <int W>
 static double score_pair(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
 {
@@ -120,11 +124,14 @@ static void run(int n_sym, const List &A, const List &B, int mode, const double 
             // the sweep's two-step bound: signatures first, the exact intersection only when they meet
             const int u = fz_common_chars(sa, sb);
             const bool maybe = (sa.sig & sb.sig) != 0;
-            float ub = fz_upper_bound(sa, sb, mode, u, maybe ? -1 : 0);
+            int miss_a = 0, miss_b = 0;
+            if (g_pres_a) fz_presence_miss(g_pres_a + (size_t)i * kFuzzPresWords, g_pres_b + (size_t)j * kFuzzPresWords, miss_a, miss_b);
+            float ub = fz_upper_bound(sa, sb, mode, u, maybe ? -1 : 0, -1.0f, miss_a, miss_b);
             if (maybe) {
                 uint32_t ca, cb;
                 fz_intersect<W>(F, T, ca, cb);
-                const float ub2 = fz_upper_bound(sa, sb, mode, u, ca ? 1 : 0, ca ? fz_token_set_bound<W>(F, ca, T.lb[2], T.tb, u) : -1.0f);
+                const float ub2 = fz_upper_bound(sa, sb, mode, u, ca ? 1 : 0,
+                                                 ca ? fz_token_set_bound<W>(F, ca, T.lb[2], T.tb, u, miss_a, miss_b) : -1.0f, miss_a, miss_b);
                 if (ub2 > ub + 1e-3f) ub = -1000.0f;      // the refined bound must never exceed the coarse one (flagged for the test)
                 else ub = ub2;
             }

@@ -33,8 +33,10 @@ def host():
     return lib
 
 
-def run_pairs(lib, W, alpha, A, B, mode, cur, share=0):
+def run_pairs(lib, W, alpha, A, B, mode, cur, share=0, presence=False):
     lib.k7_host_set_share(share)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    lib.k7_host_set_presence(vp(A["pres"]) if presence else None, vp(B["pres"]) if presence else None)
     out = np.empty((A["n"], B["n"]), np.float64)
     ub = np.empty((A["n"], B["n"]), np.float32)
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
@@ -153,3 +155,40 @@ def test_window_sweeps_on_a_three_letter_alphabet(host, oracle_mod, W):
                 reach = truth >= cur[:, None]
                 np.testing.assert_array_equal(s2[reach], truth[reach], err_msg=f"{mode} share {share}")
                 assert (s2 <= truth).all()
+
+
+@pytest.mark.parametrize("W,seed,long_words", CASES)
+@pytest.mark.parametrize("mode", MODES)
+def test_symbol_presence_bound_is_valid(host, oracle_mod, mode, W, seed, long_words):
+    """the bound with the symbol-presence term (k7_core.h: fz_presence_miss -- on the CPU only so far): still an upper bound
+    of the true score in every mode and word class, never above the bound without the term"""
+    fl, tl = _lists(seed + 50, 40, 90, long_words)
+    fl += ["this is a test", "fuzzy was a bear", "", "a", "zzz", "qq rr", "new  york"]
+    tl += ["this is a new test!!!", "fuzzy fuzzy was a bear", "", "this is a test!", "new mets", "a\tb  a", "york new"]
+    fl = [s for s in fl if len(s) <= 64 * W and len(set(s.split())) <= 32]
+    alpha = k7_prep.Alphabet(tl)
+    A, B = k7_prep.prepare(fl, alpha, False), k7_prep.prepare(tl, alpha, True)
+    truth = oracle_mod.fuzz_matrix(fl, tl, mode)
+    _, ub0 = run_pairs(host, W, alpha, A, B, mode, np.zeros(len(fl)))
+    _, ub1 = run_pairs(host, W, alpha, A, B, mode, np.zeros(len(fl)), presence=True)
+    assert (ub1 > -999).all()
+    assert (ub1 + SLACK >= truth).all(), (mode, float((truth - ub1).max()))
+    assert (ub1 <= ub0 + 1e-4).all()
+
+
+def test_symbol_presence_bound_is_useful(host, oracle_mod):
+    """what the term is worth on real titles: the pairs that reach the row's true best score, with and without it"""
+    from polyfuzz_amd import datasets
+    fl, tl = datasets.c3_lists(4000)
+    fl = [s for s in fl if len(s) <= 64 and len(set(s.split())) <= 32][:40]
+    alpha = k7_prep.Alphabet(tl)
+    A, B = k7_prep.prepare(fl, alpha, False), k7_prep.prepare(tl, alpha, True)
+    for mode in ("WRatio", "partial_ratio"):
+        truth = oracle_mod.fuzz_matrix(fl, tl, mode)
+        best = truth.max(axis=1)[:, None]
+        _, ub0 = run_pairs(host, 1, alpha, A, B, mode, np.zeros(len(fl)))
+        _, ub1 = run_pairs(host, 1, alpha, A, B, mode, np.zeros(len(fl)), presence=True)
+        assert (ub1 + SLACK >= truth).all()
+        k0, k1 = (ub0 + SLACK >= best).mean(), (ub1 + SLACK >= best).mean()
+        print(f"{mode}: pairs reaching the row's best: {k0:.4f} -> {k1:.4f} with symbol presence")
+        assert k1 < 0.85 * k0, (mode, k0, k1)
