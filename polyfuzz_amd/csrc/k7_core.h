@@ -629,11 +629,12 @@ PFZ_HD int fz_common_chars(const FuzzSummary &a, const FuzzSummary &b)
     return (a.usum + b.usum - sad) >> 1;
 }
 
-// Symbol presence (NOT YET IN THE KERNEL: measured on the CPU, tests/test_k7_core_cpu.py::test_symbol_presence_bound -- a third
-// fewer pairs reach a row's best score on config 3's titles; the device side needs 32 B more per to-string summary).
-// pres: one bit per symbol rank (mod 256), the space left out -- joined forms gain and lose spaces.  Folding ranks onto
+// Symbol presence (NOT YET IN THE KERNEL: measured on the CPU, tests/test_k7_core_cpu.py::test_symbol_presence_bound_* -- 30 %
+// fewer pairs reach a row's best score on config 3's titles, with 64 bits as well as with 256; the device side needs 8 B
+// more per to-string summary and ~16 vector instructions per pair in sweep 1).
+// pres: one bit per symbol rank (mod 64), the space left out -- joined forms gain and lose spaces.  Folding ranks onto
 // shared bits only merges symbols: a bit absent on the other side still means every symbol on it is absent there.
-constexpr int kFuzzPresWords = 8;
+constexpr int kFuzzPresWords = 2;
 PFZ_HD void fz_presence_miss(const uint32_t *pa, const uint32_t *pb, int &miss_a, int &miss_b)
 {
     int na = 0, nb = 0, common = 0;

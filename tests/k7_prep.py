@@ -65,13 +65,15 @@ def prepare(strings, alpha, is_to_list):
         else:
             hist.append([h[4 * d] | h[4 * d + 1] << 8 | h[4 * d + 2] << 16 | h[4 * d + 3] << 24 for d in range(N_CLASSES // 4)])
             usum.append(sum(h))
-    # symbol presence: one bit per symbol rank (mod 256), the space left out (see fz_presence_miss)
-    pres = np.zeros((len(strings), 8), np.uint32)
+    # symbol presence: 64 bits, bit = symbol rank mod 64, the space left out (see fz_presence_miss; ranks are code-point
+    # order: dealing the symbols to the bits by frequency instead was measured WORSE -- a rare symbol that shares its bit
+    # with a frequent one is never missed)
+    pres = np.zeros((len(strings), 2), np.uint32)
     for i, s in enumerate(strings):
         for c in set(s):
             r = alpha.rank.get(c, 0)
             if r and not c.isspace():
-                pres[i, (r & 255) >> 5] |= np.uint32(1 << (r & 31))
+                pres[i, (r & 63) >> 5] |= np.uint32(1 << (r & 31))
     return {"n": len(strings), "pres": pres, "sym": [np.array(x or [0], np.uint16) for x in sym], "off": [np.array(x, np.int64) for x in off],
             "tag": np.array(tag or [0], np.uint8), "tok_off": np.array(tok_off, np.int64), "tok_id": np.array(tok_id or [0], np.int32),
             "tok_len": np.array(tok_len or [0], np.int32), "hist": np.array(hist, np.uint32).reshape(len(strings), N_CLASSES // 4),
