@@ -143,6 +143,9 @@ struct pfz_fuzz_plan {
     int4 *meta3 = nullptr;               // [n_groups * 64] {symbol offset, tag offset, token offset, padded form length}
     int4 *meta4 = nullptr;               // [n_groups * 64] ids of the first four distinct tokens (-1: none)
     uint4 *hist = nullptr;               // [n_groups][2][64]
+#ifdef PFZ_K7_PRESENCE
+    uint2 *pres = nullptr;               // [n_groups * 64] symbol presence (fz_presence_miss)
+#endif
     std::vector<int32_t> big_slots;      // to-strings with more than 32 distinct tokens (scored by the general kernel)
     int32_t *d_big_slots = nullptr;
     ~pfz_fuzz_plan()
@@ -150,6 +153,9 @@ struct pfz_fuzz_plan {
         for (void *p : {(void *)lut, (void *)cls, (void *)table, (void *)t_tok_id, (void *)b_orig, (void *)sym, (void *)tag, (void *)tok_id,
                         (void *)tok_len, (void *)meta, (void *)meta2, (void *)meta3, (void *)meta4, (void *)hist, (void *)d_big_slots})
             if (p) pfz::pool_free(p);
+#ifdef PFZ_K7_PRESENCE
+        if (pres) pfz::pool_free(pres);
+#endif
     }
 };
 
@@ -391,6 +397,9 @@ struct PackArgs {
     int32_t *p_tok_id, *p_tok_len;
     int4 *meta, *meta2, *meta4;
     uint4 *hist;
+#ifdef PFZ_K7_PRESENCE
+    uint2 *pres;
+#endif
     int64_t n_slots;
 };
 
@@ -412,8 +421,14 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
         A.meta4[slot] = make_int4(-1, -1, -1, -1);
         A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
         A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef PFZ_K7_PRESENCE
+        A.pres[slot] = make_uint2(0u, 0u);
+#endif
         return;
     }
+#ifdef PFZ_K7_PRESENCE
+    uint32_t pw[2] = {0u, 0u};
+#endif
     const int4 rec = A.meta3[slot];
     const int64_t o = A.off[j];
     const int len[3] = {(int)(A.off[j + 1] - o), A.len1[j], A.len2[j]};
@@ -427,6 +442,9 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
             if (p < len[v]) {
                 const uint32_t c = load_unit(A.form[v], A.cw, o + p);
                 sy = c < A.lut_len ? (int)A.lut[c] : 0;
+#ifdef PFZ_K7_PRESENCE
+                if (v == 0 && sy && sy != A.space_rank) pw[(sy & 63) >> 5] |= 1u << (sy & 31);
+#endif
                 if (v == 0 && with_hist && sy) {
                     const int cl = A.cls[sy];
                     hw[cl >> 2] += 1u << (8 * (cl & 3));
@@ -466,6 +484,9 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
     A.meta4[slot] = make_int4(first[0], first[1], first[2], first[3]);
     A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
     A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+#ifdef PFZ_K7_PRESENCE
+    A.pres[slot] = make_uint2(pw[0], pw[1]);
+#endif
 }
 
 template <typename T> static int up(pfz_ctx *ctx, T **dst, const std::vector<T> &v)
@@ -611,6 +632,9 @@ static int build_plan(pfz_ctx *ctx, pfz_strings *T)
     PFZ_TRY(pool_alloc(ctx, &pl->meta2, n_slots * sizeof(int4)));
     PFZ_TRY(pool_alloc(ctx, &pl->meta4, n_slots * sizeof(int4)));
     PFZ_TRY(pool_alloc(ctx, &pl->hist, n_slots * 2 * sizeof(uint4)));
+#ifdef PFZ_K7_PRESENCE
+    PFZ_TRY(pool_alloc(ctx, &pl->pres, n_slots * sizeof(uint2)));
+#endif
     if (n_groups > 0) {
         PackArgs P;
         P.form[0] = T->chars;
@@ -639,6 +663,9 @@ static int build_plan(pfz_ctx *ctx, pfz_strings *T)
         P.meta2 = pl->meta2;
         P.meta4 = pl->meta4;
         P.hist = pl->hist;
+#ifdef PFZ_K7_PRESENCE
+        P.pres = pl->pres;
+#endif
         P.n_slots = n_groups * 64;
         hipLaunchKernelGGL(k7_pack, dim3((unsigned)((n_groups * 64 + 255) / 256)), dim3(256), 0, ctx->stream, P);
         PFZ_HIP(hipGetLastError());
@@ -698,6 +725,9 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
     __shared__ uint64_t s_tmask[kFuzzMaxTokens * W], s_smask[kFuzzMaxTokens * W];
     __shared__ int s_cnt[4 * kFuzzHistWords];
     __shared__ uint32_t s_hist[kFuzzHistWords], s_sig[2];
+#ifdef PFZ_K7_PRESENCE
+    __shared__ uint32_t s_pres[2];
+#endif
     __shared__ double red_s[kK7Waves];
     __shared__ int red_i[kK7Waves];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
@@ -791,6 +821,9 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         const int64_t a0 = A.a_off[row];
         // ---- the from-string's tables, class histogram, tokens
         if (tid < 4 * kFuzzHistWords) s_cnt[tid] = 0;
+#ifdef PFZ_K7_PRESENCE
+        if (tid < 2) s_pres[tid] = 0u;
+#endif
         if (tid == 0) {
             s_nspace = 0;
             s_best = cur0;
@@ -807,6 +840,9 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     if (v == 0) {
                         atomicAdd(&s_cnt[A.cls[sy]], 1);
                         if (sy == A.space_rank) atomicAdd(&s_nspace, 1);
+#ifdef PFZ_K7_PRESENCE
+                        else atomicOr(&s_pres[(sy & 63) >> 5], 1u << (sy & 31));
+#endif
                     }
                 }
             }
@@ -866,6 +902,10 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         for (int d = 0; d < kFuzzHistWords; ++d) sa.hist[d] = s_hist[d];
         sa.usum = s_usum;
         sa.sig = (uint64_t)s_sig[0] | (uint64_t)s_sig[1] << 32;
+#ifdef PFZ_K7_PRESENCE
+        const uint32_t pres_a0 = s_pres[0], pres_a1 = s_pres[1];
+        const int n_pres_a = __popc(pres_a0) + __popc(pres_a1);
+#endif
         const int skip = A.skip_idx ? A.skip_idx[row] : -1;
 
         auto cur_now = [&]() {
@@ -890,6 +930,9 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         struct Meta {
             int4 m, m2, m4;
             uint4 h0, h1;
+#ifdef PFZ_K7_PRESENCE
+            uint2 p;
+#endif
         };
         auto load_meta = [&](int g) {
             const int slot = g * 64 + lane;
@@ -899,6 +942,9 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
             x.m4 = A.b_meta4[slot];
             x.h0 = A.b_hist[(g * 2 + 0) * 64 + lane];
             x.h1 = A.b_hist[(g * 2 + 1) * 64 + lane];
+#ifdef PFZ_K7_PRESENCE
+            x.p = A.b_pres[slot];
+#endif
             return x;
         };
         // float32 upper bound of the pair (from-string, to-string x) FROM REGISTERS ONLY; valid = a real candidate of this
@@ -941,8 +987,15 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     nc += hit ? 1 : 0;
                     sect_chars += hit ? len : 0;
                 }
-            const float tset = nc != 0 ? fz_token_set_bound_n(F.la[2], F.ta, m.z, m.w, uu, nc, sect_chars) : -1.0f;
-            return fz_upper_bound(sa, sb, mode, uu, coarse ? -1 : (nc != 0 ? 1 : 0), coarse ? -1.0f : tset);
+#ifdef PFZ_K7_PRESENCE
+            // symbols of the one string that the other lacks (fz_presence_miss, the from-side's bits in scalar registers)
+            const int pres_common = __popc(pres_a0 & x.p.x) + __popc(pres_a1 & x.p.y);
+            const int miss_a = n_pres_a - pres_common, miss_b = __popc(x.p.x) + __popc(x.p.y) - pres_common;
+#else
+            constexpr int miss_a = 0, miss_b = 0;
+#endif
+            const float tset = nc != 0 ? fz_token_set_bound_n(F.la[2], F.ta, m.z, m.w, uu, nc, sect_chars, miss_a, miss_b) : -1.0f;
+            return fz_upper_bound(sa, sb, mode, uu, coarse ? -1 : (nc != 0 ? 1 : 0), coarse ? -1.0f : tset, miss_a, miss_b);
         };
         RowBest best = {-1.0, INT_MAX};
         tick(0);
@@ -1441,6 +1494,9 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     A.b_meta3 = pl->meta3;
     A.b_meta4 = pl->meta4;
     A.b_hist = pl->hist;
+#ifdef PFZ_K7_PRESENCE
+    A.b_pres = pl->pres;
+#endif
     A.n_groups = (int32_t)pl->n_groups;
     A.n_sym1 = pl->n_sym + 1;
     A.mode = scorer;
