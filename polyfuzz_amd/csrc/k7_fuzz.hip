@@ -443,7 +443,8 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
                 const uint32_t c = load_unit(A.form[v], A.cw, o + p);
                 sy = c < A.lut_len ? (int)A.lut[c] : 0;
 #ifdef PFZ_K7_PRESENCE
-                if (v == 0 && sy && sy != A.space_rank) pw[(sy & 63) >> 5] |= 1u << (sy & 31);
+                // (no whitespace symbol: the joined forms hold single spaces where the string had any run of them)
+                if (v == 0 && sy && !is_space_cp(c)) pw[(sy & 63) >> 5] |= 1u << (sy & 31);
 #endif
                 if (v == 0 && with_hist && sy) {
                     const int cl = A.cls[sy];
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                         atomicAdd(&s_cnt[A.cls[sy]], 1);
                         if (sy == A.space_rank) atomicAdd(&s_nspace, 1);
 #ifdef PFZ_K7_PRESENCE
-                        else atomicOr(&s_pres[(sy & 63) >> 5], 1u << (sy & 31));
+                        if (!is_space_cp(c)) atomicOr(&s_pres[(sy & 63) >> 5], 1u << (sy & 31));      // (no whitespace symbol: see k7_pack)
 #endif
                     }
                 }
