@@ -270,6 +270,11 @@ struct FuzzSweep {
     PFZ_LDS_U16 *stage;
     int stage_stride;      // (in elements)
     bool narrow;           // the column holds bytes (an alphabet of at most 255 symbols: half the scratch memory)
+    // (an experiment of tests/k7_core_host.cpp, not in the kernel: forms of at most 64 symbols) bit p of live_to: the to-form's
+    // symbol at p occurs in the from-form; bit q of live_from: the from-form's symbol at q occurs in the to-form.  A window
+    // that moves on gains matches only from LIVE positions that enter it.
+    bool has_live;
+    uint64_t live_to, live_from;
 };
 
 // copy a to-form of at most kFuzzStage symbols into the scratch column (a window sweep re-reads it |from| times)
@@ -292,6 +297,8 @@ PFZ_HD void fz_sweep_begin(FuzzSweep &S, int v, int la, int lb, int w, int w_end
                            int stage_stride, bool narrow = false)
 {
     S.narrow = narrow;
+    S.has_live = false;
+    S.live_to = S.live_from = 0ull;
     S.v = v;
     S.la = la;
     S.lb = lb;
@@ -364,7 +371,18 @@ PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double
     // one subtraction; the shrinking windows at the end are tried one by one
     int d = 1;
     const int last_whole = ll - lm;
-    if (idx < last_whole) {
+    if (S.has_live) {
+        // the window d positions on holds at most the matches of this one plus the live positions that entered
+        const uint64_t live = of_to ? S.live_to : S.live_from;
+        int entered = 0;
+        while (idx + d < ll) {
+            const int wl = fz_min(lm, ll - idx - d), enter = idx + wlen + d - 1;
+            entered += enter < ll ? (int)((live >> enter) & 1ull) : 0;
+            if (worth(fz_min(l + entered, wl), lm + wl)) break;
+            ++d;
+        }
+    }
+    else if (idx < last_whole) {
         const int sum = 2 * lm;
         int need = bl * sum / bs + 1;                        // ... to beat the best so far
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -379,7 +397,7 @@ PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double
         // the first of the shrinking windows)
         d = need > lm ? last_whole + 1 - idx : fz_min(fz_max(need - l, 1), last_whole + 1 - idx);
     }
-    if (idx + d > last_whole)
+    if (!S.has_live && idx + d > last_whole)
         while (idx + d < ll) {
             const int wl = fz_min(lm, ll - idx - d);
             if (worth(fz_min(l + d, wl), lm + wl)) break;

@@ -25,6 +25,24 @@ extern "C" void k7_host_set_share(int share) { g_share = share; }
 static const uint32_t *g_pres_a = nullptr, *g_pres_b = nullptr;
 extern "C" void k7_host_set_presence(const uint32_t *a, const uint32_t *b) { g_pres_a = a, g_pres_b = b; }
 
+// the window sweeps' experiment: live masks (FuzzSweep::has_live), and a count of the windows swept
+static int g_live = 0;
+static long long g_windows = 0;
+extern "C" void k7_host_set_live(int on) { g_live = on; }
+extern "C" long long k7_host_windows() { const long long n = g_windows; g_windows = 0; return n; }
+
+template <int W>
+static void set_live(FuzzSweep &S, const FuzzFrom<W> &F, const FuzzTo &T, int v)
+{
+    if (!g_live || F.la[v] > 64 || T.lb[v] > 64) return;
+    S.has_live = true;
+    for (int p = 0; p < T.lb[v]; ++p) {
+        const uint64_t pmv = F.pm[((size_t)T.sym[v][p] * 3 + v) * W];      // (forms within 64 symbols: the first word is all)
+        S.live_from |= pmv;
+        S.live_to |= (uint64_t)(pmv != 0) << p;
+    }
+}
+
 template <int W>
 static double score_pair(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
 {
@@ -38,7 +56,9 @@ static double score_pair(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
         for (int w0 = 0; w0 < n_win; w0 += g_share) {
             FuzzSweep S;
             fz_sweep_begin(S, v, F.la[v], T.lb[v], w0, w0 + g_share < n_win ? w0 + g_share : n_win, T.sym[v], nullptr, 0);
-            while (!fz_sweep_window<W>(S, F, f, cur - 1e-6)) {}
+            set_live<W>(S, F, T, v);
+            ++g_windows;
+            while (!fz_sweep_window<W>(S, F, f, cur - 1e-6)) ++g_windows;
             const double part = fz_sweep_score(mode, v, F.la[0], T.lb[0], fz_ratio_of(S.bl, S.bs));
             if (part > sc) sc = part;
         }

@@ -192,3 +192,32 @@ def test_symbol_presence_bound_is_useful(host, oracle_mod):
         k0, k1 = (ub0 + SLACK >= best).mean(), (ub1 + SLACK >= best).mean()
         print(f"{mode}: pairs reaching the row's best: {k0:.4f} -> {k1:.4f} with symbol presence")
         assert k1 < 0.85 * k0, (mode, k0, k1)
+
+
+@pytest.mark.parametrize("W,seed,long_words", CASES[:2])
+@pytest.mark.parametrize("mode", ["WRatio", "partial_ratio", "partial_token_ratio"])
+def test_window_sweeps_with_live_masks(host, oracle_mod, mode, W, seed, long_words):
+    """an experiment for the next round (FuzzSweep::has_live, not in the kernel): a window that moves on gains matches only
+    from entering positions whose symbol the other string has at all -- exact as before, and fewer windows swept"""
+    host.k7_host_windows.restype = ctypes.c_longlong
+    fl, tl = _lists(seed + 7, 40, 90, long_words)
+    fl += ["this is a test", "abc", "a", "mets mets mets new"]
+    tl += ["this is a new test!!!", "cab", "a", "new mets", "abcabcabc"]
+    fl = [s for s in fl if len(s) <= 64 * W and len(set(s.split())) <= 32]
+    alpha = k7_prep.Alphabet(tl)
+    A, B = k7_prep.prepare(fl, alpha, False), k7_prep.prepare(tl, alpha, True)
+    truth = oracle_mod.fuzz_matrix(fl, tl, mode)
+    swept = {}
+    try:
+        for live in (0, 1):
+            host.k7_host_set_live(live)
+            host.k7_host_windows()
+            for cur in (np.zeros(len(fl)), truth.max(axis=1), np.quantile(truth, 0.8, axis=1)):
+                score, _ = run_pairs(host, W, alpha, A, B, mode, cur, share=16)
+                reach = truth >= cur[:, None]
+                np.testing.assert_array_equal(score[reach], truth[reach])
+                assert (score <= truth).all()
+            swept[live] = host.k7_host_windows()
+    finally:
+        host.k7_host_set_live(0)
+    assert swept[1] <= swept[0]
