@@ -275,6 +275,7 @@ struct FuzzSweep {
     // that moves on gains matches only from LIVE positions that enter it.
     bool has_live;
     uint64_t live_to, live_from;
+    int n_swept;           // (LIVE) windows whose recurrence was run: the others were settled by their live positions
 };
 
 // copy a to-form of at most kFuzzStage symbols into the scratch column (a window sweep re-reads it |from| times)
@@ -299,6 +300,7 @@ PFZ_HD void fz_sweep_begin(FuzzSweep &S, int v, int la, int lb, int w, int w_end
     S.narrow = narrow;
     S.has_live = false;
     S.live_to = S.live_from = 0ull;
+    S.n_swept = 0;
     S.v = v;
     S.la = la;
     S.lb = lb;
@@ -320,7 +322,8 @@ PFZ_HD int fz_sweep_sym(const FuzzSweep &S, int pos)
 // sweeps window S.w and moves S.w to the next window that can matter; true: the share is done.  A window matters when it
 // can beat the best so far AND reach `thr` after the factor f the caller's formula multiplies partial_ratio by
 // (200 lcs f / sum >= thr; thr is the caller's floor minus a margin far above the rounding of these products).
-template <int W>
+// LIVE (an experiment of the CPU harness, not instantiated by the kernel): use S.live_to / live_from -- see FuzzSweep.
+template <int W, bool LIVE = false>
 PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double thr)
 {
     const int la = S.la, lb = S.lb, v = S.v;
@@ -344,7 +347,19 @@ PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double
 #pragma unroll
     for (int w = 0; w < W; ++w) V[w] = ~0ull;
     const bool prefixes = of_to && idx == 0;
-    for (int k = t0; k < t1; k += 4) {
+    // (live masks: a window matches at most its live positions -- and any part of it at least as many characters as it
+    // matches; when that cannot matter, the window is not swept and the count stands in for its LCS in the step below)
+    auto live_in = [&](int lo, int len) {
+        const uint64_t live = of_to ? S.live_to : S.live_from;
+        return fz_popc64((live >> lo) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull)));
+    };
+    int l_known = -1;
+    if constexpr (LIVE) {
+        const int c = fz_min(live_in(idx, wlen), wlen);
+        if (!worth(c, lm + (idx == 0 ? c : wlen))) l_known = c;
+        S.n_swept += l_known < 0;
+    }
+    for (int k = t0; k < t1 && (!LIVE || l_known < 0); k += 4) {
         int sy[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) sy[q] = k + q < t1 ? fz_sweep_sym(S, k + q) : 0;
@@ -363,26 +378,28 @@ PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double
                 if (look) cand(fz_zeros_below<W>(V, la), la + fed);
         }
     }
-    const int l = fz_zeros_below<W>(V, c_hi) - fz_zeros_below<W>(V, c_lo);
-    cand(l, lm + wlen);
-    if (!of_to && idx == 0)
-        for (int k = 1; k < lb; ++k) cand(fz_zeros_below<W>(V, k), lb + k);          // prefixes of the from-form
+    const int l = LIVE && l_known >= 0 ? l_known : fz_zeros_below<W>(V, c_hi) - fz_zeros_below<W>(V, c_lo);
+    if (!LIVE || l_known < 0) {
+        cand(l, lm + wlen);
+        if (!of_to && idx == 0)
+            for (int k = 1; k < lb; ++k) cand(fz_zeros_below<W>(V, k), lb + k);          // prefixes of the from-form
+    }
     // the next window that can matter.  Whole windows (starts up to ll - lm) all need the same LCS: the step over them is
     // one subtraction; the shrinking windows at the end are tried one by one
     int d = 1;
     const int last_whole = ll - lm;
-    if (S.has_live) {
+    if constexpr (LIVE) {
         // the window d positions on holds at most the matches of this one plus the live positions that entered
         const uint64_t live = of_to ? S.live_to : S.live_from;
         int entered = 0;
         while (idx + d < ll) {
             const int wl = fz_min(lm, ll - idx - d), enter = idx + wlen + d - 1;
             entered += enter < ll ? (int)((live >> enter) & 1ull) : 0;
-            if (worth(fz_min(l + entered, wl), lm + wl)) break;
+            if (worth(fz_min(fz_min(l + entered, live_in(idx + d, wl)), wl), lm + wl)) break;
             ++d;
         }
     }
-    else if (idx < last_whole) {
+    if (!LIVE && idx < last_whole) {
         const int sum = 2 * lm;
         int need = bl * sum / bs + 1;                        // ... to beat the best so far
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -397,7 +414,7 @@ PFZ_HD bool fz_sweep_window(FuzzSweep &S, const FuzzFrom<W> &F, double f, double
         // the first of the shrinking windows)
         d = need > lm ? last_whole + 1 - idx : fz_min(fz_max(need - l, 1), last_whole + 1 - idx);
     }
-    if (!S.has_live && idx + d > last_whole)
+    if (!LIVE && idx + d > last_whole)
         while (idx + d < ll) {
             const int wl = fz_min(lm, ll - idx - d);
             if (worth(fz_min(l + d, wl), lm + wl)) break;

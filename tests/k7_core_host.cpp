@@ -57,8 +57,14 @@ static double score_pair(const FuzzFrom<W> &F, FuzzTo &T, int mode, double cur)
             FuzzSweep S;
             fz_sweep_begin(S, v, F.la[v], T.lb[v], w0, w0 + g_share < n_win ? w0 + g_share : n_win, T.sym[v], nullptr, 0);
             set_live<W>(S, F, T, v);
-            ++g_windows;
-            while (!fz_sweep_window<W>(S, F, f, cur - 1e-6)) ++g_windows;
+            if (S.has_live) {
+                while (!fz_sweep_window<W, true>(S, F, f, cur - 1e-6)) {}
+                g_windows += S.n_swept;
+            }
+            else {
+                ++g_windows;
+                while (!fz_sweep_window<W>(S, F, f, cur - 1e-6)) ++g_windows;
+            }
             const double part = fz_sweep_score(mode, v, F.la[0], T.lb[0], fz_ratio_of(S.bl, S.bs));
             if (part > sc) sc = part;
         }
