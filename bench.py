@@ -261,14 +261,57 @@ def k3_parity(job, idx, val, rows, e_idx, e_val, a3, b3, n_col):
             "ok": bool(max_err <= 1e-5 and hard == 0)}
 
 
-def k3_cpu_and_parity(job, idx, val, seconds, all_cores=True, min_rows=0):
+ORACLE_VECTORISE_MAX_STRINGS = 250_000     # the Python restatement of the vectoriser does ~20 us per string and pass
+
+
+def oracle_matrices(job, from_strings, to_strings):
+    """The lists vectorised by the ORACLE (oracle/tfidf_oracle.py == scikit-learn bit for bit; reference _tfidf.py:102-118:
+    fit on to + from, or on the one list of a self-match) and the device's K1 / K2 output held against it: CSR structure
+    equal, values within one fp32 rounding.  Returns (a3, b3, n_col, record) or None when the lists are too long for the
+    Python restatement to stay inside the bench's time budget."""
+    import oracle
+    n = len(from_strings) + (0 if to_strings is None else len(to_strings))
+    if n > ORACLE_VECTORISE_MAX_STRINGS:
+        return None
+    t0 = time.perf_counter()
+    o = oracle.TfidfOracle()
+    if to_strings is None:
+        o.fit(from_strings)
+        a3 = b3 = o.transform(from_strings)
+    else:
+        o.fit(list(to_strings) + list(from_strings))
+        a3, b3 = o.transform(from_strings), o.transform(to_strings)
+    dt = time.perf_counter() - t0
+    d_a, d_b, n_col = job.host_matrices()
+    rec = {"what": "device CSR (K1/K2) vs oracle/tfidf_oracle.py (== sklearn TfidfVectorizer bit for bit) on the same lists",
+           "strings": n, "vocab_device": int(n_col), "vocab_oracle": len(o.vocabulary), "oracle_seconds": round(dt, 2)}
+    ok = n_col == len(o.vocabulary)
+    err = 0.0
+    for dev, orc in ((d_a, a3), (d_b, b3)):
+        ok = ok and np.array_equal(dev[0], orc[0]) and np.array_equal(dev[1], orc[1])
+        if ok and len(orc[2]):
+            err = max(err, float(np.abs(dev[2] - orc[2]).max()))
+    rec.update({"indptr_and_indices_equal": bool(ok), "max_abs_value_err": err if ok else None, "ok": bool(ok and err <= 2e-7)})
+    return a3, b3, len(o.vocabulary), rec
+
+
+def k3_cpu_and_parity(job, idx, val, seconds, all_cores=True, min_rows=0, lists=None):
     """CPU arm (ii): oracle/cossim_topn.c on ONE core -- how PolyFuzz calls sparse_dot_topn (_utils.py:82) -- over a
     seeded random sample of from-rows sized to `seconds` (at least min_rows); arm (iii): the same on all host cores (row
-    ranges on threads; ctypes releases the GIL).  The sample's results are also the parity check of the GPU result."""
+    ranges on threads; ctypes releases the GIL).  The sample's results are also the parity check of the GPU result.
+    lists = (from strings, to strings or None): the CPU side then starts from the STRINGS -- the oracle vectoriser builds the
+    float64 matrices the oracle product runs on, and the device's CSR is checked against them (`parity_check.vectoriser`);
+    without them (lists too long for the Python vectoriser) the oracle product runs on the device-built CSR."""
     import concurrent.futures as cf
     import oracle
     oracle.build_native()
-    a3, b3, n_col = job.host_matrices()
+    vec_rec = {"ok": None, "what": "not run: the oracle product ran on the device-built CSR (lists too long for the Python "
+                                   "restatement of the vectoriser inside the bench's time budget)"}
+    om = oracle_matrices(job, *lists) if lists is not None else None
+    if om is not None:
+        a3, b3, n_col, vec_rec = om
+    else:
+        a3, b3, n_col = job.host_matrices()
     n_from, excl = len(a3[0]) - 1, job.self_match
     rng = np.random.default_rng(SEED)
 
@@ -301,7 +344,12 @@ def k3_cpu_and_parity(job, idx, val, seconds, all_cores=True, min_rows=0):
             arms.append({"arm": "iii: the same on all host cores", "value": len(ranges) * per_thread * float(job.n_to) / dt3,
                          "unit": "pairs/s", "cores": len(ranges), "kind": "port",
                          "sample": f"{len(ranges)} threads x {per_thread} from-rows x all {job.n_to} to-rows, {dt3:.1f} s"})
-    return base, arms, k3_parity(job, idx, val, rows, e_idx, e_val, a3, b3, n_col)
+    par = k3_parity(job, idx, val, rows, e_idx, e_val, a3, b3, n_col)
+    par["matrices"] = ("oracle-built float64 CSR (the whole chain K1 -> K2 -> index -> K3 against the whole restated chain)"
+                       if om is not None else "device-built CSR (K3 alone)")
+    par["vectoriser"] = vec_rec
+    par["ok"] = bool(par["ok"] and vec_rec["ok"] is not False)
+    return base, arms, par
 
 
 def reference_backend_arm(names, top_n):
@@ -463,7 +511,7 @@ def run_tfidf(world, ctx, args, from_shard=None, to_list=None, top_n=None, steps
         if not args.no_cpu_baseline:
             out["cpu_baseline"], out["cpu_baseline_arms"], out["parity_check"] = k3_cpu_and_parity(
                 job, res[0], res[1], args.cpu_seconds if cpu_seconds is None else cpu_seconds, all_cores=all_cores_arm,
-                min_rows=min_parity_rows)
+                min_rows=min_parity_rows, lists=(from_shard, to_list))
     return out, job, res
 
 

@@ -73,9 +73,10 @@ class EditDistance(BaseMatcher):
               **kwargs) -> pd.DataFrame:
         """ Best match (first maximum of the ratio) of every from-string (reference _distance.py:46-87).
 
-        `re_train=False` (what PolyFuzz.transform passes, polyfuzz.py:234-240) matches against the to-list of
-        the previous call, whose device copy and K4 plan (alphabet, length-sorted packed groups) are still
-        resident: no upload, no preparation. """
+        The reference scores against the to_list it is handed, always (`PolyFuzz.transform` passes `self.to_list`,
+        polyfuzz.py:234-240).  `re_train=False` only lets this matcher re-use what is resident: when the list it is handed
+        IS the previous call's (the same object, or an equal list), its device copy and K4 plan (alphabet, length-sorted
+        packed groups) are used again -- no upload, no preparation.  Any other list is uploaded. """
         t0 = time.perf_counter()
         pending, names = self._best(from_list, to_list, reuse_to=kwargs.get("re_train", True) is False)
         from_col = object_column(from_list)          # host work while the device scores
@@ -101,21 +102,24 @@ class EditDistance(BaseMatcher):
             for j, s in enumerate(names):
                 first.setdefault(s, j)
             skip = np.fromiter((first[s] for s in from_list), np.int32, len(from_list))
-        elif reuse_to and self._to_names is not None:
-            names = self._to_names
         else:
             names = to_list
+        # the resident copy stands for the list it was made from and for no other
+        reuse_to = (reuse_to and not self_match and self._to_dev is not None
+                    and (to_list is self._to_names or to_list == self._to_names))
+        held = (self._to_dev, self._to_names)
+        self._to_dev = self._to_names = None      # set again below, once this call's to-list is resident
         if len(names) - (1 if self_match else 0) <= 0 and len(from_list) > 0:
             raise ValueError("attempt to get argmax of an empty sequence")   # np.argmax([]) in the reference
         from ._rapidfuzz import best_choice_async, upload_for
         name = self._scorer_name              # "ratio": K4; the other rapidfuzz.fuzz scorers: K4 on transformed strings, or K7
         to_dev = None
         if not self_match:
-            if reuse_to and self._to_dev is not None:
-                to_dev = self._to_dev
+            if reuse_to:
+                to_dev = held[0]
             else:
                 to_dev = upload_for(ctx, name, names)
-                self._to_dev, self._to_names = to_dev, names
+            self._to_dev, self._to_names = to_dev, names
         return best_choice_async(ctx, name, from_list, names, skip, self_match, to_dev=to_dev), names
 
     # a matcher is pickled by joblib (reference _distance.py:77, polyfuzz.py:429-457): device handles stay behind

@@ -141,12 +141,18 @@ class RapidFuzz(BaseMatcher):
               **kwargs) -> pd.DataFrame:
         """ Best choice of the to-list for every from-string (reference _rapidfuzz.py:61-113).
 
-        `re_train=False` (what PolyFuzz.transform passes, polyfuzz.py:234-240) matches against the to-list of the previous
-        call, whose device copy, token forms and plan are still resident: no upload, no preparation. """
+        The reference scores against the to_list it is handed, always (`PolyFuzz.transform` passes `self.to_list`,
+        polyfuzz.py:234-240).  `re_train=False` only lets this matcher re-use what is resident: when the list it is handed IS
+        the previous call's (the same object, or an equal list), its device copy, token forms and plan are used again -- no
+        upload, no preparation.  Any other list is uploaded. """
         ctx = _lib.Context.default()
         self_match = to_list is None
-        reuse = kwargs.get("re_train", True) is False and not self_match and self._to_names is not None
-        names = from_list if self_match else (self._to_names if reuse else to_list)
+        # the resident copy stands for the list it was made from and for no other (ADVICE r3)
+        reuse = (kwargs.get("re_train", True) is False and not self_match and self._to_dev is not None
+                 and (to_list is self._to_names or to_list == self._to_names))
+        held = self._to_dev
+        self._to_dev = self._to_names = None      # set again below, once this call's to-list is resident
+        names = from_list if self_match else to_list
         n = len(from_list)
         skip = None
         if self_match:
@@ -159,8 +165,8 @@ class RapidFuzz(BaseMatcher):
             idx, score = np.full(n, -1, np.int32), np.zeros(n)             # extractOne over no choices: None
             from_col = object_column(from_list)
         else:
-            if not self_match and not reuse:
-                self._to_dev, self._to_names = upload_for(ctx, self._scorer_name, names), names
+            if not self_match:
+                self._to_dev, self._to_names = (held if reuse else upload_for(ctx, self._scorer_name, names)), names
             pending = best_choice_async(ctx, self._scorer_name, from_list, names, skip, self_match,
                                         to_dev=None if self_match else self._to_dev)
             from_col = object_column(from_list)                              # (host work while the device scores)

@@ -35,4 +35,6 @@ def golden():
     for name in ("readme_cases", "company_c2_lists", "company_self_list", "titles_lists", "titles_self_list"):
         with open(os.path.join(g, name + ".json")) as f:
             out[name] = json.load(f)
+    with open(os.path.join(g, "lcs_golden.json"), encoding="utf-8") as f:
+        out["lcs_golden"] = json.load(f)          # textdistance.lcsseq + nltk.edit_distance (make_golden_lcs.py)
     return out

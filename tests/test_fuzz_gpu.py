@@ -317,3 +317,48 @@ def test_alphabet_size_and_the_scratch_columns(ctx, oracle_mod, n_chars):
         e_idx, e_score = oracle_mod.fuzz_extract_one(fl, tl, mode)
         np.testing.assert_array_equal(score, e_score, err_msg=mode)
         np.testing.assert_array_equal(idx, e_idx, err_msg=mode)
+
+
+def test_re_train_false_scores_against_the_list_it_is_given(ctx):
+    """ADVICE r3: `match(..., re_train=False)` re-uses the resident to-list only when the list handed in IS that list;
+    the reference's RapidFuzz / EditDistance always score against the to_list they are given (PolyFuzz.transform hands them
+    `self.to_list`, polyfuzz.py:234-240).  match(X, B) -> a self-match of A -> transform-style match(E, A): against A."""
+    from polyfuzz_amd.models import EditDistance, RapidFuzz
+    a, b = _lists(11, 40, 60)
+    x, e = _lists(12, 30, 25)
+    for make in (lambda: RapidFuzz(), lambda: RapidFuzz(scorer="ratio"), lambda: EditDistance(normalize=False)):
+        fresh = make().match(e, a)
+        m = make()
+        m.match(x, b)
+        m.match(a)                                            # a fit on one list: self-match, leaves nothing of B behind
+        assert m._to_dev is None and m._to_names is None
+        assert m.match(e, a, re_train=False).equals(fresh)
+        assert m._to_names is a
+        held = m._to_dev
+        assert m.match(x, a, re_train=False).equals(make().match(x, a)) and m._to_dev is held      # same object: resident copy
+        assert m.match(x, list(a), re_train=False).equals(make().match(x, a)) and m._to_dev is held  # an equal list: too
+        assert m.match(x, b, re_train=False).equals(make().match(x, b)) and m._to_dev is not held  # another list: uploaded
+
+
+def test_rapidfuzz_pin_fixture(ctx):
+    """tests/golden/rapidfuzz_pin.json (tests/golden/pin_rapidfuzz.py: boundary cases -- WRatio's gates at exactly 1.5 and
+    exactly 8, whitespace-only strings, exotic separators, long needles -- and real titles): `process.extractOne` of every
+    a[i] against all of b under all ten rapidfuzz.fuzz scorers, and the score of every pair (a[i], b[i]) as a one-choice
+    extractOne.  The file's "source" says whether its numbers are rapidfuzz's own or the oracle's restatement."""
+    import json
+    import os
+    from polyfuzz_amd.models._rapidfuzz import best_choice
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rapidfuzz_pin.json"), encoding="utf-8") as fh:
+        pin = json.load(fh)
+    a, b = pin["a"], pin["b"]
+    assert len(pin["scorers"]) == 10 and len(pin["wratio_ratio8"]["pairs"]) >= 8 and pin["wratio_ratio8"]["chosen"] == "lt8"
+    for name in pin["scorers"]:
+        idx, score = best_choice(ctx, name, a, b, None, False)
+        exp = np.array(pin["extract_one"][name])
+        np.testing.assert_array_equal(score, exp[:, 1], err_msg=name)
+        np.testing.assert_array_equal(idx, exp[:, 0].astype(np.int32), err_msg=name)
+    for name in ("WRatio", "partial_ratio", "token_set_ratio", "partial_token_ratio", "QRatio", "token_sort_ratio"):
+        got = [float(best_choice(ctx, name, [x], [y], None, False)[1][0]) for x, y in zip(a, b)]
+        np.testing.assert_array_equal(np.array(got), np.array(pin["pair_scores"][name]), err_msg=name)
+    for rec in pin["wratio_ratio8"]["pairs"]:                # the chosen reading of the 8x gate, by name
+        assert float(best_choice(ctx, "WRatio", [rec["a"]], [rec["b"]], None, False)[1][0]) == rec[pin["wratio_ratio8"]["chosen"]]

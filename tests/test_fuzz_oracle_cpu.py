@@ -2,6 +2,7 @@
 publishes for them (README / API documentation) -- PARITY UNPINNED beyond these -- and its own consistency rules."""
 import itertools
 
+import numpy as np
 import pytest
 
 
@@ -88,3 +89,46 @@ def test_c_restatement_equals_the_python_one_bit_for_bit(oracle_mod):
     c_idx, c_score = oracle_mod.fuzz_extract_one(own, own, "WRatio", skip=skip, rows=(3, 45))
     assert idx[3:] == c_idx.tolist() and score[3:] == c_score.tolist()
     assert np.array_equal(oracle_mod.fuzz_extract_one(["a"], [], "WRatio")[0], [-1])
+
+
+def _pin():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rapidfuzz_pin.json"), encoding="utf-8") as fh:
+        return json.load(fh)
+
+
+def test_rapidfuzz_pin_fixture_vs_both_restatements(oracle_mod):
+    """tests/golden/rapidfuzz_pin.json (made by tests/golden/pin_rapidfuzz.py; "source" = rapidfuzz's own numbers once the
+    script has run where the library is importable, the oracle's until then): every pair score and every extractOne under
+    all ten scorers, against oracle/fuzz_scorers.py AND oracle/fuzz_scorers.c; the boundary cases are there by construction
+    (length ratio exactly 1.5 -> the partial branch, exactly 8 -> recorded under both readings, the chosen one named)."""
+    from oracle import fuzz_scorers as f
+    pin = _pin()
+    a, b = pin["a"], pin["b"]
+    assert sum(1 for x, y in zip(a, b) if x and y and 2 * max(len(x), len(y)) == 3 * min(len(x), len(y))) >= 7
+    assert sum(1 for x, y in zip(a, b) if x and y and max(len(x), len(y)) == 8 * min(len(x), len(y))) >= 9
+    for name in pin["scorers"]:
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert f.SCORERS[name](x, y) == pin["pair_scores"][name][i], (name, x, y)
+            assert oracle_mod.fuzz_score(x, y, name) == pin["pair_scores"][name][i], (name, x, y)
+        idx, score = oracle_mod.fuzz_extract_one(a, b, name)
+        exp = np.array(pin["extract_one"][name])
+        np.testing.assert_array_equal(score, exp[:, 1])
+        np.testing.assert_array_equal(idx, exp[:, 0].astype(np.int32))
+    r8 = pin["wratio_ratio8"]
+    assert r8["chosen"] == "lt8"
+    for rec in r8["pairs"]:
+        assert f.WRatio(rec["a"], rec["b"]) == rec["lt8"] and rec["le8"] >= rec["lt8"]
+        assert rec["le8"] != rec["lt8"] or f.ratio(rec["a"], rec["b"]) == rec["lt8"]     # the gate matters on these pairs
+
+
+def test_real_rapidfuzz_when_importable(oracle_mod):
+    """Where rapidfuzz IS importable this is the pin itself: the library against the oracle on the fixture's strings."""
+    pytest.importorskip("rapidfuzz")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import pin_rapidfuzz
+    a, b = pin_rapidfuzz.strings()
+    assert pin_rapidfuzz.diff(pin_rapidfuzz.from_rapidfuzz(a, b), pin_rapidfuzz.from_oracle(a, b)) == []

@@ -30,6 +30,19 @@ def test_published_rapidfuzz_values(ctx):
     assert m[2, 2] == 100.0 and m[3, 2] == 0.0 and m[2, 0] == 0.0
 
 
+def test_third_party_lcs_pin(ctx, golden):
+    """K4 against the third-party fixture directly (textdistance.lcsseq / nltk.edit_distance, make_golden_lcs.py): the
+    diagonal of the all-pairs matrix of the fixture's 3 029 pairs, no oracle in between."""
+    pairs = golden["lcs_golden"]["pairs"]
+    fl, tl = [p[0] for p in pairs], [p[1] for p in pairs]
+    m, _ = _matrix(ctx, fl, tl)
+    lensum = np.array([len(a) + len(b) for a, b in zip(fl, tl)], np.float64)
+    dist = np.array([p[3] for p in pairs], np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        expect = np.where(lensum > 0, (1.0 - dist / lensum) * 100, 100.0)
+    np.testing.assert_array_equal(np.diagonal(m), expect)
+
+
 def test_titles_bit_exact_vs_oracle(ctx, oracle_mod, golden):
     t = golden["titles_lists"]
     fl, tl = t["from_list"], t["to_list"]
