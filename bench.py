@@ -57,7 +57,7 @@ MIN_SIM = 0.0
 HBM_PEAK_GBS = 8000.0            # HBM3E 8.0 TB/s spec
 LDS_BYTES_PER_CLK_CU = 128.0     # LDS bandwidth per CU
 N_CU, CLK_HZ = 256, 2.4e9
-LDS_ATOMIC_LANES_PER_S = 4.0e12  # measured ds_add_u32 rate, all CUs (tools/ubench/lds_atomic.hip: 6.6 lanes/clk/CU)
+LDS_ATOMIC_LANES_PER_S = 4.059e12  # measured ds_add_u32 rate, all CUs: profiles/r04_ubench/lds_atomic.txt (tools/ubench/lds_atomic.hip, 6.61 lanes/clk/CU)
 INT32_PEAK_TOPS = N_CU * 4 * 32 * CLK_HZ / 1e12      # 32-bit integer issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T/s
 FP32_MFMA_PEAK_TFLOPS = 157.3
 SEED = 20260924                  # of every random row sample below
@@ -178,20 +178,21 @@ def the_list(args):
     return synth.company_names(args.n, seed=5678), "synthetic"
 
 
-def workload_key(args):
-    return f"company_names[:{args.n}] self-match top-{args.top_n}"
+def traffic_key(args, label_key=None):
+    """key of a workload in profiles/k3_hbm_traffic.json"""
+    if label_key is not None:
+        return label_key
+    return "headline" if (args.n == N_NAMES and args.top_n == TOP_N) else f"company_names[:{args.n}] self-match top-{args.top_n}"
 
 
-def recorded_traffic(args):
-    """Bytes per K3 launch that missed L2 (rocprofv3 PMC passes; a bench run cannot collect PMC itself); only
-    valid for the workload it was recorded on."""
+def recorded_traffic(key):
+    """Bytes per K3 launch that missed L2 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, tools/pmc_traffic.sh ->
+    profiles/k3_hbm_traffic.json; a bench run cannot collect PMC itself); only valid for the workload it was recorded on."""
     try:
         with open(os.path.join(REPO, "profiles", "k3_hbm_traffic.json")) as f:
-            rec = json.load(f)
-        if rec.get("workload") != workload_key(args):
-            return None, None
-        return float(rec["hbm_bytes_per_launch"]), rec.get("note")
-    except (OSError, KeyError, ValueError):
+            rec = json.load(f)["records"][key]
+        return float(rec["hbm_bytes_per_launch"]), f"{rec['note']} [{rec['kernel']}, {rec['source']}]"
+    except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
 
@@ -206,11 +207,15 @@ def median(xs):
 # ---- K3: roofline object, CPU arms, random-row parity ------------------------------------------------------------
 
 def k3_roofline(job, stats, k3_ms, k3_launches, top_n, traffic=None, traffic_note=None):
-    """The contract's figure prices SURVEY section 8d's ALGORITHMIC bytes (one 8-byte posting per multiply-add + the
-    from-side CSR once + the results once) against the HBM peak -- that is `hbm_priced_*` and can exceed 1, because the
-    postings are served by L2 / Infinity Cache.  `frac` is against the resource that binds the kernel: the LDS floor =
-    every multiply-add is one ds_add_u32 lane at the measured atomic rate + every accumulator cell of every
-    (from-row, to-block) read and cleared once."""
+    """The bench contract's roofline object for K3, the same keys every round:
+      achieved / peak / frac   SURVEY section 8d's ALGORITHMIC bytes of one launch (one 8-byte posting per multiply-add + the
+                               from-side CSR once + the results once) / the kernel's average launch time, against the 8 TB/s HBM
+                               peak.  == frac_hbm_priced.  It can exceed 1: the postings are served by L2 / Infinity Cache.
+      frac_lds_floor           the resource that does bind the kernel: every multiply-add is one ds_add_u32 lane at the measured
+                               rate (profiles/r04_ubench/lds_atomic.txt) + every accumulator cell of every (from-row, to-block)
+                               read and cleared once at the LDS bandwidth; floor / launch time.
+      traffic                  bytes per launch that left L2 (PMC record, profiles/k3_hbm_traffic.json), or null
+      compulsory_bytes         inputs once + results once"""
     k3_avg_s = (k3_ms / max(1, k3_launches)) * 1e-3
     ix = job.index.info()
     bytes_alg = 8.0 * stats["madds"] + 8.0 * stats["nnz_from"] + 8.0 * job.n_from * top_n
@@ -218,24 +223,27 @@ def k3_roofline(job, stats, k3_ms, k3_launches, top_n, traffic=None, traffic_not
     cells = float(job.n_from) * ix["n_blocks"] * ix["block_cols"]
     lds_bw = N_CU * LDS_BYTES_PER_CLK_CU * CLK_HZ
     lds_floor_s = stats["madds"] / LDS_ATOMIC_LANES_PER_S + cells * 8.0 / lds_bw
+    # compulsory: the from-side CSR once, the to-side index as it lies in HBM (padded pieces + table) once, the results once
+    compulsory = 8.0 * stats["nnz_from"] + 4.0 * (job.n_from + 1) + 8.0 * float(ix["n_pieces"]) * float(ix["piece_postings"]) + float(ix["table_bytes"]) \
+        + 8.0 * job.n_from * top_n
     return {
-        "kernel": "k3_cossim_topn", "bound": "lds",
-        # LDS bytes of the launch (an atomic lane priced at the measured ds_add_u32 rate: 128 B/clk / 6.6 lanes/clk = 19.4 B)
-        # over the launch time, against the LDS bandwidth of the chip
-        "achieved": lds_floor_s * lds_bw / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0, "peak": lds_bw / 1e9,
-        "unit": "GB/s of LDS bandwidth",
-        "frac": lds_floor_s / k3_avg_s if k3_avg_s > 0 else 0.0,
-        "frac_of_lds_floor": lds_floor_s / k3_avg_s if k3_avg_s > 0 else 0.0,
-        "lds_floor_ms": lds_floor_s * 1e3, "avg_launch_ms": k3_avg_s * 1e3, "launches": k3_launches,
-        "lds_floor_what": f"{stats['madds']:.4g} ds_add_u32 lanes at {LDS_ATOMIC_LANES_PER_S:.1e}/s + {cells:.4g} accumulator "
-                          f"cells x 8 B (read + clear) at {lds_bw / 1e12:.1f} TB/s of LDS bandwidth",
-        "hbm_priced_achieved_gbs": hbm_priced, "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_priced_frac": hbm_priced / HBM_PEAK_GBS,
+        "kernel": "k3_cossim_topn", "bound": "hbm",
+        "achieved": hbm_priced, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_priced / HBM_PEAK_GBS,
+        "frac_hbm_priced": hbm_priced / HBM_PEAK_GBS,
+        "frac_lds_floor": lds_floor_s / k3_avg_s if k3_avg_s > 0 else 0.0,
+        "binding_resource": "lds (atomics + accumulator sweep), not HBM",
         "algorithmic_bytes_per_launch": bytes_alg,
+        "compulsory_bytes": compulsory,
         "traffic": traffic,
+        "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
         "traffic_note": traffic_note or "no PMC record for this workload (profiles/k3_hbm_traffic.json)",
-        "bound_note": "frac = LDS floor / measured launch time (the binding resource: LDS atomics + the accumulator sweep); "
-                      "hbm_priced_frac prices the ALGORITHMIC bytes of SURVEY section 8d against the 8 TB/s HBM peak and is "
-                      "not a utilisation -- the padded index (tens of MB) is served by L2 / Infinity Cache",
+        "lds_floor_ms": lds_floor_s * 1e3, "avg_launch_ms": k3_avg_s * 1e3, "launches": k3_launches,
+        "lds_floor_what": f"{stats['madds']:.4g} ds_add_u32 lanes at {LDS_ATOMIC_LANES_PER_S:.3e}/s (profiles/r04_ubench/"
+                          f"lds_atomic.txt) + {cells:.4g} accumulator cells x 8 B (read + clear) at {lds_bw / 1e12:.2f} TB/s of "
+                          f"LDS bandwidth ({N_CU} CU x {LDS_BYTES_PER_CLK_CU:.0f} B/clk x {CLK_HZ / 1e9:.1f} GHz)",
+        "bound_note": "frac = frac_hbm_priced = SURVEY 8d's algorithmic bytes / launch time / 8 TB/s: a PRICE, not a "
+                      "utilisation -- the padded index (tens of MB) is served by L2 / Infinity Cache, `traffic` is what left L2; "
+                      "frac_lds_floor is against the resource that binds the kernel",
     }
 
 
@@ -459,7 +467,7 @@ def contract(metric, value, unit, world, args, steps, warmup, wall, scaling, dty
 
 def run_tfidf(world, ctx, args, from_shard=None, to_list=None, top_n=None, steps=None, warmup=None, self_match=True,
               shard_desc="the whole list", n_from_total=None, label=None, cpu_seconds=None, min_parity_rows=0,
-              all_cores_arm=True, kind="real", shard_offset=0, rows_per_rank=None):
+              all_cores_arm=True, kind="real", shard_offset=0, rows_per_rank=None, traffic_label=None):
     """One TfidfMatchJob under the clock.  Returns (contract-shaped record incl. roofline / cpu_baseline / parity_check,
     job, (idx, val) of the last step)."""
     from polyfuzz_amd import pipeline
@@ -485,7 +493,7 @@ def run_tfidf(world, ctx, args, from_shard=None, to_list=None, top_n=None, steps
         return None, job, None
     kernel_ms = {name: round(ctx.prof_get(name)[0] / 3, 4) for name in pipeline.PROFILED_KERNELS}
     stats = job.stats()
-    traffic, traffic_note = recorded_traffic(args) if label is None else (None, "not recorded for this configuration")
+    traffic, traffic_note = recorded_traffic(traffic_key(args, traffic_label))
     out = contract(
         "string-pairs/sec, TF-IDF cosine top-n 100k x 100k (value = device-resident step; match_pairs_per_s = the "
         "SURVEY section 8d metric over .match() wall; latency.top1_single_query_ms = top-1 match latency)"
@@ -523,13 +531,18 @@ def headline(world, ctx, args):
     if size == 1:
         kw = dict(from_shard=names, to_list=None, shard_desc="the whole list", n_from_total=n)
     elif scaling == "strong":
-        b, e = pipeline.shard_bounds(n, size, rank)
-        kw = dict(from_shard=names[b:e], to_list=names, shard_offset=b, rows_per_rank=pipeline.shard_bounds(n, size, 0)[1],
-                  shard_desc=f"rows [{b}, {e}) of the list", n_from_total=n)
+        bounds = pipeline.balanced_bounds(names, size)       # equal characters, not equal rows: the list is sorted and skewed
+        b, e = bounds[rank]
+        kw = dict(from_shard=names[b:e], to_list=names, shard_offset=b, rows_per_rank=max(y - x for x, y in bounds),
+                  shard_desc=f"rows [{b}, {e}) of the list (cost-balanced cuts)", n_from_total=n)
     else:
-        shard = names if rank == 0 else synth.company_names(n, seed=1234 + rank)
-        kw = dict(from_shard=shard, to_list=names, shard_offset=rank * n, rows_per_rank=n, n_from_total=n * size,
-                  shard_desc="rank 0: the list itself, rank r > 0: synthetic names of the same token statistics")
+        # weak scaling: every rank matches ITS OWN batch of 100 000 query names against the replicated list.  There is one real
+        # list, so every rank's batch is that list (the headline self-match on every GPU, results all-gathered): per-rank work is
+        # identical by construction, which is what "weak" promises.  (Rounds 1-3 gave the ranks r > 0 synthetic names: they
+        # cost 19 - 24 % more per row than the real ones -- tools/predict_scaling.py, profiles/r04_predicted_scaling.json -- a
+        # difference of workload that the driver's efficiency figure would have read as a loss of scaling.)
+        kw = dict(from_shard=names, to_list=names, shard_offset=0, rows_per_rank=n, n_from_total=n * size,
+                  shard_desc="every rank: the list itself as its batch of from-rows (self-match against the replicated list)")
     out, job, res = run_tfidf(world, ctx, args, kind=kind, min_parity_rows=5000 if n >= 50_000 else 0, **kw)
     if out is None:
         return None
@@ -565,7 +578,7 @@ def run_c2(world, ctx, args, steps=20, warmup=3):
                               label="TFIDF(min_similarity=0, top_n=5).match(from, to): config 2, 10 000 x 10 000 real company "
                                     "names (default_rng(0) permutation; SURVEY section 8d)",
                               shard_desc="the whole from-list", cpu_seconds=min(args.cpu_seconds, 3.0), min_parity_rows=2000,
-                              all_cores_arm=False)
+                              all_cores_arm=False, traffic_label="c2_tfidf_10k")
     if out is not None and world.size == 1 and not args.no_match_wall:
         m = TFIDF(n_gram_range=(3, 3), min_similarity=0, top_n=5)
         m.match(fl, tl)
@@ -591,7 +604,7 @@ def run_tfidf_1m(world, ctx, args, steps=3, warmup=1):
                               label="one GPU's shard of config 4: 125 000 synthetic from-names x 1 000 000 synthetic to-names, "
                                     "top-10 (TfidfMatchJob, lists resident)", kind="synthetic",
                               shard_desc="rows of rank 0 of 8", cpu_seconds=min(args.cpu_seconds, 4.0), min_parity_rows=64,
-                              all_cores_arm=False)
+                              all_cores_arm=False, traffic_label="tfidf_1m_shard")
     if out is not None:
         out["host_generation_s"] = round(t_gen, 2)
         out["index"] = job.index.info()
@@ -615,9 +628,10 @@ def run_editdistance(world, ctx, args, steps=None, warmup=None, cpu_seconds=None
     warmup = args.warmup if warmup is None else warmup
     fl, tl = datasets.c3_lists(2_000 if args.small else 20_000)
     n = len(fl)
-    b, e = pipeline.shard_bounds(n, world.size, world.rank)
+    bounds = pipeline.balanced_bounds(fl, world.size)      # equal characters per rank: a from-title costs its length x the to-list
+    b, e = bounds[world.rank]
     comm, exchange = world.comm(ctx) if world.size > 1 else (None, "none (single GPU)")
-    job = pipeline.BestChoiceJob(ctx, fl[b:e], tl, scorer="ratio", comm=comm, rows_per_rank=pipeline.shard_bounds(n, world.size, 0)[1])
+    job = pipeline.BestChoiceJob(ctx, fl[b:e], tl, scorer="ratio", comm=comm, rows_per_rank=max(y - x for x, y in bounds))
     plan = job.plan_info()
     wall, result = timed_steps(world, ctx, job.step, steps, warmup)
     k4_ms, k4_launches = ctx.prof_get("k4_indel")
@@ -625,7 +639,7 @@ def run_editdistance(world, ctx, args, steps=None, warmup=None, cpu_seconds=None
         return None
     idx, score = job.result_host(result)
     if world.size > 1:
-        sizes = [pipeline.shard_bounds(n, world.size, r)[1] - pipeline.shard_bounds(n, world.size, r)[0] for r in range(world.size)]
+        sizes = [y - x for x, y in bounds]
         idx, score = pipeline.BestChoiceJob.unpad(idx, score, sizes, job.rows_per_rank)
     k4_step_s = k4_ms / steps * 1e-3
     # algorithmic work: one 5-operation word update (u = V & M; V = (V + u) | (V ^ u), + the table look-up) per
@@ -689,16 +703,17 @@ def run_rapidfuzz(world, ctx, args, steps=3, warmup=1, cpu_seconds=None):
     from polyfuzz_amd.models import RapidFuzz
     fl, tl = datasets.c3_lists(2_000 if args.small else 20_000)
     n = len(fl)
-    b, e = pipeline.shard_bounds(n, world.size, world.rank)
+    bounds = pipeline.balanced_bounds(fl, world.size)      # equal characters per rank: a from-title costs its length x the to-list
+    b, e = bounds[world.rank]
     comm, exchange = world.comm(ctx) if world.size > 1 else (None, "none (single GPU)")
-    job = pipeline.BestChoiceJob(ctx, fl[b:e], tl, scorer="WRatio", comm=comm, rows_per_rank=pipeline.shard_bounds(n, world.size, 0)[1])
+    job = pipeline.BestChoiceJob(ctx, fl[b:e], tl, scorer="WRatio", comm=comm, rows_per_rank=max(y - x for x, y in bounds))
     wall, result = timed_steps(world, ctx, job.step, steps, warmup, prof_level=True)
     k7_ms, k7_launches = ctx.prof_get("k7_fuzz")
     if world.rank != 0:
         return None
     idx, score = job.result_host(result)
     if world.size > 1:
-        sizes = [pipeline.shard_bounds(n, world.size, r)[1] - pipeline.shard_bounds(n, world.size, r)[0] for r in range(world.size)]
+        sizes = [y - x for x, y in bounds]
         idx, score = pipeline.BestChoiceJob.unpad(idx, score, sizes, job.rows_per_rank)
     out = contract("string-pairs/sec, RapidFuzz() = process.extractOne(scorer=fuzz.WRatio) per from-string, 20k x 20k IMDB titles",
                    float(n) * float(len(tl)) * steps / wall, "pairs/s", world, args, steps, warmup, wall,

@@ -51,16 +51,27 @@ def build_host_helpers(force=False, verbose=False):
     return PACK_PATH
 
 
-OBJ_DIR = os.path.join(CSRC, "_obj")
+OBJ_ROOT = os.path.join(CSRC, "_obj")
+
+
+def _compile_flags():
+    return [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PFZ_EXTRA_HIPCC_FLAGS", "").split()
+
+
+def _obj_dir():
+    """csrc/_obj/<hash of the compile flags>: objects built under other flags (a -D variant through
+    PFZ_EXTRA_HIPCC_FLAGS) are never linked into this build, nor this build's objects into theirs."""
+    import hashlib
+    return os.path.join(OBJ_ROOT, hashlib.sha256(" ".join(_compile_flags()).encode()).hexdigest()[:12])
 
 
 def _compile_one(src, force, verbose):
-    """one translation unit -> csrc/_obj/<name>.o (skipped when newer than the source and every header)"""
-    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    """one translation unit -> csrc/_obj/<flags>/<name>.o (skipped when newer than the source and every header)"""
+    obj = os.path.join(_obj_dir(), os.path.basename(src)[:-4] + ".o")
     deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj, False
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PFZ_EXTRA_HIPCC_FLAGS", "").split()
+    flags = _compile_flags()
     cmd = [_hipcc()] + flags + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd))
@@ -77,7 +88,7 @@ def build(force=False, verbose=False, out=None):
     if not force and out is None and not is_stale():
         return lib
     import concurrent.futures as cf
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(_obj_dir(), exist_ok=True)
     with cf.ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
         objs = [o for o, _ in ex.map(lambda s: _compile_one(s, force, verbose), sources())]
     rocm_lib = "/opt/rocm/lib"

@@ -329,6 +329,12 @@ class DeviceTopN(_Handle):
         check(ctx.lib.pfz_topn_upload(ctx.h, t.h, _ptr(idx), _ptr(val)))
         return t
 
+    def upload(self, idx, val):
+        """overwrite the whole buffer with host arrays of its shape"""
+        idx = np.ascontiguousarray(idx, np.int32).reshape(self.n_rows, self.ntop)
+        val = np.ascontiguousarray(val, np.float32).reshape(self.n_rows, self.ntop)
+        check(self.ctx.lib.pfz_topn_upload(self.ctx.h, self.h, _ptr(idx), _ptr(val)))
+
     def device_ptrs(self):
         pi, pv = c_vp(), c_vp()
         check(self.ctx.lib.pfz_topn_device_ptrs(self.h, ctypes.byref(pi), ctypes.byref(pv), None, None))

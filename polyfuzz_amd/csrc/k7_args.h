@@ -24,9 +24,7 @@ struct FuzzArgs {
     const int32_t *b_tok_id, *b_tok_len;
     const int4 *b_meta, *b_meta2, *b_meta3, *b_meta4;
     const uint4 *b_hist;
-#ifdef PFZ_K7_PRESENCE
-    const uint2 *b_pres;         // [slot] symbol presence, 64 bits (k7_core.h: fz_presence_miss) -- an experiment, not in the default build
-#endif
+    const uint2 *b_pres;         // [slot] symbol presence, 64 bits (k7_core.h: fz_presence_miss): part of the bound since round 4
     const int32_t *big_slots;    // general kernel: only these to-slots (n_big > 0), else all
     int32_t n_big;
     int32_t n_groups, n_sym1, mode;

@@ -79,7 +79,7 @@ __device__ inline int sweep_share_log2(int n_windows)
 // heavy-row hand-over (see FuzzArgs::cont_list): a row that has scored kHandBatches batches and still has kHandMinGroups
 // groups to go leaves them to continuation units -- as many (up to kContParts) as leave each about kHandBatches batches
 constexpr int kHandBatches = 64, kHandMinGroups = 16, kContParts = 64;
-constexpr int kHandShortLen = 6, kHandShortBatches = 24;      // ... a from-string of up to 6 characters from 24 batches on
+constexpr int kHandShortLen = 8, kHandShortBatches = 24;      // ... a from-string of up to 8 characters from 24 batches on (round 4, with the presence bound: 6 -> 8)
 static bool mode_sweeps_windows(int mode) { return mode != kTokenSetRatio && mode != kTokenRatio; }
 
 __device__ inline uint32_t load_unit(const void *p, int width, int64_t i)
@@ -143,9 +143,7 @@ struct pfz_fuzz_plan {
     int4 *meta3 = nullptr;               // [n_groups * 64] {symbol offset, tag offset, token offset, padded form length}
     int4 *meta4 = nullptr;               // [n_groups * 64] ids of the first four distinct tokens (-1: none)
     uint4 *hist = nullptr;               // [n_groups][2][64]
-#ifdef PFZ_K7_PRESENCE
     uint2 *pres = nullptr;               // [n_groups * 64] symbol presence (fz_presence_miss)
-#endif
     std::vector<int32_t> big_slots;      // to-strings with more than 32 distinct tokens (scored by the general kernel)
     int32_t *d_big_slots = nullptr;
     ~pfz_fuzz_plan()
@@ -153,9 +151,7 @@ struct pfz_fuzz_plan {
         for (void *p : {(void *)lut, (void *)cls, (void *)table, (void *)t_tok_id, (void *)b_orig, (void *)sym, (void *)tag, (void *)tok_id,
                         (void *)tok_len, (void *)meta, (void *)meta2, (void *)meta3, (void *)meta4, (void *)hist, (void *)d_big_slots})
             if (p) pfz::pool_free(p);
-#ifdef PFZ_K7_PRESENCE
         if (pres) pfz::pool_free(pres);
-#endif
     }
 };
 
@@ -397,9 +393,7 @@ struct PackArgs {
     int32_t *p_tok_id, *p_tok_len;
     int4 *meta, *meta2, *meta4;
     uint4 *hist;
-#ifdef PFZ_K7_PRESENCE
     uint2 *pres;
-#endif
     int64_t n_slots;
 };
 
@@ -421,14 +415,10 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
         A.meta4[slot] = make_int4(-1, -1, -1, -1);
         A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
         A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
-#ifdef PFZ_K7_PRESENCE
         A.pres[slot] = make_uint2(0u, 0u);
-#endif
         return;
     }
-#ifdef PFZ_K7_PRESENCE
     uint32_t pw[2] = {0u, 0u};
-#endif
     const int4 rec = A.meta3[slot];
     const int64_t o = A.off[j];
     const int len[3] = {(int)(A.off[j + 1] - o), A.len1[j], A.len2[j]};
@@ -442,10 +432,8 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
             if (p < len[v]) {
                 const uint32_t c = load_unit(A.form[v], A.cw, o + p);
                 sy = c < A.lut_len ? (int)A.lut[c] : 0;
-#ifdef PFZ_K7_PRESENCE
                 // (no whitespace symbol: the joined forms hold single spaces where the string had any run of them)
                 if (v == 0 && sy && !is_space_cp(c)) pw[(sy & 63) >> 5] |= 1u << (sy & 31);
-#endif
                 if (v == 0 && with_hist && sy) {
                     const int cl = A.cls[sy];
                     hw[cl >> 2] += 1u << (8 * (cl & 3));
@@ -485,9 +473,7 @@ __global__ __launch_bounds__(256) void k7_pack(PackArgs A)
     A.meta4[slot] = make_int4(first[0], first[1], first[2], first[3]);
     A.hist[(g * 2 + 0) * 64 + lane] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
     A.hist[(g * 2 + 1) * 64 + lane] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
-#ifdef PFZ_K7_PRESENCE
     A.pres[slot] = make_uint2(pw[0], pw[1]);
-#endif
 }
 
 template <typename T> static int up(pfz_ctx *ctx, T **dst, const std::vector<T> &v)
@@ -633,9 +619,7 @@ static int build_plan(pfz_ctx *ctx, pfz_strings *T)
     PFZ_TRY(pool_alloc(ctx, &pl->meta2, n_slots * sizeof(int4)));
     PFZ_TRY(pool_alloc(ctx, &pl->meta4, n_slots * sizeof(int4)));
     PFZ_TRY(pool_alloc(ctx, &pl->hist, n_slots * 2 * sizeof(uint4)));
-#ifdef PFZ_K7_PRESENCE
     PFZ_TRY(pool_alloc(ctx, &pl->pres, n_slots * sizeof(uint2)));
-#endif
     if (n_groups > 0) {
         PackArgs P;
         P.form[0] = T->chars;
@@ -664,9 +648,7 @@ static int build_plan(pfz_ctx *ctx, pfz_strings *T)
         P.meta2 = pl->meta2;
         P.meta4 = pl->meta4;
         P.hist = pl->hist;
-#ifdef PFZ_K7_PRESENCE
         P.pres = pl->pres;
-#endif
         P.n_slots = n_groups * 64;
         hipLaunchKernelGGL(k7_pack, dim3((unsigned)((n_groups * 64 + 255) / 256)), dim3(256), 0, ctx->stream, P);
         PFZ_HIP(hipGetLastError());
@@ -726,9 +708,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
     __shared__ uint64_t s_tmask[kFuzzMaxTokens * W], s_smask[kFuzzMaxTokens * W];
     __shared__ int s_cnt[4 * kFuzzHistWords];
     __shared__ uint32_t s_hist[kFuzzHistWords], s_sig[2];
-#ifdef PFZ_K7_PRESENCE
     __shared__ uint32_t s_pres[2];
-#endif
     __shared__ double red_s[kK7Waves];
     __shared__ int red_i[kK7Waves];
     __shared__ unsigned long long s_best;          // bits of the best score any lane of the workgroup has found so far (>= 0)
@@ -737,6 +717,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mode = A.mode, parts = A.parts;
     const bool use_tokens = mode_uses_tokens(mode);
+    const bool use_pres = mode != kTokenSetRatio && mode != kTokenRatio;      // the symbol-presence term of the bound (see bound_of)
 
     for (int p = tid; p < A.n_sym1 * 3 * W; p += kK7Threads) pm[p] = 0ull;
     __syncthreads();
@@ -822,9 +803,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         const int64_t a0 = A.a_off[row];
         // ---- the from-string's tables, class histogram, tokens
         if (tid < 4 * kFuzzHistWords) s_cnt[tid] = 0;
-#ifdef PFZ_K7_PRESENCE
         if (tid < 2) s_pres[tid] = 0u;
-#endif
         if (tid == 0) {
             s_nspace = 0;
             s_best = cur0;
@@ -841,9 +820,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     if (v == 0) {
                         atomicAdd(&s_cnt[A.cls[sy]], 1);
                         if (sy == A.space_rank) atomicAdd(&s_nspace, 1);
-#ifdef PFZ_K7_PRESENCE
                         if (!is_space_cp(c)) atomicOr(&s_pres[(sy & 63) >> 5], 1u << (sy & 31));      // (no whitespace symbol: see k7_pack)
-#endif
                     }
                 }
             }
@@ -903,10 +880,8 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         for (int d = 0; d < kFuzzHistWords; ++d) sa.hist[d] = s_hist[d];
         sa.usum = s_usum;
         sa.sig = (uint64_t)s_sig[0] | (uint64_t)s_sig[1] << 32;
-#ifdef PFZ_K7_PRESENCE
         const uint32_t pres_a0 = s_pres[0], pres_a1 = s_pres[1];
         const int n_pres_a = __popc(pres_a0) + __popc(pres_a1);
-#endif
         const int skip = A.skip_idx ? A.skip_idx[row] : -1;
 
         auto cur_now = [&]() {
@@ -931,9 +906,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         struct Meta {
             int4 m, m2, m4;
             uint4 h0, h1;
-#ifdef PFZ_K7_PRESENCE
             uint2 p;
-#endif
         };
         auto load_meta = [&](int g) {
             const int slot = g * 64 + lane;
@@ -943,9 +916,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
             x.m4 = A.b_meta4[slot];
             x.h0 = A.b_hist[(g * 2 + 0) * 64 + lane];
             x.h1 = A.b_hist[(g * 2 + 1) * 64 + lane];
-#ifdef PFZ_K7_PRESENCE
-            x.p = A.b_pres[slot];
-#endif
+            x.p = use_pres ? A.b_pres[slot] : make_uint2(0u, 0u);
             return x;
         };
         // float32 upper bound of the pair (from-string, to-string x) FROM REGISTERS ONLY; valid = a real candidate of this
@@ -988,13 +959,16 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     nc += hit ? 1 : 0;
                     sect_chars += hit ? len : 0;
                 }
-#ifdef PFZ_K7_PRESENCE
             // symbols of the one string that the other lacks (fz_presence_miss, the from-side's bits in scalar registers)
-            const int pres_common = __popc(pres_a0 & x.p.x) + __popc(pres_a1 & x.p.y);
-            const int miss_a = n_pres_a - pres_common, miss_b = __popc(x.p.x) + __popc(x.p.y) - pres_common;
-#else
-            constexpr int miss_a = 0, miss_b = 0;
-#endif
+            // (only where it pays: the scorers that sweep windows, WRatio included -- 20k x 20k titles, WRatio 8.38 -> 8.04 ms
+            // with 3.8 % of the pairs scored instead of 6.0 %; token_ratio, which sweeps none, 5.33 -> 5.86 ms for 2.5 %
+            // instead of 2.9 %: there the bits stay out, a wave-uniform choice)
+            int miss_a = 0, miss_b = 0;
+            if (use_pres) {
+                const int pres_common = __popc(pres_a0 & x.p.x) + __popc(pres_a1 & x.p.y);
+                miss_a = n_pres_a - pres_common;
+                miss_b = __popc(x.p.x) + __popc(x.p.y) - pres_common;
+            }
             const float tset = nc != 0 ? fz_token_set_bound_n(F.la[2], F.ta, m.z, m.w, uu, nc, sect_chars, miss_a, miss_b) : -1.0f;
             return fz_upper_bound(sa, sb, mode, uu, coarse ? -1 : (nc != 0 ? 1 : 0), coarse ? -1.0f : tset, miss_a, miss_b);
         };
@@ -1495,9 +1469,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     A.b_meta3 = pl->meta3;
     A.b_meta4 = pl->meta4;
     A.b_hist = pl->hist;
-#ifdef PFZ_K7_PRESENCE
     A.b_pres = pl->pres;
-#endif
     A.n_groups = (int32_t)pl->n_groups;
     A.n_sym1 = pl->n_sym + 1;
     A.mode = scorer;
@@ -1539,8 +1511,11 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     PFZ_TRY(d_cont.alloc((size_t)cont_cap * 3 * sizeof(int4)));
     PFZ_TRY(d_cont_cur.alloc((size_t)cont_cap * 3 * sizeof(unsigned long long)));
     // the bound cache: a byte per (workgroup, to-slot), a stretch of its own for every launch (they may run side by side).
-    // Few enough persistent workgroups that it stays within 16 GiB (4096 of them up to four million to-strings)
-    const int64_t grid_cap = std::max<int64_t>(64, std::min<int64_t>(max_grid, ((int64_t)16 << 30) / (3 * std::max<int64_t>(pl->n_groups, 1) * 64)));
+    // Few enough persistent workgroups that it stays within a budget: 1/16 of the device's memory, 16 GiB at most (288 GB:
+    // 4096 workgroups up to four million to-strings) -- of the TOTAL, not of what happens to be free, so that the sizes,
+    // and with them the blocks the caching allocator holds, are the same on every call
+    const int64_t ubc_budget = std::max<int64_t>((int64_t)64 << 20, std::min<int64_t>((int64_t)16 << 30, (int64_t)(ctx->prop.totalGlobalMem / 16)));
+    const int64_t grid_cap = std::max<int64_t>(64, std::min<int64_t>(max_grid, ubc_budget / (3 * std::max<int64_t>(pl->n_groups, 1) * 64)));
     auto grid_of = [&](int c, bool hand) { return hand ? grid_cap : std::min<int64_t>((int64_t)cls[c].size() * parts_of[c], grid_cap); };
     const bool hand_over = !getenv("PFZ_K7_NO_HANDOVER");
     // (a launch that hands rows over has spare stretches: a handed-over row keeps the one its bytes are in; when they run out,
@@ -1552,8 +1527,8 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         ubc_at[c] = ubc_slots;
         if (cls[c].empty()) continue;
         const bool hand = hand_over && parts_of[c] == 1 && kK7Waves == 1;
-        // (half the rows at most are ever heavy; 2 GiB of spare stretches at most)
-        const int64_t spare = hand ? std::min<int64_t>((int64_t)cls[c].size() / 2 + 64, ((int64_t)2 << 30) / region_bytes) : 0;
+        // (half the rows at most are ever heavy; an eighth of the budget -- 2 GiB -- of spare stretches at most)
+        const int64_t spare = hand ? std::min<int64_t>((int64_t)cls[c].size() / 2 + 64, (ubc_budget / 8) / region_bytes) : 0;
         ubc_regions[c] = grid_of(c, hand) + spare;
         ubc_slots += ubc_regions[c] * region_bytes;
     }
@@ -1571,6 +1546,13 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     const bool side = !cls[0].empty() && (!cls[1].empty() || !cls[2].empty()) && !getenv("PFZ_K7_NO_SIDE_STREAM");
     bool used_side = false;
     if (side) PFZ_TRY(ensure_side_stream(ctx));
+    // an error return between a side-stream launch and its join must not free the buffers that launch is still using
+    // (the DevBufs above are destroyed after this guard: it is declared after them)
+    struct SideGuard {
+        pfz_ctx *ctx;
+        bool *used;
+        ~SideGuard() { if (*used) (void)hipStreamSynchronize(ctx->stream2); }
+    } side_guard{ctx, &used_side};
     ProfScope ps_all(ctx, "k7_fuzz");
     for (int c = 2; c >= 0; --c) {       // (the side-stream launches first: the persistent waves of class 0 would keep them out)
         if (cls[c].empty() || n_to == 0) continue;
@@ -1630,6 +1612,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     if (used_side) {
         PFZ_HIP(hipEventRecord(ctx->side_events[1], ctx->stream2));
         PFZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_events[1], 0));
+        used_side = false;          // joined: from here on the main stream orders everything (the guard stands down)
     }
     A.cont_list = nullptr;
     if (n_to > 0) {

@@ -35,6 +35,25 @@ def shard_bounds(n, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def balanced_bounds(strings, world):
+    """Contiguous row shards [(begin, end)] * world of a from-list, cut so that every shard holds the same number of
+    CHARACTERS rather than the same number of rows.  A from-row's cost in K3 is a constant (the accumulator sweeps) plus
+    the postings of its n-grams, in K4 / K7 its length times the to-list's characters -- both grow with the string's
+    length, and a sorted list is skewed (the reference's company names: equal row counts leave the slowest of 8 shards
+    11 % above the mean by the LDS-floor model, equal characters 2 %; tools/predict_scaling.py measures it).  Every rank
+    computes the same cuts from the same list; shards stay contiguous, so results concatenate in order."""
+    n = len(strings)
+    if world <= 1 or n == 0:
+        return [(0, n)] + [(n, n)] * (max(world, 1) - 1)
+    cost = np.fromiter((len(s) + 1 for s in strings), np.int64, n)
+    cs = np.cumsum(cost)
+    edges = [0] + [int(np.searchsorted(cs, cs[-1] * r // world, side="left")) for r in range(1, world)] + [n]
+    edges = [min(max(e, 0), n) for e in edges]
+    for i in range(1, len(edges)):           # monotone (degenerate lists)
+        edges[i] = max(edges[i], edges[i - 1])
+    return list(zip(edges[:-1], edges[1:]))
+
+
 class HipEngine:
     """The device operations a match job is made of, on libpolyfuzz_hip.so."""
 
@@ -91,6 +110,10 @@ class TfidfMatchJob:
             if not self.self_match or self.shard_offset != 0:
                 raise ValueError("to_list=None means a whole-list self-match (self_match=True, shard_offset=0)")
             self.n_to, self.to_dev = self.n_from, self.from_dev
+        elif to_list is from_shard and self.self_match and self.shard_offset == 0:
+            # the rank's from-rows ARE the whole replicated list (bench.py's weak scaling: every rank its own copy of the
+            # query batch): one upload, one vectorisation
+            self.n_to, self.to_dev = self.n_from, self.from_dev
         else:
             self.n_to = len(to_list)
             self.to_dev = self.eng.upload_strings(to_list)
@@ -117,7 +140,7 @@ class TfidfMatchJob:
             self.vec = eng.fit(self.params, self.to_dev, self.from_dev)
         self.to_csr = eng.transform(self.vec, self.to_dev)
         self.index = eng.build_index(self.to_csr)
-        if self.self_match and not sharded and self.n_from == self.n_to and self.shard_offset == 0:
+        if self.self_match and self.shard_offset == 0 and (self.to_dev is self.from_dev or (not sharded and self.n_from == self.n_to)):
             self.from_csr = self.to_csr            # the same rows: vectorise once (reference _tfidf.py:114-116)
         else:
             self.from_csr = eng.transform(self.vec, self.from_dev)
@@ -243,6 +266,7 @@ class BestChoiceJob:
         if self.rows_per_rank < self.n_from:
             raise ValueError("rows_per_rank is smaller than this rank's shard")
         self.k4 = scorer in _K4_SCORERS
+        self._qfix = None
         self.f_dev = upload_for(ctx, scorer, self.from_shard)
         self.t_dev = upload_for(ctx, scorer, to_list)
         self.local = _lib.DeviceTopN.alloc(ctx, max(self.rows_per_rank, 1), 2)
@@ -255,12 +279,32 @@ class BestChoiceJob:
         """the cached to-side plan: K4's (alphabet, groups, character steps) or K7's (alphabet, groups, tokens)"""
         return _lib.indel_plan_info(self.ctx, self.t_dev) if self.k4 else _lib.fuzz_plan_info(self.ctx, self.t_dev)
 
+    def _qratio_rows(self):
+        """QRatio = ratio except that an EMPTY from-string scores 0 against every choice (also the empty one, which ratio
+        scores 100): its first best is simply its first choice.  [(local row, first choice)] of this shard's empty strings."""
+        if self._qfix is None:
+            self._qfix = []
+            if self.scorer == "QRatio":
+                for i, s in enumerate(self.from_shard):
+                    if len(s) == 0:
+                        first = next((j for j in range(len(self.to_list)) if not (self.skip is not None and j == self.skip[i])), -1)
+                        self._qfix.append((i, first))
+        return self._qfix
+
     def step(self):
         if self.n_from and len(self.to_list):
             if self.k4:
                 _lib.indel_argmax_dev(self.ctx, self.f_dev, self.t_dev, self.local, self.skip)
             else:
                 _lib.fuzz_extract_one_dev(self.ctx, self.f_dev, self.t_dev, self.scorer, self.local, self.skip)
+            fix = self._qratio_rows()
+            if fix:
+                # patched in the shard's OWN block before the all-gather, so every rank ends with the same rows (ADVICE r3);
+                # empty from-strings under QRatio are rare enough for a host round trip of the block
+                idx, val = self.local.download()
+                for i, first in fix:
+                    idx[i, 0], val[i, :] = first, 0.0
+                self.local.upload(idx, val)
         if self.gathered is not None:
             self.comm.allgather_topn(self.local, self.gathered)
         return self.gathered if self.gathered is not None else self.local
@@ -270,16 +314,6 @@ class BestChoiceJob:
         idx, score = _lib.best_from_topn(*result.download())
         if self.gathered is None:
             idx, score = idx[:self.n_from], score[:self.n_from]
-        if self.scorer == "QRatio":
-            # QRatio = ratio except that an EMPTY from-string scores 0 against every choice (also the empty one, which
-            # ratio scores 100): its first best is its first choice
-            rows = range(len(idx)) if self.gathered is None else range(self.comm.rank * self.rows_per_rank,
-                                                                       self.comm.rank * self.rows_per_rank + self.n_from)
-            for r, s in zip(rows, self.from_shard):
-                if len(s) == 0:
-                    i = r if self.gathered is None else r - self.comm.rank * self.rows_per_rank
-                    first = next((j for j in range(len(self.to_list)) if not (self.skip is not None and j == self.skip[i])), -1)
-                    idx[r], score[r] = first, 0.0
         return idx, score
 
     def roofline(self, step_s, peak_tops):

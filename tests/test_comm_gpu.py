@@ -154,7 +154,11 @@ def test_world2_best_choice_job_edit_distance_and_wratio(oracle_mod):
     bounds = [pipeline.shard_bounds(len(fl), 2, r) for r in range(2)]
     sizes = [e - b for b, e in bounds]
     rpr = max(sizes)
-    for scorer in ("ratio", "WRatio"):
+    fl = list(fl)
+    fl[3] = fl[40] = fl[60] = ""          # empty from-strings in BOTH shards: QRatio scores them 0 against everything
+    tl = list(tl)
+    tl[7] = ""
+    for scorer in ("ratio", "WRatio", "QRatio"):
         def rank_fn(r):
             b, e = bounds[r]
             job = pipeline.BestChoiceJob(ctxs[r], fl[b:e], tl, scorer=scorer, comm=comms[r], rows_per_rank=rpr)
@@ -166,7 +170,7 @@ def test_world2_best_choice_job_edit_distance_and_wratio(oracle_mod):
         if scorer == "ratio":
             e_idx, e_score = oracle_mod.indel_argmax(fl, tl)
         else:
-            e_idx, e_score = f.extract_one_all(fl, tl, f.WRatio)
+            e_idx, e_score = f.extract_one_all(fl, tl, f.SCORERS[scorer])
         for idx, score in outs:
             np.testing.assert_array_equal(idx, single[0])
             np.testing.assert_array_equal(score, single[1])

@@ -173,3 +173,19 @@ def test_frame_helper_equals_numpy_twin(threads, monkeypatch):
     # the few-queries-against-a-long-list path takes the list as it is (no object-array copy of it)
     df = _utils.topn_to_frame(np.array([[4999]], np.int32), np.array([[0.5]], np.float32), ["q"], to_list, 1)
     assert df["To"].tolist() == [to_list[4999]]
+
+
+def test_balanced_bounds_cover_everything_and_balance_characters():
+    """pipeline.balanced_bounds: contiguous, covering, monotone cuts with (nearly) equal character counts; degenerate lists."""
+    from polyfuzz_amd.pipeline import balanced_bounds
+    rng = np.random.default_rng(3)
+    strings = ["x" * int(k) for k in np.sort(rng.integers(1, 90, 5000))]      # sorted = skewed, like the reference's lists
+    for world in (1, 2, 3, 8):
+        bounds = balanced_bounds(strings, world)
+        assert len(bounds) == world and bounds[0][0] == 0 and bounds[-1][1] == len(strings)
+        assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:])) and all(b <= e for b, e in bounds)
+        chars = [sum(len(s) + 1 for s in strings[b:e]) for b, e in bounds]
+        assert max(chars) <= 1.02 * (sum(chars) / world) + 100
+    assert balanced_bounds([], 4) == [(0, 0)] * 4
+    assert [e - b for b, e in balanced_bounds(["a"], 3)] .count(1) == 1
+    assert sum(e - b for b, e in balanced_bounds(["", "", ""], 2)) == 3

@@ -212,3 +212,48 @@ def test_scatter_round_shapes(ctx, oracle_mod, shape):
     idx, val = _run(ctx, a3, b3, n_col, 7, 0.0)
     exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col, 7, 0.0)
     assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, n_col)
+
+
+@pytest.mark.parametrize("knobs", [
+    {"PFZ_K3_LS_BLOCKS": "1"}, {"PFZ_K3_LS_BLOCKS": "2"}, {"PFZ_K3_LS_BLOCKS": "4"},
+    {"PFZ_K3_BLOCK": "4096", "PFZ_K3_LS_BLOCKS": "1"}, {"PFZ_K3_BLOCK": "4096", "PFZ_K3_LS_BLOCKS": "2"},
+    {"PFZ_K3_LS_BLOCKS": "1", "PFZ_K3_LS_WAVES": "2"}, {"PFZ_K3_LS_BLOCKS": "8", "PFZ_K3_LS_CHUNK": "5"},
+    {"PFZ_K3_LS_BLOCKS": "2", "PFZ_K3_LS_CHUNK": "1"},
+])
+@pytest.mark.parametrize("ntop,lb,diag", [(5, 0.0, False), (1, 0.0, True), (10, 0.2, False), (32, 0.0, True)])
+def test_lockstep_kernel_equals_the_row_major_kernel(ctx, oracle_mod, monkeypatch, knobs, ntop, lb, diag):
+    """k3_lockstep.hip (to-block-major: slices of to-blocks outer, batches of four from-rows inner, the rows' top-n state
+    carried through HBM between slices) against the main kernel on the same index -- bit for bit, every slice width and
+    block size, with and without the diagonal -- and against the oracle.  The lists: 3 000 from-rows incl. empty rows, rows
+    of more than 64 n-grams (the slow loop) and batches whose four rows do not fit 64 lanes (several windows); 9 000
+    to-rows = 5 / 3 blocks."""
+    from polyfuzz_amd import _lib
+    rng = np.random.default_rng(41)
+    n_col = 700
+    a3 = random_csr(rng, 3000, n_col, 0.02, empty_rows=(0, 5, 6, 7, 8, 2999))
+    # a few heavy from-rows: > 64 entries, and runs of 20..30-entry rows (four of them overflow one window)
+    ip, ix_, dv = [np.array(x) for x in a3]
+    heavy = random_csr(rng, 40, n_col, 0.12)
+    mid = random_csr(rng, 200, n_col, 0.035)
+    def cat(parts):
+        ptr = [0]
+        for p in parts:
+            ptr.extend((np.asarray(p[0][1:]) + ptr[-1]).tolist())
+        return (np.array(ptr, np.int64), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
+    a3 = cat([(ip, ix_, dv), heavy, mid])
+    n_b = len(a3[0]) - 1 if diag else 9000
+    b3 = a3 if diag else random_csr(rng, n_b, n_col, 0.02)
+    for k, v in knobs.items():
+        if k == "PFZ_K3_BLOCK":
+            monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PFZ_K3_LOCKSTEP", "0")
+    ref_idx, ref_val = _run(ctx, a3, b3, n_col, ntop, lb, diag)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col, ntop, lb, exclude_diag=diag)
+    assert_topn_parity(ref_idx, ref_val, exp_idx, exp_val, oracle_mod, a3, b3, n_col, exclude_diag=diag)
+    monkeypatch.setenv("PFZ_K3_LOCKSTEP", "1")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for _ in range(2):              # twice: the pull counters and the state scratch are re-used
+        idx, val = _run(ctx, a3, b3, n_col, ntop, lb, diag)
+        np.testing.assert_array_equal(idx, ref_idx)
+        np.testing.assert_array_equal(val, ref_val)
