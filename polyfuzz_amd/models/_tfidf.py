@@ -22,9 +22,9 @@ from ._base import BaseMatcher
 from ._utils import topn_to_frame, object_column, clip_top_n, FrameBuilder, _METHODS
 
 _SPLIT_MIN_ROWS = 20000      # from-rows from which match() pipelines several K3 launches with the frame building
-_SPLIT_EVENT = 56            # context event slots 56 .. 60: launch i done
+_SPLIT_EVENT = 56            # context event slots 56 .. : launch i done
 # shares of the from-rows per launch: the last part's columns are built AFTER the device has finished, so it is the small one
-_SPLIT_SHARES = {2: (0.6, 0.4), 5: (0.27, 0.27, 0.24, 0.14, 0.08)}
+_SPLIT_SHARES = {2: (0.6, 0.4), 5: (0.4, 0.3, 0.2, 0.1)}      # (profiles/experiments/r04_match_split_probe.txt)
 
 
 def _clean_string(string: str) -> str:
@@ -142,7 +142,7 @@ class TFIDF(BaseMatcher):
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
         n = len(from_list)
         names = from_list if self_match else to_list
-        # A big match is enqueued as two (five from 40k rows) launches over the from-rows: each part's result is
+        # A big match is enqueued as two (four from 40k rows) launches over the from-rows: each part's result is
         # downloaded on a side stream and turned into frame columns while the device works on the next parts, so only
         # the last part's columns are built after the device has finished
         split = n >= _SPLIT_MIN_ROWS and top_n >= 1 and _lib._pack is not None and isinstance(names, (list, tuple))
