@@ -15,7 +15,7 @@ def avg(db_path, counter):
     """(kernel name, dispatches, average per dispatch) of the K3 kernel with the most dispatches"""
     db = sqlite3.connect(db_path)
     rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? and "
-                      "kernel_name like '%k3_cossim_topn_kernel%' group by kernel_name order by sum(value) desc", (counter,)).fetchall()
+                      "(kernel_name like '%k3_cossim_topn_kernel%' or kernel_name like '%k3_lockstep_kernel%') group by kernel_name order by sum(value) desc", (counter,)).fetchall()
     return rows[0] if rows else (None, 0, None)
 
 
