@@ -223,15 +223,9 @@ __device__ inline int2 load_piece_entry(const char *__restrict__ post_bytes, int
 #endif
 }
 
-// PK (k3_pair.hip): two from-rows share one accumulator word, 16 bits each -- the value of a posting of the second row
-// goes to the upper half: sh_t (1 or 65536) is the piece's multiplier, broadcast like its descriptor.  (A multiplier, not
-// a shift count: hipcc 7.2 folds the DPP broadcast of a shift COUNT into v_lshlrev_b32_dpp on the wrong operand -- the
-// hardware then shifts the BROADCAST VALUE by the lane's own count, tools/ubench/dpp_shift.hip -- while the 24-bit multiply
-// is commutative, full rate, and exact here: value < 2^16.)
-template <int S, bool PK = false> __device__ inline void apply_entry(int *acc, const int2 &pe, float as_t, int sh_t = 1)
+template <int S> __device__ inline void apply_entry(int *acc, const int2 &pe, float as_t)
 {
-    int v = (int)(__int_as_float(row_bcast_i<S>(__float_as_int(as_t))) * __int_as_float(pe.y));
-    if (PK) v = (int)__umul24((uint32_t)v, (uint32_t)row_bcast_i<S>(sh_t));
+    const int v = (int)(__int_as_float(row_bcast_i<S>(__float_as_int(as_t))) * __int_as_float(pe.y));
 #if PFZ_K3_EXP == 1      // no LDS atomics
     if (v == 0x7fffffff) atomicAdd((int *)((char *)acc + pe.x), v);
 #elif PFZ_K3_EXP == 3    // conflict-free LDS addresses
@@ -241,18 +235,18 @@ template <int S, bool PK = false> __device__ inline void apply_entry(int *acc, c
 #endif
 }
 
-template <bool PK, int... S>
-__device__ inline void run_steps_seq(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8, int sh_t,
+template <int... S>
+__device__ inline void run_steps_seq(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8,
                                      std::integer_sequence<int, S...>)
 {
     const int2 pe[sizeof...(S)] = {load_piece_entry<S>(post_bytes, addr_t, sub8)...};
-    (apply_entry<S, PK>(acc, pe[S], as_t, sh_t), ...);
+    (apply_entry<S>(acc, pe[S], as_t), ...);
 }
 
-template <int NS, bool PK = false>
-__device__ inline void run_steps(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8, int sh_t = 1)
+template <int NS>
+__device__ inline void run_steps(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8)
 {
-    run_steps_seq<PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t, std::make_integer_sequence<int, NS>{});
+    run_steps_seq(acc, post_bytes, addr_t, as_t, sub8, std::make_integer_sequence<int, NS>{});
 }
 
 __device__ inline int dpp_max_scan(int m)
@@ -276,10 +270,8 @@ __device__ inline int dpp_max_scan(int m)
 // quarter q of the wave processes pieces 4s + q, s = 0.., so the four quarters stay busy to the last step
 // whatever T is.  Owner search, once per round: every list that overlaps the round's window writes its lane
 // number at the window position of its first piece, a prefix maximum spreads it over the list's pieces.
-// PK: the lanes from `split` on hold the n-grams of a SECOND from-row, whose values go to the upper 16 bits of the cells.
-template <bool PK = false>
 __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_bytes, int *mark, int np, int st, float as,
-                                      int lane, int src4, int sub8, int dummy_addr, int split = 64)
+                                      int lane, int src4, int sub8, int dummy_addr)
 {
     // inclusive scan over the 64 lanes with DPP adds (no LDS traffic, unlike __shfl_up/ds_bpermute)
     int pin = np;
@@ -297,7 +289,6 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
 #if PFZ_K3_EXP == 4      // no owner search: every lane takes a piece of its own list
         const int addr_t = np > 0 ? (int)((uint32_t)(st + ((r0 + pt) % np)) << 7) : dummy_addr;
         const float as_t = as;
-        const int sh_t = 1;
 #else
         const int rel = excl - r0;
         mark[lane] = 0;
@@ -309,7 +300,6 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
         const float as_t = __int_as_float(__builtin_amdgcn_ds_bpermute(o4, __float_as_int(as)));
         const int P = r0 + pt;
         const int addr_t = P < total ? (int)((uint32_t)(b_o + P) << 7) : dummy_addr;
-        const int sh_t = PK ? (o4 >= 4 * split ? 65536 : 1) : 1;               // (o4 = 4 x the owner lane)
         wave_sync();                                                         // mark[] is rewritten by the next round
 #endif
         const int left = total - r0;
@@ -318,28 +308,28 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
         const int ng = left >= 64 ? 8 : (left + 7) >> 3;
 #if PFZ_K3_EXP == 6      // groups of four steps only
         if (ng <= 4) {
-            if (ng <= 2) run_steps<4, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
-            else run_steps<8, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
+            if (ng <= 2) run_steps<4>(acc, post_bytes, addr_t, as_t, sub8);
+            else run_steps<8>(acc, post_bytes, addr_t, as_t, sub8);
         } else {
-            if (ng <= 6) run_steps<12, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
-            else run_steps<16, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
+            if (ng <= 6) run_steps<12>(acc, post_bytes, addr_t, as_t, sub8);
+            else run_steps<16>(acc, post_bytes, addr_t, as_t, sub8);
         }
 #else
         if (ng <= 4) {
             if (ng <= 2) {
-                if (ng == 1) run_steps<2, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
-                else run_steps<4, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
+                if (ng == 1) run_steps<2>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<4>(acc, post_bytes, addr_t, as_t, sub8);
             } else {
-                if (ng == 3) run_steps<6, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
-                else run_steps<8, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
+                if (ng == 3) run_steps<6>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<8>(acc, post_bytes, addr_t, as_t, sub8);
             }
         } else {
             if (ng <= 6) {
-                if (ng == 5) run_steps<10, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
-                else run_steps<12, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
+                if (ng == 5) run_steps<10>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<12>(acc, post_bytes, addr_t, as_t, sub8);
             } else {
-                if (ng == 7) run_steps<14, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
-                else run_steps<16, PK>(acc, post_bytes, addr_t, as_t, sub8, sh_t);
+                if (ng == 7) run_steps<14>(acc, post_bytes, addr_t, as_t, sub8);
+                else run_steps<16>(acc, post_bytes, addr_t, as_t, sub8);
             }
         }
 #endif
@@ -351,13 +341,5 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
 bool k3_lockstep_wanted(const pfz_ctx *ctx, const pfz_index *ix, int64_t n_rows, int32_t ntop);
 int k3_lockstep_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t n_rows, int32_t ntop,
                        int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset, pfz_topn *out);
-
-// ---- host side, k3_pair.hip ---------------------------------------------------------------------------------------
-// Two from-rows per wave with 16-bit sums as a filter + exact sums of the survivors; the rows the filter cannot decide come
-// back as a device-side list for the exact kernel.
-bool k3_pair_wanted(const pfz_ctx *ctx, const pfz_index *ix, int64_t n_rows, int32_t ntop, int n_slices);
-int k3_pair_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t n_rows, int32_t ntop,
-                   int32_t thr0, int scale_log2, int32_t exclude_diag, int64_t diag_offset, pfz_topn *out, int32_t **flag_rows,
-                   int32_t **n_flag);
 
 }  // namespace pfz

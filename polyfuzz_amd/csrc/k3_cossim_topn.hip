@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
     int32_t n_a, const int32_t *__restrict__ tab, const int2 *__restrict__ post, int32_t nb, int32_t n_pieces,
     int32_t ntop, int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset,
     int32_t *__restrict__ out_idx, float *__restrict__ out_val, int32_t ablate, int32_t n_slices,
-    uint64_t *__restrict__ part_keys, const int32_t *__restrict__ row_list, const int32_t *__restrict__ row_count)
+    uint64_t *__restrict__ part_keys)
 {
     // accumulators first: this struct is the kernel's only LDS object, so they land at LDS address 0 and a
     // posting's byte offset IS its LDS address (run_steps)
@@ -290,11 +290,9 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
 
     // Work item = (from-row, to-slice).  The to-blocks are cut into n_slices contiguous
     // ranges and item i works on slice i % n_slices (small query batches: fill the chip).
-    // row_list (k3_pair.hip's rows for the exact kernel; n_slices == 1 then): only these rows, their number read here
     const int per_slice = (nb + n_slices - 1) / n_slices;
-    const int n_items = row_list ? *row_count : n_a * n_slices;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int row = row_list ? row_list[item] : item / n_slices, slice = row_list ? 0 : item - row * n_slices;
+    for (int item = blockIdx.x; item < n_a * n_slices; item += gridDim.x) {
+        const int row = item / n_slices, slice = item - row * n_slices;
         const int b_lo = slice * per_slice, b_hi = min(nb, b_lo + per_slice);
         const int p0 = a_indptr[row], p1 = a_indptr[row + 1];
         const int nnz = p1 - p0;
@@ -508,17 +506,6 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
             hipLaunchKernelGGL(k_index_fill, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices, B->data,
                                (int32_t)B->n_rows, (int32_t)nb, block, cnt.p, ix->tab, ix->post);
     }
-    // The indexed matrix itself, for k3_pair_finish (the exact sums of a from-row's candidate columns are dot products with
-    // to-ROWS): a copy, so that the index stays independent of the CSR handle it was built from; only where that kernel
-    // can run (to-sides that stay out of the lock-step regime).
-    if (any && B->n_rows <= 250000 && !getenv("PFZ_K3_NO_ROW_COPY")) {
-        PFZ_TRY(pool_alloc(ctx, &ix->b_indptr, (size_t)(B->n_rows + 1) * sizeof(int32_t)));
-        PFZ_TRY(pool_alloc(ctx, &ix->b_indices, (size_t)std::max<int64_t>(B->nnz, 1) * sizeof(int32_t)));
-        PFZ_TRY(pool_alloc(ctx, &ix->b_data, (size_t)std::max<int64_t>(B->nnz, 1) * sizeof(float)));
-        PFZ_HIP(hipMemcpyAsync(ix->b_indptr, B->indptr, (size_t)(B->n_rows + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-        PFZ_HIP(hipMemcpyAsync(ix->b_indices, B->indices, (size_t)B->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-        PFZ_HIP(hipMemcpyAsync(ix->b_data, B->data, (size_t)B->nnz * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    }
     PFZ_HIP(hipGetLastError());
     *out = ix.release();
     return PFZ_OK;
@@ -530,9 +517,6 @@ void pfz_index_free(pfz_index *ix)
     if (ix->ctx) (void)hipSetDevice(ix->ctx->device);
     if (ix->tab) pool_free(ix->tab);
     if (ix->post) pool_free(ix->post);
-    if (ix->b_indptr) pool_free(ix->b_indptr);
-    if (ix->b_indices) pool_free(ix->b_indices);
-    if (ix->b_data) pool_free(ix->b_data);
     delete ix;
 }
 
@@ -616,21 +600,6 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
         const int per_slice = (ix->n_blocks + n_slices - 1) / n_slices;
         n_slices = (ix->n_blocks + per_slice - 1) / per_slice;
     }
-    if (k3_pair_wanted(ctx, ix, n_rows, ntop, n_slices)) {
-        // two from-rows per wave with 16-bit sums as a filter, exact sums of the survivors, and the exact kernel for the few
-        // rows the filter cannot decide (k3_pair.hip): a fixed grid that reads their number on the device
-        ProfScope ps(ctx, "k3_cossim_topn");
-        int32_t *flag_rows = nullptr, *n_flag = nullptr;
-        PFZ_TRY(k3_pair_launch(ctx, ix, A, row_begin, n_rows, ntop, thr0, k, exclude_diag, diag_offset, out, &flag_rows, &n_flag));
-        const int64_t fb = std::min<int64_t>(n_rows, (int64_t)ctx->prop.multiProcessorCount * 8);
-        hipLaunchKernelGGL((k3_cossim_topn_kernel<2048, 96>), dim3((unsigned)fb), dim3(64), 0, ctx->stream, A->indptr + row_begin,
-                           A->indices, A->data, (int32_t)n_rows, ix->tab, ix->post, ix->n_blocks, ix->n_pieces, ntop, thr0, scale,
-                           inv_scale, exclude_diag, diag_offset + row_begin, out->idx + row_begin * ntop,
-                           out->val + row_begin * ntop, 0, 1, (uint64_t *)nullptr, (const int32_t *)flag_rows,
-                           (const int32_t *)n_flag);
-        PFZ_HIP(hipGetLastError());
-        return PFZ_OK;
-    }
     uint64_t *part = nullptr;
     if (n_slices > 1) {
         PFZ_TRY(ensure_scratch(ctx, (size_t)n_rows * (size_t)n_slices * (size_t)ntop * sizeof(uint64_t)));
@@ -650,7 +619,7 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
                        A->indptr + row_begin, A->indices, A->data, (int32_t)n_rows, ix->tab, ix->post,          \
                        ix->n_blocks, ix->n_pieces, ntop, thr0, scale, inv_scale, exclude_diag,                  \
                        diag_offset + row_begin, out->idx + row_begin * ntop, out->val + row_begin * ntop,       \
-                       ablate, n_slices, part, (const int32_t *)nullptr, (const int32_t *)nullptr)
+                       ablate, n_slices, part)
 #define PFZ_K3_CASE(CC)                              \
     case CC:                                         \
         if (cap == 96) PFZ_K3_LAUNCH(CC, 96);        \

@@ -94,9 +94,6 @@ struct pfz_index {
     int32_t *tab = nullptr;  // [n_cols * n_blocks + 2] first piece of every list
     int2 *post = nullptr;    // [(n_pieces + 1) * 16]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
     float max_norm = 1.f;    // of the indexed matrix' rows
-    // the indexed matrix itself (a copy; k3_pair_finish re-computes exact sums against to-rows), or NULL
-    int32_t *b_indptr = nullptr, *b_indices = nullptr;
-    float *b_data = nullptr;
 };
 
 struct pfz_topn {

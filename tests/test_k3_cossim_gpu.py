@@ -257,48 +257,3 @@ def test_lockstep_kernel_equals_the_row_major_kernel(ctx, oracle_mod, monkeypatc
         idx, val = _run(ctx, a3, b3, n_col, ntop, lb, diag)
         np.testing.assert_array_equal(idx, ref_idx)
         np.testing.assert_array_equal(val, ref_val)
-
-
-@pytest.mark.parametrize("ntop,lb,diag", [(5, 0.0, False), (1, 0.0, True), (10, 0.2, False), (16, 0.0, True), (5, 0.75, False),
-                                          (3, 1e-4, True)])
-def test_pair_kernel_equals_the_row_major_kernel(ctx, oracle_mod, monkeypatch, ntop, lb, diag):
-    """k3_pair.hip (two from-rows per wave, 16-bit sums as a FILTER, exact sums of the surviving columns, the exact kernel for
-    the rows the filter cannot decide) against the row-major kernel -- bit for bit -- and against the oracle.  The from-rows:
-    an odd number of them, empty rows, rows of more than 64 n-grams (exact kernel), neighbours that do not fit 64 lanes
-    together (one after the other), rows with fewer than ntop matches (the filter cannot see sums that round to 0); the
-    to-rows: 60 copies of one row and 40 of another (more than 32 columns inside the margin: exact kernel)."""
-    rng = np.random.default_rng(43)
-    n_col = 600
-
-    def cat(parts):
-        ptr = [0]
-        for p in parts:
-            ptr.extend((np.asarray(p[0][1:]) + ptr[-1]).tolist())
-        return (np.array(ptr, np.int64), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
-
-    def rep(row3, times):
-        return cat([row3] * times)
-    base = random_csr(rng, 2501, n_col, 0.022, empty_rows=(0, 1, 700, 2500))
-    heavy = random_csr(rng, 31, n_col, 0.13)              # 66 .. 100 n-grams
-    mid = random_csr(rng, 120, n_col, 0.06)               # ~36: two of them do not fit 64 lanes
-    lonely = random_csr(rng, 10, n_col + 40, 0.001)       # 1 n-gram each, mostly in columns nothing else uses
-    lonely = (lonely[0], np.minimum(lonely[1] + 0, n_col + 39), lonely[2])
-    n_col_all = n_col + 40
-    one = random_csr(rng, 1, n_col, 0.02)
-    two = random_csr(rng, 1, n_col, 0.03)
-    a3 = cat([base, heavy, mid, lonely, one, two])
-    if diag:
-        a3 = cat([a3, rep(one, 60), rep(two, 40)])
-        b3 = a3
-    else:
-        b3 = cat([random_csr(rng, 5000, n_col, 0.02), rep(one, 60), random_csr(rng, 2000, n_col, 0.025), rep(two, 40), lonely])
-    monkeypatch.setenv("PFZ_K3_SLICES", "1")
-    monkeypatch.setenv("PFZ_K3_PAIR", "0")
-    ref_idx, ref_val = _run(ctx, a3, b3, n_col_all, ntop, lb, diag)
-    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col_all, ntop, lb, exclude_diag=diag)
-    assert_topn_parity(ref_idx, ref_val, exp_idx, exp_val, oracle_mod, a3, b3, n_col_all, exclude_diag=diag, max_near_tie_frac=0.05)
-    monkeypatch.setenv("PFZ_K3_PAIR", "1")
-    for _ in range(2):
-        idx, val = _run(ctx, a3, b3, n_col_all, ntop, lb, diag)
-        np.testing.assert_array_equal(idx, ref_idx)
-        np.testing.assert_array_equal(val, ref_val)
