@@ -213,6 +213,149 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_extract_wave: one WAVE per string, one LANE per character (round 4).
+// ---------------------------------------------------------------------------
+// The thread-per-string kernel above runs as long as the longest string of a wave takes (~0.25 us per character of
+// divergent clean / window code): 60 us for a list of 10 000 names that keeps 40 CUs busy.  Here a wave takes a string
+// 64 characters at a time: every lane classifies its character, ballots + bit counts give each kept character its
+// place in the cleaned sequence (a ' ' is put in front of it when spaces lie between it and the kept character before),
+// the cleaned symbols go to an LDS line, and then every lane builds the n-grams that END at its position -- the last
+// `hi` symbols, the distance to the last breaking symbol -- and the codes are compacted into the string's slots by ballot.
+// Same codes, same counts as k_extract (the order inside a string's slots differs: k_rows_* sort them anyway).
+// For lists of up to 32 768 strings whose longest has at most kWaveMaxLen characters; the others take k_extract.
+constexpr int kWaveMaxLen = 256;
+constexpr int kWaveStringsMax = 128;       // strings per workgroup at most: one LDS bitmap, one staged stretch of characters
+
+template <int CW, bool LB, typename CODE>
+__global__ __launch_bounds__(256) void k_extract_wave(const void *__restrict__ chars_v, const int64_t *__restrict__ off,
+                                                       int64_t n, ExtractParams P, const uint32_t *__restrict__ alpha_map,
+                                                       uint64_t *__restrict__ slots, int32_t *__restrict__ row_cnt,
+                                                       uint32_t *__restrict__ bitmap, int32_t per_wg)
+{
+    constexpr int kStageBytes = 24 * 1024;
+    __shared__ uint32_t stage[kStageBytes / 4];
+    __shared__ uint32_t lbm[LB ? kLdsBitmapWords : 1];
+    __shared__ uint32_t s_sym[4][kWaveMaxLen];          // cleaned symbols; bit 31 = breaks every window it is in
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (LB)
+        for (int t = threadIdx.x; t < P.bitmap_words; t += 256) lbm[t] = 0u;
+    const int64_t i0 = (int64_t)blockIdx.x * per_wg;
+    const int64_t i_end = i0 + per_wg < n ? i0 + per_wg : n;
+    const int64_t byte0 = off[i0] * CW, byte1 = off[i_end] * CW;
+    const int64_t base4 = byte0 & ~(int64_t)3;
+    const bool staged = byte1 - base4 <= kStageBytes;
+    if (staged) {
+        const uint32_t *src = (const uint32_t *)((const uint8_t *)chars_v + base4);
+        const int words = (int)((byte1 - base4 + 3) >> 2);     // the buffer is padded by 16 bytes
+        for (int t = threadIdx.x; t < words; t += 256) stage[t] = src[t];
+    }
+    __syncthreads();
+    const int R = P.hi - P.lo + 1, w = P.w, hi = P.hi;
+    constexpr int kBits = (int)sizeof(CODE) * 8;
+    uint32_t *sym = s_sym[wave];
+    const uint64_t below = (1ull << lane) - 1ull;       // lanes before this one
+
+    for (int64_t i = i0 + wave; i < i_end; i += 4) {
+        const int64_t b = off[i], e = off[i + 1];
+        const int len = (int)(e - b);
+        // ---- pass 1: the cleaned symbol sequence -------------------------------------------------------------------
+        int n_out = 0;
+        bool pend = false, any = false;                 // a ' ' since the last kept character / any kept character so far
+        for (int c0 = 0; c0 < len; c0 += 64) {
+            const int p = c0 + lane;
+            uint32_t c = 0xffffffffu;
+            if (p < len) {
+                if (staged) {
+                    const int o = (int)((b + p) * CW - base4);
+                    c = CW == 1 ? (uint32_t)((const uint8_t *)stage)[o] : stage[o >> 2];
+                } else {
+                    c = CW == 1 ? (uint32_t)((const uint8_t *)chars_v)[b + p] : ((const uint32_t *)chars_v)[b + p];
+                }
+            }
+            if (P.clean) {
+                // reference _tfidf.py:142-146 on code points <= 0xFF: lower(), keep [a-z0-9 ], collapse runs of ' ', strip
+                if (c >= 'A' && c <= 'Z') c += 32;
+                const bool letter = c >= 'a' && c <= 'z', digit = c >= '0' && c <= '9';
+                const bool keep = letter || digit;
+                const uint64_t keepm = __ballot(keep), spm = __ballot(c == ' ');
+                const uint64_t kb = keepm & below;                                     // kept characters before this one
+                const int q = kb ? 63 - __clzll((long long)kb) : -1;                   // ... the nearest of them
+                const uint64_t between = spm & below & ~((q >= 0 ? (2ull << q) : 1ull) - 1ull);      // spaces in (q, lane)
+                const bool first = kb == 0ull && !any;                                 // the string's first kept character
+                const bool sp_before = keep && !first && (between != 0ull || (kb == 0ull && pend));
+                const uint64_t esm = __ballot(sp_before);
+                const int pos = n_out + __popcll(kb) + __popcll(esm & (below | (1ull << lane)));
+                if (sp_before) sym[pos - 1] = 1u | (P.remove_space ? 0x80000000u : 0u);
+                if (keep) sym[pos] = letter ? c - 'a' + 12u : c - '0' + 2u;
+                n_out += __popcll(keepm) + __popcll(esm);
+                if (keepm) {
+                    const int last = 63 - __clzll((long long)keepm);
+                    pend = last < 63 && (spm >> (last + 1)) != 0ull;
+                    any = true;
+                } else {
+                    pend = pend || spm != 0ull;
+                }
+            } else {
+                // every character is a symbol: its rank in the fitted alphabet (0 = unknown: breaks), ' ' breaks when asked to
+                if (p < len) {
+                    const uint32_t m = (int64_t)c < P.alpha_len ? alpha_map[c] : 0u;
+                    sym[p] = m | ((m == 0u || (P.remove_space && c == ' ')) ? 0x80000000u : 0u);
+                }
+                n_out = len;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- pass 2: the n-grams that end at every position ---------------------------------------------------------
+        uint64_t *out = slots + b * R;
+        int cnt = 0;
+        for (int p0 = 0; p0 < n_out; p0 += 64) {
+            const int p = p0 + lane;
+            CODE win = 0;
+            int run = 0;                                   // symbols ending at p without a break (at most hi)
+            bool open = p < n_out;
+            for (int j = 0; j < hi; ++j) {
+                uint32_t sj = 0x80000000u;
+                if (p - j >= 0 && p < n_out) sj = sym[p - j];
+                open = open && !(sj & 0x80000000u);
+                run += open ? 1 : 0;
+                win |= (CODE)((CODE)(sj & 0x7fffffffu) << (j * w));
+            }
+            for (int nn = P.lo; nn <= hi; ++nn) {
+                const bool pred = run >= nn;
+                const uint64_t mk = __ballot(pred);
+                if (pred) {
+                    const CODE code = (CODE)((win & (CODE)((CODE)~(CODE)0 >> (kBits - nn * w))) << ((hi - nn) * w));
+                    out[cnt + __popcll(mk & below)] = code;
+                    if (bitmap) {
+                        const uint32_t bit = 1u << ((uint32_t)code & 31u);
+                        if (LB) {
+                            uint32_t *wp = &lbm[code >> 5];
+                            if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit)) atomicOr(wp, bit);
+                        } else {
+                            uint32_t *wp = &bitmap[code >> 5];
+                            if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
+                        }
+                    }
+                }
+                cnt += __popcll(mk);
+            }
+        }
+        if (lane == 0) row_cnt[i] = cnt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();               // the symbol line is reused by the wave's next string
+    }
+    if (LB && bitmap) {
+        __syncthreads();
+#pragma unroll 8
+        for (int t = threadIdx.x; t < P.bitmap_words; t += 256) {
+            const uint32_t wv = lbm[t], gv = bitmap[t];
+            if (wv & ~gv) atomicOr(&bitmap[t], wv);
+        }
+    }
+}
+
 // Distinct code points of a list -> bitmap over the Unicode range.  Code points below 2048 (every Latin
 // text) are collected in LDS first and flushed once per workgroup; the others probe the global word before
 // setting it.  (One unconditional global atomicOr per character meant millions of atomics on the three or
@@ -654,9 +797,26 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
                     v->bits_per_char, (int32_t)(bitmap_words <= kLdsBitmapWords ? bitmap_words : 0), v->alpha_map_len};
     const bool lds_bitmap = mark && bitmap_words <= kLdsBitmapWords;
     ProfScope ps(ctx, "k1_extract");
+    // a wave per string (a lane per character) when every string fits the wave's symbol line; PFZ_K1_EXTRACT=thread forces
+    // the thread-per-string kernel (tests)
+    const char *which = getenv("PFZ_K1_EXTRACT");
+    const bool wave = s->max_len <= kWaveMaxLen && (which ? which[0] == 'w' : s->n <= 32768);
+    // (10 000 + 10 000 names, both launches: thread per string 0.119 ms; a wave per string with 16 / 32 / 64 / 128 strings per
+    // workgroup 0.091 / 0.068 / 0.077 / 0.104 ms.  At 100 000 strings the thread-per-string kernel wins, 0.071 against 0.115 ms:
+    // a wave's strings are a chain of dependent LDS round trips, and there the chip is full of threads anyway)
+    int per_wg = 32;
+    if (const char *e = getenv("PFZ_K1_WAVE_STRINGS")) per_wg = std::max(4, std::min(kWaveStringsMax, atoi(e)));
 #define PFZ_EXTRACT(CW, LB)                                                                                          \
     do {                                                                                                             \
-        if (v->code_bits <= 32)                                                                                      \
+        if (wave && v->code_bits <= 32)                                                                              \
+            hipLaunchKernelGGL((k_extract_wave<CW, LB, uint32_t>), dim3(grid_for(s->n, per_wg)), dim3(256), 0,       \
+                               ctx->stream, s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,       \
+                               mark ? v->bitmap : nullptr, per_wg);                                                  \
+        else if (wave)                                                                                               \
+            hipLaunchKernelGGL((k_extract_wave<CW, LB, uint64_t>), dim3(grid_for(s->n, per_wg)), dim3(256), 0,       \
+                               ctx->stream, s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,       \
+                               mark ? v->bitmap : nullptr, per_wg);                                                  \
+        else if (v->code_bits <= 32)                                                                                 \
             hipLaunchKernelGGL((k_extract<CW, LB, uint32_t>), dim3(grid_for(s->n)), dim3(256), 0, ctx->stream,       \
                                s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,                    \
                                mark ? v->bitmap : nullptr);                                                          \

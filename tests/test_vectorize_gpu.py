@@ -156,3 +156,27 @@ def test_errors(ctx):
         _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 11, 1, 1), s, None)     # 66-bit codes: more than a uint64
     with pytest.raises(_lib.PfzError):
         _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 2, 1, 1), s, None)
+
+
+@pytest.mark.parametrize("clean", [True, False])
+@pytest.mark.parametrize("rng,remove_space", [((3, 3), True), ((2, 4), True), ((1, 2), False), ((3, 6), True)])
+def test_wave_per_string_extract_equals_thread_per_string(ctx, oracle_mod, monkeypatch, clean, rng, remove_space):
+    """k_extract_wave (a wave per string, a lane per character: round 4) against k_extract (a thread per string) and the
+    oracle, on strings built to sit on its seams: lengths 0 / 1 / 63 / 64 / 65 / 127 / 128 / 129 / 200 / 256 (the chunk
+    boundaries of the 64-lane passes), runs of blanks across a boundary, leading / trailing blanks, punctuation and tabs
+    that vanish, upper case, digits; more strings than one workgroup takes (128)."""
+    r = np.random.default_rng(9)
+    alphabet = list("abcdeXYZ0189") + [" "] * 4 + list(",.-\t&'")
+    strings = []
+    for n in [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 256] * 6 + list(r.integers(0, 120, 400)):
+        strings.append("".join(r.choice(alphabet, size=int(n))))
+    strings += [" " * 70 + "ab cd" + " " * 70, "a" + " " * 63 + "b", "ab" + " " * 62 + "cd" + " " * 64 + "ef", "x" * 256, " " * 256]
+    out = {}
+    for which in ("wave", "thread"):
+        monkeypatch.setenv("PFZ_K1_EXTRACT", which)
+        vec, (a,) = _device_vectorize(ctx, strings, None, rng[0], rng[1], clean, remove_space)
+        out[which] = a
+    for x, y in zip(out["wave"][:3], out["thread"][:3]):
+        np.testing.assert_array_equal(x, y)                         # the very same CSR, bit for bit
+    o = oracle_mod.TfidfOracle(n_gram_range=rng, clean=clean, remove_space_ngrams=remove_space).fit(strings)
+    _check_csr(out["wave"], o.transform(strings), len(o.vocabulary))
