@@ -134,7 +134,12 @@ def test_world2_to_side_sharding_and_merge(oracle_mod, self_match):
     for (idx, val), idf in outs:
         np.testing.assert_array_equal(idf, single.vec.export()[1])          # the sharded fit is the global fit
         assert np.abs(val - e_val).max() <= 1e-5
-        assert (idx != e_idx).any(axis=1).sum() <= 2 and (idx != s_idx).any(axis=1).sum() <= 2
+        assert (idx != e_idx).any(axis=1).sum() <= 2
+        # bit-identical to the single-context job: device-vectorised rows are L2-normalised, every shard's index and the
+        # single index use the same fixed-point scale (norm bound 1), and integer sums do not depend on how the to-rows
+        # were cut -- the merge is by (sum desc, GLOBAL index asc), the single kernel's own order
+        np.testing.assert_array_equal(idx, s_idx)
+        np.testing.assert_array_equal(val, s_val)
     np.testing.assert_array_equal(outs[0][0][0], outs[1][0][0])
     for c in comms:
         c.free()
