@@ -257,3 +257,33 @@ def test_lockstep_kernel_equals_the_row_major_kernel(ctx, oracle_mod, monkeypatc
         idx, val = _run(ctx, a3, b3, n_col, ntop, lb, diag)
         np.testing.assert_array_equal(idx, ref_idx)
         np.testing.assert_array_equal(val, ref_val)
+
+
+def test_sparse_dot_topn_pin_fixture(ctx):
+    """K3 against tests/golden/sparse_dot_topn_pin.json (pin_sparse_dot_topn.py: `awesome_cossim_topn(A, B.T, ntop,
+    lower_bound)` on the README lists and 300 x 291 real company names -- the library's own rows once the script has run where
+    it is importable, the oracle's until then): kept columns per row equal except where the fixture's own scores are within
+    2e-6 of each other or of the bound (fp32 cannot order those), scores within 1e-5."""
+    import importlib
+    import json
+    import os
+    import sys
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    pin = json.load(open(os.path.join(g, "sparse_dot_topn_pin.json"), encoding="utf-8"))
+    sys.path.insert(0, g)
+    mod = importlib.import_module("pin_sparse_dot_topn")
+    t = lambda m: (m.indptr.astype(np.int64), m.indices.astype(np.int32), m.data.astype(np.float64))
+    for (name, fl, tl, a, b, ntop, lb), rec in zip(mod.cases(), pin["cases"]):
+        idx, val = _run(ctx, t(a), t(b), a.shape[1], ntop, lb)
+        soft = 0
+        for r, exp in enumerate(rec["rows"]):
+            got = [(int(j), float(v)) for j, v in zip(idx[r], val[r]) if j >= 0]
+            e_cols, e_vals = [c for c, _ in exp], [v for _, v in exp]
+            if [c for c, _ in got] != e_cols:
+                near = any(abs(x - y) < 2e-6 for x, y in zip(e_vals, e_vals[1:])) or any(abs(v - lb) < 2e-6 for v in e_vals) or \
+                    any(abs(v - lb) < 2e-6 for _, v in got)
+                assert near, (name, ntop, lb, r, got, exp)
+                soft += 1
+                continue
+            assert all(abs(v - w) <= 1e-5 for (_, v), w in zip(got, e_vals))
+        assert soft <= 3, (name, ntop, lb, soft)
