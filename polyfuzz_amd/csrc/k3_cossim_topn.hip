@@ -103,8 +103,10 @@ __global__ __launch_bounds__(256) void k_index_fill(const int32_t *__restrict__ 
 // pieces per list (before the scan).  sub != NULL (LDS-histogram path): the counts arrive per (list, sub-block) --
 // kSub workgroups share a to-block -- and are turned in place into each sub-block's first position inside the list.
 constexpr int kSub = 4;
+// heavy != NULL: the lists of at least bank_min postings are noted for k_index_bank_order (heavy[0] = how many, then the slots)
 __global__ __launch_bounds__(256) void k_index_pieces(int32_t *__restrict__ cnt, int32_t *__restrict__ sub, int64_t slots,
-                                                       int32_t *__restrict__ tab)
+                                                       int32_t *__restrict__ tab, int32_t *__restrict__ heavy, int32_t heavy_cap,
+                                                       int32_t bank_min)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= slots) return;
@@ -118,6 +120,10 @@ __global__ __launch_bounds__(256) void k_index_pieces(int32_t *__restrict__ cnt,
         c = cnt[i];
     }
     tab[i] = (c + kPiece - 1) / kPiece;
+    if (heavy && c >= bank_min) {           // (a few thousand of them: the device-scope atomic does not matter here)
+        const int at = atomicAdd(&heavy[0], 1);
+        if (at < heavy_cap) heavy[1 + at] = (int32_t)i;
+    }
 }
 
 // Padding entries of every list (positions count .. 16*pieces) and the dummy piece at n_pieces: value 0
@@ -379,6 +385,66 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
     }
 }
 
+// Bank order (round 4).  A ds_add_u32 of the scatter covers 64 consecutive postings of a heavy list, and the LDS serialises
+// lanes that hit the same bank (word address mod 32 = to-row mod 32): in arrival order a list's rows are a random subset
+// of the block and 38 % of the kernel's LDS cycles are bank conflicts (rocprofv3: 489 M of 1292 M per 100k x 100k launch).
+// The order of the postings inside a list is free (integer sums), so the lists with at least kBankMin postings are
+// re-dealt: posting i gets the rank j it has among the postings of its bank, and the list is written out by (j, bank) --
+// banks cycle 0, 1, 2 ... 31, 0, 1 ... as long as every bank has postings left, so any 64 consecutive postings hit every
+// bank about twice, wherever a round's piece numbering happens to cut.  One wave per heavy list; results are unchanged.
+constexpr int kBankMin = 64, kBankCap = 1024;     // (kBankMin: tuning knob PFZ_K3_BANK_MIN -- 16 ... 128 give the same K3 time)
+__global__ __launch_bounds__(256) void k_index_bank_order(const int32_t *__restrict__ cnt, const int32_t *__restrict__ tab,
+                                                           const int32_t *__restrict__ heavy, int32_t heavy_cap,
+                                                           int2 *__restrict__ post)
+{
+    __shared__ int2 s_buf[4][kBankCap];
+    __shared__ int s_cnt[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int2 *buf = s_buf[wave];
+    int *bc = s_cnt[wave];
+    // one wave per heavy list (the lists of one heavy n-gram are neighbours in slot order, and the list k_index_pieces
+    // left is in no particular order: taking them round-robin spreads them over the waves)
+    const int n_heavy = min(heavy[0], heavy_cap);
+    const int n_waves = (int)gridDim.x * 4;
+    for (int h = (int)blockIdx.x * 4 + wave; h < n_heavy; h += n_waves) {
+        {
+            const int64_t slot = heavy[1 + h];
+            const int c = min(cnt[slot], kBankCap);
+            const int64_t base = (int64_t)tab[slot] * kPiece;
+            if (lane < 32) bc[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // rank of every posting inside its bank (any order inside a bank will do)
+            for (int i = lane; i < c; i += 64) {
+                int2 pe = post[base + i];
+                const int b = (pe.x >> 2) & 31;
+                const int j = atomicAdd(&bc[b], 1);
+                buf[i] = make_int2(pe.x, pe.y);
+                // (the rank travels in the upper bits of the offset: offsets are < 4 * 4096 = 2^14)
+                buf[i].x = pe.x | (j << 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int my_cnt = lane < 32 ? bc[lane] : 0;
+            for (int i = lane; i < c + 63 - (c + 63) % 64; i += 64) {
+                const bool on = i < c;
+                int2 pe = on ? buf[i] : make_int2(0, 0);
+                const int j = (int)((uint32_t)pe.x >> 16), b = (pe.x >> 2) & 31;
+                // position by (j, bank): the postings of ranks below j, plus the banks below b that reach rank j
+                int pos = 0;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    const int cq = __shfl(my_cnt, q, 64);
+                    pos += min(cq, j) + ((q < b && cq > j) ? 1 : 0);
+                }
+                if (on) post[base + pos] = make_int2(pe.x & 0xffff, pe.y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // Merge the n_slices partial top-n key lists of every from-row (one wave per row).
 __global__ __launch_bounds__(256) void k3_merge_slices(const uint64_t *__restrict__ part_keys, int32_t n_a,
                                                        int32_t n_slices, int32_t ntop, float inv_scale,
@@ -467,6 +533,19 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     } else {
         PFZ_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
     }
+    // the heavy lists, for k_index_bank_order (only where the counts survive the fill: the LDS-histogram path)
+    // ... and where K3 is long enough to pay for the pass: 100k x 100k K3 2.80 -> 2.63 ms for 0.02 ms, 125k x 1M 33.7 -> 33.0 ms
+    // for 0.05; at 10k x 10k (K3 0.07 ms) it only costs.  PFZ_K3_BANK_ORDER=1 forces it (tests)
+    const char *bo_env = getenv("PFZ_K3_BANK_ORDER");
+    const bool bank_order = any && lds_hist && !getenv("PFZ_K3_NO_BANK_ORDER") &&
+                            ((bo_env && atoi(bo_env) > 0) || (!bo_env && B->n_rows >= 32768));
+    const int32_t bank_min = std::max(2, env_int("PFZ_K3_BANK_MIN", kBankMin));
+    const int32_t heavy_cap = (int32_t)std::min<int64_t>(slots, (int64_t)1 << 22);
+    Tmp heavy;
+    if (bank_order) {
+        PFZ_TRY(pool_alloc(ctx, &heavy.p, (size_t)(heavy_cap + 1) * sizeof(int32_t)));
+        PFZ_HIP(hipMemsetAsync(heavy.p, 0, sizeof(int32_t), ctx->stream));
+    }
     const int32_t words = (int32_t)((B->n_cols + 1) / 2);
     const unsigned row_grid = (unsigned)((B->n_rows * 16 + 255) / 256);
     const unsigned slot_grid = (unsigned)((slots + kPiece + 255) / 256);
@@ -481,7 +560,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
                 hipLaunchKernelGGL(k_index_count, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
                                    (int32_t)B->n_rows, (int32_t)nb, block, cnt.p);
             hipLaunchKernelGGL(k_index_pieces, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, lds_hist ? sub.p : nullptr, slots,
-                               ix->tab);
+                               ix->tab, heavy.p, heavy_cap, bank_min);
         }
         PFZ_TRY(exclusive_scan_i32(ctx, ix->tab, slots));   // tab[i] = first piece of list i, tab[slots] = pieces
         PFZ_HIP(hipMemcpyAsync(&n_pieces, ix->tab + slots, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -505,6 +584,11 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
         else if (any)
             hipLaunchKernelGGL(k_index_fill, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices, B->data,
                                (int32_t)B->n_rows, (int32_t)nb, block, cnt.p, ix->tab, ix->post);
+    }
+    if (bank_order) {
+        ProfScope ps(ctx, "k_index_bank_order");
+        hipLaunchKernelGGL(k_index_bank_order, dim3((unsigned)ctx->prop.multiProcessorCount * 4), dim3(256), 0, ctx->stream, cnt.p,
+                           ix->tab, heavy.p, heavy_cap, ix->post);
     }
     PFZ_HIP(hipGetLastError());
     *out = ix.release();

@@ -25,7 +25,7 @@ import numpy as np
 from . import _lib
 
 PROFILED_KERNELS = ("k1_extract", "k2_rows_short", "k2_rows_long", "k2_df_hist", "k2_finalize", "k_index_count",
-                    "k_index_fill", "k3_cossim_topn")
+                    "k_index_fill", "k_index_bank_order", "k3_cossim_topn")
 
 
 def shard_bounds(n, world, rank):
