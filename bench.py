@@ -221,13 +221,21 @@ def k3_roofline(job, stats, k3_ms, k3_launches, top_n, traffic=None, traffic_not
     bytes_alg = 8.0 * stats["madds"] + 8.0 * stats["nnz_from"] + 8.0 * job.n_from * top_n
     hbm_priced = bytes_alg / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0
     cells = float(job.n_from) * ix["n_blocks"] * ix["block_cols"]
+    madds_done = stats["madds"]
+    sym_launches, sym_rows = job.index.symmetric_launches()
+    symmetric = sym_launches > 0 and sym_rows >= job.n_from and "madds_symmetric" in stats
+    if symmetric:
+        # a list against itself ran in K3's symmetric form (k3_symmetric.hip): every unordered pair of rows scored once.  The
+        # SURVEY figure (`frac`) prices the job as the reference's library does it -- every ordered pair --; the LDS floor is
+        # priced on what this kernel executes
+        madds_done, cells = stats["madds_symmetric"], stats["cells_symmetric"]
     lds_bw = N_CU * LDS_BYTES_PER_CLK_CU * CLK_HZ
-    lds_floor_s = stats["madds"] / LDS_ATOMIC_LANES_PER_S + cells * 8.0 / lds_bw
+    lds_floor_s = madds_done / LDS_ATOMIC_LANES_PER_S + cells * 8.0 / lds_bw
     # compulsory: the from-side CSR once, the to-side index as it lies in HBM (padded pieces + table) once, the results once
     compulsory = 8.0 * stats["nnz_from"] + 4.0 * (job.n_from + 1) + 8.0 * float(ix["n_pieces"]) * float(ix["piece_postings"]) + float(ix["table_bytes"]) \
         + 8.0 * job.n_from * top_n
     return {
-        "kernel": "k3_cossim_topn", "bound": "hbm",
+        "kernel": "k3_cossim_topn" + (" (symmetric form: k3_sym_kernel passes 0-2 + k3_sym_merge)" if symmetric else ""), "bound": "hbm",
         "achieved": hbm_priced, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_priced / HBM_PEAK_GBS,
         "frac_hbm_priced": hbm_priced / HBM_PEAK_GBS,
         "frac_lds_floor": lds_floor_s / k3_avg_s if k3_avg_s > 0 else 0.0,
@@ -238,7 +246,8 @@ def k3_roofline(job, stats, k3_ms, k3_launches, top_n, traffic=None, traffic_not
         "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
         "traffic_note": traffic_note or "no PMC record for this workload (profiles/k3_hbm_traffic.json)",
         "lds_floor_ms": lds_floor_s * 1e3, "avg_launch_ms": k3_avg_s * 1e3, "launches": k3_launches,
-        "lds_floor_what": f"{stats['madds']:.4g} ds_add_u32 lanes at {LDS_ATOMIC_LANES_PER_S:.3e}/s (profiles/r04_ubench/"
+        "multiply_adds_executed": madds_done, "symmetric_form": bool(symmetric),
+        "lds_floor_what": f"{madds_done:.4g} ds_add_u32 lanes at {LDS_ATOMIC_LANES_PER_S:.3e}/s (profiles/r04_ubench/"
                           f"lds_atomic.txt) + {cells:.4g} accumulator cells x 8 B (read + clear) at {lds_bw / 1e12:.2f} TB/s of "
                           f"LDS bandwidth ({N_CU} CU x {LDS_BYTES_PER_CLK_CU:.0f} B/clk x {CLK_HZ / 1e9:.1f} GHz)",
         "bound_note": "frac = frac_hbm_priced = SURVEY 8d's algorithmic bytes / launch time / 8 TB/s: a PRICE, not a "

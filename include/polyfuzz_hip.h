@@ -100,6 +100,10 @@ int pfz_index_info(const pfz_index *ix, int64_t *n_rows, int64_t *n_cols, int64_
 /* the index stores every (n-gram, to-block) posting list padded to whole pieces of `piece_postings`
  * (16) postings = one 128-byte line each: number of pieces (index bytes = 128 * (n_pieces + 1)) */
 int pfz_index_pieces(const pfz_index *ix, int64_t *n_pieces, int64_t *piece_postings);
+/* how often pfz_cossim_topn[_rows] on this index took the symmetric form (a list against itself, reference
+ * _tfidf.py:113-116 -> _utils.py:82-87: every unordered pair of rows scored once, csrc/k3_symmetric.hip), and how many
+ * from-rows those launches covered -- the bench prices its roofline by the kernel that ran */
+int pfz_index_symmetric_launches(const pfz_index *ix, int64_t *launches, int64_t *rows);
 
 int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out);
 void pfz_topn_free(pfz_topn *t);
@@ -124,6 +128,10 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
  * _utils.py:84-87; diag_offset = global index of from-row 0 when the from
  * side is a row shard).  lower_bound < 0 is treated as 0 (non-positive scores
  * are "no match" in the reference's output contract, _utils.py:122-123).
+ * When from_matrix IS the matrix the index was built from, exclude_diag != 0 and diag_offset == 0 -- a list against
+ * itself -- lists of 32 768 to 250 000 rows (ntop <= 32) take the symmetric form: C is symmetric bit for bit in this
+ * arithmetic, so every unordered pair of rows is scored once and handed to both rows; same results (PFZ_K3_SYM=0 / 1:
+ * never / whenever possible).
  * Limits: 1 <= ntop <= 1024 (PFZ_ERR_UNSUPPORTED beyond; above 128 a larger, slower candidate buffer); fewer than 2^25
  * 16-posting index pieces (4 GiB) in the to-side; n_cols equal on both sides.  `out` may have MORE rows than the from-matrix (a padded
  * shard buffer for the equal-sized all-gather): the extra rows are not touched.
@@ -134,7 +142,8 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from
 
 /* The same for from-rows [row_begin, row_end) only (results into the same rows of `out`; exclude_diag still means
  * j == global from-row + diag_offset).  Lets a caller split one match into launches and consume the first part
- * (pfz_event_record + pfz_topn_download_rows_after) while the next one runs. */
+ * (pfz_event_record + pfz_topn_download_rows_after) while the next one runs.  (Row ranges of a self-match that ascend
+ * from row 0 without gaps, into the same `out`, continue one symmetric session; any other order is served row by row.) */
 int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,
                          int64_t row_begin, int64_t row_end, int32_t ntop, float lower_bound,
                          int32_t exclude_diag, int64_t diag_offset, pfz_topn *out);

@@ -342,4 +342,14 @@ bool k3_lockstep_wanted(const pfz_ctx *ctx, const pfz_index *ix, int64_t n_rows,
 int k3_lockstep_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t n_rows, int32_t ntop,
                        int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset, pfz_topn *out);
 
+
+// ---- host side, k3_symmetric.hip ---------------------------------------------------------------------------------
+// The symmetric form of K3 for a self-match (every unordered pair scored once).  k3_sym_wanted: 0 = not a job for it,
+// 1 = start a session with this row range, 2 = the range continues the running session.
+int k3_sym_wanted(const pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
+                  int32_t thr0, float scale, int32_t exclude_diag, int64_t diag_offset, const pfz_topn *out);
+int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
+                  int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start);
+void k3_sym_free(pfz_index *ix);
+
 }  // namespace pfz

@@ -524,6 +524,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     ix->block_cols = block;
     ix->n_blocks = (int32_t)nb;
     ix->max_norm = B->max_norm;
+    ix->src_serial = B->serial;
     struct Tmp {
         int32_t *p = nullptr;
         ~Tmp() { if (p) pool_free(p); }
@@ -607,6 +608,7 @@ void pfz_index_free(pfz_index *ix)
 {
     if (!ix) return;
     if (ix->ctx) (void)hipSetDevice(ix->ctx->device);
+    k3_sym_free(ix);
     if (ix->tab) pool_free(ix->tab);
     if (ix->post) pool_free(ix->post);
     delete ix;
@@ -669,6 +671,11 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     const float scale = (float)ldexp(1.0, k), inv_scale = (float)ldexp(1.0, -k);
     const double thr_d = floor((double)lower_bound * (double)scale);
     const int32_t thr0 = thr_d >= 2147483000.0 ? 2147483000 : (int32_t)thr_d;
+    // a list against itself: every unordered pair once (k3_symmetric.hip), whole jobs and ascending row ranges of one
+    if (const int sym = k3_sym_wanted(ctx, ix, A, row_begin, row_end, ntop, thr0, scale, exclude_diag, diag_offset, out)) {
+        ProfScope ps(ctx, "k3_cossim_topn");
+        return k3_sym_launch(ctx, ix, A, row_begin, row_end, ntop, thr0, scale, inv_scale, out, sym == 1);
+    }
     if (k3_lockstep_wanted(ctx, ix, n_rows, ntop)) {     // big to-sides: all waves on the same to-blocks (k3_lockstep.hip)
         ProfScope ps(ctx, "k3_cossim_topn");
         return k3_lockstep_launch(ctx, ix, A, row_begin, n_rows, ntop, thr0, scale, inv_scale, exclude_diag, diag_offset, out);

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <atomic>
 
 #include "polyfuzz_hip.h"
 
@@ -40,6 +41,15 @@ constexpr int kWave = 64;
 // CU's 160 KiB, i.e. vocabularies of up to 73 728 n-grams; larger ones fall back to global atomics
 constexpr int kHistWords = 36864;
 constexpr int kEventSlots = 64;
+
+// every CSR matrix gets a number of its own: "is this the matrix the index was built from?" (k3_symmetric.hip) must not be
+// answered by pointers, which the caching allocator hands out again
+inline uint64_t next_serial()
+{
+    static std::atomic<uint64_t> s{1};
+    return s.fetch_add(1);
+}
+struct K3SymState;   // k3_symmetric.hip: the exchange buffers and the running session of a symmetric self-match
 
 struct ProfEntry {
     std::vector<hipEvent_t> begin, end;  // recorded pairs not yet folded in
@@ -80,6 +90,7 @@ struct pfz_csr {
     int32_t *indices = nullptr;  // [nnz]
     float *data = nullptr;       // [nnz]
     float max_norm = 1.f;        // upper bound of the rows' L2 norms (sizes K3's fixed-point scale)
+    uint64_t serial = pfz::next_serial();   // unique per matrix; the contents never change after creation
 };
 
 // Inverted index of the to-side: for n-gram id k and to-row block b (block =
@@ -94,6 +105,8 @@ struct pfz_index {
     int32_t *tab = nullptr;  // [n_cols * n_blocks + 2] first piece of every list
     int2 *post = nullptr;    // [(n_pieces + 1) * 16]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
     float max_norm = 1.f;    // of the indexed matrix' rows
+    uint64_t src_serial = 0; // pfz_csr::serial of the matrix it was built from
+    mutable pfz::K3SymState *sym = nullptr;   // k3_symmetric.hip, allocated by the first symmetric self-match on this index
 };
 
 struct pfz_topn {

@@ -9,6 +9,7 @@ the device through the C ABI; the fitted vocabulary, idf and to-side index stay
 resident in HBM between `match(..., re_train=False)` calls (reference
 polyfuzz.py:234-240, "production" path).
 """
+import os
 import re
 import time
 from typing import List, Tuple
@@ -25,6 +26,16 @@ _SPLIT_MIN_ROWS = 20000      # from-rows from which match() pipelines several K3
 _SPLIT_EVENT = 56            # context event slots 56 .. : launch i done
 # shares of the from-rows per launch: the last part's columns are built AFTER the device has finished, so it is the small one
 _SPLIT_SHARES = {2: (0.6, 0.4), 5: (0.4, 0.3, 0.2, 0.1)}      # (profiles/experiments/r04_match_split_probe.txt)
+
+
+def _split_shares(n):
+    """shares of the from-rows per K3 launch of a big match (PFZ_MATCH_SHARES=0.4,0.3,0.2,0.1 overrides: tuning)"""
+    env = os.environ.get("PFZ_MATCH_SHARES")
+    if env:
+        sh = tuple(float(x) for x in env.split(","))
+        if len(sh) >= 1 and all(x > 0 for x in sh) and len(sh) <= 8:
+            return tuple(x / sum(sh) for x in sh)
+    return _SPLIT_SHARES[5 if n >= 2 * _SPLIT_MIN_ROWS else 2]
 
 
 def _clean_string(string: str) -> str:
@@ -147,7 +158,7 @@ class TFIDF(BaseMatcher):
         # the last part's columns are built after the device has finished
         split = n >= _SPLIT_MIN_ROWS and top_n >= 1 and _lib._pack is not None and isinstance(names, (list, tuple))
         if split:
-            shares = _SPLIT_SHARES[5 if n >= 2 * _SPLIT_MIN_ROWS else 2]
+            shares = _split_shares(n)
             n_parts, cuts, acc = len(shares), [0], 0.0
             for f in shares[:-1]:
                 acc += f

@@ -175,8 +175,19 @@ class TfidfMatchJob:
         (fp, fi, _), (tp, ti, _), n_cols = self.host_matrices()
         df_from = np.bincount(fi, minlength=n_cols).astype(np.float64)
         df_to = np.bincount(ti, minlength=n_cols).astype(np.float64)
-        return {"vocab": int(n_cols), "nnz_from": int(fp[-1]), "nnz_to": int(tp[-1]),
-                "madds": float((df_from * df_to).sum())}
+        out = {"vocab": int(n_cols), "nnz_from": int(fp[-1]), "nnz_to": int(tp[-1]),
+               "madds": float((df_from * df_to).sum())}
+        if self.from_csr is self.to_csr and self.index is not None:
+            # what the symmetric form of K3 (k3_symmetric.hip) executes for this self-match: the pairs inside a to-block in both
+            # directions (pass 0), the pairs of different blocks once (pass 1); every row sweeps its own block and those above
+            info = self.index.info()
+            c, nb = info["block_cols"], info["n_blocks"]
+            row_of = np.repeat(np.arange(len(tp) - 1, dtype=np.int64), np.diff(tp))
+            per_list = np.bincount(ti.astype(np.int64) * nb + row_of // c, minlength=n_cols * nb).astype(np.float64)
+            madds_diag = float((per_list * per_list).sum())
+            out["madds_symmetric"] = 0.5 * (out["madds"] + madds_diag)
+            out["cells_symmetric"] = float(((nb - np.arange(len(tp) - 1, dtype=np.int64) // c) * c).sum())
+        return out
 
 
 class ToShardedMatchJob:

@@ -288,3 +288,114 @@ def test_sparse_dot_topn_pin_fixture(ctx):
                 continue
             assert all(abs(v - w) <= 1e-5 for (_, v), w in zip(got, e_vals))
         assert soft <= 3, (name, ntop, lb, soft)
+
+
+def _sym_lists(rng, n, n_col, weird=True):
+    """A self-match list of n rows over n_col (+1) columns for the symmetric kernel's tests: random rows incl. empty ones,
+    rows of more than 64 n-grams, runs of DUPLICATE rows (exact ties across blocks), and -- `weird` -- one row of block 3
+    whose only n-gram it shares with 400 rows of block 0 and with nobody of its own block (threshold 0 after the own-block
+    pass: it is sent more candidates than its push slots hold and is recomputed in full)."""
+    base = random_csr(rng, n, n_col, 0.02, empty_rows=(0, 7, 2048, n - 1))
+    ip, ix_, dv = [np.array(x) for x in base]
+    rows = [(ix_[ip[r]:ip[r + 1]].copy(), dv[ip[r]:ip[r + 1]].copy()) for r in range(n)]
+    heavy = random_csr(rng, 30, n_col, 0.12)
+    for k in range(30):                                  # rows of > 64 n-grams, spread over the blocks
+        r = (k * 293 + 11) % n
+        rows[r] = (heavy[1][heavy[0][k]:heavy[0][k + 1]].copy(), heavy[2][heavy[0][k]:heavy[0][k + 1]].copy())
+    for src in (100, 2500, 5000):                        # duplicates of one row in every block: exact ties, column order decides
+        for r in range(src + 1, n, 997):
+            rows[r] = (rows[src][0].copy(), rows[src][1].copy())
+    if weird:
+        sp = n_col                                       # the extra column
+        for r in range(5, 5 + 2 * 400, 2):
+            c, v = rows[r]
+            c, v = np.append(c, sp).astype(np.int32), np.append(v * 0.8, 0.6)
+            rows[r] = (c, v / np.sqrt((v * v).sum()))
+        rows[3 * 2048 + 17] = (np.array([sp], np.int32), np.array([1.0]))
+    ptr = np.zeros(n + 1, np.int64)
+    for r in range(n):
+        ptr[r + 1] = ptr[r] + len(rows[r][0])
+    return (ptr, np.concatenate([c for c, _ in rows]).astype(np.int32), np.concatenate([v for _, v in rows]).astype(np.float64))
+
+
+def _self_match(ctx, a3, n_col, ntop, lb, ranges=None, repeats=1):
+    """device-level self-match (one matrix, its own index: what TFIDF.match(list) enqueues), whole or in row ranges"""
+    from polyfuzz_amd import _lib
+    csr = _lib.DeviceCSR.upload(ctx, a3[0], a3[1], a3[2], n_col)
+    index = _lib.DeviceIndex.build(ctx, csr)
+    n = len(a3[0]) - 1
+    out = None
+    for _ in range(repeats):
+        if ranges is None:
+            out = _lib.cossim_topn(ctx, index, csr, ntop, lb, exclude_diag=True, out=out)
+        else:
+            for lo, hi in ranges:
+                out = _lib.cossim_topn(ctx, index, csr, ntop, lb, exclude_diag=True, out=out, rows=(lo, hi))
+    return out.download()
+
+
+@pytest.mark.parametrize("ntop,lb", [(5, 0.0), (1, 0.0), (10, 0.2), (32, 0.0)])
+def test_symmetric_kernel_equals_the_row_major_kernel(ctx, oracle_mod, monkeypatch, ntop, lb):
+    """k3_symmetric.hip (every unordered pair of rows scored once, candidates handed to the higher row through HBM) against
+    the row-major kernel on the same matrix -- bit for bit -- and against the oracle: 9 500 rows = 5 blocks, empty rows,
+    rows of more than 64 n-grams, duplicate rows in every block, a row that overflows its push slots."""
+    rng = np.random.default_rng(77)
+    n, n_col = 9500, 700
+    a3 = _sym_lists(rng, n, n_col)
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    ref_idx, ref_val = _self_match(ctx, a3, n_col + 1, ntop, lb)
+    if ntop == 5:
+        exp_idx, exp_val = oracle_mod.cossim_topn(a3, a3, n_col + 1, ntop, lb, exclude_diag=True)
+        assert_topn_parity(ref_idx, ref_val, exp_idx, exp_val, oracle_mod, a3, a3, n_col + 1, exclude_diag=True)
+    monkeypatch.setenv("PFZ_K3_SYM", "1")
+    idx, val = _self_match(ctx, a3, n_col + 1, ntop, lb, repeats=2)      # twice: the session buffers are re-used
+    np.testing.assert_array_equal(idx, ref_idx)
+    np.testing.assert_array_equal(val, ref_val)
+
+
+def test_symmetric_kernel_in_row_ranges(ctx, monkeypatch):
+    """A self-match enqueued in ascending row ranges (what TFIDF.match does so that frame building overlaps the device): the
+    symmetric session carries over; ranges that do not continue it fall back to the row-major kernel -- same result always."""
+    rng = np.random.default_rng(78)
+    n, n_col = 9500, 700
+    a3 = _sym_lists(rng, n, n_col)
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    ref_idx, ref_val = _self_match(ctx, a3, n_col + 1, 5, 0.0)
+    monkeypatch.setenv("PFZ_K3_SYM", "1")
+    for ranges in ([(0, 3000), (3000, 3001), (3001, 8100), (8100, n)],      # a session in four parts
+                   [(0, 4096), (4096, n)],                                   # cuts on a block boundary
+                   [(0, 2000), (5000, n), (2000, 5000)],                     # the second range does not continue: row-major
+                   [(4000, n), (0, 4000)]):                                  # starts in the middle: row-major, then a session's first part
+        idx, val = _self_match(ctx, a3, n_col + 1, 5, 0.0, ranges=ranges)
+        np.testing.assert_array_equal(idx, ref_idx)
+        np.testing.assert_array_equal(val, ref_val)
+
+
+def test_symmetric_kernel_on_real_names(ctx, oracle_mod, monkeypatch):
+    """40 000 real company names against themselves (20 blocks; the automatic choice takes the symmetric kernel from 32 768
+    rows on): equal to the row-major kernel bit for bit, top-5 and top-1, and the unnormalised-matrix scale path."""
+    from polyfuzz_amd import datasets, _lib
+    from polyfuzz_amd.models import TFIDF
+    names = datasets.load_company_names()[:40000]
+    res = {}
+    for sym in ("0", "auto"):
+        if sym == "auto":
+            monkeypatch.delenv("PFZ_K3_SYM", raising=False)
+        else:
+            monkeypatch.setenv("PFZ_K3_SYM", sym)
+        for ntop in (5, 1):
+            m = TFIDF(min_similarity=0.0, top_n=ntop)
+            res[sym, ntop] = m.match_device(names).download()
+    for ntop in (5, 1):
+        np.testing.assert_array_equal(res["auto", ntop][0], res["0", ntop][0])
+        np.testing.assert_array_equal(res["auto", ntop][1], res["0", ntop][1])
+    # rows with norms far from 1 (the fixed-point scale follows the norm bound): still symmetric bit for bit
+    rng = np.random.default_rng(5)
+    a3 = _sym_lists(rng, 6000, 500, weird=False)
+    a3 = (a3[0], a3[1], a3[2] * 7.5)
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    r0 = _self_match(ctx, a3, 501, 5, 0.0)
+    monkeypatch.setenv("PFZ_K3_SYM", "1")
+    r1 = _self_match(ctx, a3, 501, 5, 0.0)
+    np.testing.assert_array_equal(r1[0], r0[0])
+    np.testing.assert_array_equal(r1[1], r0[1])
