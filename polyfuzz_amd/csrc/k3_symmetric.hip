@@ -10,7 +10,7 @@
 // it hands to row i.  Scatter and sweep work halve; the price is a second filter in the sweep (is this sum a candidate
 // for the ROW OF THE CELL?) and a small exchange through HBM.
 //
-// How.  Three passes over one kernel (K3SymArgs::mode) + a merge:
+// How.  Three passes of one kernel template (k3_sym_kernel<C, MODE>) + a merge:
 //   0  every row x its OWN block (both directions of a pair inside a block are computed: no exchange there) -> the
 //      row's first top-n and threshold, written to HBM (keys[row][ntop], thrv[row]) and, as the upper 16 bits of the
 //      threshold, into thr16 in the order the sweep reads a block's cells.  On a sorted list (the reference's company
@@ -63,7 +63,6 @@ struct K3SymArgs {
     const int2 *post;
     int32_t nb, n_pieces, ntop, thr0;
     float scale, inv_scale;
-    int32_t mode;             // 0: own block -> state; 1: the blocks above -> state + pushes; 2: all blocks of the listed rows -> result
     int32_t row_begin, row_end;   // the rows of this launch (modes 0 and 1, merge)
     int32_t *thrv;            // [n]           published thresholds (accept sum > thr)
     uint16_t *thr16;          // [nb * C]      their upper halves, in sweep order (see thr16_pos); rows >= n: 0x7f7f
@@ -73,6 +72,7 @@ struct K3SymArgs {
     int32_t *ovf;             // [1 + n]       ovf[0] = number of rows to recompute, then the rows
     int32_t *out_idx;
     float *out_val;
+    int32_t exp;              // timing experiments (PFZ_K3_SYM_EXP, results wrong on purpose): 1 = no second filter, 2 = no threshold loads, 4 = no publishing
 };
 
 // where the upper half of row `row`'s threshold sits: a sweep step t of lane l reads the int4 slots i0 = 128 t + l and
@@ -172,7 +172,9 @@ __device__ inline void sweep_block_sym(int4 *acc4, uint64_t *cand, TopState &st,
     }
 }
 
-template <int C>
+// MODE: the pass (0: own block -> state; 1: the blocks above -> state + pushes; 2: all blocks of the listed rows -> result) --
+// a template parameter so that every pass is a kernel of its own name in a trace and carries only its own code
+template <int C, int MODE>
 __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
 {
     static_assert(C == kSymC, "thr16_pos() is written for 2048-row blocks");
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     __shared__ __attribute__((aligned(16))) struct {
         int acc[C];
         uint64_t cand[kSymCap];
-        uint64_t fbuf[kSymF];
+        uint64_t fbuf[MODE == 1 ? kSymF : 1];      // (only pass 1 hands candidates over)
     } sm;
     int *const acc = sm.acc;
     uint64_t *const cand = sm.cand;
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     const int src4 = (4 * (lane & 15) + (lane >> 4)) * 4;
     const int sub8 = (lane & 15) * 8;
     const int dummy_addr = a.n_pieces << 7;
-    const int nb = a.nb, ntop = a.ntop, mode = a.mode;
+    const int nb = a.nb, ntop = a.ntop;
+    constexpr int mode = MODE;
     const int4 *thr16q = (const int4 *)a.thr16;
 
     int n_items = a.row_end - a.row_begin;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             // the thresholds of the block's first two sweep steps, in flight across the scatter (the other two follow inside the sweep)
             const int4 *tq_blk = thr16q + (int64_t)b * NT * 64;
             int4 qa = make_int4(0x7fff7fff, 0x7fff7fff, 0x7fff7fff, 0x7fff7fff), qb = qa;
-            if (mode == 1) {
+            if (mode == 1 && !(a.exp & 2)) {
                 qa = tq_blk[lane];
                 qb = tq_blk[64 + lane];
             }
@@ -292,9 +295,9 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                         st.thr = t > st.thr ? t : st.thr;
                     }
                 }
-                sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, tq_blk, fbuf, fcnt, a, inv_row, mode == 1);
+                sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, tq_blk, fbuf, fcnt, a, inv_row, mode == 1 && !(a.exp & 1));
                 wave_sync();
-                if (mode == 1 && st.thr > pub) {        // tell the rows below: fewer of their sums are candidates of this row
+                if (mode == 1 && st.thr > pub && !(a.exp & 4)) {        // tell the rows below: fewer of their sums are candidates of this row
                     pub = st.thr;
                     if (lane == 0) {
                         a.thrv[row] = pub;
@@ -473,29 +476,27 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.ovf = s->ovf;
     a.out_idx = out->idx;
     a.out_val = out->val;
+    a.exp = sym_env_int("PFZ_K3_SYM_EXP", 0);
     if (start) {
         // pass 0 over ALL rows: every row's first threshold is there before anybody hands anything over
         PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
         PFZ_HIP(hipMemsetAsync(s->thr16, 0x7f, (size_t)nb * kSymC * sizeof(uint16_t), ctx->stream));
-        a.mode = 0;
         a.row_begin = 0;
         a.row_end = (int32_t)n;
-        hipLaunchKernelGGL((k3_sym_kernel<kSymC>), dim3((unsigned)n), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3((unsigned)n), dim3(64), 0, ctx->stream, a);
     }
     PFZ_HIP(hipMemsetAsync(s->ovf, 0, sizeof(int32_t), ctx->stream));
     // pass 1: the rows of this range that have blocks above their own
     const int64_t last_block_row = (int64_t)(nb - 1) * kSymC;
-    a.mode = 1;
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)(row_end < last_block_row ? row_end : last_block_row);
     if (a.row_end > a.row_begin)
-        hipLaunchKernelGGL((k3_sym_kernel<kSymC>), dim3((unsigned)(a.row_end - a.row_begin)), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(a.row_end - a.row_begin)), dim3(64), 0, ctx->stream, a);
     // merge, then the rows that were sent too much
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)row_end;
     hipLaunchKernelGGL(k3_sym_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, ctx->stream, a);
-    a.mode = 2;
-    hipLaunchKernelGGL((k3_sym_kernel<kSymC>), dim3(1024), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(1024), dim3(64), 0, ctx->stream, a);
     PFZ_HIP(hipGetLastError());
     s->next_row = row_end;
     s->launches += 1;
