@@ -48,7 +48,7 @@ constexpr int kSymKeep = 32;       // keys a row keeps between the passes at mos
 #define PFZ_K3_SYM_F 128           // (tuning knobs of tools/build_variant.sh)
 #endif
 #ifndef PFZ_K3_SYM_PUSH
-#define PFZ_K3_SYM_PUSH 256
+#define PFZ_K3_SYM_PUSH 1024
 #endif
 constexpr int kSymF = PFZ_K3_SYM_F;         // staged foreign candidates per wave (flushed above kSymF - 64)
 constexpr int kSymPush = PFZ_K3_SYM_PUSH;   // push slots per row; a row that is sent more is recomputed in full
@@ -89,7 +89,8 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 // sign bits of (upper half of sum) - (upper half of threshold) for two sums: clear = candidate
 __device__ inline uint32_t upper_diff(int s_lo, int s_hi, int thr_pair)
 {
-    const uint32_t p = ((uint32_t)s_lo >> 16) | ((uint32_t)s_hi & 0xffff0000u);
+    // {s_hi[31:16], s_lo[31:16]}: v_perm_b32 with selector 0x07060302 (bytes 3, 2 of the first operand over bytes 3, 2 of the second)
+    const uint32_t p = __builtin_amdgcn_perm((uint32_t)s_hi, (uint32_t)s_lo, 0x07060302u);
     const short2v d = __builtin_bit_cast(short2v, p) - __builtin_bit_cast(short2v, (uint32_t)thr_pair);   // v_pk_sub_i16
     return __builtin_bit_cast(uint32_t, d);
 }
@@ -137,19 +138,32 @@ __device__ inline void foreign8(uint64_t *fbuf, int &fcnt, const int4 &v0, const
 // |sum| stays below 2^31 / 1.0001, pfz_cossim_topn_rows); those of steps 2 / 3 are loaded from tq_blk while steps 0 / 1
 // are worked on.  hand_over = pass 1.  (Two rolled iterations of two steps, like the main kernel's sweep: the code of the
 // rare paths exists twice, not four times.)
+#ifndef PFZ_K3_SYM_TQ4
+#define PFZ_K3_SYM_TQ4 0           // 1: the thresholds of all four sweep steps are loaded before the scatter (16 registers across it)
+#endif
 template <int N4, int kCap>
 __device__ inline void sweep_block_sym(int4 *acc4, uint64_t *cand, TopState &st, int col0, int self_col, int ntop, int lane,
-                                       int zero, int4 qa, int4 qb, const int4 *tq_blk, uint64_t *fbuf, int &fcnt,
-                                       const K3SymArgs &a, uint32_t inv_row, bool hand_over)
+                                       int zero, int4 qa, int4 qb,
+#if PFZ_K3_SYM_TQ4
+                                       int4 qc, int4 qd,
+#else
+                                       const int4 *tq_blk,
+#endif
+                                       uint64_t *fbuf, int &fcnt, const K3SymArgs &a, uint32_t inv_row, bool hand_over)
 {
     static_assert(N4 / 128 == 4, "four sweep steps per block");
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         const int4 qq[2] = {qa, qb};
+#if PFZ_K3_SYM_TQ4
+        qa = qc;
+        qb = qd;
+#else
         if (h == 0 && hand_over) {
             qa = tq_blk[2 * 64 + lane];
             qb = tq_blk[3 * 64 + lane];
         }
+#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i0 = (2 * h + u) * 128 + lane, i1 = i0 + 64;
@@ -262,9 +276,16 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             // the thresholds of the block's first two sweep steps, in flight across the scatter (the other two follow inside the sweep)
             const int4 *tq_blk = thr16q + (int64_t)b * NT * 64;
             int4 qa = make_int4(0x7fff7fff, 0x7fff7fff, 0x7fff7fff, 0x7fff7fff), qb = qa;
+#if PFZ_K3_SYM_TQ4
+            int4 qc = qa, qd = qa;
+#endif
             if (mode == 1 && !(a.exp & 2)) {
                 qa = tq_blk[lane];
                 qb = tq_blk[64 + lane];
+#if PFZ_K3_SYM_TQ4
+                qc = tq_blk[128 + lane];
+                qd = tq_blk[192 + lane];
+#endif
             }
             bool touched = __ballot(e > s) != 0;
             if (touched) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
@@ -295,7 +316,11 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                         st.thr = t > st.thr ? t : st.thr;
                     }
                 }
+                #if PFZ_K3_SYM_TQ4
+                sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, qc, qd, fbuf, fcnt, a, inv_row, mode == 1 && !(a.exp & 1));
+#else
                 sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, tq_blk, fbuf, fcnt, a, inv_row, mode == 1 && !(a.exp & 1));
+#endif
                 wave_sync();
                 if (mode == 1 && st.thr > pub && !(a.exp & 4)) {        // tell the rows below: fewer of their sums are candidates of this row
                     pub = st.thr;
@@ -496,7 +521,7 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)row_end;
     hipLaunchKernelGGL(k3_sym_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(1024), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3((unsigned)ctx->prop.multiProcessorCount * 16), dim3(64), 0, ctx->stream, a);
     PFZ_HIP(hipGetLastError());
     s->next_row = row_end;
     s->launches += 1;

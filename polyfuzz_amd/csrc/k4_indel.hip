@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
             const int orig = A.b_orig[slot];
             if (orig >= 0) {
                 const int lb = A.b_len[slot];
-                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = orig == skip ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
-                if (orig != skip) {
+                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = choice_left_out(orig, skip) ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
+                if (!choice_left_out(orig, skip)) {
                     if (m + lb == 0) take(best, 1, 1, orig);
                     else take(best, lcs, m + lb, orig);
                 }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, NS == 8 ? 6 : 7) void k4_indel_quad_kernel(Ind
                     // (the per-pair epilogue was 28 % of the kernel, what-if build 2)
                     const uint32_t l = mul_u24((uint32_t)l_a, (uint32_t)best[k].mx), r = mul_u24((uint32_t)best[k].lcs, (uint32_t)m_a);
                     bool wins = (l > r) | ((l == r) & (orig < best[k].idx));
-                    if (A.skip_idx) wins = wins & (orig != skip[k]);
+                    if (A.skip_idx) wins = wins & !choice_left_out(orig, skip[k]);
                     best[k].lcs = wins ? l_a : best[k].lcs;
                     best[k].mx = wins ? m_a : best[k].mx;
                     best[k].idx = wins ? orig : best[k].idx;
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void k4_indel_general_kernel(IndelArgs A, int3
             const int orig = A.b_orig[slot];
             if (orig >= 0) {
                 const int lb = A.b_len[slot];
-                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = orig == skip ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
-                if (orig != skip) {
+                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = choice_left_out(orig, skip) ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
+                if (!choice_left_out(orig, skip)) {
                     if (m + lb == 0) take(best, 1, 1, orig);
                     else take(best, lcs, m + lb, orig);
                 }

@@ -943,7 +943,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         };
         auto bound_of = [&](const Meta &x, bool &valid, bool &coarse) -> float {
             const int4 m = x.m;
-            valid = x.m2.w >= 0 && x.m2.w != skip && m.w <= kFuzzMaxTokens;
+            valid = x.m2.w >= 0 && !choice_left_out(x.m2.w, skip) && m.w <= kFuzzMaxTokens;
             const FuzzSummary sb = summary_of(x);
             const int uu = fz_common_chars(sa, sb);
             const bool maybe = use_tokens && (sa.sig & sb.sig) != 0ull;

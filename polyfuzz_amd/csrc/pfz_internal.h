@@ -167,6 +167,12 @@ struct pfz_tfidf {
 
 namespace pfz {
 
+// Skip codes of the best-choice kernels (K4 / K7, `skip_idx[from-row]`): -1 = no choice is left out; s >= 0 = choice s is (a
+// self-match leaves out the from-string's own first occurrence, reference _distance.py:93-96); s <= -2 = every choice up
+// to and including -2 - s is -- the reference RapidFuzz matcher's shared, shrinking list (_rapidfuzz.py:103-104 with
+// n_jobs = 1: when row i is scored the rows 0 .. i have been removed).
+__host__ __device__ inline bool choice_left_out(int orig, int skip) { return orig == skip || orig <= -2 - skip; }
+
 // Owns a half-built object until the entry point succeeds: an error return (PFZ_TRY / PFZ_HIP /
 // PFZ_REQUIRE) releases it through its own free function instead of leaking the device buffers.
 template <typename T, void (*Free)(T *)> struct Owner {
