@@ -21,8 +21,12 @@ constexpr int kPiece = 16;        // postings per piece (one 128-byte line, one 
 // ---------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------
+#ifndef PFZ_K3_SHFL_MAX
+#define PFZ_K3_SHFL_MAX 0      // 1: the wave maximum by twelve ds_bpermute (the form of rounds 1-4, kept for A/B builds)
+#endif
 __device__ inline uint64_t wave_max_u64(uint64_t v)
 {
+#if PFZ_K3_SHFL_MAX
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         uint32_t lo = __shfl_xor((uint32_t)v, d, 64);
@@ -31,6 +35,30 @@ __device__ inline uint64_t wave_max_u64(uint64_t v)
         v = o > v ? o : v;
     }
     return v;
+#else
+    // DPP instead of LDS round trips: the inclusive prefix maximum of dpp_max_scan() below on both halves of the key (row_shr
+    // 1, 2, 4, 8 inside each 16-lane row, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; a lane without a
+    // source reads 0, the identity of an unsigned maximum) -- lane 63 ends up with the maximum of the wave, read back as a
+    // scalar.  A compaction is `keep` of these in a row, each waiting for the one before: twelve dependent ds_bpermute
+    // (~1.5k clocks) against six DPP steps of five instructions.
+#define PFZ_MAX_STEP(ctrl, rmask)                                                                           \
+    {                                                                                                       \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, rmask, 0xf, false);         \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, rmask, 0xf, false);  \
+        const uint64_t o = ((uint64_t)hi << 32) | lo;                                                       \
+        v = o > v ? o : v;                                                                                  \
+    }
+    PFZ_MAX_STEP(0x111, 0xf)
+    PFZ_MAX_STEP(0x112, 0xf)
+    PFZ_MAX_STEP(0x114, 0xf)
+    PFZ_MAX_STEP(0x118, 0xf)
+    PFZ_MAX_STEP(0x142, 0xa)
+    PFZ_MAX_STEP(0x143, 0xc)
+#undef PFZ_MAX_STEP
+    const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t rh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((uint64_t)rh << 32) | rl;
+#endif
 }
 
 // The workgroup is ONE wave: its LDS operations execute in program order, so
