@@ -171,6 +171,19 @@ __device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0
     }
 }
 
+__device__ inline int dpp_max_scan(int m)
+{
+    // inclusive prefix maximum over the 64 lanes (values >= 0): row_shr 1,2,4,8 inside each 16-lane row,
+    // then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
+    return m;
+}
+
 // Warm start of the threshold from the first block a from-row touches.  With the threshold still at the
 // lower bound every non-zero sum of that block would be pushed (and compacted away again).  The k-th
 // largest of the 64 lanes' own maxima is a lower bound of the k-th largest sum of the block (each lane
@@ -189,12 +202,8 @@ __device__ inline int warm_threshold(const int4 *acc4, int i_begin, int k, int l
     }
     int best = 0;
     for (int r = 0; r < k; ++r) {
-        best = lm;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const int o = __shfl_xor(best, d, 64);
-            best = o > best ? o : best;
-        }
+        // (the wave maximum of non-negative values: lane 63 of the DPP prefix maximum -- six DPP steps instead of six ds_bpermute)
+        best = __builtin_amdgcn_readlane(dpp_max_scan(lm), 63);
         if (best == 0) break;          // fewer than k positive sums
         if (lm == best) lm = 0;
     }
@@ -275,19 +284,6 @@ template <int NS>
 __device__ inline void run_steps(int *acc, const char *__restrict__ post_bytes, int addr_t, float as_t, int sub8)
 {
     run_steps_seq(acc, post_bytes, addr_t, as_t, sub8, std::make_integer_sequence<int, NS>{});
-}
-
-__device__ inline int dpp_max_scan(int m)
-{
-    // inclusive prefix maximum over the 64 lanes (values >= 0): row_shr 1,2,4,8 inside each 16-lane row,
-    // then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, false));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, false));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, false));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, false));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
-    return m;
 }
 
 // Scatter the (k,b) lists of up to 64 n-grams of one from-row into the accumulators.

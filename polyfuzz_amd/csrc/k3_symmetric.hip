@@ -48,11 +48,13 @@ constexpr int kSymKeep = 32;       // keys a row keeps between the passes at mos
 #define PFZ_K3_SYM_F 128           // (tuning knobs of tools/build_variant.sh)
 #endif
 #ifndef PFZ_K3_SYM_PUSH
-#define PFZ_K3_SYM_PUSH 1024
+#define PFZ_K3_SYM_PUSH 256
 #endif
 constexpr int kSymF = PFZ_K3_SYM_F;         // staged foreign candidates per wave (flushed above kSymF - 64)
 constexpr int kSymPush = PFZ_K3_SYM_PUSH;   // push slots per row; a row that is sent more is recomputed in full
 constexpr int kSymMergeCap = kSymPush + 64;
+constexpr int kSymSlices = 8;      // pass 2: a row that is recomputed in full is cut into at most this many slices of to-blocks ...
+constexpr int kSymSlicedRows = 4096;   // ... for the first so many rows of the list (a single wave takes ~100 us for a whole row)
 constexpr int kSymExt = 4;         // pass 0: blocks beyond its own a weak row may look at for its first threshold
 
 struct K3SymArgs {
@@ -71,6 +73,8 @@ struct K3SymArgs {
     int32_t *push_cnt;        // [n]
     uint64_t *push_buf;       // [n][kSymPush] keys sum << 32 | ~(row that found it)
     int32_t *ovf;             // [1 + n]       ovf[0] = number of rows to recompute, then the rows
+    uint64_t *part;           // [kSymSlicedRows][n_sl][ntop]  pass 2 in slices: the partial top-n of (row, slice of the to-blocks)
+    int32_t ovf_base, ovf_max, n_sl;   // pass 2: listed rows [ovf_base, ovf_base + ovf_max), each cut into n_sl slices (1: whole rows -> result)
     int32_t *out_idx;
     float *out_val;
     int32_t weak_thr;         // pass 0: a row whose threshold is below this after its own block looks at up to kSymExt more blocks
@@ -222,14 +226,27 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     const int4 *thr16q = (const int4 *)a.thr16;
 
     int n_items = a.row_end - a.row_begin;
+    const int n_sl = mode == 2 ? a.n_sl : 1;
+    const int per_sl = (nb + n_sl - 1) / n_sl;
     if (mode == 2) {
-        n_items = a.ovf[0];
-        n_items = n_items > a.n ? a.n : n_items;
+        int n_ovf = a.ovf[0];
+        n_ovf = n_ovf > a.n ? a.n : n_ovf;
+        const int hi = n_ovf < a.ovf_base + a.ovf_max ? n_ovf : a.ovf_base + a.ovf_max;
+        n_items = hi > a.ovf_base ? (hi - a.ovf_base) * n_sl : 0;
     }
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int row = mode == 2 ? a.ovf[1 + item] : a.row_begin + item;
+        const int row = mode == 2 ? a.ovf[1 + a.ovf_base + item / n_sl] : a.row_begin + item;
         const int own = row / C;
         int b_lo = 0, b_hi = nb, b_first = own;      // (b_hi grows in an extended pass 0)
+        if (mode == 2 && n_sl > 1) {
+            b_lo = (item % n_sl) * per_sl;
+            b_hi = b_lo + per_sl < nb ? b_lo + per_sl : nb;
+            b_first = own >= b_lo && own < b_hi ? own : b_lo;
+            if (b_lo >= b_hi) {       // (an empty trailing slice)
+                if (lane < ntop) a.part[(int64_t)item * ntop + lane] = 0ull;
+                continue;
+            }
+        }
         if (mode == 0) {
             b_lo = own;
             b_hi = own + 1;
@@ -353,7 +370,9 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
 
         if (fcnt) flush_foreign(fbuf, fcnt, lane, a, inv_row);
         compact<kSymCap>(cand, st, ntop, lane);
-        if (mode == 2) {
+        if (mode == 2 && n_sl > 1) {
+            if (lane < ntop) a.part[(int64_t)item * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
+        } else if (mode == 2) {
             for (int r = lane; r < ntop; r += 64) {
                 const uint64_t key = r < st.cnt ? cand[r] : 0ull;
                 a.out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
@@ -424,6 +443,40 @@ __global__ __launch_bounds__(256) void k3_sym_merge(const K3SymArgs a)
     }
 }
 
+// pass 2 in slices: the n_sl partial top-n lists of every recomputed row -> its result (one wave per row)
+__global__ __launch_bounds__(256) void k3_sym_merge_slices(const K3SymArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][256];
+    static_assert(kSymSlices * kSymKeep <= 256, "the partial lists of a row fit one 256-key compaction");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t *cand = cand_all[wave];
+    const int ntop = a.ntop, n_sl = a.n_sl;
+    int n_ovf = a.ovf[0];
+    n_ovf = n_ovf > a.n ? a.n : n_ovf;
+    const int rows = n_ovf < a.ovf_max ? n_ovf : a.ovf_max;      // (ovf_base == 0: the sliced rows are the first of the list)
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        const int row = a.ovf[1 + r];
+        TopState st;
+        st.cnt = 0;
+        st.thr = 0;
+        st.pushed = 0;
+        const int total = n_sl * ntop;
+        for (int e0 = 0; e0 < total; e0 += 64) {
+            const uint64_t k = e0 + lane < total ? a.part[(int64_t)r * total + e0 + lane] : 0ull;
+            const uint64_t mk = __ballot(k != 0ull);
+            if (k) cand[st.cnt + __popcll(mk & ((1ull << lane) - 1ull))] = k;
+            st.cnt += __popcll(mk);
+        }
+        compact<256>(cand, st, ntop, lane);
+        for (int q = lane; q < ntop; q += 64) {
+            const uint64_t key = q < st.cnt ? cand[q] : 0ull;
+            a.out_idx[(int64_t)row * ntop + q] = key ? (int32_t)(~(uint32_t)key) : -1;
+            a.out_val[(int64_t)row * ntop + q] = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
+        }
+        wave_sync();
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 
 struct K3SymState {
@@ -435,6 +488,7 @@ struct K3SymState {
     int32_t *push_cnt = nullptr;
     uint64_t *push_buf = nullptr;
     int32_t *ovf = nullptr;
+    uint64_t *part = nullptr;
     // the running session: the next range must start where the last one ended, with the same job
     int64_t next_row = -1;
     uint64_t a_serial = 0;
@@ -454,6 +508,7 @@ void k3_sym_free(pfz_index *ix)
     if (s->push_cnt) pool_free(s->push_cnt);
     if (s->push_buf) pool_free(s->push_buf);
     if (s->ovf) pool_free(s->ovf);
+    if (s->part) pool_free(s->part);
     delete s;
     ix->sym = nullptr;
 }
@@ -504,8 +559,9 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
         PFZ_TRY(pool_alloc(ctx, &s->push_cnt, (size_t)n * sizeof(int32_t)));
         PFZ_TRY(pool_alloc(ctx, &s->push_buf, (size_t)n * kSymPush * sizeof(uint64_t)));
         PFZ_TRY(pool_alloc(ctx, &s->ovf, (size_t)(n + 1) * sizeof(int32_t)));
+        PFZ_TRY(pool_alloc(ctx, &s->part, (size_t)kSymSlicedRows * kSymSlices * kSymKeep * sizeof(uint64_t)));
     }
-    if (!s->thrv || !s->thr16 || !s->keys || !s->push_cnt || !s->push_buf || !s->ovf) {
+    if (!s->thrv || !s->thr16 || !s->keys || !s->push_cnt || !s->push_buf || !s->ovf || !s->part) {
         set_error("pfz_cossim_topn (symmetric): the session buffers of this index could not be allocated earlier");
         return PFZ_ERR_INVALID;
     }
@@ -529,6 +585,10 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.push_cnt = s->push_cnt;
     a.push_buf = s->push_buf;
     a.ovf = s->ovf;
+    a.part = s->part;
+    a.ovf_base = 0;
+    a.ovf_max = 0;
+    a.n_sl = 1;
     a.out_idx = out->idx;
     a.out_val = out->val;
     a.exp = sym_env_int("PFZ_K3_SYM_EXP", 0);
@@ -557,7 +617,23 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)row_end;
     hipLaunchKernelGGL(k3_sym_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3((unsigned)ctx->prop.multiProcessorCount * 16), dim3(64), 0, ctx->stream, a);
+    // pass 2: the first kSymSlicedRows of the listed rows in slices of the to-blocks (a whole row is ~100 us of one wave: a handful
+    // of rows would cost that much wall time), their partial lists merged; whatever is listed beyond, as whole rows
+    {
+        const unsigned grid2 = (unsigned)ctx->prop.multiProcessorCount * 16;
+        const int per = (nb + kSymSlices - 1) / kSymSlices;
+        a.n_sl = (nb + per - 1) / per;
+        a.ovf_base = 0;
+        a.ovf_max = kSymSlicedRows;
+        if (a.n_sl > 1) {
+            hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL(k3_sym_merge_slices, dim3(256), dim3(256), 0, ctx->stream, a);
+            a.ovf_base = kSymSlicedRows;
+        }
+        a.n_sl = 1;
+        a.ovf_max = (int32_t)n;
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
+    }
     PFZ_HIP(hipGetLastError());
     s->next_row = row_end;
     s->launches += 1;
