@@ -207,7 +207,12 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
  * are empty).  skip_idx (host, one entry per from-string of the whole list, or
  * NULL) restates list.remove(from_string) of the self-match path
  * (_distance.py:93-96): skip_idx[i] is the index of the FIRST to-entry equal
- * to from-string i (-1: none) and is not a candidate for row i.
+ * to from-string i (-1: none) and is not a candidate for row i.  A code
+ * skip_idx[i] <= -2 leaves out EVERY to-entry up to and including -2 - skip_idx[i]:
+ * the RapidFuzz matcher's shared list that shrinks as its rows are processed
+ * (_rapidfuzz.py:103-104 with n_jobs = 1: -2 - i for row i); a row that is left
+ * without a candidate gets index -1, score 0.  One call uses one of the two
+ * forms (entries >= 0, or codes <= -2; -1 goes with either): PFZ_ERR_INVALID otherwise.
  * Rows [from_begin, from_end) are scored (a row shard); out_idx / out_score
  * are host buffers of from_end - from_begin entries.  Blocks. */
 int pfz_indel_argmax(pfz_ctx *ctx, const pfz_strings *from_strings, const pfz_strings *to_strings,
@@ -245,7 +250,8 @@ int pfz_indel_plan_info(pfz_ctx *ctx, const pfz_strings *to_strings, int64_t *n_
  * scorer: 0 WRatio, 1 partial_ratio, 2 token_set_ratio, 3 token_ratio, 4 partial_token_sort_ratio,
  * 5 partial_token_set_ratio, 6 partial_token_ratio (ratio / QRatio / token_sort_ratio are one string per list
  * element: pfz_indel_argmax).  skip_idx (host, one entry per from-string of the whole list, or NULL): a to-index
- * left out for from-string i (self-match: the first list element equal to it, _rapidfuzz.py:103-104).
+ * left out for from-string i (self-match: the first list element equal to it), or a code <= -2: every to-index up to
+ * and including -2 - skip_idx[i] is left out (the reference's shared, shrinking list, _rapidfuzz.py:103-104; see pfz_indel_argmax).
  * out_idx[i] = -1 / out_score[i] = 0 when there is no choice; scores are rapidfuzz's 0..100 float64.
  * Strings of any length and token count are accepted: from-strings beyond 256 characters or 32 distinct tokens (and
  * to-strings beyond 32 distinct tokens) take a general -- slow -- kernel.  out_idx / out_score: host buffers of

@@ -70,3 +70,34 @@ def sklearn_backend_match(from_list, to_list=None, top_n=1, n_gram_range=(3, 3),
     if timings is not None:
         timings.update({"vectorise_s": t1 - t0, "cosine_sort_s": t2 - t1, "frame_s": t3 - t2, "total_s": t3 - t0})
     return df
+
+
+def rapidfuzz_shared_list_self_match(names, scorer="WRatio", score_cutoff=0.0, use_c=True):
+    """The reference RapidFuzz matcher's self-match as its code runs it with n_jobs = 1 (polyfuzz/models/_rapidfuzz.py:86-113):
+    ONE copy of the list, `to_list.remove(from_string)` before every `process.extractOne(from_string, to_list, score_cutoff=
+    self.score_cutoff, scorer=self.scorer)` -- restated literally, list.remove included, so that what is left of the list is
+    whatever Python leaves.  Returns (From, To (None = no match), Similarity = score / 100), lists of len(names).
+    score_cutoff is the constructor's 0..1 value (the class multiplies by 100).  use_c: the scorers of fuzz_scorers.c
+    (== fuzz_scorers.py bit for bit) instead of the Python ones -- the same numbers, fast enough for a few thousand names."""
+    from . import fuzz_scorers, native
+    to_list = list(names)
+    cut = score_cutoff * 100
+    frm, to, sim = [], [], []
+    for s in names:
+        to_list.remove(s)
+        best_j, best = -1, 0.0
+        if to_list:
+            if use_c:
+                idx, score = native.fuzz_extract_one([s], to_list, scorer)
+                best_j, best = int(idx[0]), float(score[0])
+            else:
+                idx, score = fuzz_scorers.extract_one_all([s], to_list, fuzz_scorers.SCORERS[scorer])
+                best_j, best = idx[0], score[0]
+        frm.append(s)
+        if best_j >= 0 and best >= cut:            # extractOne: the first best choice, None below score_cutoff
+            to.append(to_list[best_j])
+            sim.append(best / 100)
+        else:
+            to.append(None)
+            sim.append(0.0)
+    return frm, to, sim

@@ -80,7 +80,8 @@ struct IndelArgs {
     const int32_t *b_len;      // [n_groups*64]
     const int32_t *b_orig;     // [n_groups*64] original to-index, -1 = padding lane
     int32_t n_groups;
-    const int32_t *skip_idx;   // [n_from] or NULL
+    const int32_t *skip_idx;   // [n_from] or NULL (decoded: pfz_internal.h decode_skip_codes)
+    int32_t skip_up_to;        // 0: choice skip_idx[row] is left out; 1: every choice up to skip_idx[row] is
     int32_t n_sym1;            // alphabet size + 1 (symbol 0 = padding)
     int64_t from_begin;
     int64_t n_to;
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(256) void k4_indel_kernel(IndelArgs A)
             const int orig = A.b_orig[slot];
             if (orig >= 0) {
                 const int lb = A.b_len[slot];
-                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = choice_left_out(orig, skip) ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
-                if (!choice_left_out(orig, skip)) {
+                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = choice_left_out(orig, skip, A.skip_up_to) ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
+                if (!choice_left_out(orig, skip, A.skip_up_to)) {
                     if (m + lb == 0) take(best, 1, 1, orig);
                     else take(best, lcs, m + lb, orig);
                 }
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, NS == 8 ? 6 : 7) void k4_indel_quad_kernel(Ind
                     // (the per-pair epilogue was 28 % of the kernel, what-if build 2)
                     const uint32_t l = mul_u24((uint32_t)l_a, (uint32_t)best[k].mx), r = mul_u24((uint32_t)best[k].lcs, (uint32_t)m_a);
                     bool wins = (l > r) | ((l == r) & (orig < best[k].idx));
-                    if (A.skip_idx) wins = wins & !choice_left_out(orig, skip[k]);
+                    if (A.skip_idx) wins = wins & (A.skip_up_to ? orig > skip[k] : orig != skip[k]);
                     best[k].lcs = wins ? l_a : best[k].lcs;
                     best[k].mx = wins ? m_a : best[k].mx;
                     best[k].idx = wins ? orig : best[k].idx;
@@ -478,8 +479,8 @@ __global__ __launch_bounds__(256) void k4_indel_general_kernel(IndelArgs A, int3
             const int orig = A.b_orig[slot];
             if (orig >= 0) {
                 const int lb = A.b_len[slot];
-                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = choice_left_out(orig, skip) ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
-                if (!choice_left_out(orig, skip)) {
+                if (A.matrix) A.matrix[((int64_t)row - A.from_begin) * A.n_to + orig] = choice_left_out(orig, skip, A.skip_up_to) ? -1.0 : ratio_of(lcs, (int64_t)m + lb);
+                if (!choice_left_out(orig, skip, A.skip_up_to)) {
                     if (m + lb == 0) take(best, 1, 1, orig);
                     else take(best, lcs, m + lb, orig);
                 }
@@ -746,9 +747,13 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
     for (DevBuf *b : {&d_skip, &d_oidx, &d_oscore, &d_matrix, &d_rows[0], &d_rows[1], &d_rows[2], &d_rows[3], &d_rows[4], &d_rows[5],
                       &d_rows[6], &d_pm, &d_v})
         b->ctx = ctx;
+    int skip_up_to = 0;
     if (skip_idx) {
+        std::vector<int32_t> codes(skip_idx, skip_idx + F->n);
+        skip_up_to = decode_skip_codes(codes);
+        PFZ_REQUIRE(skip_up_to >= 0, "pfz_indel_argmax: skip_idx mixes single choices (>= 0) and 'up to' codes (<= -2)");
         PFZ_TRY(d_skip.alloc((size_t)F->n * sizeof(int32_t)));
-        PFZ_TRY(copy_h2d(ctx, d_skip.p, skip_idx, (size_t)F->n * sizeof(int32_t)));
+        PFZ_TRY(copy_h2d(ctx, d_skip.p, codes.data(), (size_t)F->n * sizeof(int32_t)));
     }
     PFZ_TRY(d_oidx.alloc((size_t)n_rows * sizeof(int32_t)));
     PFZ_TRY(d_oscore.alloc((size_t)n_rows * sizeof(double)));
@@ -767,6 +772,7 @@ static int indel_run(pfz_ctx *ctx, const pfz_strings *F, const pfz_strings *T_c,
     A.b_orig = pl->b_orig;
     A.n_groups = (int32_t)pl->n_groups;
     A.skip_idx = skip_idx ? (const int32_t *)d_skip.p : nullptr;
+    A.skip_up_to = skip_up_to;
     A.n_sym1 = pl->n_sym + 1;
     A.from_begin = begin;
     A.n_to = n_to;

@@ -28,7 +28,8 @@ struct FuzzArgs {
     const int32_t *big_slots;    // general kernel: only these to-slots (n_big > 0), else all
     int32_t n_big;
     int32_t n_groups, n_sym1, mode;
-    const int32_t *skip_idx;     // [n_from] or NULL
+    const int32_t *skip_idx;     // [n_from] or NULL (decoded: pfz_internal.h decode_skip_codes)
+    int32_t skip_up_to;          // 0: choice skip_idx[row] is left out; 1: every choice up to skip_idx[row] is
     // every launch leaves the best of its (row, part) in part_*[row_slot * n_parts_total + part0 + part]
     int32_t parts, part0, n_parts_total;
     const int32_t *row_slot;     // [n_rows] position of the row in the output range

@@ -943,7 +943,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         };
         auto bound_of = [&](const Meta &x, bool &valid, bool &coarse) -> float {
             const int4 m = x.m;
-            valid = x.m2.w >= 0 && !choice_left_out(x.m2.w, skip) && m.w <= kFuzzMaxTokens;
+            valid = x.m2.w >= 0 && !choice_left_out(x.m2.w, skip, A.skip_up_to) && m.w <= kFuzzMaxTokens;
             const FuzzSummary sb = summary_of(x);
             const int uu = fz_common_chars(sa, sb);
             const bool maybe = use_tokens && (sa.sig & sb.sig) != 0ull;
@@ -1404,9 +1404,13 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         }
         a_tok_id = (const int32_t *)d_aid.p;
     }
+    int skip_up_to = 0;
     if (skip_idx) {
+        std::vector<int32_t> codes(skip_idx, skip_idx + F->n);
+        skip_up_to = decode_skip_codes(codes);
+        PFZ_REQUIRE(skip_up_to >= 0, "pfz_fuzz_extract_one: skip_idx mixes single choices (>= 0) and 'up to' codes (<= -2)");
         PFZ_TRY(d_skip.alloc((size_t)F->n * sizeof(int32_t)));
-        PFZ_TRY(copy_h2d(ctx, d_skip.p, skip_idx, (size_t)F->n * sizeof(int32_t)));
+        PFZ_TRY(copy_h2d(ctx, d_skip.p, codes.data(), (size_t)F->n * sizeof(int32_t)));
     }
     if (h_counters) {
         PFZ_TRY(d_counters.alloc(4 * sizeof(unsigned long long)));
@@ -1474,6 +1478,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
     A.n_sym1 = pl->n_sym + 1;
     A.mode = scorer;
     A.skip_idx = skip_idx ? (const int32_t *)d_skip.p : nullptr;
+    A.skip_up_to = skip_up_to;
     A.counters = h_counters ? (unsigned long long *)d_counters.p : nullptr;
 
     // how many workgroups share a from-string's to-groups (few from-strings: split, as K4 does), per class; then one slot for

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k7_general_kernel(FuzzArgs A, GeneralScra
             const int slot = A.n_big > 0 ? A.big_slots[k] : (int)k;
             const int4 m = A.b_meta[slot];
             const int orig = A.b_meta2[slot].w;
-            if (orig < 0 || choice_left_out(orig, skip)) continue;
+            if (orig < 0 || choice_left_out(orig, skip, A.skip_up_to)) continue;
             const int4 rec = A.b_meta3[slot];
             const int lb[3] = {m.x, m.y, m.z}, tb = m.w;
             Seq fb[3];

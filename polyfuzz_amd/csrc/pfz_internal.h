@@ -167,11 +167,25 @@ struct pfz_tfidf {
 
 namespace pfz {
 
-// Skip codes of the best-choice kernels (K4 / K7, `skip_idx[from-row]`): -1 = no choice is left out; s >= 0 = choice s is (a
-// self-match leaves out the from-string's own first occurrence, reference _distance.py:93-96); s <= -2 = every choice up
+// Skip codes of the best-choice kernels (K4 / K7, `skip_idx[from-row]`, host): -1 = no choice is left out; s >= 0 = choice s is
+// (a self-match leaves out the from-string's own first occurrence, reference _distance.py:93-96); s <= -2 = every choice up
 // to and including -2 - s is -- the reference RapidFuzz matcher's shared, shrinking list (_rapidfuzz.py:103-104 with
-// n_jobs = 1: when row i is scored the rows 0 .. i have been removed).
-__host__ __device__ inline bool choice_left_out(int orig, int skip) { return orig == skip || orig <= -2 - skip; }
+// n_jobs = 1: when row i is scored the rows 0 .. i have been removed).  One call uses one of the two forms (-1 goes with
+// either): decode_skip_codes() says which -- 0: "equal", the array as it is; 1: "up to", the array rewritten to the last
+// choice left out (-1: none); -1: both forms in one array (refused) -- and the kernels test choice_left_out(orig, s, up_to).
+inline int decode_skip_codes(std::vector<int32_t> &v)
+{
+    bool eq = false, le = false;
+    for (int32_t x : v) {
+        eq |= x >= 0;
+        le |= x <= -2;
+    }
+    if (eq && le) return -1;
+    if (!le) return 0;
+    for (int32_t &x : v) x = x <= -2 ? -2 - x : -1;
+    return 1;
+}
+__host__ __device__ inline bool choice_left_out(int orig, int s, int up_to) { return up_to ? orig <= s : orig == s; }
 
 // Owns a half-built object until the entry point succeeds: an error return (PFZ_TRY / PFZ_HIP /
 // PFZ_REQUIRE) releases it through its own free function instead of leaking the device buffers.

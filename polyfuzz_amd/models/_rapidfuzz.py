@@ -16,10 +16,13 @@ rapidfuzz 3.x semantics: no default processor (strings are scored as given).  An
 Strings of any length and token count are accepted; from-strings beyond 256 characters or 32 distinct tokens (and
 to-strings beyond 32 distinct tokens) take K7's general kernel, which is slow.
 
-Deviation, on purpose: the reference removes the from-string from ONE shared copy of the list
-(`to_list.remove(from_string)`, _rapidfuzz.py:103-104), so with n_jobs=1 the list shrinks as rows are processed
-and later from-strings can no longer match earlier ones.  Here a self-match excludes only the first list element
-equal to the from-string, for that from-string (the behaviour of EditDistance, _distance.py:93-96).
+Self-match.  The reference removes the from-string from ONE shared copy of the list (`to_list.remove(from_string)`,
+_rapidfuzz.py:103-104), so with n_jobs=1 the list shrinks as rows are processed: row i is scored against the strings AFTER
+it only, the last row against nothing.  By default a self-match here excludes only the first list element equal to the
+from-string, for that from-string (the behaviour of EditDistance, _distance.py:93-96; SURVEY App. B calls the shrinking list
+a bug).  `reference_self_match = True` (attribute, or keyword of `match`) reproduces the reference's frame instead -- on the
+device: every choice up to and including the row itself is left out (skip codes, csrc/pfz_internal.h) -- held to frames of
+the reference class itself (tests/golden/make_golden_rapidfuzz_self.py).
 
 PARITY UNPINNED: rapidfuzz is not installable in the build container; the scorer is the oracle's restatement
 (oracle/indel.c), extractOne's tie / cut-off rules are restated from rapidfuzz's documentation.
@@ -47,6 +50,11 @@ def _scorer_name(scorer) -> str:
     if "rapidfuzz" not in (getattr(scorer, "__module__", "") or ""):
         return repr(scorer)
     return getattr(scorer, "__name__", repr(scorer))
+
+
+def _left_out(choice: int, skip: int) -> bool:
+    """the skip codes of the best-choice kernels (csrc/pfz_internal.h: choice_left_out)"""
+    return choice == skip or choice <= -2 - skip
 
 
 def _transform(name, strings):
@@ -96,7 +104,7 @@ def best_choice_async(ctx, name, from_list, names, skip, self_match, to_dev=None
                 # QRatio differs from ratio only when BOTH strings are empty (0 instead of 100): an empty from-string
                 # scores 0 against every choice, so its first best is simply its first choice
                 for i in [i for i, s in enumerate(from_list) if len(s) == 0]:
-                    first_choice = next((j for j in range(len(names)) if not (skip is not None and j == skip[i])), -1)
+                    first_choice = next((j for j in range(len(names)) if not (skip is not None and _left_out(j, int(skip[i])))), -1)
                     idx[i], score[i] = first_choice, 0.0
     return _PendingBest(out, n, fix)
 
@@ -133,6 +141,7 @@ class RapidFuzz(BaseMatcher):
         self.scorer = scorer
         self._scorer_name = name
         self.n_jobs = n_jobs
+        self.reference_self_match = False        # True: a self-match as the reference's shared, shrinking list gives it (n_jobs = 1)
         self._to_dev = self._to_names = None     # device copy (+ cached plan) of the last to-list
 
     def match(self,
@@ -155,7 +164,11 @@ class RapidFuzz(BaseMatcher):
         names = from_list if self_match else to_list
         n = len(from_list)
         skip = None
-        if self_match:
+        if self_match and kwargs.get("reference_self_match", self.reference_self_match):
+            # _rapidfuzz.py:86-104 with n_jobs = 1: when row i is scored, list.remove has taken the rows 0 .. i out of the shared
+            # list (the first remaining element equal to from_list[i] is row i itself), and what is left keeps its order
+            skip = (-2 - np.arange(n, dtype=np.int64)).astype(np.int32)
+        elif self_match:
             first = {}
             for j, s in enumerate(names):
                 first.setdefault(s, j)

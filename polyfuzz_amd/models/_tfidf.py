@@ -26,15 +26,21 @@ _SPLIT_MIN_ROWS = 20000      # from-rows from which match() pipelines several K3
 _SPLIT_EVENT = 56            # context event slots 56 .. : launch i done
 # shares of the from-rows per launch: the last part's columns are built AFTER the device has finished, so it is the small one
 _SPLIT_SHARES = {2: (0.6, 0.4), 5: (0.4, 0.3, 0.2, 0.1)}      # (profiles/experiments/r04_match_split_probe.txt)
+# a list against itself runs K3's symmetric form (csrc/k3_symmetric.hip): a row only walks the to-blocks from its own upwards, so
+# the first rows are the expensive ones and the ranges are cut accordingly (profiles/experiments/r04_match_split_symmetric.txt)
+_SPLIT_SHARES_SELF = (0.3, 0.3, 0.25, 0.15)
+_SYMMETRIC_ROWS = (32768, 250000)       # the list sizes K3 takes in its symmetric form (pfz_cossim_topn, include/polyfuzz_hip.h)
 
 
-def _split_shares(n):
+def _split_shares(n, self_match=False):
     """shares of the from-rows per K3 launch of a big match (PFZ_MATCH_SHARES=0.4,0.3,0.2,0.1 overrides: tuning)"""
     env = os.environ.get("PFZ_MATCH_SHARES")
     if env:
         sh = tuple(float(x) for x in env.split(","))
         if len(sh) >= 1 and all(x > 0 for x in sh) and len(sh) <= 8:
             return tuple(x / sum(sh) for x in sh)
+    if self_match and _SYMMETRIC_ROWS[0] <= n <= _SYMMETRIC_ROWS[1] and n >= 2 * _SPLIT_MIN_ROWS and os.environ.get("PFZ_K3_SYM") != "0":
+        return _SPLIT_SHARES_SELF
     return _SPLIT_SHARES[5 if n >= 2 * _SPLIT_MIN_ROWS else 2]
 
 
@@ -158,7 +164,7 @@ class TFIDF(BaseMatcher):
         # the last part's columns are built after the device has finished
         split = n >= _SPLIT_MIN_ROWS and top_n >= 1 and _lib._pack is not None and isinstance(names, (list, tuple))
         if split:
-            shares = _split_shares(n)
+            shares = _split_shares(n, self_match)
             n_parts, cuts, acc = len(shares), [0], 0.0
             for f in shares[:-1]:
                 acc += f

@@ -298,7 +298,8 @@ class BestChoiceJob:
             if self.scorer == "QRatio":
                 for i, s in enumerate(self.from_shard):
                     if len(s) == 0:
-                        first = next((j for j in range(len(self.to_list)) if not (self.skip is not None and j == self.skip[i])), -1)
+                        first = next((j for j in range(len(self.to_list))
+                                      if not (self.skip is not None and (j == self.skip[i] or j <= -2 - int(self.skip[i])))), -1)
                         self._qfix.append((i, first))
         return self._qfix
 

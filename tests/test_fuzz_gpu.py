@@ -362,3 +362,34 @@ def test_rapidfuzz_pin_fixture(ctx):
         np.testing.assert_array_equal(np.array(got), np.array(pin["pair_scores"][name]), err_msg=name)
     for rec in pin["wratio_ratio8"]["pairs"]:                # the chosen reading of the 8x gate, by name
         assert float(best_choice(ctx, "WRatio", [rec["a"]], [rec["b"]], None, False)[1][0]) == rec[pin["wratio_ratio8"]["chosen"]]
+
+
+def test_rapidfuzz_reference_self_match(ctx):
+    """RapidFuzz.match(names, reference_self_match=True): the reference's shared, shrinking list (_rapidfuzz.py:103-104, n_jobs
+    = 1) on the device -- skip code -2 - i leaves out every choice up to row i itself.  Against frames of the REFERENCE CLASS
+    (tests/golden/rapidfuzz_selfmatch_golden.json: the oracle's scorers stubbed in for rapidfuzz) and, on 1 500 real titles with
+    repeats, against the literal restatement over the C scorers; K4 (ratio) and K7 (WRatio, token_set_ratio, partial_ratio)."""
+    import json
+    import os
+    from oracle import reference_path
+    from polyfuzz_amd.models import RapidFuzz
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = json.load(open(os.path.join(here, "golden", "rapidfuzz_selfmatch_golden.json"), encoding="utf-8"))
+    for case in g["cases"]:
+        names = g["names"][:case["n"]] if "n" in case else g["names"]
+        m = RapidFuzz(score_cutoff=case["score_cutoff"], scorer=case["scorer"])
+        m.reference_self_match = True
+        df = m.match(list(names))
+        assert df["From"].tolist() == case["From"]
+        assert df["To"].tolist() == case["To"], (case["scorer"], case["score_cutoff"])
+        assert df["Similarity"].tolist() == case["Similarity"]
+        if "n" not in case:     # the default stays what it was: only the row's own first occurrence is left out
+            assert RapidFuzz(score_cutoff=case["score_cutoff"], scorer=case["scorer"]).match(list(names))["To"].tolist() != case["To"]
+    from polyfuzz_amd import datasets
+    titles = list(datasets.load_movie_titles().values())[0]
+    names = titles[:1450] + titles[100:150]            # repeats: list.remove takes the first equal element left
+    for scorer, cutoff in (("WRatio", 0.0), ("ratio", 0.55)):
+        frm, to, sim = reference_path.rapidfuzz_shared_list_self_match(names, scorer, cutoff)
+        df = RapidFuzz(score_cutoff=cutoff, scorer=scorer).match(list(names), reference_self_match=True)
+        assert df["To"].tolist() == to
+        assert df["Similarity"].tolist() == sim

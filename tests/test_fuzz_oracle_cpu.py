@@ -132,3 +132,25 @@ def test_real_rapidfuzz_when_importable(oracle_mod):
     import pin_rapidfuzz
     a, b = pin_rapidfuzz.strings()
     assert pin_rapidfuzz.diff(pin_rapidfuzz.from_rapidfuzz(a, b), pin_rapidfuzz.from_oracle(a, b)) == []
+
+
+def test_shared_list_self_match_restatement_equals_the_reference_class():
+    """oracle.reference_path.rapidfuzz_shared_list_self_match (the literal restatement of _rapidfuzz.py:86-113 with n_jobs = 1:
+    one shared list that shrinks) against frames the REFERENCE CLASS produced in the build container with the oracle's scorers
+    stubbed in for rapidfuzz (tests/golden/make_golden_rapidfuzz_self.py): From / To cell for cell, Similarity bit for bit --
+    with the Python scorers and with the C ones."""
+    import json
+    import os
+    from oracle import reference_path
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rapidfuzz_selfmatch_golden.json"),
+                       encoding="utf-8"))
+    for case in g["cases"]:
+        names = g["names"][:case["n"]] if "n" in case else g["names"]
+        for use_c in (True, False):
+            if not use_c and case["scorer"] not in ("ratio", "WRatio") :
+                continue                                  # (the Python scorers are slow: two scorers do)
+            frm, to, sim = reference_path.rapidfuzz_shared_list_self_match(names, case["scorer"], case["score_cutoff"], use_c=use_c)
+            assert frm == case["From"]
+            assert to == case["To"], (case["scorer"], case["score_cutoff"])
+            assert sim == case["Similarity"]
+        assert to[-1] is None and sim[-1] == 0.0          # the last row has nothing left to match

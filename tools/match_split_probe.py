@@ -14,6 +14,7 @@ if len(sys.argv) > 1:      # python tools/match_split_probe.py 0.4,0.3,0.2,0.1 0
     SHARES = [tuple(float(x) for x in a.split(",")) for a in sys.argv[1:]]
 for shares in SHARES:
     _tfidf._SPLIT_SHARES[5] = shares
+    _tfidf._SPLIT_SHARES_SELF = shares
     m = TFIDF(min_similarity=0, top_n=5)
     for _ in range(3):
         m.match(names)
