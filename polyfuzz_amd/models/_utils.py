@@ -66,6 +66,21 @@ class FrameBuilder:
         self.from_col = object_column(from_list) if from_col is None else from_col
         self.names = [np.empty(self.n, dtype=object) for _ in range(top_n)]
         self.sims = [np.empty(self.n, np.float64) for _ in range(top_n)]
+        # The DataFrame is wrapped around the (still empty) columns NOW -- the caller is waiting for the device anyway, and
+        # pandas takes ~0.5 ms to look at eleven 100 000-element columns -- and `fill` writes through the arrays it shares
+        # with them.  Only if this pandas really shares them (copy=False is a request): otherwise frame() builds it at the end.
+        self._frame = None
+        if self.n and top_n and os.environ.get("PFZ_EARLY_FRAME", "1") != "0":
+            # (pandas scans an object column for date-likes until it meets a non-null: an all-None column is scanned to its end.
+            # The first slot holds a string while the frame is made, and None again before anything is filled in)
+            for a in self.names:
+                a[0] = ""
+            f = self._wrap()
+            for a in self.names:
+                a[0] = None
+            if np.shares_memory(f["To"].values, self.names[0]) and np.shares_memory(f["Similarity"].values, self.sims[0]) and \
+                    np.shares_memory(f.iloc[:, -1].values, self.sims[-1]):
+                self._frame = f
 
     def fill(self, idx, val, row0=0):
         m = len(idx)
@@ -77,12 +92,15 @@ class FrameBuilder:
                                 tuple(a.ctypes.data + 8 * row0 for a in self.names),
                                 tuple(a.ctypes.data + 8 * row0 for a in self.sims), _FILL_THREADS)
 
-    def frame(self):
+    def _wrap(self):
         data = {"From": self.from_col}
         for r in range(self.top_n):
             data["To" if r == 0 else f"To_{r + 1}"] = self.names[r]
             data["Similarity" if r == 0 else f"Similarity_{r + 1}"] = self.sims[r]
         return pd.DataFrame(data, copy=False)
+
+    def frame(self):
+        return self._frame if self._frame is not None else self._wrap()
 
 
 def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_list: List[str],
