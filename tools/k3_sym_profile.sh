@@ -1,7 +1,7 @@
 #!/bin/bash
-# second GPU run of K3's symmetric form: where its time goes.  Per-pass kernel times (rocprofv3 --kernel-trace --stats), what-if
-# builds of the second filter (PFZ_K3_SYM_EXP: results wrong on purpose), one PMC pass.  usage (GPU box): bash tools/r4_sym2.sh
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r4_sym2; mkdir -p $O
+# K3's symmetric form (csrc/k3_symmetric.hip): where its time goes.  Per-pass kernel times (rocprofv3 --kernel-trace --stats), what-if
+# builds of the second filter (PFZ_K3_SYM_EXP: results wrong on purpose), one PMC pass.  usage (GPU box): bash tools/k3_sym_profile.sh
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/k3_sym_profile; mkdir -p $O
 B="python bench.py --no-configs --steps 10 --warmup 2 --no-cpu-baseline --no-match-wall"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/stats -o bench -- $B > $O/stats.log 2>&1; echo "stats rc=$?"
 python tools/rocprof_summary.py $O/stats/bench_results.db 2>&1 | head -14 | cut -c1-130
