@@ -132,7 +132,8 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
  * itself -- lists of 32 768 to 250 000 rows (ntop <= 32) take the symmetric form: C is symmetric bit for bit in this
  * arithmetic, so every unordered pair of rows is scored once and handed to both rows; same results (PFZ_K3_SYM=0 / 1:
  * never / whenever possible).
- * Limits: 1 <= ntop <= 1024 (PFZ_ERR_UNSUPPORTED beyond; above 128 a larger, slower candidate buffer); fewer than 2^25
+ * Limits: ntop >= 1 (above 128 a larger, slower candidate buffer; above 1024 passes of 1024, each continuing below the
+ * last key of the one before -- the reference clips top_n to the number of distinct to-strings only, _utils.py:54-56); fewer than 2^25
  * 16-posting index pieces (4 GiB) in the to-side; n_cols equal on both sides.  `out` may have MORE rows than the from-matrix (a padded
  * shard buffer for the equal-sized all-gather): the extra rows are not touched.
  * Enqueues on the context stream. */

@@ -152,14 +152,17 @@ __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane,
 }
 
 // push the entries of one int4 (columns j0..j0+3) that beat the threshold
-template <int kCap>
-__device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0, int self_col, int ntop, int lane)
+// (kBounded: ... and whose key is below `ub` -- the deep top-n of pfz_cossim_topn_rows asks for "the next 1024 after this key")
+template <int kCap, bool kBounded = false>
+__device__ inline void push4(uint64_t *cand, TopState &st, const int4 &v, int j0, int self_col, int ntop, int lane,
+                             uint64_t ub = ~0ull)
 {
     const int vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int j = j0 + c;
-        const bool pred = vv[c] > st.thr && j != self_col;
+        bool pred = vv[c] > st.thr && j != self_col;
+        if (kBounded) pred = pred && ((((uint64_t)(uint32_t)vv[c] << 32) | (uint32_t)(~j)) < ub);
         const uint64_t mk = __ballot(pred);
         if (mk) {
             const int pos = st.cnt + __popcll(mk & ((1ull << lane) - 1ull));
@@ -212,9 +215,9 @@ __device__ inline int warm_threshold(const int4 *acc4, int i_begin, int k, int l
 
 // Read, clear and filter one block of accumulators: int4 slots [0, N4) of the block whose first column is
 // col0.  (The accumulators start at LDS address 0.)
-template <int N4, int kCap>
+template <int N4, int kCap, bool kBounded = false>
 __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int col0, int self_col, int ntop, int lane,
-                                   int zero)
+                                   int zero, uint64_t ub = ~0ull)
 {
     static_assert(N4 % 128 == 0, "a wave sweeps whole 128-slot steps");
 #pragma unroll 2
@@ -228,8 +231,8 @@ __device__ inline void sweep_block(int4 *acc4, uint64_t *cand, TopState &st, int
         acc4[i1] = make_int4(zero, zero, zero, zero);
         const int mx = max3i(max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y), max3i(v1.z, v1.w, v1.w));
         if (__ballot(mx > st.thr)) {
-            push4<kCap>(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
-            push4<kCap>(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane);
+            push4<kCap, kBounded>(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane, ub);
+            push4<kCap, kBounded>(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane, ub);
         }
     }
 }

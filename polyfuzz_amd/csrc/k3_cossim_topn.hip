@@ -268,13 +268,15 @@ __global__ __launch_bounds__(1024) void k_index_fill_lds(const int32_t *__restri
 }
 
 // C to-rows per block; the (one-wave) workgroup owns one from-row at a time.
-template <int C, int kCap>
+// kBounded (the deep top-n, ntop > kMaxTop: pfz_cossim_topn_rows): only keys below ub[row] count -- "the next ntop after the
+// last key of the pass before" --, and the row's last key (0: the row is exhausted) replaces ub[row] at the end
+template <int C, int kCap, bool kBounded = false>
 __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
     const int32_t *__restrict__ a_indptr, const int32_t *__restrict__ a_idx, const float *__restrict__ a_val,
     int32_t n_a, const int32_t *__restrict__ tab, const int2 *__restrict__ post, int32_t nb, int32_t n_pieces,
     int32_t ntop, int32_t thr0, float scale, float inv_scale, int32_t exclude_diag, int64_t diag_offset,
     int32_t *__restrict__ out_idx, float *__restrict__ out_val, int32_t ablate, int32_t n_slices,
-    uint64_t *__restrict__ part_keys)
+    uint64_t *__restrict__ part_keys, uint64_t *__restrict__ ub = nullptr)
 {
     // accumulators first: this struct is the kernel's only LDS object, so they land at LDS address 0 and a
     // posting's byte offset IS its LDS address (run_steps)
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
             nxt0 = trow[b_first + 1];
         }
 
-        bool warmed = ablate == 3;   // (3: timing experiment without the threshold warm start)
+        bool warmed = ablate == 3 || kBounded;   // (3: timing experiment without the threshold warm start; the warm start counts sums a bound may exclude)
+        const uint64_t ub_row = kBounded ? ub[row] : ~0ull;
         for (int it = 0, b = b_first; it < n_blk; ++it) {
             const int s = cur0, e = have0 ? nxt0 : cur0;
             const int b_next = b + 1 < b_hi ? b + 1 : b_lo;
@@ -373,13 +376,14 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
                         st.thr = t > st.thr ? t : st.thr;
                     }
                 }
-                sweep_block<N4, kCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero);
+                sweep_block<N4, kCap, kBounded>(acc4, cand, st, b * C, self_col, ntop, lane, zero, ub_row);
                 wave_sync();      // acc is zero again
             }
             b = b_next;
         }
 
         compact<kCap>(cand, st, ntop, lane);
+        if (kBounded && lane == 0) ub[row] = st.cnt == ntop ? cand[ntop - 1] : 0ull;     // (fewer than ntop: nothing is left below)
         for (int r = lane; r < ntop; r += 64) {
             const uint64_t key = r < st.cnt ? cand[r] : 0ull;
             if (n_slices > 1) {   // partial result of this slice; k3_merge_slices finishes the row
@@ -484,6 +488,19 @@ __global__ __launch_bounds__(256) void k3_merge_slices(const uint64_t *__restric
         out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
         out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * inv_scale : 0.f;
     }
+}
+
+// deep top-n: the columns [col0, col0 + w) of a result whose rows are ntop wide <- a w-wide pass result
+__global__ __launch_bounds__(256) void k_topn_place(const int32_t *__restrict__ t_idx, const float *__restrict__ t_val, int64_t n_rows,
+                                                    int32_t w, int32_t ntop, int32_t col0, int32_t *__restrict__ out_idx,
+                                                    float *__restrict__ out_val)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * w) return;
+    const int64_t r = i / w;
+    const int c = (int)(i - r * w);
+    out_idx[r * ntop + col0 + c] = t_idx[i];
+    out_val[r * ntop + col0 + c] = t_val[i];
 }
 
 static int env_int(const char *name, int dflt)
@@ -650,10 +667,6 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
                 "pfz_cossim_topn_rows: rows [%lld, %lld) outside [0, %lld)", (long long)row_begin, (long long)row_end,
                 (long long)A->n_rows);
     PFZ_REQUIRE(ntop >= 1, "pfz_cossim_topn: ntop must be >= 1 (got %d)", ntop);
-    if (ntop > kMaxTop) {
-        set_error("pfz_cossim_topn: ntop=%d exceeds the kernel's limit of %d", ntop, kMaxTop);
-        return PFZ_ERR_UNSUPPORTED;
-    }
     PFZ_REQUIRE(A->n_cols == ix->n_cols, "pfz_cossim_topn: from-matrix has %lld columns, index has %lld",
                 (long long)A->n_cols, (long long)ix->n_cols);
     PFZ_REQUIRE(out->n_rows >= A->n_rows && out->ntop == ntop, "pfz_cossim_topn: result buffer is %lldx%d, need %lldx%d",
@@ -671,6 +684,45 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     const float scale = (float)ldexp(1.0, k), inv_scale = (float)ldexp(1.0, -k);
     const double thr_d = floor((double)lower_bound * (double)scale);
     const int32_t thr0 = thr_d >= 2147483000.0 ? 2147483000 : (int32_t)thr_d;
+    if (ntop > kMaxTop) {
+        // Deep top-n (the reference clips top_n to the number of distinct to-strings only, _utils.py:54-56): passes of kMaxTop.
+        // A pass keeps, per row, the kMaxTop best keys BELOW the last key of the pass before (keys are distinct: sum << 32 |
+        // ~column), so the passes continue each other exactly; a row that runs out of candidates is marked exhausted.
+        struct Tmp {
+            void *p = nullptr;
+            ~Tmp() { if (p) pool_free(p); }
+        } t_idx, t_val, ub;
+        PFZ_TRY(pool_alloc(ctx, &t_idx.p, (size_t)n_rows * kMaxTop * sizeof(int32_t)));
+        PFZ_TRY(pool_alloc(ctx, &t_val.p, (size_t)n_rows * kMaxTop * sizeof(float)));
+        PFZ_TRY(pool_alloc(ctx, &ub.p, (size_t)n_rows * sizeof(uint64_t)));
+        PFZ_HIP(hipMemsetAsync(ub.p, 0xff, (size_t)n_rows * sizeof(uint64_t), ctx->stream));
+        const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * 16 * 64 * 8;
+        const unsigned grid = (unsigned)(n_rows < max_grid ? n_rows : max_grid);
+        ProfScope ps(ctx, "k3_cossim_topn");
+        for (int32_t col0 = 0; col0 < ntop; col0 += kMaxTop) {
+            const int32_t w = ntop - col0 < kMaxTop ? ntop - col0 : kMaxTop;
+#define PFZ_K3_DEEP(CC)                                                                                                   \
+    hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, 1152, true>), dim3(grid), dim3(64), 0, ctx->stream, A->indptr + row_begin,     \
+                       A->indices, A->data, (int32_t)n_rows, ix->tab, ix->post, ix->n_blocks, ix->n_pieces, w, thr0, scale,      \
+                       inv_scale, exclude_diag, diag_offset + row_begin, (int32_t *)t_idx.p, (float *)t_val.p, 0, 1,              \
+                       (uint64_t *)nullptr, (uint64_t *)ub.p)
+            switch (ix->block_cols) {
+            case 1024: PFZ_K3_DEEP(1024); break;
+            case 1536: PFZ_K3_DEEP(1536); break;
+            case 2048: PFZ_K3_DEEP(2048); break;
+            case 4096: PFZ_K3_DEEP(4096); break;
+            default:
+                set_error("pfz_cossim_topn: no kernel for block size %d", ix->block_cols);
+                return PFZ_ERR_INVALID;
+            }
+#undef PFZ_K3_DEEP
+            hipLaunchKernelGGL(k_topn_place, dim3((unsigned)((n_rows * w + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const int32_t *)t_idx.p, (const float *)t_val.p, n_rows, w, ntop, col0, out->idx + row_begin * ntop,
+                               out->val + row_begin * ntop);
+        }
+        PFZ_HIP(hipGetLastError());
+        return PFZ_OK;
+    }
     // a list against itself: every unordered pair once (k3_symmetric.hip), whole jobs and ascending row ranges of one
     if (const int sym = k3_sym_wanted(ctx, ix, A, row_begin, row_end, ntop, thr0, scale, exclude_diag, diag_offset, out)) {
         ProfScope ps(ctx, "k3_cossim_topn");

@@ -9,6 +9,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 
@@ -257,26 +258,41 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
     if (!PyArg_ParseTuple(args, "OKKnnO!O!i", &names, &idx_addr, &val_addr, &n, &top_n, &PyTuple_Type, &obj_addrs,
                           &PyTuple_Type, &sim_addrs, &n_threads))
         return NULL;
-    if (n < 0 || top_n < 1 || top_n > 1024 || PyTuple_GET_SIZE(obj_addrs) != top_n || PyTuple_GET_SIZE(sim_addrs) != top_n) {
+    if (n < 0 || top_n < 1 || top_n > (1 << 24) || PyTuple_GET_SIZE(obj_addrs) != top_n || PyTuple_GET_SIZE(sim_addrs) != top_n) {
         PyErr_SetString(PyExc_ValueError, "fill_columns(): need top_n object and top_n float64 column addresses");
         return NULL;
     }
     PyObject *seq = PySequence_Fast(names, "fill_columns() expects a sequence of names");
     if (!seq) return NULL;
-    PyObject **obj[1024];
-    double *sim[1024];
+    /* (1024 column pairs on the stack; a deeper top_n -- the device side has no limit -- on the heap) */
+    PyObject **obj_stack[1024];
+    double *sim_stack[1024];
+    PyObject ***obj = obj_stack;
+    double **sim = sim_stack;
+    void *heap = NULL;
+    if (top_n > 1024) {
+        heap = malloc((size_t)top_n * (sizeof(PyObject **) + sizeof(double *)));
+        if (!heap) {
+            Py_DECREF(seq);
+            return PyErr_NoMemory();
+        }
+        obj = (PyObject ***)heap;
+        sim = (double **)((char *)heap + (size_t)top_n * sizeof(PyObject **));
+    }
     Py_ssize_t old_none = 0;
     for (Py_ssize_t r = 0; r < top_n; ++r) {
         obj[r] = (PyObject **)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(obj_addrs, r));
         sim[r] = (double *)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(sim_addrs, r));
         if (PyErr_Occurred()) {
             Py_DECREF(seq);
+            free(heap);
             return NULL;
         }
         for (Py_ssize_t i = 0; i < n; ++i) {
             if (obj[r][i] == Py_None) ++old_none;     /* np.empty(n, object) holds n references to None */
             else if (obj[r][i] != NULL) {
                 Py_DECREF(seq);
+                free(heap);
                 PyErr_SetString(PyExc_ValueError, "fill_columns(): the object columns must be fresh np.empty arrays");
                 return NULL;
             }
@@ -314,6 +330,7 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
     }
     release_overwritten_none(old_none);        /* the references the overwritten slots held */
     Py_DECREF(seq);
+    free(heap);
     Py_RETURN_NONE;
 }
 

@@ -104,7 +104,7 @@ class TFIDF(BaseMatcher):
         model_id: The name of the particular instance, used when comparing models
         remove_space_ngrams: Remove n-grams that contain a space
 
-    Limits of the device path (loud `PfzUnsupported`, there is no CPU fallback): top_n <= 1024 (beyond 128 with a larger, slower candidate buffer); n-grams whose
+    Limits of the device path (loud `PfzUnsupported`, there is no CPU fallback): (top_n: any; beyond 128 with a larger, slower candidate buffer, beyond 1024 in passes of 1024); n-grams whose
     code (n x bits per alphabet symbol) exceeds 64 bits, e.g. 11-grams of cleaned text; fewer than 2^28
     n-gram occurrences in the to-list.
     """

@@ -189,3 +189,21 @@ def test_balanced_bounds_cover_everything_and_balance_characters():
     assert balanced_bounds([], 4) == [(0, 0)] * 4
     assert [e - b for b, e in balanced_bounds(["a"], 3)] .count(1) == 1
     assert sum(e - b for b, e in balanced_bounds(["", "", ""], 2)) == 3
+
+
+def test_frame_beyond_1024_match_columns():
+    """top_n has no device-side limit any more (passes of 1024): the CPython frame helper keeps up -- 1 100 (To, Similarity)
+    column pairs from the heap instead of its 1024-entry stack arrays, equal to the numpy twin."""
+    from polyfuzz_amd import _lib
+    from polyfuzz_amd.models._utils import topn_to_frame, _topn_to_frame_numpy
+    if _lib._pack is None:
+        pytest.skip("_pack.so not built")
+    rng = np.random.default_rng(0)
+    names = [f"n{i}" for i in range(50)]
+    n, top = 40, 1100
+    idx = rng.integers(-1, 50, (n, top)).astype(np.int32)
+    val = rng.random((n, top)).astype(np.float32)
+    val[idx < 0] = 0
+    a = topn_to_frame(idx, val, names[:n], names, top)
+    b = _topn_to_frame_numpy(idx, val, names[:n], names, top)
+    assert a.shape == (n, 1 + 2 * top) and a.equals(b)

@@ -147,8 +147,54 @@ def test_bad_arguments(ctx):
     e3 = (np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
     with pytest.raises(PfzError):
         _lib.cossim_topn_host(ctx, e3, e3, 4, 0, 0.0)
-    with pytest.raises(NotImplementedError):
-        _lib.cossim_topn_host(ctx, e3, e3, 4, 1025, 0.0)
+    idx, val = _lib.cossim_topn_host(ctx, e3, e3, 4, 1025, 0.0)      # beyond 1024: passes of 1024 (no limit any more)
+    assert idx.shape == (1, 1025) and (idx == -1).all() and (val == 0).all()
+
+
+@pytest.mark.parametrize("ntop,lb,diag", [(1500, 0.0, False), (2300, 0.0, True), (1025, 0.1, False), (2048, 0.0, False)])
+def test_deep_top_n(ctx, oracle_mod, ntop, lb, diag):
+    """top_n beyond the 1024 keys one pass keeps (the reference clips top_n to the number of distinct to-strings only,
+    _utils.py:54-56): passes of 1024, each continuing strictly below the last key of the pass before -- against the oracle,
+    with exact ties across the pass boundary (duplicate to-rows), rows that run out of positive sums before top_n, a lower
+    bound, and the diagonal left out."""
+    rng = np.random.default_rng(314)
+    n_col = 60                                       # few columns: most pairs share one, rows have > 2000 positive sums
+    a3 = random_csr(rng, 300, n_col, 0.08, empty_rows=(4,))
+    b3 = random_csr(rng, 2600, n_col, 0.08, empty_rows=(7, 1000))
+    if diag:
+        a3 = b3
+    else:
+        # duplicate to-rows: equal sums in long runs, the column index decides -- also where a pass ends
+        bp, bi, bv = [np.array(x) for x in b3]
+        rows = [(bi[bp[r]:bp[r + 1]], bv[bp[r]:bp[r + 1]]) for r in range(len(bp) - 1)]
+        for r in range(50, 2600, 2):
+            rows[r] = rows[r % 40]
+        ptr = np.zeros(len(rows) + 1, np.int64)
+        for r, (c, _) in enumerate(rows):
+            ptr[r + 1] = ptr[r] + len(c)
+        b3 = (ptr, np.concatenate([c for c, _ in rows]).astype(np.int32), np.concatenate([v for _, v in rows]).astype(np.float64))
+    idx, val = _run(ctx, a3, b3, n_col, ntop, lb, diag)
+    exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col, ntop, lb, exclude_diag=diag)
+    assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, n_col, exclude_diag=diag)
+    # canonical order inside every row: scores descend, equal scores by ascending column
+    v64 = val.astype(np.float64)
+    assert (np.diff(v64, axis=1) <= 0).all()
+    same = (np.diff(v64, axis=1) == 0) & (idx[:, 1:] >= 0)
+    assert (np.diff(idx, axis=1)[same] > 0).all()
+    assert ((idx >= 0).sum(axis=1) < ntop).any()     # some rows do run out
+
+
+def test_tfidf_match_top_n_beyond_1024(ctx):
+    """TFIDF(top_n=1100).match on 1 300 real names: the frame has 1 + 2 * 1100 columns (top_n clipped to the distinct to-strings
+    as in the reference), its first columns equal the top-5 frame's."""
+    from polyfuzz_amd import datasets
+    from polyfuzz_amd.models import TFIDF
+    names = datasets.load_company_names()[:1300]
+    deep = TFIDF(min_similarity=0.0, top_n=1100).match(names[:200], names)
+    top5 = TFIDF(min_similarity=0.0, top_n=5).match(names[:200], names)
+    assert deep.shape == (200, 1 + 2 * 1100)
+    for c in top5.columns:
+        assert deep[c].tolist() == top5[c].tolist(), c
 
 
 @pytest.mark.parametrize("fa,fb", [(7.5, 3.0), (1e-3, 2e-2), (300.0, 1e-4)])

@@ -45,8 +45,18 @@ def test_k7_longer_classes(kernels):
 
 def test_k3_headline_kernel_keeps_18_workgroups_per_cu(kernels):
     """2048 accumulator columns + the 96-key candidate buffer: 8960 B; one more 256-B step is a workgroup per CU less."""
-    k = _one(kernels, "void pfz::k3_cossim_topn_kernel<2048, 96>(")
+    k = _one(kernels, "void pfz::k3_cossim_topn_kernel<2048, 96, false>(")
     assert k["lds"] <= 8960 and k["vgpr"] <= 72 and k["scratch"] == 0, k
+
+
+def test_k3_symmetric_passes_keep_their_workgroups_per_cu(kernels):
+    """k3_symmetric.hip: pass 1 carries the 128-entry staging buffer of the candidates it hands over (9984 B: 16 workgroups per
+    CU, and its registers must allow 4 waves per SIMD); passes 0 and 2 are the row-major kernel's size (18 per CU)."""
+    p1 = _one(kernels, "void pfz::k3_sym_kernel<2048, 1>(")
+    assert p1["lds"] <= 10240 and p1["vgpr"] <= 96 and p1["scratch"] == 0, p1
+    for mode in (0, 2):
+        k = _one(kernels, f"void pfz::k3_sym_kernel<2048, {mode}>(")
+        assert k["lds"] <= 9102 and k["vgpr"] <= 96 and k["scratch"] == 0, k
 
 
 def test_no_scratch_outside_k7(kernels):
