@@ -176,11 +176,12 @@ def test_deep_top_n(ctx, oracle_mod, ntop, lb, diag):
     idx, val = _run(ctx, a3, b3, n_col, ntop, lb, diag)
     exp_idx, exp_val = oracle_mod.cossim_topn(a3, b3, n_col, ntop, lb, exclude_diag=diag)
     assert_topn_parity(idx, val, exp_idx, exp_val, oracle_mod, a3, b3, n_col, exclude_diag=diag)
-    # canonical order inside every row: scores descend, equal scores by ascending column
-    v64 = val.astype(np.float64)
-    assert (np.diff(v64, axis=1) <= 0).all()
-    same = (np.diff(v64, axis=1) == 0) & (idx[:, 1:] >= 0)
-    assert (np.diff(idx, axis=1)[same] > 0).all()
+    # scores descend across the pass boundaries too (the order of exact ties -- by column -- is part of the parity check above;
+    # two DIFFERENT integer sums may round to the same fp32 score, so equal scores alone say nothing about the columns)
+    assert (np.diff(val.astype(np.float64), axis=1) <= 0).all()
+    for r in range(len(idx)):                        # no column twice in a row
+        got = idx[r][idx[r] >= 0]
+        assert len(set(got.tolist())) == len(got)
     assert ((idx >= 0).sum(axis=1) < ntop).any()     # some rows do run out
 
 
