@@ -48,14 +48,13 @@ constexpr int kSymKeep = 32;       // keys a row keeps between the passes at mos
 #define PFZ_K3_SYM_F 128           // (tuning knobs of tools/build_variant.sh)
 #endif
 #ifndef PFZ_K3_SYM_PUSH
-#define PFZ_K3_SYM_PUSH 256
+#define PFZ_K3_SYM_PUSH 512
 #endif
 constexpr int kSymF = PFZ_K3_SYM_F;         // staged foreign candidates per wave (flushed above kSymF - 64)
 constexpr int kSymPush = PFZ_K3_SYM_PUSH;   // push slots per row; a row that is sent more is recomputed in full
 constexpr int kSymMergeCap = kSymPush + 64;
 constexpr int kSymSlices = 8;      // pass 2: a row that is recomputed in full is cut into at most this many slices of to-blocks ...
 constexpr int kSymSlicedRows = 4096;   // ... for the first so many rows of the list (a single wave takes ~100 us for a whole row)
-constexpr int kSymExt = 4;         // pass 0: blocks beyond its own a weak row may look at for its first threshold
 
 struct K3SymArgs {
     const int32_t *a_indptr;
@@ -77,7 +76,6 @@ struct K3SymArgs {
     int32_t ovf_base, ovf_max, n_sl;   // pass 2: listed rows [ovf_base, ovf_base + ovf_max), each cut into n_sl slices (1: whole rows -> result)
     int32_t *out_idx;
     float *out_val;
-    int32_t weak_thr;         // pass 0: a row whose threshold is below this after its own block looks at up to kSymExt more blocks
     int32_t exp;              // timing experiments (PFZ_K3_SYM_EXP, results wrong on purpose): 1 = no second filter, 2 = no threshold loads, 4 = no publishing
 };
 
@@ -237,7 +235,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int row = mode == 2 ? a.ovf[1 + a.ovf_base + item / n_sl] : a.row_begin + item;
         const int own = row / C;
-        int b_lo = 0, b_hi = nb, b_first = own;      // (b_hi grows in an extended pass 0)
+        int b_lo = 0, b_hi = nb, b_first = own;
         if (mode == 2 && n_sl > 1) {
             b_lo = (item % n_sl) * per_sl;
             b_hi = b_lo + per_sl < nb ? b_lo + per_sl : nb;
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         int pub = st.thr;
         int fcnt = 0;
 
-        int n_blk = b_hi - b_lo;
+        const int n_blk = b_hi - b_lo;
         int cur0 = 0, nxt0 = 0;
         float as0 = 0.f;
         const bool have0 = lane < nnz;
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                         st.thr = t > st.thr ? t : st.thr;
                     }
                 }
-                #if PFZ_K3_SYM_TQ4
+#if PFZ_K3_SYM_TQ4
                 sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, qc, qd, fbuf, fcnt, a, inv_row, mode == 1 && !(a.exp & 1));
 #else
                 sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, tq_blk, fbuf, fcnt, a, inv_row, mode == 1 && !(a.exp & 1));
@@ -350,22 +348,6 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                 }
             }
             b = b_next;
-            if (mode == 0 && it + 1 == n_blk && n_blk <= kSymExt && b_hi < nb) {
-                // Pass 0, the row's last block so far: a row whose best matches are not in its own block (no ntop positive sums
-                // there, or weak ones) would start pass 1 with a threshold near 0 and be sent every non-zero sum of the list.
-                // It looks at the next block as well -- for the THRESHOLD only: the keys it writes are those of its own block,
-                // pass 1 finds the others again, and hands the block's sums over, as for every row.
-                compact<kSymCap>(cand, st, ntop, lane);
-                if (st.thr < a.weak_thr) {
-                    b = b_hi;
-                    ++b_hi;
-                    ++n_blk;
-                    if (have0) {
-                        cur0 = trow[b];
-                        nxt0 = trow[b + 1];
-                    }
-                }
-            }
         }
 
         if (fcnt) flush_foreign(fbuf, fcnt, lane, a, inv_row);
@@ -379,16 +361,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                 a.out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
             }
         } else {
-            uint64_t k = lane < st.cnt && lane < ntop ? cand[lane] : 0ull;
-            if (mode == 0 && n_blk > 1) {      // an extended pass 0 keeps its own block's keys (still sorted, zeros at the end)
-                if (k && (int)(~(uint32_t)k) / C != own) k = 0ull;
-                const uint64_t mk = __ballot(k != 0ull);
-                wave_sync();
-                if (k) cand[__popcll(mk & ((1ull << lane) - 1ull))] = k;
-                wave_sync();
-                k = lane < __popcll(mk) ? cand[lane] : 0ull;
-            }
-            if (lane < ntop) a.keys[(int64_t)row * ntop + lane] = k;
+            if (lane < ntop) a.keys[(int64_t)row * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
             if (lane == 0 && (mode == 0 || st.thr > pub)) {
                 a.thrv[row] = st.thr;
                 a.thr16[thr16_pos(row)] = (uint16_t)((uint32_t)st.thr >> 16);
@@ -592,12 +565,6 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.out_idx = out->idx;
     a.out_val = out->val;
     a.exp = sym_env_int("PFZ_K3_SYM_EXP", 0);
-    {
-        // "weak": below 0.15 of the largest sum a pair of rows can reach (cosine 0.15 for L2-normalised rows)
-        const double w = 0.15 * (double)A->max_norm * (double)ix->max_norm * (double)scale;
-        a.weak_thr = w >= 2147483000.0 ? 2147483000 : (int32_t)w;
-        if (sym_env_int("PFZ_K3_SYM_NO_EXT", 0)) a.weak_thr = 0;
-    }
     if (start) {
         // pass 0 over ALL rows: every row's first threshold is there before anybody hands anything over
         PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));

@@ -70,7 +70,7 @@ class FrameBuilder:
         # pandas takes ~0.5 ms to look at eleven 100 000-element columns -- and `fill` writes through the arrays it shares
         # with them.  Only if this pandas really shares them (copy=False is a request): otherwise frame() builds it at the end.
         self._frame = None
-        if self.n and top_n and os.environ.get("PFZ_EARLY_FRAME", "1") != "0":
+        if self.n >= 8192 and top_n and os.environ.get("PFZ_EARLY_FRAME", "1") != "0":     # (a small frame is made in no time, and the sharing checks below would be most of a single query's host time)
             # (pandas scans an object column for date-likes until it meets a non-null: an all-None column is scanned to its end.
             # The first slot holds a string while the frame is made, and None again before anything is filled in)
             for a in self.names:
