@@ -337,6 +337,66 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(int32_t *__restrict
     }
 }
 
+// The same scan in ONE launch (decoupled look-back): a tile takes a ticket (so every tile before it is running or done),
+// scans its 4096 items, publishes its sum, and its first thread walks back over the tiles before it -- adding sums until it
+// meets a tile that already knows its whole prefix -- then publishes its own.  A state word is (epoch * 4 + kind) << 32 | value,
+// kind 1 = the tile's sum, 2 = the sum through the tile; every call has a new epoch, so the words are never cleared, and the
+// last tile puts the ticket counter back to 0.  Agent-scope loads / stores: the tiles run on different XCDs.
+// (Three launches -- ~15 us on a 10 000-string list whose whole fit + transform + index + match is 0.4 ms -- were the price of
+// the version above, which stays for PFZ_SCAN3=1.)
+__global__ __launch_bounds__(kScanThreads) void k_scan_lookback(int32_t *__restrict__ data, int64_t n, uint64_t *__restrict__ state,
+                                                                uint32_t *__restrict__ ticket, uint32_t epoch4, int32_t n_tiles)
+{
+    __shared__ int32_t lds4[kScanThreads / 64];
+    __shared__ int32_t s_tile, s_prefix;
+    if (threadIdx.x == 0) s_tile = (int32_t)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    const int64_t base = (int64_t)tile * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int32_t v[kScanItems];
+    int32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        const int64_t p = base + i;
+        v[i] = (p < n) ? data[p] : 0;
+        s += v[i];
+    }
+    int32_t tot;
+    int32_t ex = block_excl_scan(s, lds4, &tot);
+    if (threadIdx.x == 0) {
+        int32_t prefix = 0;
+        if (tile > 0) {
+            __hip_atomic_store(&state[tile], ((uint64_t)(epoch4 + 1u) << 32) | (uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int p = tile - 1;; --p) {
+                uint64_t w;
+                for (;;) {
+                    w = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t f = (uint32_t)(w >> 32);
+                    if (f == epoch4 + 1u || f == epoch4 + 2u) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                prefix += (int32_t)(uint32_t)w;
+                if ((uint32_t)(w >> 32) == epoch4 + 2u) break;
+            }
+        }
+        __hip_atomic_store(&state[tile], ((uint64_t)(epoch4 + 2u) << 32) | (uint32_t)(prefix + tot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = prefix;
+        if (tile == n_tiles - 1) {
+            data[n] = prefix + tot;      // the grand total
+            *ticket = 0u;                // (every ticket has been taken: this tile holds the last one)
+        }
+    }
+    __syncthreads();
+    ex += s_prefix;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        const int64_t p = base + i;
+        if (p < n) data[p] = ex;
+        ex += v[i];
+    }
+}
+
 int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n)
 {
     if (n <= 0) {
@@ -344,6 +404,30 @@ int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n)
         return PFZ_OK;
     }
     const int64_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    static const bool three = getenv("PFZ_SCAN3") != nullptr;
+    if (!three && n_tiles < (1 << 24)) {
+        if ((size_t)n_tiles > ctx->scan_tiles) {
+            // (grown, never shrunk; the old words may still be read by a scan in flight on this stream: stream order frees it)
+            size_t cap = ctx->scan_tiles ? ctx->scan_tiles : 1024;
+            while (cap < (size_t)n_tiles) cap *= 2;
+            uint64_t *fresh = nullptr;
+            PFZ_TRY(pool_alloc(ctx, &fresh, (cap + 1) * sizeof(uint64_t)));
+            PFZ_HIP(hipMemsetAsync(fresh, 0, (cap + 1) * sizeof(uint64_t), ctx->stream));
+            if (ctx->scan_state) pool_free(ctx->scan_state);
+            ctx->scan_state = fresh;
+            ctx->scan_tiles = cap;
+            ctx->scan_epoch = 0;
+        }
+        if (ctx->scan_epoch >= (1u << 29)) {          // (the epoch field is 30 bits: start over on clean words)
+            PFZ_HIP(hipMemsetAsync(ctx->scan_state, 0, (ctx->scan_tiles + 1) * sizeof(uint64_t), ctx->stream));
+            ctx->scan_epoch = 0;
+        }
+        const uint32_t epoch4 = ++ctx->scan_epoch * 4u;
+        hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)n_tiles), dim3(kScanThreads), 0, ctx->stream, data, n, ctx->scan_state,
+                           (uint32_t *)(ctx->scan_state + ctx->scan_tiles), epoch4, (int32_t)n_tiles);
+        PFZ_HIP(hipGetLastError());
+        return PFZ_OK;
+    }
     PFZ_TRY(ensure_scratch(ctx, (size_t)n_tiles * sizeof(int32_t)));
     int32_t *tile_sums = (int32_t *)ctx->scratch;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(kScanThreads), 0, ctx->stream, data, n, tile_sums);

@@ -78,6 +78,10 @@ struct pfz_ctx {
     size_t stage_bytes = 0, stage_off = 0;
     char *stage2 = nullptr;               // pinned staging of the side stream's downloads (pfz_topn_download_rows_after)
     size_t stage2_bytes = 0;
+    // single-pass scan (exclusive_scan_i32): per-tile state words + the tile ticket, zeroed once; every call has its own epoch
+    uint64_t *scan_state = nullptr;
+    size_t scan_tiles = 0;
+    uint32_t scan_epoch = 0;
     // caching allocator state: size class -> free blocks
     std::map<size_t, std::vector<void *>> pool_free_lists;
     size_t pool_cached_bytes = 0, pool_live_bytes = 0;

@@ -5,7 +5,7 @@
 tag=${1:-r04b}
 mkdir -p gpurun_out
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 600 python -m pytest tests/test_matchers_gpu.py tests/test_fullsize_gpu.py tests/test_facade_flow_gpu.py tests/test_k3_cossim_gpu.py tests/test_fuzz_gpu.py -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_matchers_gpu.py tests/test_fullsize_gpu.py tests/test_facade_flow_gpu.py tests/test_k3_cossim_gpu.py tests/test_fuzz_gpu.py tests/test_vectorize_gpu.py tests/test_comm_gpu.py -q 2>&1 | grep -E "passed|failed|error" | tail -3
 timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench rc=$?"; tail -c 400 gpurun_out/${tag}_bench.err
 timeout 900 bash tools/profile_bench.sh gpurun_out/${tag}_profile > gpurun_out/${tag}_profile.log 2>&1
