@@ -17,16 +17,20 @@
 //      names are) a row's best matches sit next to it: the thresholds are high from the start.
 //   1  row j x the blocks ABOVE its own: state restored, scatter as ever; the sweep tests every sum against the row's
 //      own threshold (as ever) and, packed two to a word, the upper halves of the eight sums of a lane against the
-//      upper halves of their eight rows' thresholds (v_pk_sub_i16 x 4, three ANDs, one compare).  The 16 bytes of
-//      thresholds per lane and step are loaded before the block's scatter and are long there when the sweep wants them.
+//      upper halves of their eight rows' thresholds (v_perm_b32 x 4, v_pk_sub_i16 x 4, two v_bitop3, one compare).  The
+//      16 bytes of thresholds per lane and step are loaded before the block's scatter (steps 0 / 1) and while those are
+//      swept (steps 2 / 3): they are long there when the sweep wants them.
 //      A hit (conservative: upper halves only) goes into a 128-entry LDS buffer as (sum, row of the cell); the buffer
 //      is flushed -- one returning atomic per entry on push_cnt[i], one store into push_buf[i] -- when it is half full
-//      and at the end of the row: about once per row.  A row that raises its own threshold publishes it (thrv, thr16):
-//      later pushers of its block are filtered harder.  Stale reads of either only let more candidates through.
+//      and at the end of the row: about once per row (23 candidates per row on the 100 000 company names).  A row that
+//      raises its own threshold publishes it (thrv, thr16) -- for whoever sees it: the stores reach the other XCDs' L2s
+//      when the kernel ends, measured effect none; stale reads only let more candidates through.
 //   merge  row i's own keys + what was pushed to it -> the sorted top-n (compact<> of k3_core.h, one wave per row).
-//      A row that was pushed more than kSymPush candidates (a row without ntop positive matches in its own block keeps
+//      A row that was pushed more than kSymPush candidates (195 of the 100 000 names: strings with hundreds of
+//      near-equals elsewhere in the list; or a row without ntop positive matches in its own block, which keeps
 //      threshold 0 and is sent every non-zero sum) is noted and
-//   2  recomputed in full, the row-major way, by the same kernel.
+//   2  recomputed in full, the row-major way, by the same kernel -- in slices of the to-blocks, whose partial lists a
+//      second merge joins: a whole row is ~100 us of one wave, and a handful of rows would cost the job that long.
 // Every candidate that can be in row i's top-n passes a filter that is never tighter than the row's own running
 // threshold (which only rises), and the final selection is by key (sum desc, column asc): the result is the row-major
 // kernel's, bit for bit (tests/test_k3_cossim_gpu.py::test_symmetric_*).
