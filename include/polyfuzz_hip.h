@@ -129,7 +129,7 @@ int pfz_topn_device_ptrs(const pfz_topn *t, void **idx_dev, void **val_dev, int6
  * side is a row shard).  lower_bound < 0 is treated as 0 (non-positive scores
  * are "no match" in the reference's output contract, _utils.py:122-123).
  * When from_matrix IS the matrix the index was built from, exclude_diag != 0 and diag_offset == 0 -- a list against
- * itself -- lists of 32 768 to 250 000 rows (ntop <= 32) take the symmetric form: C is symmetric bit for bit in this
+ * itself -- lists of 20 480 to 250 000 rows (ntop <= 32) take the symmetric form: C is symmetric bit for bit in this
  * arithmetic, so every unordered pair of rows is scored once and handed to both rows; same results (PFZ_K3_SYM=0 / 1:
  * never / whenever possible).
  * Limits: ntop >= 1 (above 128 a larger, slower candidate buffer; above 1024 passes of 1024, each continuing below the

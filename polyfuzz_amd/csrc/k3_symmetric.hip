@@ -515,7 +515,7 @@ int k3_sym_wanted(const pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int
     // auto: where halving K3 pays for five more launches and the state round trip, and where the row-major kernel is the one that
     // would run (k3_lockstep.hip takes the to-sides beyond 250 000 rows); a first range of less than a fifth of the rows is a
     // shard of a bigger job (bench --scaling strong), not the start of a whole self-match
-    if (ix->n_rows < sym_env_int("PFZ_K3_SYM_MIN", 32768) || ix->n_rows > 250000) return 0;
+    if (ix->n_rows < sym_env_int("PFZ_K3_SYM_MIN", 20480) || ix->n_rows > 250000) return 0;
     return (row_end - row_begin) * 5 >= ix->n_rows ? 1 : 0;
 }
 

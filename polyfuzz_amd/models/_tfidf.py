@@ -29,7 +29,7 @@ _SPLIT_SHARES = {2: (0.6, 0.4), 5: (0.4, 0.3, 0.2, 0.1)}      # (profiles/experi
 # a list against itself runs K3's symmetric form (csrc/k3_symmetric.hip): a row only walks the to-blocks from its own upwards, so
 # the first rows are the expensive ones and the ranges are cut accordingly (profiles/experiments/r04_match_split_symmetric.txt)
 _SPLIT_SHARES_SELF = (0.3, 0.3, 0.25, 0.15)
-_SYMMETRIC_ROWS = (32768, 250000)       # the list sizes K3 takes in its symmetric form (pfz_cossim_topn, include/polyfuzz_hip.h)
+_SYMMETRIC_ROWS = (20480, 250000)       # the list sizes K3 takes in its symmetric form (pfz_cossim_topn, include/polyfuzz_hip.h)
 
 
 def _split_shares(n, self_match=False):

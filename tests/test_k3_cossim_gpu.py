@@ -419,7 +419,7 @@ def test_symmetric_kernel_in_row_ranges(ctx, monkeypatch):
 
 
 def test_symmetric_kernel_on_real_names(ctx, oracle_mod, monkeypatch):
-    """40 000 real company names against themselves (20 blocks; the automatic choice takes the symmetric kernel from 32 768
+    """40 000 real company names against themselves (20 blocks; the automatic choice takes the symmetric kernel from 20 480
     rows on): equal to the row-major kernel bit for bit, top-5 and top-1, and the unnormalised-matrix scale path."""
     from polyfuzz_amd import datasets, _lib
     from polyfuzz_amd.models import TFIDF
