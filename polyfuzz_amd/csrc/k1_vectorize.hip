@@ -39,6 +39,7 @@
 namespace pfz {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr int kShortMax = 128;     // n-grams per string k_rows_short sorts in a wave's registers (one or two keys per lane)
 constexpr int kLongMax = 4096;     // n-grams per string sorted in LDS by k_rows_long
 constexpr int kLongTile = 16;      // strings per scheduling tile of k_rows_long
 constexpr int kMaxCodeBits = 64;     // n-gram codes are uint64
@@ -563,12 +564,61 @@ __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ 
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const int cnt = row_cnt[row];
-    if (cnt > 64) return;  // k_rows_long
+    if (cnt > kShortMax) return;  // k_rows_long
     if (cnt == 0) {
         if (lane == 0) row_nnz[row] = 0;
         return;
     }
     uint64_t *base = slots + off[row] * R;
+    if (cnt > 64) {
+        // 65 .. 128 n-grams: two keys per lane (elements lane and lane + 64 of a 128-key bitonic network), still one wave and
+        // no barrier.  (k_rows_long sorts in LDS with a workgroup barrier per stage: ~30 us for ONE such string, and a list of
+        // names has a few -- 21 of the 100 000 company names, none beyond 87 n-grams -- so that launch was pure latency.)
+        uint32_t k0 = vocab_rank(V, base[lane]);
+        uint32_t k1 = lane + 64 < cnt ? vocab_rank(V, base[lane + 64]) : kInvalid;
+#pragma unroll
+        for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j == 64) {                      // (k == 128) the partner is the lane's other key; the last merge ascends
+                    const uint32_t mn = k0 < k1 ? k0 : k1, mx = k0 < k1 ? k1 : k0;
+                    k0 = mn;
+                    k1 = mx;
+                } else {
+                    const uint32_t o0 = __shfl_xor(k0, j, 64), o1 = __shfl_xor(k1, j, 64);
+                    const bool lower = (lane & j) == 0;
+                    const bool asc0 = (lane & k) == 0, asc1 = ((lane + 64) & k) == 0;     // element index & k
+                    const uint32_t mn0 = k0 < o0 ? k0 : o0, mx0 = k0 < o0 ? o0 : k0;
+                    const uint32_t mn1 = k1 < o1 ? k1 : o1, mx1 = k1 < o1 ? o1 : k1;
+                    k0 = (lower == asc0) ? mn0 : mx0;
+                    k1 = (lower == asc1) ? mn1 : mx1;
+                }
+            }
+        }
+        // run lengths over the 128 sorted keys (element e = lane + 64 r)
+        const uint32_t p0 = __shfl_up(k0, 1, 64), last0 = __shfl(k0, 63, 64);
+        uint32_t p1 = __shfl_up(k1, 1, 64);
+        if (lane == 0) p1 = last0;
+        const bool v0 = k0 != kInvalid, v1 = k1 != kInvalid;
+        const bool h0 = v0 && (lane == 0 || k0 != p0), h1 = v1 && k1 != p1;
+        const uint64_t H0 = __ballot(h0), H1 = __ballot(h1);
+        const int nvalid = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+        const uint64_t below = (1ull << lane) - 1ull;
+        const uint64_t above0 = lane == 63 ? 0ull : (H0 >> (lane + 1)), above1 = lane == 63 ? 0ull : (H1 >> (lane + 1));
+        if (h0) {
+            const int next = above0 ? lane + 1 + __builtin_ctzll(above0) : (H1 ? 64 + __builtin_ctzll(H1) : nvalid);
+            base[__popcll(H0 & below)] = ((uint64_t)(uint32_t)(next - lane) << 32) | k0;
+            df.add(k0, row);
+        }
+        if (h1) {
+            const int e = lane + 64;
+            const int next = above1 ? e + 1 + __builtin_ctzll(above1) : nvalid;
+            base[__popcll(H0) + __popcll(H1 & below)] = ((uint64_t)(uint32_t)(next - e) << 32) | k1;
+            df.add(k1, row);
+        }
+        if (lane == 0) row_nnz[row] = __popcll(H0) + __popcll(H1);
+        return;
+    }
     uint32_t key = kInvalid;
     if (lane < cnt) key = vocab_rank(V, base[lane]);
     // 64-lane bitonic sort, ascending
@@ -599,7 +649,7 @@ __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// k_rows_long: one workgroup per string with > 64 n-grams.
+// k_rows_long: one workgroup per string with > kShortMax (128) n-grams.
 //   cnt <= kLongMax : keys sorted in LDS; otherwise in a global scratch slab.
 // ---------------------------------------------------------------------------
 // Sort + run-length encode one long string.  KEYS is either an LDS array or a
@@ -685,7 +735,7 @@ __global__ __launch_bounds__(256) void k_rows_long(const int64_t *__restrict__ o
         if (threadIdx.x == 0) n_long = 0;
         __syncthreads();
         const int64_t mine = tile * kLongTile + threadIdx.x;
-        if ((int)threadIdx.x < kLongTile && mine < n && row_cnt[mine] > 64) long_rows[atomicAdd(&n_long, 1)] = (int)threadIdx.x;
+        if ((int)threadIdx.x < kLongTile && mine < n && row_cnt[mine] > kShortMax) long_rows[atomicAdd(&n_long, 1)] = (int)threadIdx.x;
         __syncthreads();
         const int m = n_long;
         for (int i = 0; i < m; ++i) {
@@ -848,7 +898,7 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df)
         hipLaunchKernelGGL(k_rows_short, dim3(grid_for(s->n, 4)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, V,
                            s->slots, s->row_cnt, row_nnz, df);
     }
-    if (s->max_len * R > 64) {
+    if (s->max_len * R > kShortMax) {
         const int64_t max_cnt = s->max_len * R;
         const int64_t n_tiles = (s->n + kLongTile - 1) / kLongTile;
         unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 2048);

@@ -180,3 +180,30 @@ def test_wave_per_string_extract_equals_thread_per_string(ctx, oracle_mod, monke
         np.testing.assert_array_equal(x, y)                         # the very same CSR, bit for bit
     o = oracle_mod.TfidfOracle(n_gram_range=rng, clean=clean, remove_space_ngrams=remove_space).fit(strings)
     _check_csr(out["wave"], o.transform(strings), len(o.vocabulary))
+
+
+@pytest.mark.parametrize("clean", [True, False])
+def test_rows_of_65_to_128_ngrams(ctx, oracle_mod, clean):
+    """Strings of 65 .. 128 n-grams are sorted by one wave with two keys per lane (k_rows_short) instead of a workgroup with a
+    barrier per stage (k_rows_long, from 129 on): every count around the seams -- 63 .. 66 and 126 .. 131 n-grams --, strings
+    made of few distinct n-grams (long runs of equal keys across the two registers), strings with characters outside the
+    fitted vocabulary, 3-grams alone and a range of n; CSR against the oracle, bit for bit in structure."""
+    rng = np.random.default_rng(9)
+    docs = []
+    for n_grams in list(range(61, 70)) + list(range(120, 134)) + [90, 100, 110]:
+        length = n_grams + 2                                   # 3-grams of a string without blanks: len - 2
+        docs.append("".join(chr(97 + int(c)) for c in rng.integers(0, 26, length)))
+        docs.append("".join("ab"[int(c)] for c in rng.integers(0, 2, length)))        # eight distinct 3-grams at most
+        docs.append(("xyz" * 60)[:length])                                              # three distinct 3-grams
+    docs += ["short", "", "abc"]
+    vec, (a,) = _device_vectorize(ctx, docs, None, 3, 3, clean)
+    o = oracle_mod.TfidfOracle(n_gram_range=(3, 3), clean=clean).fit(docs)
+    _check_csr(a, o.transform(docs), len(o.vocabulary))
+    # out-of-vocabulary n-grams at transform time, and two n values (R = 2 slots per character)
+    fit_docs = docs[::2]
+    vec2, _ = _device_vectorize(ctx, fit_docs, None, 2, 3, clean)
+    from polyfuzz_amd import _lib
+    new = [d[:40] + "QQ" + d[40:] for d in docs if 45 <= len(d) <= 66]
+    got = vec2.transform(_lib.DeviceStrings.upload(ctx, new)).download()
+    o2 = oracle_mod.TfidfOracle(n_gram_range=(2, 3), clean=clean).fit(fit_docs)
+    _check_csr(got, o2.transform(new), len(o2.vocabulary))
