@@ -83,6 +83,25 @@ __device__ inline int max3i(int a, int b, int c)
     return r;
 }
 
+// inclusive prefix maximum over the 64 lanes, unsigned (lane 63 = the wave maximum): row_shr 1, 2, 4, 8 inside each 16-lane
+// row, then row_bcast:15 into rows 1, 3 and row_bcast:31 into rows 2, 3; a lane without a source reads 0
+__device__ inline uint32_t dpp_umax_scan(uint32_t m)
+{
+#define PFZ_UMAX_STEP(ctrl, rmask)                                                                    \
+    {                                                                                                 \
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, ctrl, rmask, 0xf, false); \
+        m = o > m ? o : m;                                                                            \
+    }
+    PFZ_UMAX_STEP(0x111, 0xf)
+    PFZ_UMAX_STEP(0x112, 0xf)
+    PFZ_UMAX_STEP(0x114, 0xf)
+    PFZ_UMAX_STEP(0x118, 0xf)
+    PFZ_UMAX_STEP(0x142, 0xa)
+    PFZ_UMAX_STEP(0x143, 0xc)
+#undef PFZ_UMAX_STEP
+    return m;
+}
+
 struct TopState {
     int cnt;      // wave-uniform number of keys in cand[]
     int thr;      // accept sum > thr
@@ -131,21 +150,37 @@ __device__ inline void compact(uint64_t *cand, TopState &st, int ntop, int lane,
         return;
     }
     const int keep = st.cnt < ntop ? st.cnt : ntop;
-    uint64_t best = 0;
-    for (int r = 0; r < keep; ++r) {
-        uint64_t m = e[0];
+    // One round per kept key: the wave maximum of the SUMS (upper halves: six v_max_u32 with the DPP operand folded in), then,
+    // among the keys with that sum, the maximum of the lower halves (~column: the smallest column wins a tie) -- two 32-bit
+    // prefix maxima instead of one 64-bit one (six steps of two DPP moves, a 64-bit compare and two selects: round 4).
+    uint32_t hi[kPer], lo[kPer];
 #pragma unroll
-        for (int i = 1; i < kPer; ++i) m = e[i] > m ? e[i] : m;
-        best = wave_max_u64(m);
+    for (int i = 0; i < kPer; ++i) {
+        hi[i] = (uint32_t)(e[i] >> 32);
+        lo[i] = (uint32_t)e[i];
+    }
+    uint32_t bh = 0, bl = 0;
+    for (int r = 0; r < keep; ++r) {
+        uint32_t mh = hi[0];
+#pragma unroll
+        for (int i = 1; i < kPer; ++i) mh = hi[i] > mh ? hi[i] : mh;
+        bh = (uint32_t)__builtin_amdgcn_readlane((int)dpp_umax_scan(mh), 63);
+        uint32_t ml = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const uint32_t c = hi[i] == bh ? lo[i] : 0u;
+            ml = c > ml ? c : ml;
+        }
+        bl = (uint32_t)__builtin_amdgcn_readlane((int)dpp_umax_scan(ml), 63);
 #pragma unroll
         for (int i = 0; i < kPer; ++i)
-            if (e[i] == best) e[i] = 0ull;
-        if (lane == 0) cand[r] = best;
+            if (hi[i] == bh && lo[i] == bl) hi[i] = lo[i] = 0u;      // (keys are distinct: exactly one entry of the wave)
+        if (lane == 0) cand[r] = ((uint64_t)bh << 32) | bl;
     }
     st.cnt = keep;
     if (keep == ntop) {
         // from now on only sums >= the ntop-th best can matter
-        const int t = (int)(uint32_t)(best >> 32) - 1;
+        const int t = (int)bh - 1;
         st.thr = t > st.thr ? t : st.thr;
     }
     wave_sync();
@@ -376,7 +411,7 @@ int k3_lockstep_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int6
 int k3_sym_wanted(const pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
                   int32_t thr0, float scale, int32_t exclude_diag, int64_t diag_offset, const pfz_topn *out);
 int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
-                  int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start);
+                  int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start, bool *declined);
 void k3_sym_free(pfz_index *ix);
 
 }  // namespace pfz

@@ -137,13 +137,22 @@ __global__ __launch_bounds__(256) void k_index_pieces(int32_t *__restrict__ cnt,
 // Padding entries of every list (positions count .. 16*pieces) and the dummy piece at n_pieces: value 0
 // -- they add nothing -- at accumulator offsets spread over 64 cells, so the padding lanes of one
 // ds_add_u32 do not pile up on one LDS address.
+// pblk != NULL: the to-block of every piece of the list is noted as well (slot i = n-gram * nb + block)
 __global__ __launch_bounds__(256) void k_index_pad(const int32_t *__restrict__ cnt, const int32_t *__restrict__ tab,
-                                                    int64_t slots, int32_t n_pieces, int2 *__restrict__ post)
+                                                    int64_t slots, int32_t n_pieces, int2 *__restrict__ post,
+                                                    uint16_t *__restrict__ pblk, int32_t nb)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < kPiece) post[(int64_t)n_pieces * kPiece + i] = make_int2((int)i * 4, 0);
+    if (i == 0 && pblk) pblk[n_pieces] = 0;
     if (i >= slots) return;
     const int c = cnt[i];
+    if (c == 0) return;
+    if (pblk) {
+        const uint16_t b = (uint16_t)((uint32_t)i % (uint32_t)nb);      // (slots < 2^31, pfz_index_build)
+        const int first = tab[i], last = first + (c + kPiece - 1) / kPiece;
+        for (int p = first; p < last; ++p) pblk[p] = b;
+    }
     if ((c & (kPiece - 1)) == 0) return;
     const int64_t base = (int64_t)tab[i] * kPiece;
     const int end = (c + kPiece - 1) & ~(kPiece - 1);
@@ -599,11 +608,13 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     }
     ix->n_pieces = n_pieces;
     PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)(n_pieces + 1) * kPiece * sizeof(int2)));
+    if (block == 2048 && nb >= 2 && nb < 65536)      // (what the symmetric form of a self-match reads: k3_symmetric.hip)
+        PFZ_TRY(pool_alloc(ctx, &ix->pblk, (size_t)(n_pieces + 1) * sizeof(uint16_t)));
     {
         ProfScope ps(ctx, "k_index_fill");
         // (before the fill: the global-atomics fill counts cnt down)
         hipLaunchKernelGGL(k_index_pad, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, ix->tab, any ? slots : 0, n_pieces,
-                           ix->post);
+                           ix->post, ix->pblk, (int32_t)nb);
         if (any && lds_hist)
             hipLaunchKernelGGL(k_index_fill_lds, dim3((unsigned)nb * kSub), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
                                B->data, (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab, sub.p, ix->post);
@@ -628,6 +639,7 @@ void pfz_index_free(pfz_index *ix)
     k3_sym_free(ix);
     if (ix->tab) pool_free(ix->tab);
     if (ix->post) pool_free(ix->post);
+    if (ix->pblk) pool_free(ix->pblk);
     delete ix;
 }
 
@@ -726,7 +738,9 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     // a list against itself: every unordered pair once (k3_symmetric.hip), whole jobs and ascending row ranges of one
     if (const int sym = k3_sym_wanted(ctx, ix, A, row_begin, row_end, ntop, thr0, scale, exclude_diag, diag_offset, out)) {
         ProfScope ps(ctx, "k3_cossim_topn");
-        return k3_sym_launch(ctx, ix, A, row_begin, row_end, ntop, thr0, scale, inv_scale, out, sym == 1);
+        bool declined = false;
+        const int rc = k3_sym_launch(ctx, ix, A, row_begin, row_end, ntop, thr0, scale, inv_scale, out, sym == 1, &declined);
+        if (!declined) return rc;      // (declined: no memory for the session buffers -- the row-major kernel below needs none)
     }
     if (k3_lockstep_wanted(ctx, ix, n_rows, ntop)) {     // big to-sides: all waves on the same to-blocks (k3_lockstep.hip)
         ProfScope ps(ctx, "k3_cossim_topn");

@@ -10,21 +10,30 @@
 // it hands to row i.  Scatter and sweep work halve; the price is a second filter in the sweep (is this sum a candidate
 // for the ROW OF THE CELL?) and a small exchange through HBM.
 //
-// How.  Three passes of one kernel template (k3_sym_kernel<C, MODE>) + a merge:
+// How.  Three passes of one kernel template (k3_sym_kernel<C, MODE>), a re-deal of the accumulator slots, and a merge:
 //   0  every row x its OWN block (both directions of a pair inside a block are computed: no exchange there) -> the
-//      row's first top-n and threshold, written to HBM (keys[row][ntop], thrv[row]) and, as the upper 16 bits of the
-//      threshold, into thr16 in the order the sweep reads a block's cells.  On a sorted list (the reference's company
-//      names are) a row's best matches sit next to it: the thresholds are high from the start.
-//   1  row j x the blocks ABOVE its own: state restored, scatter as ever; the sweep tests every sum against the row's
-//      own threshold (as ever) and, packed two to a word, the upper halves of the eight sums of a lane against the
-//      upper halves of their eight rows' thresholds (v_perm_b32 x 4, v_pk_sub_i16 x 4, two v_bitop3, one compare).  The
-//      16 bytes of thresholds per lane and step are loaded before the block's scatter (steps 0 / 1) and while those are
-//      swept (steps 2 / 3): they are long there when the sweep wants them.
-//      A hit (conservative: upper halves only) goes into a 128-entry LDS buffer as (sum, row of the cell); the buffer
-//      is flushed -- one returning atomic per entry on push_cnt[i], one store into push_buf[i] -- when it is half full
-//      and at the end of the row: about once per row (23 candidates per row on the 100 000 company names).  A row that
-//      raises its own threshold publishes it (thrv, thr16) -- for whoever sees it: the stores reach the other XCDs' L2s
-//      when the kernel ends, measured effect none; stale reads only let more candidates through.
+//      row's first top-n and threshold, written to HBM (keys[row][ntop], thrv[row]).  On a sorted list (the reference's
+//      company names are) a row's best matches sit next to it: the thresholds are high from the start.
+//   order (round 5)  The second filter of pass 1 -- "is this sum a candidate for the row of the CELL?" -- used to test
+//      every sum against its own row's threshold (eight 16-bit thresholds per lane and sweep step: 11 vector
+//      instructions and 16 bytes of loads per step, a quarter of pass 1).  Which accumulator slot a to-row's sums land
+//      in is free, so after pass 0 every block's rows are RE-DEALT TO THE SLOTS BY THRESHOLD (k3_sym_order): the eight
+//      slots a lane reads in one sweep step hold rows of neighbouring thresholds, and one comparison of the lane's
+//      maximum against the minimum of those eight (gmin) decides the step.  The re-deal keeps every row in its LDS bank
+//      (slot = row mod 32): row r of bank class rho = r mod 32 gets rank i among the 64 rows of its class, the eight
+//      lanes l = rho / 4 + 8 k of the four sweep steps own the class' 64 slots, ranks 2 p and 2 p + 1 go to (step p / 8,
+//      lane rho / 4 + 8 (p mod 8)) -- so the bank order of the heavy lists (k_index_bank_order) survives, and the
+//      re-dealt index is the old one with the postings' slot fields rewritten (k3_sym_repost: one pass over a copy).
+//      CPU simulation on the 100 000 names (tools/sim_sym_slot_order.py): a step enters the rare path in 25 % of the
+//      cases (exact per-row test: 15 %; groups of eight rows as they lie: 54 %).
+//   1  row j x the blocks ABOVE its own: state restored, scatter as ever (on the re-dealt postings); the sweep tests the
+//      maximum of a lane's eight sums against min(the row's own threshold, gmin of the lane's eight slots) -- two vector
+//      instructions, 4 bytes of loads per lane and step, in flight across the scatter.  The rare path loads the eight
+//      rows of the lane's slots (inv8) and their exact thresholds (thr8), keeps what beats the row's own threshold
+//      (key = sum, true column) and puts what beats the CELL's row's threshold into a 128-entry LDS buffer as (sum, row
+//      of the cell); the buffer is flushed -- one returning atomic per entry on push_cnt[i], one store into
+//      push_buf[i] -- when it is half full and at the end of the row: about once per row (23 candidates per row on
+//      the 100 000 company names).
 //   merge  row i's own keys + what was pushed to it -> the sorted top-n (compact<> of k3_core.h, one wave per row).
 //      A row that was pushed more than kSymPush candidates (195 of the 100 000 names: strings with hundreds of
 //      near-equals elsewhere in the list; or a row without ntop positive matches in its own block, which keeps
@@ -59,6 +68,10 @@ constexpr int kSymPush = PFZ_K3_SYM_PUSH;   // push slots per row; a row that is
 constexpr int kSymMergeCap = kSymPush + 64;
 constexpr int kSymSlices = 8;      // pass 2: a row that is recomputed in full is cut into at most this many slices of to-blocks ...
 constexpr int kSymSlicedRows = 4096;   // ... for the first so many rows of the list (a single wave takes ~100 us for a whole row)
+#ifndef PFZ_K3_SYM_EXP
+#define PFZ_K3_SYM_EXP 0           // timing experiments (tools/build_variant.sh -DPFZ_K3_SYM_EXP=n: results wrong on purpose); 0 = the product
+#endif
+constexpr int kNoThr = 0x7fffffff;     // threshold of a slot without a row (the last block's tail): no sum reaches it
 
 struct K3SymArgs {
     const int32_t *a_indptr;
@@ -66,130 +79,201 @@ struct K3SymArgs {
     const float *a_val;
     int32_t n;                // rows of the matrix == to-rows of the index
     const int32_t *tab;
-    const int2 *post;
+    const int2 *post;         // the index' postings: passes 0 and 2
+    const int2 *post_sym;     // the same pieces with the slot fields re-dealt by threshold: pass 1
+    const uint16_t *pblk;     // [n_pieces + 1] to-block of every piece
     int32_t nb, n_pieces, ntop, thr0;
     float scale, inv_scale;
     int32_t row_begin, row_end;   // the rows of this launch (modes 0 and 1, merge)
-    int32_t *thrv;            // [n]           published thresholds (accept sum > thr)
-    uint16_t *thr16;          // [nb * C]      their upper halves, in sweep order (see thr16_pos); rows >= n: 0x7f7f
-    uint64_t *keys;           // [n][ntop]     a row's own candidates, sorted, 0 = none
+    int32_t *thrv;            // [n]              a row's threshold after pass 0 (accept sum > thr)
+    uint16_t *slot4;          // [nb * C]         4 * (slot of to-row b * C + r): its accumulator's byte offset in pass 1
+    int32_t *gmin;            // [nb][64][4]      (block, lane, sweep step) -> the minimum threshold of the lane's eight slots
+    int32_t *thr_slot;        // [nb * C]         cell (block * C + slot) -> the threshold of the row that owns the slot
+    uint16_t *row_slot;       // [nb * C]         ... and that row (inside the block)
+    uint64_t *keys;           // [n][ntop]        a row's own candidates, sorted, 0 = none
     int32_t *push_cnt;        // [n]
-    uint64_t *push_buf;       // [n][kSymPush] keys sum << 32 | ~(row that found it)
-    int32_t *ovf;             // [1 + n]       ovf[0] = number of rows to recompute, then the rows
+    uint64_t *push_buf;       // [n][kSymPush]    keys sum << 32 | ~(row that found it)
+    int32_t *ovf;             // [1 + n]          ovf[0] = number of rows to recompute, then the rows
     uint64_t *part;           // [kSymSlicedRows][n_sl][ntop]  pass 2 in slices: the partial top-n of (row, slice of the to-blocks)
     int32_t ovf_base, ovf_max, n_sl;   // pass 2: listed rows [ovf_base, ovf_base + ovf_max), each cut into n_sl slices (1: whole rows -> result)
     int32_t *out_idx;
     float *out_val;
-    int32_t exp;              // timing experiments (PFZ_K3_SYM_EXP, results wrong on purpose): 1 = no second filter, 2 = no threshold loads, 4 = no publishing
 };
 
-// where the upper half of row `row`'s threshold sits: a sweep step t of lane l reads the int4 slots i0 = 128 t + l and
-// i0 + 64, i.e. the to-rows 512 t + 4 l + c and 512 t + 256 + 4 l + c of the block -- eight thresholds, one 16-byte load
-__device__ inline int64_t thr16_pos(int row)
+// ---- the re-deal of a block's rows to the accumulator slots (after pass 0) -------------------------------------------
+
+// slot of the row with rank i (0 = lowest threshold) among the 64 rows of bank class rho of its block; *t / *l: the sweep
+// step and the lane that read the slot, *e: its place among the lane's eight sums (v0.x .. v0.w, v1.x .. v1.w)
+__host__ __device__ inline int sym_slot(int rho, int i, int *t, int *l, int *e)
 {
-    const int b = row / kSymC, lr = row - b * kSymC;
-    const int t = lr >> 9, rem = lr & 511, half = rem >> 8, q = rem & 255;
-    return ((((int64_t)b * (kSymC / 512) + t) * 64 + (q >> 2)) * 8) + half * 4 + (q & 3);
+    const int p = i >> 1, half = i & 1, c = rho & 3;
+    *t = p >> 3;
+    *l = (rho >> 2) + 8 * (p & 7);
+    *e = half * 4 + c;
+    return 512 * *t + 256 * half + 4 * *l + c;       // = rho (mod 32): the row stays in its LDS bank
 }
 
-typedef short short2v __attribute__((ext_vector_type(2)));
-
-// sign bits of (upper half of sum) - (upper half of threshold) for two sums: clear = candidate
-__device__ inline uint32_t upper_diff(int s_lo, int s_hi, int thr_pair)
+// one workgroup per to-block: thresholds of pass 0 -> slot4, gmin, thr_slot, row_slot.  A wave ranks two bank classes (lane q =
+// row rho + 32 q) by counting: rank = number of rows of the class with a smaller (threshold, q).
+__global__ __launch_bounds__(1024) void k3_sym_order(const K3SymArgs a)
 {
-    // {s_hi[31:16], s_lo[31:16]}: v_perm_b32 with selector 0x07060302 (bytes 3, 2 of the first operand over bytes 3, 2 of the second)
-    const uint32_t p = __builtin_amdgcn_perm((uint32_t)s_hi, (uint32_t)s_lo, 0x07060302u);
-    const short2v d = __builtin_bit_cast(short2v, p) - __builtin_bit_cast(short2v, (uint32_t)thr_pair);   // v_pk_sub_i16
-    return __builtin_bit_cast(uint32_t, d);
+    __shared__ int s_gmin[256];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 256) s_gmin[threadIdx.x] = kNoThr;
+    __syncthreads();
+    for (int rho = wave * 2; rho < wave * 2 + 2; ++rho) {
+        const int r = rho + 32 * lane;
+        const int row = b * kSymC + r;
+        const int thr = row < a.n ? a.thrv[row] : kNoThr;
+        // (thresholds are >= 0: they start at thr0 >= 0 and only rise)
+        const uint64_t key = ((uint64_t)(uint32_t)thr << 6) | (uint32_t)lane;
+        int rank = 0;
+#pragma unroll 16
+        for (int m = 0; m < 64; ++m) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, m);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), m);
+            rank += ((((uint64_t)hi << 32) | lo) < key) ? 1 : 0;
+        }
+        int t, l, e;
+        const int slot = sym_slot(rho, rank, &t, &l, &e);
+        a.slot4[(int64_t)b * kSymC + r] = (uint16_t)(slot * 4);
+        a.thr_slot[(int64_t)b * kSymC + slot] = thr;
+        a.row_slot[(int64_t)b * kSymC + slot] = (uint16_t)r;
+        atomicMin(&s_gmin[t * 64 + l], thr);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int t = threadIdx.x >> 6, l = threadIdx.x & 63;
+        a.gmin[((int64_t)b * 64 + l) * 4 + t] = s_gmin[threadIdx.x];
+    }
 }
 
-__device__ inline void flush_foreign(uint64_t *fbuf, int &fcnt, int lane, const K3SymArgs &a, uint32_t inv_row)
+// post -> post_sym: every posting's slot field through its block's slot4 (a thread takes two postings = 16 bytes; padding
+// entries keep their value 0 and get the slot of whatever row they named: any slot will do for them)
+__global__ __launch_bounds__(256) void k3_sym_repost(const K3SymArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // pair of postings
+    if (i >= ((int64_t)a.n_pieces + 1) * (kPiece / 2)) return;
+    const int piece = (int)(i >> 3);
+    const int b = a.pblk[piece];
+    int4 e = ((const int4 *)a.post)[i];
+    const uint16_t *s4 = a.slot4 + (int64_t)b * kSymC;
+    if (piece < a.n_pieces) {           // (the all-zero dummy piece stays as it is)
+        e.x = s4[e.x >> 2];
+        e.z = s4[e.z >> 2];
+    }
+    ((int4 *)a.post_sym)[i] = e;
+}
+
+// ---- pass 1's hand-over ------------------------------------------------------------------------------------------------
+
+// Staged candidates of pass 1: sum << 32 | flags << 30 | cell, cell = block * C + slot (n < 2^30).  The sweep knows a cell by
+// its SLOT; which row owns the slot (row_slot) and that row's exact threshold (thr_slot) are looked up when the stage is
+// drained -- 64 entries per round trip instead of a dependent load in the sweep (measured, first version of the re-dealt
+// slots: the loads in the sweep's rare path cost as much as the per-row filter they replaced).
+constexpr uint32_t kStageOwn = 1u << 30;     // the sum beat the from-row's own threshold: a candidate of the from-row
+constexpr uint32_t kStageFgn = 1u << 31;     // the sum beat the minimum threshold of its lane's eight slots: maybe a candidate of the cell's row
+
+template <int kCap>
+__device__ inline void drain_stage(uint64_t *cand, TopState &st, uint64_t *fbuf, int &fcnt, int ntop, int lane,
+                                   const K3SymArgs &a, uint32_t inv_row)
 {
     wave_sync();
-    for (int e = lane; e < fcnt; e += 64) {
-        const uint64_t en = fbuf[e];
-        const int i = (int)(uint32_t)en;
-        const int pos = atomicAdd(&a.push_cnt[i], 1);
-        if (pos < kSymPush) a.push_buf[(int64_t)i * kSymPush + pos] = (en & 0xffffffff00000000ull) | inv_row;
+    for (int e0 = 0; e0 < fcnt; e0 += 64) {
+        const bool on = e0 + lane < fcnt;
+        const uint64_t en = on ? fbuf[e0 + lane] : 0ull;
+        const uint32_t lo = (uint32_t)en;
+        const int cell = (int)(lo & 0x3fffffffu);
+        const int x = (int)(uint32_t)(en >> 32);
+        int rowl = 0, thr = kNoThr;
+        if (on) {
+            rowl = a.row_slot[cell];
+            thr = a.thr_slot[cell];
+        }
+        const int row = (cell & ~(kSymC - 1)) + rowl;
+        if ((lo & kStageFgn) && x > thr) {         // one returning atomic, one store
+            const int pos = atomicAdd(&a.push_cnt[row], 1);
+            if (pos < kSymPush) a.push_buf[(int64_t)row * kSymPush + pos] = (en & 0xffffffff00000000ull) | inv_row;
+        }
+        const bool own = (lo & kStageOwn) && x > st.thr;      // (the threshold may have risen since the sum was staged)
+        const uint64_t mo = __ballot(own);
+        if (mo) {
+            const int pos = st.cnt + __popcll(mo & ((1ull << lane) - 1ull));
+            if (own) cand[pos] = (en & 0xffffffff00000000ull) | (uint32_t)(~row);
+            st.cnt += __popcll(mo);
+            st.pushed = 1;
+            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane, false);
+        }
     }
     wave_sync();
     fcnt = 0;
 }
 
-// the eight sums of one sweep step (to-rows j0 .. j0+3 and j1 .. j1+3) against the upper halves of those rows' thresholds
-// (q: two per word, in that order) -- the rare path.  (Unrolled: with a rolled loop the compiler keeps the eight sums in
-// scratch memory, stores in the hot path included.)
-__device__ inline void foreign8(uint64_t *fbuf, int &fcnt, const int4 &v0, const int4 &v1, const int4 &q, int j0, int j1,
-                                int lane, const K3SymArgs &a, uint32_t inv_row)
+// One sum of the rare path: staged when it beats lim = min(the from-row's own threshold, gmin of the lane's eight slots).
+template <int kCap>
+__device__ inline void stage1(uint64_t *cand, TopState &st, uint64_t *fbuf, int &fcnt, int x, int lim, int tg, int cell, int ntop,
+                              int lane, const K3SymArgs &a, uint32_t inv_row)
 {
-    const int xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    const int ws[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int x = xs[c];
-        const int tt = (c & 1) ? (int)((uint32_t)ws[c >> 1] >> 16) : (ws[c >> 1] & 0xffff);
-        const int j = (c < 4 ? j0 : j1) + (c & 3);
-        // (conservative: sum > thr implies >= of the upper halves; never a zero or negative sum)
-        const bool pred = (x >> 16) >= tt && x > a.thr0;
-        const uint64_t mk = __ballot(pred);
-        if (mk) {
-            const int pos = fcnt + __popcll(mk & ((1ull << lane) - 1ull));
-            if (pred) fbuf[pos] = ((uint64_t)(uint32_t)x << 32) | (uint32_t)j;
-            fcnt += __popcll(mk);
-            if (fcnt > kSymF - 64) flush_foreign(fbuf, fcnt, lane, a, inv_row);
-        }
+    const bool any = x > lim;
+    const uint64_t mk = __ballot(any);
+    if (mk) {
+        const int pos = fcnt + __popcll(mk & ((1ull << lane) - 1ull));
+        if (any)
+            fbuf[pos] = ((uint64_t)(uint32_t)x << 32) | (x > st.thr ? kStageOwn : 0u) | (x > tg ? kStageFgn : 0u) | (uint32_t)cell;
+        fcnt += __popcll(mk);
+        if (fcnt > kSymF - 64) drain_stage<kCap>(cand, st, fbuf, fcnt, ntop, lane, a, inv_row);
     }
 }
 
-// sweep_block of k3_core.h with the second filter.  qa / qb: the upper halves of the thresholds of the eight to-rows whose
-// sums this lane reads in steps 0 / 1 (0x7fff.. where there is nothing to hand over: no sum's upper half reaches that --
-// |sum| stays below 2^31 / 1.0001, pfz_cossim_topn_rows); those of steps 2 / 3 are loaded from tq_blk while steps 0 / 1
-// are worked on.  hand_over = pass 1.  (Two rolled iterations of two steps, like the main kernel's sweep: the code of the
-// rare paths exists twice, not four times.)
-#ifndef PFZ_K3_SYM_TQ4
-#define PFZ_K3_SYM_TQ4 0           // 1: the thresholds of all four sweep steps are loaded before the scatter (16 registers across it)
-#endif
+// The rare path of a sweep step of pass 1: some lane's maximum beats lim.  v0 / v1: the lane's eight sums, cell0 / cell1: the
+// cells of v0.x / v1.x; pa / pb / pc: the partial maxima the sweep has anyway (of v0.xyz, of v0.w v1.xy, of v1.zw) -- only the
+// sums under a partial maximum that beats lim are looked at one by one (a step that gets here has one such lane, as a rule).
+template <int kCap>
+__device__ inline void stage8(uint64_t *cand, TopState &st, uint64_t *fbuf, int &fcnt, const int4 &v0, const int4 &v1, int pa,
+                              int pb, int pc, int lim, int tg, int cell0, int cell1, int ntop, int lane, const K3SymArgs &a,
+                              uint32_t inv_row)
+{
+    if (__ballot(pa > lim)) {
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.x, lim, tg, cell0, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.y, lim, tg, cell0 + 1, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.z, lim, tg, cell0 + 2, ntop, lane, a, inv_row);
+    }
+    if (__ballot(pb > lim)) {
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.w, lim, tg, cell0 + 3, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.x, lim, tg, cell1, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.y, lim, tg, cell1 + 1, ntop, lane, a, inv_row);
+    }
+    if (__ballot(pc > lim)) {
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.z, lim, tg, cell1 + 2, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.w, lim, tg, cell1 + 3, ntop, lane, a, inv_row);
+    }
+}
+
+// sweep_block of k3_core.h for pass 1: the block's accumulators are in threshold order (k3_sym_order), tq = gmin of this
+// lane's four sweep steps.  (Two rolled iterations of two steps, like the main kernel's sweep: the code of the rare path
+// exists twice, not four times.)
 template <int N4, int kCap>
-__device__ inline void sweep_block_sym(int4 *acc4, uint64_t *cand, TopState &st, int col0, int self_col, int ntop, int lane,
-                                       int zero, int4 qa, int4 qb,
-#if PFZ_K3_SYM_TQ4
-                                       int4 qc, int4 qd,
-#else
-                                       const int4 *tq_blk,
-#endif
-                                       uint64_t *fbuf, int &fcnt, const K3SymArgs &a, uint32_t inv_row, bool hand_over)
+__device__ inline void sweep_block_handover(int4 *acc4, uint64_t *cand, TopState &st, int b, int ntop, int lane, int zero,
+                                            int4 tq, uint64_t *fbuf, int &fcnt, const K3SymArgs &a, uint32_t inv_row)
 {
     static_assert(N4 / 128 == 4, "four sweep steps per block");
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
-        const int4 qq[2] = {qa, qb};
-#if PFZ_K3_SYM_TQ4
-        qa = qc;
-        qb = qd;
-#else
-        if (h == 0 && hand_over) {
-            qa = tq_blk[2 * 64 + lane];
-            qb = tq_blk[3 * 64 + lane];
-        }
-#endif
+        const int tg[2] = {tq.x, tq.y};
+        tq.x = tq.z;
+        tq.y = tq.w;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i0 = (2 * h + u) * 128 + lane, i1 = i0 + 64;
+            const int t = 2 * h + u;
+            const int i0 = t * 128 + lane, i1 = i0 + 64;
             const int4 v0 = acc4[i0], v1 = acc4[i1];
             acc4[i0] = make_int4(zero, zero, zero, zero);
             acc4[i1] = make_int4(zero, zero, zero, zero);
-            const int mx = max3i(max3i(v0.x, v0.y, v0.z), max3i(v0.w, v1.x, v1.y), max3i(v1.z, v1.w, v1.w));
-            const uint32_t d = upper_diff(v0.x, v0.y, qq[u].x) & upper_diff(v0.z, v0.w, qq[u].y) &
-                               upper_diff(v1.x, v1.y, qq[u].z) & upper_diff(v1.z, v1.w, qq[u].w);
-            const bool f = hand_over && (d & 0x80008000u) != 0x80008000u;       // some upper half reaches its row's
-            const bool own = mx > st.thr;
-            if (__ballot(own || f)) {
-                if (__ballot(own)) {
-                    push4<kCap>(cand, st, v0, col0 + i0 * 4, self_col, ntop, lane);
-                    push4<kCap>(cand, st, v1, col0 + i1 * 4, self_col, ntop, lane);
-                }
-                if (__ballot(f)) foreign8(fbuf, fcnt, v0, v1, qq[u], col0 + i0 * 4, col0 + i1 * 4, lane, a, inv_row);
-            }
+            const int pa = max3i(v0.x, v0.y, v0.z), pb = max3i(v0.w, v1.x, v1.y), pc = max(v1.z, v1.w);
+            const int lim = min(st.thr, tg[u]);
+            if (__ballot(max3i(pa, pb, pc) > lim))
+                stage8<kCap>(cand, st, fbuf, fcnt, v0, v1, pa, pb, pc, lim, tg[u], b * kSymC + i0 * 4, b * kSymC + i1 * 4, ntop, lane, a,
+                             inv_row);
         }
     }
 }
@@ -199,7 +283,7 @@ __device__ inline void sweep_block_sym(int4 *acc4, uint64_t *cand, TopState &st,
 template <int C, int MODE>
 __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
 {
-    static_assert(C == kSymC, "thr16_pos() is written for 2048-row blocks");
+    static_assert(C == kSymC, "sym_slot() is written for 2048-row blocks");
     // accumulators first: they land at LDS address 0 and a posting's byte offset IS its LDS address (run_steps)
     __shared__ __attribute__((aligned(16))) struct {
         int acc[C];
@@ -214,18 +298,17 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     const int lane = threadIdx.x;
     int4 *acc4 = (int4 *)acc;
     constexpr int N4 = C / 4;
-    constexpr int NT = N4 / 128;
     int zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
     for (int t = lane; t < C / 4; t += 64) acc4[t] = make_int4(0, 0, 0, 0);
     wave_sync();
-    const char *post_bytes = (const char *)a.post;
+    constexpr int mode = MODE;
+    const char *post_bytes = (const char *)(mode == 1 ? a.post_sym : a.post);
     const int src4 = (4 * (lane & 15) + (lane >> 4)) * 4;
     const int sub8 = (lane & 15) * 8;
     const int dummy_addr = a.n_pieces << 7;
     const int nb = a.nb, ntop = a.ntop;
-    constexpr int mode = MODE;
-    const int4 *thr16q = (const int4 *)a.thr16;
+    const int4 *gmin4 = (const int4 *)a.gmin;
 
     int n_items = a.row_end - a.row_begin;
     const int n_sl = mode == 2 ? a.n_sl : 1;
@@ -276,7 +359,6 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             warmed = true;
             wave_sync();
         }
-        int pub = st.thr;
         int fcnt = 0;
 
         const int n_blk = b_hi - b_lo;
@@ -294,20 +376,11 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         for (int it = 0, b = b_first; it < n_blk; ++it) {
             const int s = cur0, e = have0 ? nxt0 : cur0;
             const int b_next = b + 1 < b_hi ? b + 1 : b_lo;
-            // the thresholds of the block's first two sweep steps, in flight across the scatter (the other two follow inside the sweep)
-            const int4 *tq_blk = thr16q + (int64_t)b * NT * 64;
-            int4 qa = make_int4(0x7fff7fff, 0x7fff7fff, 0x7fff7fff, 0x7fff7fff), qb = qa;
-#if PFZ_K3_SYM_TQ4
-            int4 qc = qa, qd = qa;
+            // pass 1: the minimum thresholds of this lane's four sweep steps, in flight across the scatter
+            int4 tq = make_int4(kNoThr, kNoThr, kNoThr, kNoThr);
+#if PFZ_K3_SYM_EXP != 1      // (what-if 1: nothing is handed over)
+            if (mode == 1) tq = gmin4[(int64_t)b * 64 + lane];
 #endif
-            if (mode == 1 && !(a.exp & 2)) {
-                qa = tq_blk[lane];
-                qb = tq_blk[64 + lane];
-#if PFZ_K3_SYM_TQ4
-                qc = tq_blk[128 + lane];
-                qd = tq_blk[192 + lane];
-#endif
-            }
             bool touched = __ballot(e > s) != 0;
             if (touched) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
             if (have0 && it + 1 < n_blk) {
@@ -337,24 +410,16 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                         st.thr = t > st.thr ? t : st.thr;
                     }
                 }
-#if PFZ_K3_SYM_TQ4
-                sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, qc, qd, fbuf, fcnt, a, inv_row, mode == 1 && !(a.exp & 1));
-#else
-                sweep_block_sym<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero, qa, qb, tq_blk, fbuf, fcnt, a, inv_row, mode == 1 && !(a.exp & 1));
-#endif
+                if (mode == 1)
+                    sweep_block_handover<N4, kSymCap>(acc4, cand, st, b, ntop, lane, zero, tq, fbuf, fcnt, a, inv_row);
+                else
+                    sweep_block<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero);
                 wave_sync();
-                if (mode == 1 && st.thr > pub && !(a.exp & 4)) {        // tell the rows below: fewer of their sums are candidates of this row
-                    pub = st.thr;
-                    if (lane == 0) {
-                        a.thrv[row] = pub;
-                        a.thr16[thr16_pos(row)] = (uint16_t)((uint32_t)pub >> 16);
-                    }
-                }
             }
             b = b_next;
         }
 
-        if (fcnt) flush_foreign(fbuf, fcnt, lane, a, inv_row);
+        if (mode == 1 && fcnt) drain_stage<kSymCap>(cand, st, fbuf, fcnt, ntop, lane, a, inv_row);
         compact<kSymCap>(cand, st, ntop, lane);
         if (mode == 2 && n_sl > 1) {
             if (lane < ntop) a.part[(int64_t)item * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
@@ -366,10 +431,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             }
         } else {
             if (lane < ntop) a.keys[(int64_t)row * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
-            if (lane == 0 && (mode == 0 || st.thr > pub)) {
-                a.thrv[row] = st.thr;
-                a.thr16[thr16_pos(row)] = (uint16_t)((uint32_t)st.thr >> 16);
-            }
+            if (mode == 0 && lane == 0) a.thrv[row] = st.thr;
         }
         wave_sync();    // cand is reused by the next item
     }
@@ -460,7 +522,11 @@ struct K3SymState {
     pfz_ctx *ctx = nullptr;
     int64_t n = 0;
     int32_t *thrv = nullptr;
-    uint16_t *thr16 = nullptr;
+    uint16_t *slot4 = nullptr;
+    int32_t *gmin = nullptr;
+    int32_t *thr_slot = nullptr;
+    uint16_t *row_slot = nullptr;
+    int2 *post_sym = nullptr;
     uint64_t *keys = nullptr;
     int32_t *push_cnt = nullptr;
     uint64_t *push_buf = nullptr;
@@ -479,13 +545,9 @@ void k3_sym_free(pfz_index *ix)
 {
     K3SymState *s = ix->sym;
     if (!s) return;
-    if (s->thrv) pool_free(s->thrv);
-    if (s->thr16) pool_free(s->thr16);
-    if (s->keys) pool_free(s->keys);
-    if (s->push_cnt) pool_free(s->push_cnt);
-    if (s->push_buf) pool_free(s->push_buf);
-    if (s->ovf) pool_free(s->ovf);
-    if (s->part) pool_free(s->part);
+    void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
+    for (void *p : bufs)
+        if (p) pool_free(p);
     delete s;
     ix->sym = nullptr;
 }
@@ -504,43 +566,66 @@ int k3_sym_wanted(const pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int
     const int force = sym_env_int("PFZ_K3_SYM", -1);    // 0: never; 1: whenever the arithmetic allows (tests); default: auto
     if (force == 0) return 0;
     if (!exclude_diag || diag_offset != 0 || A->serial != ix->src_serial || A->n_rows != ix->n_rows) return 0;
-    if (ix->block_cols != kSymC || ntop > kSymKeep || ix->n_blocks < 2 || ix->n_rows >= ((int64_t)1 << 30)) return 0;
+    if (ix->block_cols != kSymC || !ix->pblk || ntop > kSymKeep || ix->n_blocks < 2 || ix->n_rows >= ((int64_t)1 << 30)) return 0;
     const K3SymState *s = ix->sym;
+    if (s && s->n < 0) return 0;       // (the session buffers could not be allocated once: the row-major kernel serves this index)
     if (row_begin > 0) {
         const bool cont = s && s->next_row == row_begin && s->a_serial == A->serial && s->out == out && s->ntop == ntop &&
                           s->thr0 == thr0 && s->scale == scale;
         return cont ? 2 : 0;
     }
     if (force == 1) return 1;
-    // auto: where halving K3 pays for five more launches and the state round trip, and where the row-major kernel is the one that
+    // auto: where halving K3 pays for seven more launches and the state round trip, and where the row-major kernel is the one that
     // would run (k3_lockstep.hip takes the to-sides beyond 250 000 rows); a first range of less than a fifth of the rows is a
     // shard of a bigger job (bench --scaling strong), not the start of a whole self-match
     if (ix->n_rows < sym_env_int("PFZ_K3_SYM_MIN", 20480) || ix->n_rows > 250000) return 0;
     return (row_end - row_begin) * 5 >= ix->n_rows ? 1 : 0;
 }
 
+// the session buffers of an index, allocated by its first symmetric launch and kept with it
+static int sym_state_alloc(pfz_ctx *ctx, const pfz_index *ix, K3SymState *s)
+{
+    const int64_t n = ix->n_rows;
+    const size_t cells = (size_t)ix->n_blocks * kSymC;
+    PFZ_TRY(pool_alloc(ctx, &s->thrv, (size_t)n * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->slot4, cells * sizeof(uint16_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->gmin, cells / 8 * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->thr_slot, cells * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->row_slot, cells * sizeof(uint16_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->post_sym, (size_t)(ix->n_pieces + 1) * kPiece * sizeof(int2)));
+    PFZ_TRY(pool_alloc(ctx, &s->keys, (size_t)n * kSymKeep * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->push_cnt, (size_t)n * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->push_buf, (size_t)n * kSymPush * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->ovf, (size_t)(n + 1) * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->part, (size_t)kSymSlicedRows * kSymSlices * kSymKeep * sizeof(uint64_t)));
+    return PFZ_OK;
+}
+
+// *declined: the buffers of the session could not be allocated -- nothing was enqueued, the caller runs the row-major kernel
+// (which needs none of them) and this index is not asked again
 int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
-                  int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start)
+                  int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start, bool *declined)
 {
     const int64_t n = ix->n_rows;
     const int nb = ix->n_blocks;
+    *declined = false;
     K3SymState *s = ix->sym;
     if (!s) {
         s = new K3SymState();
         s->ctx = ctx;
         s->n = n;
         ix->sym = s;      // (freed with the index, whatever happens below)
-        PFZ_TRY(pool_alloc(ctx, &s->thrv, (size_t)n * sizeof(int32_t)));
-        PFZ_TRY(pool_alloc(ctx, &s->thr16, (size_t)nb * kSymC * sizeof(uint16_t)));
-        PFZ_TRY(pool_alloc(ctx, &s->keys, (size_t)n * kSymKeep * sizeof(uint64_t)));
-        PFZ_TRY(pool_alloc(ctx, &s->push_cnt, (size_t)n * sizeof(int32_t)));
-        PFZ_TRY(pool_alloc(ctx, &s->push_buf, (size_t)n * kSymPush * sizeof(uint64_t)));
-        PFZ_TRY(pool_alloc(ctx, &s->ovf, (size_t)(n + 1) * sizeof(int32_t)));
-        PFZ_TRY(pool_alloc(ctx, &s->part, (size_t)kSymSlicedRows * kSymSlices * kSymKeep * sizeof(uint64_t)));
-    }
-    if (!s->thrv || !s->thr16 || !s->keys || !s->push_cnt || !s->push_buf || !s->ovf || !s->part) {
-        set_error("pfz_cossim_topn (symmetric): the session buffers of this index could not be allocated earlier");
-        return PFZ_ERR_INVALID;
+        if (getenv("PFZ_K3_SYM_FAIL_ALLOC") || sym_state_alloc(ctx, ix, s) != PFZ_OK) {      // (the knob: tests of this fallback)
+            void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
+            for (void *p : bufs)
+                if (p) pool_free(p);
+            *s = K3SymState();
+            s->ctx = ctx;
+            s->n = -1;
+            (void)hipGetLastError();
+            *declined = true;
+            return PFZ_OK;
+        }
     }
     s->next_row = -1;     // (no session while this call can still fail)
     K3SymArgs a;
@@ -550,6 +635,8 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.n = (int32_t)n;
     a.tab = ix->tab;
     a.post = ix->post;
+    a.post_sym = s->post_sym;
+    a.pblk = ix->pblk;
     a.nb = nb;
     a.n_pieces = ix->n_pieces;
     a.ntop = ntop;
@@ -557,7 +644,10 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.scale = scale;
     a.inv_scale = inv_scale;
     a.thrv = s->thrv;
-    a.thr16 = s->thr16;
+    a.slot4 = s->slot4;
+    a.gmin = s->gmin;
+    a.thr_slot = s->thr_slot;
+    a.row_slot = s->row_slot;
     a.keys = s->keys;
     a.push_cnt = s->push_cnt;
     a.push_buf = s->push_buf;
@@ -568,21 +658,23 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.n_sl = 1;
     a.out_idx = out->idx;
     a.out_val = out->val;
-    a.exp = sym_env_int("PFZ_K3_SYM_EXP", 0);
     if (start) {
-        // pass 0 over ALL rows: every row's first threshold is there before anybody hands anything over
+        // pass 0 over ALL rows: every row's first threshold is there before anybody hands anything over; then the re-deal of
+        // every block's rows to the accumulator slots and the re-dealt copy of the postings
         PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
-        PFZ_HIP(hipMemsetAsync(s->thr16, 0x7f, (size_t)nb * kSymC * sizeof(uint16_t), ctx->stream));
         a.row_begin = 0;
         a.row_end = (int32_t)n;
         hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3((unsigned)n), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
+        const int64_t pairs = ((int64_t)ix->n_pieces + 1) * (kPiece / 2);
+        hipLaunchKernelGGL(k3_sym_repost, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, a);
     }
     PFZ_HIP(hipMemsetAsync(s->ovf, 0, sizeof(int32_t), ctx->stream));
     // pass 1: the rows of this range that have blocks above their own
     const int64_t last_block_row = (int64_t)(nb - 1) * kSymC;
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)(row_end < last_block_row ? row_end : last_block_row);
-    if (a.row_end > a.row_begin)
+    if (a.row_end > a.row_begin)      // (one row per one-wave workgroup: 2 / 4 / 22 rows per workgroup measured no faster -- the dispatcher is not what a row waits for)
         hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(a.row_end - a.row_begin)), dim3(64), 0, ctx->stream, a);
     // merge, then the rows that were sent too much
     a.row_begin = (int32_t)row_begin;

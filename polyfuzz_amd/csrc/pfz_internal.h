@@ -108,6 +108,7 @@ struct pfz_index {
     int32_t n_pieces = 0;
     int32_t *tab = nullptr;  // [n_cols * n_blocks + 2] first piece of every list
     int2 *post = nullptr;    // [(n_pieces + 1) * 16]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
+    uint16_t *pblk = nullptr; // [n_pieces + 1]  the to-block of every piece (k3_symmetric.hip re-deals a block's rows to its accumulator slots)
     float max_norm = 1.f;    // of the indexed matrix' rows
     uint64_t src_serial = 0; // pfz_csr::serial of the matrix it was built from
     mutable pfz::K3SymState *sym = nullptr;   // k3_symmetric.hip, allocated by the first symmetric self-match on this index

@@ -46,6 +46,35 @@ def test_headline_properties(headline):
     np.testing.assert_array_equal(val[best[rows[rr]], cc], val[rows[rr], 0])
 
 
+@pytest.mark.parametrize("ntop", [5, 1])
+def test_headline_symmetric_equals_row_major(headline, ctx, monkeypatch, ntop):
+    """the symmetric kernel -- the headline's kernel -- against the row-major kernel on ALL 100 000 rows,
+    top-5 and top-1, bit for bit (two launches of ~2.5 ms), and the fallback when the session buffers cannot be allocated."""
+    from polyfuzz_amd import _lib
+    names, a, idx, val, _, _ = headline
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    ix0 = _lib.DeviceIndex.build(ctx, a)
+    r_idx, r_val = _lib.cossim_topn(ctx, ix0, a, ntop, 0.0, exclude_diag=True).download()
+    assert ix0.symmetric_launches()[0] == 0
+    monkeypatch.delenv("PFZ_K3_SYM", raising=False)
+    ix1 = _lib.DeviceIndex.build(ctx, a)
+    s_idx, s_val = _lib.cossim_topn(ctx, ix1, a, ntop, 0.0, exclude_diag=True).download()
+    assert ix1.symmetric_launches()[0] == 1                   # the automatic choice at this size
+    np.testing.assert_array_equal(s_idx, r_idx)
+    np.testing.assert_array_equal(s_val, r_val)
+    if ntop == 5:
+        np.testing.assert_array_equal(idx, r_idx)             # (the fixture's result came from the automatic choice too)
+        np.testing.assert_array_equal(val, r_val)
+        monkeypatch.setenv("PFZ_K3_SYM_FAIL_ALLOC", "1")      # ADVICE r4: no session buffers -> the row-major kernel, not an error
+        ix2 = _lib.DeviceIndex.build(ctx, a)
+        f_idx, f_val = _lib.cossim_topn(ctx, ix2, a, ntop, 0.0, exclude_diag=True).download()
+        f_idx2, _ = _lib.cossim_topn(ctx, ix2, a, ntop, 0.0, exclude_diag=True).download()
+        assert ix2.symmetric_launches()[0] == 0
+        np.testing.assert_array_equal(f_idx, r_idx)
+        np.testing.assert_array_equal(f_val, r_val)
+        np.testing.assert_array_equal(f_idx2, r_idx)
+
+
 def test_headline_duplicates_tie_exactly(headline, oracle_mod):
     names, a, idx, val, _, _ = headline
     first = {}

@@ -446,3 +446,41 @@ def test_symmetric_kernel_on_real_names(ctx, oracle_mod, monkeypatch):
     r1 = _self_match(ctx, a3, 501, 5, 0.0)
     np.testing.assert_array_equal(r1[0], r0[0])
     np.testing.assert_array_equal(r1[1], r0[1])
+
+
+@pytest.mark.parametrize("n,expect_sym", [(20479, 0), (20480, 1)])
+def test_symmetric_switch_over_small(ctx, monkeypatch, n, expect_sym):
+    """Either side of the automatic choice's lower end (20 480 rows = ten to-blocks): one row fewer runs the row-major kernel,
+    the size itself the symmetric one -- the same result as the forced row-major run, bit for bit."""
+    from polyfuzz_amd import datasets, _lib
+    names = datasets.load_company_names()[:n]
+    s = _lib.DeviceStrings.upload(ctx, names)
+    a = _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 3, 1, 1), s, None).transform(s)
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    ref = _lib.cossim_topn(ctx, _lib.DeviceIndex.build(ctx, a), a, 5, 0.0, exclude_diag=True).download()
+    monkeypatch.delenv("PFZ_K3_SYM", raising=False)
+    ix = _lib.DeviceIndex.build(ctx, a)
+    got = _lib.cossim_topn(ctx, ix, a, 5, 0.0, exclude_diag=True).download()
+    assert ix.symmetric_launches()[0] == expect_sym
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("n,expect_sym", [(250000, 1), (250001, 0)])
+def test_symmetric_switch_over_large(ctx, monkeypatch, n, expect_sym):
+    """Either side of the upper end (250 000 rows: beyond, the lock-step kernel takes the self-match): synthetic
+    company-name-like strings, top-3; the forced row-major run is the reference for both."""
+    from polyfuzz_amd import synth, _lib
+    names = synth.company_names(n, seed=11)
+    s = _lib.DeviceStrings.upload(ctx, names)
+    a = _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 3, 1, 1), s, None).transform(s)
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    monkeypatch.setenv("PFZ_K3_LOCKSTEP", "0")
+    ref = _lib.cossim_topn(ctx, _lib.DeviceIndex.build(ctx, a), a, 3, 0.0, exclude_diag=True).download()
+    monkeypatch.delenv("PFZ_K3_SYM", raising=False)
+    monkeypatch.delenv("PFZ_K3_LOCKSTEP", raising=False)
+    ix = _lib.DeviceIndex.build(ctx, a)
+    got = _lib.cossim_topn(ctx, ix, a, 3, 0.0, exclude_diag=True).download()
+    assert ix.symmetric_launches()[0] == expect_sym
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
