@@ -104,6 +104,11 @@ int pfz_index_pieces(const pfz_index *ix, int64_t *n_pieces, int64_t *piece_post
  * _tfidf.py:113-116 -> _utils.py:82-87: every unordered pair of rows scored once, csrc/k3_symmetric.hip), and how many
  * from-rows those launches covered -- the bench prices its roofline by the kernel that ran */
 int pfz_index_symmetric_launches(const pfz_index *ix, int64_t *launches, int64_t *rows);
+/* census of the LAST symmetric launch on this index (waits for the stream): rows taken out of the hand-over because of
+ * their low own-block threshold ("magnets": they fetch their matches below their own block themselves) and rows that were
+ * sent more candidates than their push slots hold and were recomputed row-major -- what the tests of those two paths assert
+ * (nothing to replace in the reference: the exchange only exists because every unordered pair is scored once) */
+int pfz_index_symmetric_census(const pfz_index *ix, int64_t *magnet_rows, int64_t *recomputed_rows);
 
 int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out);
 void pfz_topn_free(pfz_topn *t);

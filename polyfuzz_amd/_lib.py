@@ -57,6 +57,7 @@ SIGNATURES = {
     "pfz_index_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
     "pfz_index_pieces": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
     "pfz_index_symmetric_launches": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
+    "pfz_index_symmetric_census": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
     "pfz_topn_alloc": (ctypes.c_int, [c_vp, c_i64, c_i32, P(c_vp)]),
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
@@ -295,6 +296,12 @@ class DeviceIndex(_Handle):
         """(launches, from-rows) of this index that K3 served in its symmetric self-match form (k3_symmetric.hip)"""
         a, b = c_i64(), c_i64()
         check(self.ctx.lib.pfz_index_symmetric_launches(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def symmetric_census(self):
+        """(magnet rows, rows recomputed row-major) of the last symmetric launch on this index (k3_symmetric.hip)"""
+        a, b = c_i64(), c_i64()
+        check(self.ctx.lib.pfz_index_symmetric_census(self.h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
 

@@ -71,6 +71,8 @@ constexpr int kSymSlicedRows = 4096;   // ... for the first so many rows of the 
 #ifndef PFZ_K3_SYM_EXP
 #define PFZ_K3_SYM_EXP 0           // timing experiments (tools/build_variant.sh -DPFZ_K3_SYM_EXP=n: results wrong on purpose); 0 = the product
 #endif
+constexpr int kSymMag = 1;          // "magnet" rows per LDS bank class and block: the rows of the lowest thresholds are taken out of the hand-over
+constexpr int kSymMagBlocks = 8;   // ... and walk the blocks below their own themselves, in items of so many to-blocks
 constexpr int kNoThr = 0x7fffffff;     // threshold of a slot without a row (the last block's tail): no sum reaches it
 
 struct K3SymArgs {
@@ -87,9 +89,11 @@ struct K3SymArgs {
     int32_t row_begin, row_end;   // the rows of this launch (modes 0 and 1, merge)
     int32_t *thrv;            // [n]              a row's threshold after pass 0 (accept sum > thr)
     uint16_t *slot4;          // [nb * C]         4 * (slot of to-row b * C + r): its accumulator's byte offset in pass 1
-    int32_t *gmin;            // [nb][64][4]      (block, lane, sweep step) -> the minimum threshold of the lane's eight slots
+    uint32_t *gmin;           // [nb][64]         (block, lane) -> byte t: the top byte of the minimum threshold of the eight slots the lane reads in sweep step t (0xff: none)
     int32_t *thr_slot;        // [nb * C]         cell (block * C + slot) -> the threshold of the row that owns the slot
     uint16_t *row_slot;       // [nb * C]         ... and that row (inside the block)
+    int32_t *mag;             // [nb][32 * kSymMag]  the magnet rows of every block (-1: none)
+    int32_t n_mag_items, mag_b0, mag_row_end;   // pass 1: the first so many items are magnet items (block mag_b0 + ..., class, slice of the lower blocks), for the magnets below mag_row_end
     uint64_t *keys;           // [n][ntop]        a row's own candidates, sorted, 0 = none
     int32_t *push_cnt;        // [n]
     uint64_t *push_buf;       // [n][kSymPush]    keys sum << 32 | ~(row that found it)
@@ -136,15 +140,29 @@ __global__ __launch_bounds__(1024) void k3_sym_order(const K3SymArgs a)
         }
         int t, l, e;
         const int slot = sym_slot(rho, rank, &t, &l, &e);
+        // Magnets: the row(s) of the lowest threshold of every bank class.  A low threshold draws candidates from every row
+        // below (93 per row for the lowest of a class, 0.3 for the highest: CPU census of the 100 000 names) and its group's
+        // minimum sends a quarter of all sweep steps into the rare path; such a row is sent nothing -- no sum reaches kNoThr --
+        // and fetches its matches in the blocks below its own itself (magnet items of pass 1).  Block 0 has nothing below.
+        const bool magnet = rank < kSymMag && row < a.n && b > 0;
+        if (rank < kSymMag) a.mag[(int64_t)b * (32 * kSymMag) + rho * kSymMag + rank] = magnet ? row : -1;
         a.slot4[(int64_t)b * kSymC + r] = (uint16_t)(slot * 4);
-        a.thr_slot[(int64_t)b * kSymC + slot] = thr;
+        a.thr_slot[(int64_t)b * kSymC + slot] = magnet ? kNoThr : thr;
         a.row_slot[(int64_t)b * kSymC + slot] = (uint16_t)r;
-        atomicMin(&s_gmin[t * 64 + l], thr);
+        if (!magnet) atomicMin(&s_gmin[t * 64 + l], thr);
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
-        const int t = threadIdx.x >> 6, l = threadIdx.x & 63;
-        a.gmin[((int64_t)b * 64 + l) * 4 + t] = s_gmin[threadIdx.x];
+    if (threadIdx.x < 64) {
+        // what the sweep compares is the TOP BYTE of sums and minima (one v_cmp_ge_u32_sdwa, four minima per dword: the 16 bytes
+        // of exact minima per lane and block cost pass 1 a tenth of its time, measured); conservative -- the exact thresholds
+        // decide when the stage is drained -- and coarse only where it does not matter: 20.0 -> 21.5 % of the sweep steps
+        // enter the rare path (CPU simulation)
+        uint32_t w = 0;
+        for (int t = 0; t < 4; ++t) {
+            const int g = s_gmin[t * 64 + threadIdx.x];
+            w |= (g == kNoThr ? 0xffu : (uint32_t)g >> 24) << (8 * t);
+        }
+        a.gmin[(int64_t)b * 64 + threadIdx.x] = w;
     }
 }
 
@@ -191,7 +209,11 @@ __device__ inline void drain_stage(uint64_t *cand, TopState &st, uint64_t *fbuf,
             thr = a.thr_slot[cell];
         }
         const int row = (cell & ~(kSymC - 1)) + rowl;
+#if PFZ_K3_SYM_EXP == 5      // (what-if 5: staged and drained, but nothing is pushed)
+        if (false) {
+#else
         if ((lo & kStageFgn) && x > thr) {         // one returning atomic, one store
+#endif
             const int pos = atomicAdd(&a.push_cnt[row], 1);
             if (pos < kSymPush) a.push_buf[(int64_t)row * kSymPush + pos] = (en & 0xffffffff00000000ull) | inv_row;
         }
@@ -209,59 +231,67 @@ __device__ inline void drain_stage(uint64_t *cand, TopState &st, uint64_t *fbuf,
     fcnt = 0;
 }
 
-// One sum of the rare path: staged when it beats lim = min(the from-row's own threshold, gmin of the lane's eight slots).
+// One sum of the rare path: staged when it beats the from-row's own threshold or reaches tgu = the (top-byte) minimum
+// threshold of the lane's eight slots, as an unsigned number with zeros below the top byte (0xff000000: nothing reaches it).
 template <int kCap>
-__device__ inline void stage1(uint64_t *cand, TopState &st, uint64_t *fbuf, int &fcnt, int x, int lim, int tg, int cell, int ntop,
+__device__ inline void stage1(uint64_t *cand, TopState &st, uint64_t *fbuf, int &fcnt, int x, uint32_t tgu, int cell, int ntop,
                               int lane, const K3SymArgs &a, uint32_t inv_row)
 {
-    const bool any = x > lim;
-    const uint64_t mk = __ballot(any);
+    const bool own = x > st.thr, fgn = (uint32_t)x >= tgu;
+    const uint64_t mk = __ballot(own || fgn);
     if (mk) {
         const int pos = fcnt + __popcll(mk & ((1ull << lane) - 1ull));
-        if (any)
-            fbuf[pos] = ((uint64_t)(uint32_t)x << 32) | (x > st.thr ? kStageOwn : 0u) | (x > tg ? kStageFgn : 0u) | (uint32_t)cell;
+        if (own || fgn)
+            fbuf[pos] = ((uint64_t)(uint32_t)x << 32) | (own ? kStageOwn : 0u) | (fgn ? kStageFgn : 0u) | (uint32_t)cell;
         fcnt += __popcll(mk);
         if (fcnt > kSymF - 64) drain_stage<kCap>(cand, st, fbuf, fcnt, ntop, lane, a, inv_row);
     }
 }
 
-// The rare path of a sweep step of pass 1: some lane's maximum beats lim.  v0 / v1: the lane's eight sums, cell0 / cell1: the
-// cells of v0.x / v1.x; pa / pb / pc: the partial maxima the sweep has anyway (of v0.xyz, of v0.w v1.xy, of v1.zw) -- only the
-// sums under a partial maximum that beats lim are looked at one by one (a step that gets here has one such lane, as a rule).
+// The rare path of a sweep step of pass 1: some lane's maximum beats the own threshold or reaches the lane's minimum.  v0 /
+// v1: the lane's eight sums, cell0 / cell1: the cells of v0.x / v1.x; pa / pb / pc: the partial maxima the sweep has anyway (of
+// v0.xyz, of v0.w v1.xy, of v1.zw) -- only the sums under a partial maximum that passes are looked at one by one (a step that
+// gets here has one such lane, as a rule).
 template <int kCap>
 __device__ inline void stage8(uint64_t *cand, TopState &st, uint64_t *fbuf, int &fcnt, const int4 &v0, const int4 &v1, int pa,
-                              int pb, int pc, int lim, int tg, int cell0, int cell1, int ntop, int lane, const K3SymArgs &a,
+                              int pb, int pc, uint32_t tgu, int cell0, int cell1, int ntop, int lane, const K3SymArgs &a,
                               uint32_t inv_row)
 {
-    if (__ballot(pa > lim)) {
-        stage1<kCap>(cand, st, fbuf, fcnt, v0.x, lim, tg, cell0, ntop, lane, a, inv_row);
-        stage1<kCap>(cand, st, fbuf, fcnt, v0.y, lim, tg, cell0 + 1, ntop, lane, a, inv_row);
-        stage1<kCap>(cand, st, fbuf, fcnt, v0.z, lim, tg, cell0 + 2, ntop, lane, a, inv_row);
+    if (__ballot(pa > st.thr || (uint32_t)pa >= tgu)) {
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.x, tgu, cell0, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.y, tgu, cell0 + 1, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.z, tgu, cell0 + 2, ntop, lane, a, inv_row);
     }
-    if (__ballot(pb > lim)) {
-        stage1<kCap>(cand, st, fbuf, fcnt, v0.w, lim, tg, cell0 + 3, ntop, lane, a, inv_row);
-        stage1<kCap>(cand, st, fbuf, fcnt, v1.x, lim, tg, cell1, ntop, lane, a, inv_row);
-        stage1<kCap>(cand, st, fbuf, fcnt, v1.y, lim, tg, cell1 + 1, ntop, lane, a, inv_row);
+    if (__ballot(pb > st.thr || (uint32_t)pb >= tgu)) {
+        stage1<kCap>(cand, st, fbuf, fcnt, v0.w, tgu, cell0 + 3, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.x, tgu, cell1, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.y, tgu, cell1 + 1, ntop, lane, a, inv_row);
     }
-    if (__ballot(pc > lim)) {
-        stage1<kCap>(cand, st, fbuf, fcnt, v1.z, lim, tg, cell1 + 2, ntop, lane, a, inv_row);
-        stage1<kCap>(cand, st, fbuf, fcnt, v1.w, lim, tg, cell1 + 3, ntop, lane, a, inv_row);
+    if (__ballot(pc > st.thr || (uint32_t)pc >= tgu)) {
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.z, tgu, cell1 + 2, ntop, lane, a, inv_row);
+        stage1<kCap>(cand, st, fbuf, fcnt, v1.w, tgu, cell1 + 3, ntop, lane, a, inv_row);
     }
 }
 
-// sweep_block of k3_core.h for pass 1: the block's accumulators are in threshold order (k3_sym_order), tq = gmin of this
-// lane's four sweep steps.  (Two rolled iterations of two steps, like the main kernel's sweep: the code of the rare path
-// exists twice, not four times.)
+// lanes whose byte 3 of `mx` reaches byte B of `q`: one VOPC instruction with sub-dword operand selection
+template <int B> __device__ inline uint64_t top_byte_reaches(int mx, uint32_t q)
+{
+    uint64_t m;
+    if (B == 0) asm("v_cmp_ge_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_0" : "=s"(m) : "v"(mx), "v"(q));
+    else asm("v_cmp_ge_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_1" : "=s"(m) : "v"(mx), "v"(q));
+    return m;
+}
+
+// sweep_block of k3_core.h for pass 1: the block's accumulators are in threshold order (k3_sym_order), tq = the top bytes of
+// gmin of this lane's four sweep steps.  (Two rolled iterations of two steps, like the main kernel's sweep: the code of the
+// rare path exists twice, not four times.)
 template <int N4, int kCap>
 __device__ inline void sweep_block_handover(int4 *acc4, uint64_t *cand, TopState &st, int b, int ntop, int lane, int zero,
-                                            int4 tq, uint64_t *fbuf, int &fcnt, const K3SymArgs &a, uint32_t inv_row)
+                                            uint32_t tq, uint64_t *fbuf, int &fcnt, const K3SymArgs &a, uint32_t inv_row)
 {
     static_assert(N4 / 128 == 4, "four sweep steps per block");
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
-        const int tg[2] = {tq.x, tq.y};
-        tq.x = tq.z;
-        tq.y = tq.w;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int t = 2 * h + u;
@@ -270,11 +300,13 @@ __device__ inline void sweep_block_handover(int4 *acc4, uint64_t *cand, TopState
             acc4[i0] = make_int4(zero, zero, zero, zero);
             acc4[i1] = make_int4(zero, zero, zero, zero);
             const int pa = max3i(v0.x, v0.y, v0.z), pb = max3i(v0.w, v1.x, v1.y), pc = max(v1.z, v1.w);
-            const int lim = min(st.thr, tg[u]);
-            if (__ballot(max3i(pa, pb, pc) > lim))
-                stage8<kCap>(cand, st, fbuf, fcnt, v0, v1, pa, pb, pc, lim, tg[u], b * kSymC + i0 * 4, b * kSymC + i1 * 4, ntop, lane, a,
-                             inv_row);
+            const int mx = max3i(pa, pb, pc);
+            const uint64_t hit = __ballot(mx > st.thr) | (u == 0 ? top_byte_reaches<0>(mx, tq) : top_byte_reaches<1>(mx, tq));
+            if (hit)
+                stage8<kCap>(cand, st, fbuf, fcnt, v0, v1, pa, pb, pc, (u == 0 ? tq << 24 : tq << 16) & 0xff000000u, b * kSymC + i0 * 4,
+                             b * kSymC + i1 * 4, ntop, lane, a, inv_row);
         }
+        tq >>= 16;
     }
 }
 
@@ -308,9 +340,8 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     const int sub8 = (lane & 15) * 8;
     const int dummy_addr = a.n_pieces << 7;
     const int nb = a.nb, ntop = a.ntop;
-    const int4 *gmin4 = (const int4 *)a.gmin;
 
-    int n_items = a.row_end - a.row_begin;
+    int n_items = a.row_end - a.row_begin + (mode == 1 ? a.n_mag_items : 0);
     const int n_sl = mode == 2 ? a.n_sl : 1;
     const int per_sl = (nb + n_sl - 1) / n_sl;
     if (mode == 2) {
@@ -320,7 +351,22 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         n_items = hi > a.ovf_base ? (hi - a.ovf_base) * n_sl : 0;
     }
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int row = mode == 2 ? a.ovf[1 + a.ovf_base + item / n_sl] : a.row_begin + item;
+        int row = mode == 2 ? a.ovf[1 + a.ovf_base + item / n_sl] : a.row_begin + item;
+        bool magnet = false;      // pass 1: this item is a magnet row x a slice of the blocks BELOW its own
+        int m_lo = 0;
+        if (mode == 1) {
+            if (item < a.n_mag_items) {
+                const int ns = (nb - 1 + kSymMagBlocks - 1) / kSymMagBlocks;
+                const int mm = item / ns;
+                m_lo = (item - mm * ns) * kSymMagBlocks;
+                row = __builtin_amdgcn_readfirstlane(a.mag[(int64_t)(a.mag_b0 + mm / (32 * kSymMag)) * (32 * kSymMag) + mm % (32 * kSymMag)]);
+                if (row < a.row_begin || row >= a.mag_row_end || m_lo >= row / C) continue;     // (-1: no magnet)
+                magnet = true;
+            } else {
+                row -= a.n_mag_items;
+                if (row >= (nb - 1) * C) continue;      // (the last block's rows have nothing above)
+            }
+        }
         const int own = row / C;
         int b_lo = 0, b_hi = nb, b_first = own;
         if (mode == 2 && n_sl > 1) {
@@ -335,10 +381,13 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         if (mode == 0) {
             b_lo = own;
             b_hi = own + 1;
+        } else if (mode == 1 && magnet) {
+            b_lo = m_lo;
+            b_hi = m_lo + kSymMagBlocks < own ? m_lo + kSymMagBlocks : own;
+            b_first = b_lo;
         } else if (mode == 1) {
             b_lo = own + 1;
             b_first = b_lo;
-            if (b_lo >= nb) continue;      // (the launch does not cover the last block's rows; kept for safety)
         }
         const int p0 = a.a_indptr[row], p1 = a.a_indptr[row + 1];
         const int nnz = p1 - p0;
@@ -353,7 +402,8 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             // the state of pass 0: threshold and the sorted keys (zeros at the end).  The marker scratch of the scatter is the
             // LAST 64 ints of cand (keys 64..95): the kept keys (< 32) are out of its way
             st.thr = a.thrv[row];
-            const uint64_t k = lane < ntop ? a.keys[(int64_t)row * ntop + lane] : 0ull;
+            // (a magnet item starts from the threshold alone: what it finds goes to the row's push slots, the keys stay with the row's own item)
+            const uint64_t k = lane < ntop && !magnet ? a.keys[(int64_t)row * ntop + lane] : 0ull;
             st.cnt = __popcll(__ballot(k != 0ull));
             if (k) cand[lane] = k;
             warmed = true;
@@ -373,20 +423,26 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             nxt0 = trow[b_first + 1];
         }
 
+        uint32_t tq_next = 0xffffffffu;      // (0xff: no sum reaches it)
+#if PFZ_K3_SYM_EXP != 1
+        if (mode == 1 && !magnet) tq_next = a.gmin[(int64_t)b_first * 64 + lane];
+#endif
         for (int it = 0, b = b_first; it < n_blk; ++it) {
             const int s = cur0, e = have0 ? nxt0 : cur0;
             const int b_next = b + 1 < b_hi ? b + 1 : b_lo;
-            // pass 1: the minimum thresholds of this lane's four sweep steps, in flight across the scatter
-            int4 tq = make_int4(kNoThr, kNoThr, kNoThr, kNoThr);
-#if PFZ_K3_SYM_EXP != 1      // (what-if 1: nothing is handed over)
-            if (mode == 1) tq = gmin4[(int64_t)b * 64 + lane];
-#endif
+            // pass 1: the minimum thresholds of this lane's four sweep steps were fetched one block ahead, like the table entries:
+            // every round of the scatter begins with s_waitcnt vmcnt(0) (the compiler's), so a load issued just before the
+            // scatter has its whole latency exposed there (measured: a tenth of pass 1)
+            const uint32_t tq = tq_next;
             bool touched = __ballot(e > s) != 0;
             if (touched) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
             if (have0 && it + 1 < n_blk) {
                 cur0 = trow[b_next];
                 nxt0 = trow[b_next + 1];
             }
+#if PFZ_K3_SYM_EXP != 1      // (what-if 1: nothing is handed over)
+            if (mode == 1 && !magnet && it + 1 < n_blk) tq_next = a.gmin[(int64_t)b_next * 64 + lane];
+#endif
             for (int c0 = p0 + 64; c0 < p1; c0 += 64) {  // rows with more than 64 n-grams
                 int s2 = 0, e2 = 0;
                 float as2 = 0.f;
@@ -421,7 +477,13 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
 
         if (mode == 1 && fcnt) drain_stage<kSymCap>(cand, st, fbuf, fcnt, ntop, lane, a, inv_row);
         compact<kSymCap>(cand, st, ntop, lane);
-        if (mode == 2 && n_sl > 1) {
+        if (mode == 1 && magnet) {
+            // what the row found below its own block, to its own push slots (the merge joins them with the row's keys)
+            if (lane < st.cnt) {
+                const int pos = atomicAdd(&a.push_cnt[row], 1);
+                if (pos < kSymPush) a.push_buf[(int64_t)row * kSymPush + pos] = cand[lane];
+            }
+        } else if (mode == 2 && n_sl > 1) {
             if (lane < ntop) a.part[(int64_t)item * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
         } else if (mode == 2) {
             for (int r = lane; r < ntop; r += 64) {
@@ -523,9 +585,10 @@ struct K3SymState {
     int64_t n = 0;
     int32_t *thrv = nullptr;
     uint16_t *slot4 = nullptr;
-    int32_t *gmin = nullptr;
+    uint32_t *gmin = nullptr;
     int32_t *thr_slot = nullptr;
     uint16_t *row_slot = nullptr;
+    int32_t *mag = nullptr;
     int2 *post_sym = nullptr;
     uint64_t *keys = nullptr;
     int32_t *push_cnt = nullptr;
@@ -545,7 +608,7 @@ void k3_sym_free(pfz_index *ix)
 {
     K3SymState *s = ix->sym;
     if (!s) return;
-    void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
+    void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
     for (void *p : bufs)
         if (p) pool_free(p);
     delete s;
@@ -589,9 +652,10 @@ static int sym_state_alloc(pfz_ctx *ctx, const pfz_index *ix, K3SymState *s)
     const size_t cells = (size_t)ix->n_blocks * kSymC;
     PFZ_TRY(pool_alloc(ctx, &s->thrv, (size_t)n * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->slot4, cells * sizeof(uint16_t)));
-    PFZ_TRY(pool_alloc(ctx, &s->gmin, cells / 8 * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->gmin, cells / 32 * sizeof(uint32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->thr_slot, cells * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->row_slot, cells * sizeof(uint16_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->mag, (size_t)ix->n_blocks * 32 * kSymMag * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->post_sym, (size_t)(ix->n_pieces + 1) * kPiece * sizeof(int2)));
     PFZ_TRY(pool_alloc(ctx, &s->keys, (size_t)n * kSymKeep * sizeof(uint64_t)));
     PFZ_TRY(pool_alloc(ctx, &s->push_cnt, (size_t)n * sizeof(int32_t)));
@@ -616,7 +680,7 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
         s->n = n;
         ix->sym = s;      // (freed with the index, whatever happens below)
         if (getenv("PFZ_K3_SYM_FAIL_ALLOC") || sym_state_alloc(ctx, ix, s) != PFZ_OK) {      // (the knob: tests of this fallback)
-            void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
+            void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
             for (void *p : bufs)
                 if (p) pool_free(p);
             *s = K3SymState();
@@ -648,6 +712,10 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.gmin = s->gmin;
     a.thr_slot = s->thr_slot;
     a.row_slot = s->row_slot;
+    a.mag = s->mag;
+    a.n_mag_items = 0;
+    a.mag_b0 = 0;
+    a.mag_row_end = 0;
     a.keys = s->keys;
     a.push_cnt = s->push_cnt;
     a.push_buf = s->push_buf;
@@ -674,8 +742,14 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     const int64_t last_block_row = (int64_t)(nb - 1) * kSymC;
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)(row_end < last_block_row ? row_end : last_block_row);
-    if (a.row_end > a.row_begin)      // (one row per one-wave workgroup: 2 / 4 / 22 rows per workgroup measured no faster -- the dispatcher is not what a row waits for)
-        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(a.row_end - a.row_begin)), dim3(64), 0, ctx->stream, a);
+    if (a.row_end < a.row_begin) a.row_end = a.row_begin;
+    // ... and, first in the grid (they are the long ones), the magnet rows of the range x slices of the blocks below their own
+    a.mag_b0 = (int32_t)(row_begin / kSymC);
+    a.mag_row_end = (int32_t)row_end;
+    a.n_mag_items = (int32_t)(((row_end - 1) / kSymC - a.mag_b0 + 1) * 32 * kSymMag * ((nb - 1 + kSymMagBlocks - 1) / kSymMagBlocks));
+    if (a.row_end - a.row_begin + a.n_mag_items > 0)      // (one row per one-wave workgroup: 2 / 4 / 22 rows per workgroup measured no faster -- the dispatcher is not what a row waits for)
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(a.row_end - a.row_begin + a.n_mag_items)), dim3(64), 0, ctx->stream, a);
+    a.n_mag_items = 0;
     // merge, then the rows that were sent too much
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)row_end;
@@ -716,5 +790,24 @@ extern "C" int pfz_index_symmetric_launches(const pfz_index *ix, int64_t *launch
     PFZ_REQUIRE(ix, "pfz_index_symmetric_launches: NULL index");
     if (launches) *launches = ix->sym ? ix->sym->launches : 0;
     if (rows) *rows = ix->sym ? ix->sym->rows : 0;
+    return PFZ_OK;
+}
+
+extern "C" int pfz_index_symmetric_census(const pfz_index *ix, int64_t *magnet_rows, int64_t *recomputed_rows)
+{
+    PFZ_REQUIRE(ix, "pfz_index_symmetric_census: NULL index");
+    int64_t mags = 0, rec = 0;
+    const pfz::K3SymState *s = ix->sym;
+    if (s && s->n > 0 && s->launches > 0) {
+        PFZ_HIP(hipSetDevice(ix->ctx->device));
+        std::vector<int32_t> mag((size_t)ix->n_blocks * 32 * pfz::kSymMag);
+        int32_t n_ovf = 0;
+        PFZ_TRY(pfz::copy_d2h(ix->ctx, mag.data(), s->mag, mag.size() * sizeof(int32_t)));
+        PFZ_TRY(pfz::copy_d2h(ix->ctx, &n_ovf, s->ovf, sizeof(int32_t)));
+        for (int32_t r : mag) mags += r >= 0;
+        rec = n_ovf;
+    }
+    if (magnet_rows) *magnet_rows = mags;
+    if (recomputed_rows) *recomputed_rows = rec;
     return PFZ_OK;
 }

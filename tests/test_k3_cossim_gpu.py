@@ -338,10 +338,9 @@ def test_sparse_dot_topn_pin_fixture(ctx):
 
 
 def _sym_lists(rng, n, n_col, weird=True):
-    """A self-match list of n rows over n_col (+1) columns for the symmetric kernel's tests: random rows incl. empty ones,
-    rows of more than 64 n-grams, runs of DUPLICATE rows (exact ties across blocks), and -- `weird` -- one row of block 3
-    whose only n-gram it shares with 400 rows of block 0 and with nobody of its own block (threshold 0 after the own-block
-    pass: it is sent more candidates than its push slots hold and is recomputed in full)."""
+    """A self-match list of n rows over n_col (+2) columns for the symmetric kernel's tests: random rows incl. empty ones,
+    rows of more than 64 n-grams, runs of DUPLICATE rows (exact ties across blocks), and -- `weird` -- two rows of block 3
+    that share their only n-gram with 600 rows of block 0 each and with nobody of their own block (see below)."""
     base = random_csr(rng, n, n_col, 0.02, empty_rows=(0, 7, 2048, n - 1))
     ip, ix_, dv = [np.array(x) for x in base]
     rows = [(ix_[ip[r]:ip[r + 1]].copy(), dv[ip[r]:ip[r + 1]].copy()) for r in range(n)]
@@ -353,19 +352,23 @@ def _sym_lists(rng, n, n_col, weird=True):
         for r in range(src + 1, n, 997):
             rows[r] = (rows[src][0].copy(), rows[src][1].copy())
     if weird:
-        sp = n_col                                       # the extra column
-        for r in range(5, 5 + 2 * 400, 2):
-            c, v = rows[r]
-            c, v = np.append(c, sp).astype(np.int32), np.append(v * 0.8, 0.6)
-            rows[r] = (c, v / np.sqrt((v * v).sum()))
-        rows[3 * 2048 + 17] = (np.array([sp], np.int32), np.array([1.0]))
+        # two rows of block 3, of ONE LDS bank class (17 and 17 + 32), each with a single n-gram of its own (extra columns) that 600
+        # rows of block 0 share and nobody of block 3: both keep threshold 0 in the own-block pass.  The lower one is its class'
+        # "magnet" (it fetches its matches below its own block itself), the other is sent 600 candidates for 512 push slots and
+        # is recomputed in full
+        for w, (sp, first) in enumerate(((n_col, 5), (n_col + 1, 6))):
+            for r in range(first, first + 2 * 600, 2):
+                c, v = rows[r]
+                c, v = np.append(c, sp).astype(np.int32), np.append(v * 0.8, 0.6)
+                rows[r] = (c, v / np.sqrt((v * v).sum()))
+            rows[3 * 2048 + 17 + 32 * w] = (np.array([sp], np.int32), np.array([1.0]))
     ptr = np.zeros(n + 1, np.int64)
     for r in range(n):
         ptr[r + 1] = ptr[r] + len(rows[r][0])
     return (ptr, np.concatenate([c for c, _ in rows]).astype(np.int32), np.concatenate([v for _, v in rows]).astype(np.float64))
 
 
-def _self_match(ctx, a3, n_col, ntop, lb, ranges=None, repeats=1):
+def _self_match(ctx, a3, n_col, ntop, lb, ranges=None, repeats=1, census=None):
     """device-level self-match (one matrix, its own index: what TFIDF.match(list) enqueues), whole or in row ranges"""
     from polyfuzz_amd import _lib
     csr = _lib.DeviceCSR.upload(ctx, a3[0], a3[1], a3[2], n_col)
@@ -378,6 +381,8 @@ def _self_match(ctx, a3, n_col, ntop, lb, ranges=None, repeats=1):
         else:
             for lo, hi in ranges:
                 out = _lib.cossim_topn(ctx, index, csr, ntop, lb, exclude_diag=True, out=out, rows=(lo, hi))
+    if census is not None:
+        census.append(index.symmetric_census())
     return out.download()
 
 
@@ -390,14 +395,19 @@ def test_symmetric_kernel_equals_the_row_major_kernel(ctx, oracle_mod, monkeypat
     n, n_col = 9500, 700
     a3 = _sym_lists(rng, n, n_col)
     monkeypatch.setenv("PFZ_K3_SYM", "0")
-    ref_idx, ref_val = _self_match(ctx, a3, n_col + 1, ntop, lb)
+    ref_idx, ref_val = _self_match(ctx, a3, n_col + 2, ntop, lb)
     if ntop == 5:
-        exp_idx, exp_val = oracle_mod.cossim_topn(a3, a3, n_col + 1, ntop, lb, exclude_diag=True)
-        assert_topn_parity(ref_idx, ref_val, exp_idx, exp_val, oracle_mod, a3, a3, n_col + 1, exclude_diag=True)
+        exp_idx, exp_val = oracle_mod.cossim_topn(a3, a3, n_col + 2, ntop, lb, exclude_diag=True)
+        assert_topn_parity(ref_idx, ref_val, exp_idx, exp_val, oracle_mod, a3, a3, n_col + 2, exclude_diag=True)
     monkeypatch.setenv("PFZ_K3_SYM", "1")
-    idx, val = _self_match(ctx, a3, n_col + 1, ntop, lb, repeats=2)      # twice: the session buffers are re-used
+    census = []
+    idx, val = _self_match(ctx, a3, n_col + 2, ntop, lb, repeats=2, census=census)      # twice: the session buffers are re-used
     np.testing.assert_array_equal(idx, ref_idx)
     np.testing.assert_array_equal(val, ref_val)
+    magnets, recomputed = census[0]
+    assert magnets == 4 * 32                  # one per LDS bank class of the blocks 1 .. 4 (block 0 has nothing below it)
+    if lb == 0.0:
+        assert recomputed >= 1                # the second weird row overflowed its push slots
 
 
 def test_symmetric_kernel_in_row_ranges(ctx, monkeypatch):
@@ -407,13 +417,13 @@ def test_symmetric_kernel_in_row_ranges(ctx, monkeypatch):
     n, n_col = 9500, 700
     a3 = _sym_lists(rng, n, n_col)
     monkeypatch.setenv("PFZ_K3_SYM", "0")
-    ref_idx, ref_val = _self_match(ctx, a3, n_col + 1, 5, 0.0)
+    ref_idx, ref_val = _self_match(ctx, a3, n_col + 2, 5, 0.0)
     monkeypatch.setenv("PFZ_K3_SYM", "1")
     for ranges in ([(0, 3000), (3000, 3001), (3001, 8100), (8100, n)],      # a session in four parts
                    [(0, 4096), (4096, n)],                                   # cuts on a block boundary
                    [(0, 2000), (5000, n), (2000, 5000)],                     # the second range does not continue: row-major
                    [(4000, n), (0, 4000)]):                                  # starts in the middle: row-major, then a session's first part
-        idx, val = _self_match(ctx, a3, n_col + 1, 5, 0.0, ranges=ranges)
+        idx, val = _self_match(ctx, a3, n_col + 2, 5, 0.0, ranges=ranges)
         np.testing.assert_array_equal(idx, ref_idx)
         np.testing.assert_array_equal(val, ref_val)
 
