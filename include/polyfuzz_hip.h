@@ -355,6 +355,15 @@ int pfz_comm_allgather_topn(pfz_comm *c, const pfz_topn *local, pfz_topn *global
  * Needed only when the to-side does not fit one GPU; world x ntop <= 1024.  Enqueues. */
 int pfz_comm_merge_to_shards(pfz_comm *c, const pfz_topn *local, int64_t to_offset, pfz_topn *out);
 int pfz_comm_barrier(pfz_comm *c);
+/* The self-match of a list against itself (reference _tfidf.py:113-116 -> _utils.py:82-91) cut over the communicator's GPUs in
+ * K3's symmetric form (every unordered pair of rows scored once over all GPUs; csrc/k3_symmetric.hip): every
+ * rank holds the whole list's matrix A and its index; rank r works on the rows r, r + world, ...; the ranks' pass-0 thresholds
+ * and their per-row candidate lists (n x ntop 64-bit keys per rank) are all-gathered; `out` (n_rows x ntop) holds the FULL result
+ * on every rank, bit-identical to pfz_cossim_topn(..., exclude_diag = 1) on one GPU.  PFZ_ERR_UNSUPPORTED when
+ * pfz_index_symmetric_ok says no (then: row shards + pfz_comm_allgather_topn). */
+int pfz_comm_cossim_topn_symmetric(pfz_comm *c, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound,
+                                   pfz_topn *out);
+int pfz_index_symmetric_ok(const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t n_parts, int32_t *yes);
 int pfz_comm_info(const pfz_comm *c, int32_t *rank, int32_t *world);
 /* pfz_tfidf_fit over a corpus that is split across the ranks of `comm`:
  * `replicated` (may be NULL) is identical on every rank and counted once --

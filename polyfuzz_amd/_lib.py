@@ -58,6 +58,8 @@ SIGNATURES = {
     "pfz_index_pieces": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
     "pfz_index_symmetric_launches": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
     "pfz_index_symmetric_census": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
+    "pfz_index_symmetric_ok": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_i32)]),
+    "pfz_comm_cossim_topn_symmetric": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_vp]),
     "pfz_topn_alloc": (ctypes.c_int, [c_vp, c_i64, c_i32, P(c_vp)]),
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
@@ -297,6 +299,12 @@ class DeviceIndex(_Handle):
         a, b = c_i64(), c_i64()
         check(self.ctx.lib.pfz_index_symmetric_launches(self.h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def symmetric_ok(self, csr, ntop, n_parts=1):
+        """may a self-match of `csr` (the matrix this index was built from) run in K3's symmetric form, cut over n_parts GPUs?"""
+        yes = c_i32()
+        check(self.ctx.lib.pfz_index_symmetric_ok(self.h, csr.h, int(ntop), int(n_parts), ctypes.byref(yes)))
+        return bool(yes.value)
 
     def symmetric_census(self):
         """(magnet rows, rows recomputed row-major) of the last symmetric launch on this index (k3_symmetric.hip)"""
@@ -732,6 +740,13 @@ class Comm(_Handle):
         if out is None:
             out = DeviceTopN.alloc(self.ctx, local.n_rows, local.ntop)
         check(self.ctx.lib.pfz_comm_merge_to_shards(self.h, local.h, int(to_offset), out.h))
+        return out
+
+    def cossim_topn_symmetric(self, index, csr, ntop, lower_bound, out=None):
+        """the self-match of the whole (replicated) list, cut over the ranks in K3's symmetric form: the FULL result on every rank"""
+        if out is None:
+            out = DeviceTopN.alloc(self.ctx, csr.n_rows, ntop)
+        check(self.ctx.lib.pfz_comm_cossim_topn_symmetric(self.h, index.h, csr.h, int(ntop), float(lower_bound), out.h))
         return out
 
     def allgather_topn(self, local, out=None):

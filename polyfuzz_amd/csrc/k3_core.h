@@ -6,6 +6,7 @@
 #pragma once
 #include "pfz_internal.h"
 
+#include <math.h>
 #include <utility>
 
 #ifndef PFZ_K3_EXP
@@ -396,6 +397,21 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
         }
 #endif
     }
+}
+
+// ---- host side: K3's fixed-point scale ------------------------------------------------------------------------------
+// |sum| <= ||a|| * ||b|| (Cauchy-Schwarz) must stay below 2^31: S = 2^k, thr0 = floor(lower_bound * S) (accept sum > thr0)
+inline void k3_fixed_point(const pfz_csr *A, const pfz_index *ix, float lower_bound, float *scale, float *inv_scale, int32_t *thr0)
+{
+    if (lower_bound < 0.f) lower_bound = 0.f;
+    const double bound = (double)A->max_norm * (double)ix->max_norm * 1.0001 + 1e-30;
+    int k = 30;
+    while (k > -60 && ldexp(bound, k) >= 2147483000.0) --k;
+    while (k < 60 && ldexp(bound, k + 1) < 1073741824.0) ++k;   // tiny norms: use the full range
+    *scale = (float)ldexp(1.0, k);
+    *inv_scale = (float)ldexp(1.0, -k);
+    const double thr_d = floor((double)lower_bound * (double)*scale);
+    *thr0 = thr_d >= 2147483000.0 ? 2147483000 : (int32_t)thr_d;
 }
 
 // ---- host side, k3_lockstep.hip ----------------------------------------------------------------------------------

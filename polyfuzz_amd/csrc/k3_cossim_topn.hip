@@ -687,15 +687,9 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     const int64_t n_rows = row_end - row_begin;      // the from-rows of this launch
     if (n_rows == 0) return PFZ_OK;
     PFZ_HIP(hipSetDevice(ctx->device));
-    if (lower_bound < 0.f) lower_bound = 0.f;
-    // fixed-point scale: |sum| <= ||a|| * ||b|| (Cauchy-Schwarz) must stay below 2^31
-    const double bound = (double)A->max_norm * (double)ix->max_norm * 1.0001 + 1e-30;
-    int k = 30;
-    while (k > -60 && ldexp(bound, k) >= 2147483000.0) --k;
-    while (k < 60 && ldexp(bound, k + 1) < 1073741824.0) ++k;   // tiny norms: use the full range
-    const float scale = (float)ldexp(1.0, k), inv_scale = (float)ldexp(1.0, -k);
-    const double thr_d = floor((double)lower_bound * (double)scale);
-    const int32_t thr0 = thr_d >= 2147483000.0 ? 2147483000 : (int32_t)thr_d;
+    float scale, inv_scale;
+    int32_t thr0;
+    k3_fixed_point(A, ix, lower_bound, &scale, &inv_scale, &thr0);
     if (ntop > kMaxTop) {
         // Deep top-n (the reference clips top_n to the number of distinct to-strings only, _utils.py:54-56): passes of kMaxTop.
         // A pass keeps, per row, the kMaxTop best keys BELOW the last key of the pass before (keys are distinct: sum << 32 |

@@ -87,6 +87,8 @@ struct K3SymArgs {
     int32_t nb, n_pieces, ntop, thr0;
     float scale, inv_scale;
     int32_t row_begin, row_end;   // the rows of this launch (modes 0 and 1, merge)
+    int32_t n_parts, my_part, per;   // the job cut over n_parts GPUs (k3_sym_sharded): this part works on the rows = my_part (mod n_parts); per = ceil(n / n_parts)
+    uint64_t *keys_out;           // != NULL: the merge / pass 2 leave every row's sorted keys here ([n][ntop]) instead of (index, score)
     int32_t *thrv;            // [n]              a row's threshold after pass 0 (accept sum > thr)
     uint16_t *slot4;          // [nb * C]         4 * (slot of to-row b * C + r): its accumulator's byte offset in pass 1
     uint32_t *gmin;           // [nb][64]         (block, lane) -> byte t: the top byte of the minimum threshold of the eight slots the lane reads in sweep step t (0xff: none)
@@ -103,6 +105,14 @@ struct K3SymArgs {
     int32_t *out_idx;
     float *out_val;
 };
+
+// Where a row's pass-0 threshold sits in thrv: by row -- or, when the job is cut over n_parts GPUs, part by part (part p's
+// rows p, p + n_parts, ... are consecutive), so that an in-place all-gather of the parts' stretches completes the array.
+__device__ inline int thr_pos(const K3SymArgs &a, int row)
+{
+    return a.n_parts == 1 ? row : (row % a.n_parts) * a.per + row / a.n_parts;
+}
+__device__ inline bool row_is_mine(const K3SymArgs &a, int row) { return a.n_parts == 1 || row % a.n_parts == a.my_part; }
 
 // ---- the re-deal of a block's rows to the accumulator slots (after pass 0) -------------------------------------------
 
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(1024) void k3_sym_order(const K3SymArgs a)
     for (int rho = wave * 2; rho < wave * 2 + 2; ++rho) {
         const int r = rho + 32 * lane;
         const int row = b * kSymC + r;
-        const int thr = row < a.n ? a.thrv[row] : kNoThr;
+        const int thr = row < a.n ? a.thrv[thr_pos(a, row)] : kNoThr;
         // (thresholds are >= 0: they start at thr0 >= 0 and only rise)
         const uint64_t key = ((uint64_t)(uint32_t)thr << 6) | (uint32_t)lane;
         int rank = 0;
@@ -310,6 +320,17 @@ __device__ inline void sweep_block_handover(int4 *acc4, uint64_t *cand, TopState
     }
 }
 
+// a row's r-th best: (index, score) of the result -- or, for a part of a job cut over several GPUs, the key itself
+__device__ inline void store_result(const K3SymArgs &a, int row, int r, uint64_t key)
+{
+    if (a.keys_out) {
+        a.keys_out[(int64_t)row * a.ntop + r] = key;
+    } else {
+        a.out_idx[(int64_t)row * a.ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
+        a.out_val[(int64_t)row * a.ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
+    }
+}
+
 // MODE: the pass (0: own block -> state; 1: the blocks above -> state + pushes; 2: all blocks of the listed rows -> result) --
 // a template parameter so that every pass is a kernel of its own name in a trace and carries only its own code
 template <int C, int MODE>
@@ -341,7 +362,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     const int dummy_addr = a.n_pieces << 7;
     const int nb = a.nb, ntop = a.ntop;
 
-    int n_items = a.row_end - a.row_begin + (mode == 1 ? a.n_mag_items : 0);
+    int n_items = (a.row_end - a.row_begin + a.n_parts - 1) / a.n_parts + (mode == 1 ? a.n_mag_items : 0);      // (every n_parts-th row)
     const int n_sl = mode == 2 ? a.n_sl : 1;
     const int per_sl = (nb + n_sl - 1) / n_sl;
     if (mode == 2) {
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         n_items = hi > a.ovf_base ? (hi - a.ovf_base) * n_sl : 0;
     }
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        int row = mode == 2 ? a.ovf[1 + a.ovf_base + item / n_sl] : a.row_begin + item;
+        int row = mode == 2 ? a.ovf[1 + a.ovf_base + item / n_sl] : a.row_begin + item * a.n_parts;
         bool magnet = false;      // pass 1: this item is a magnet row x a slice of the blocks BELOW its own
         int m_lo = 0;
         if (mode == 1) {
@@ -360,10 +381,10 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                 const int mm = item / ns;
                 m_lo = (item - mm * ns) * kSymMagBlocks;
                 row = __builtin_amdgcn_readfirstlane(a.mag[(int64_t)(a.mag_b0 + mm / (32 * kSymMag)) * (32 * kSymMag) + mm % (32 * kSymMag)]);
-                if (row < a.row_begin || row >= a.mag_row_end || m_lo >= row / C) continue;     // (-1: no magnet)
+                if (row < a.row_begin || row >= a.mag_row_end || m_lo >= row / C || !row_is_mine(a, row)) continue;     // (-1: no magnet)
                 magnet = true;
             } else {
-                row -= a.n_mag_items;
+                row -= a.n_mag_items * a.n_parts;
                 if (row >= (nb - 1) * C) continue;      // (the last block's rows have nothing above)
             }
         }
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         if (mode == 1) {
             // the state of pass 0: threshold and the sorted keys (zeros at the end).  The marker scratch of the scatter is the
             // LAST 64 ints of cand (keys 64..95): the kept keys (< 32) are out of its way
-            st.thr = a.thrv[row];
+            st.thr = a.thrv[thr_pos(a, row)];
             // (a magnet item starts from the threshold alone: what it finds goes to the row's push slots, the keys stay with the row's own item)
             const uint64_t k = lane < ntop && !magnet ? a.keys[(int64_t)row * ntop + lane] : 0ull;
             st.cnt = __popcll(__ballot(k != 0ull));
@@ -486,14 +507,10 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         } else if (mode == 2 && n_sl > 1) {
             if (lane < ntop) a.part[(int64_t)item * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
         } else if (mode == 2) {
-            for (int r = lane; r < ntop; r += 64) {
-                const uint64_t key = r < st.cnt ? cand[r] : 0ull;
-                a.out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
-                a.out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
-            }
+            for (int r = lane; r < ntop; r += 64) store_result(a, row, r, r < st.cnt ? cand[r] : 0ull);
         } else {
             if (lane < ntop) a.keys[(int64_t)row * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
-            if (mode == 0 && lane == 0) a.thrv[row] = st.thr;
+            if (mode == 0 && lane == 0) a.thrv[thr_pos(a, row)] = st.thr;
         }
         wave_sync();    // cand is reused by the next item
     }
@@ -520,7 +537,8 @@ __global__ __launch_bounds__(256) void k3_sym_merge(const K3SymArgs a)
     st.cnt = 0;
     st.thr = 0;
     st.pushed = 0;
-    const uint64_t k = lane < ntop ? a.keys[(int64_t)row * ntop + lane] : 0ull;
+    // (a part of a job cut over several GPUs: the own-block keys of a row count on the part the row belongs to)
+    const uint64_t k = lane < ntop && row_is_mine(a, row) ? a.keys[(int64_t)row * ntop + lane] : 0ull;
     if (pushed > 0) {
         const uint64_t mk = __ballot(k != 0ull);
         if (k) cand[__popcll(mk & ((1ull << lane) - 1ull))] = k;
@@ -537,11 +555,7 @@ __global__ __launch_bounds__(256) void k3_sym_merge(const K3SymArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    for (int r = lane; r < ntop; r += 64) {
-        const uint64_t key = r < st.cnt ? cand[r] : 0ull;
-        a.out_idx[(int64_t)row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
-        a.out_val[(int64_t)row * ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
-    }
+    for (int r = lane; r < ntop; r += 64) store_result(a, row, r, r < st.cnt ? cand[r] : 0ull);
 }
 
 // pass 2 in slices: the n_sl partial top-n lists of every recomputed row -> its result (one wave per row)
@@ -569,11 +583,7 @@ __global__ __launch_bounds__(256) void k3_sym_merge_slices(const K3SymArgs a)
             st.cnt += __popcll(mk);
         }
         compact<256>(cand, st, ntop, lane);
-        for (int q = lane; q < ntop; q += 64) {
-            const uint64_t key = q < st.cnt ? cand[q] : 0ull;
-            a.out_idx[(int64_t)row * ntop + q] = key ? (int32_t)(~(uint32_t)key) : -1;
-            a.out_val[(int64_t)row * ntop + q] = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
-        }
+        for (int q = lane; q < ntop; q += 64) store_result(a, row, q, q < st.cnt ? cand[q] : 0ull);
         wave_sync();
     }
 }
@@ -650,7 +660,7 @@ static int sym_state_alloc(pfz_ctx *ctx, const pfz_index *ix, K3SymState *s)
 {
     const int64_t n = ix->n_rows;
     const size_t cells = (size_t)ix->n_blocks * kSymC;
-    PFZ_TRY(pool_alloc(ctx, &s->thrv, (size_t)n * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->thrv, (size_t)(n + 64) * sizeof(int32_t)));      // (part by part, every part's stretch rounded up: k3_sym_sharded)
     PFZ_TRY(pool_alloc(ctx, &s->slot4, cells * sizeof(uint16_t)));
     PFZ_TRY(pool_alloc(ctx, &s->gmin, cells / 32 * sizeof(uint32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->thr_slot, cells * sizeof(int32_t)));
@@ -665,48 +675,53 @@ static int sym_state_alloc(pfz_ctx *ctx, const pfz_index *ix, K3SymState *s)
     return PFZ_OK;
 }
 
-// *declined: the buffers of the session could not be allocated -- nothing was enqueued, the caller runs the row-major kernel
-// (which needs none of them) and this index is not asked again
-int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
-                  int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start, bool *declined)
+// the session state of an index, created on first use; NULL: its buffers could not be allocated (now or earlier) -- nothing was
+// enqueued, the row-major kernel serves this index
+static K3SymState *sym_state_of(pfz_ctx *ctx, const pfz_index *ix)
 {
-    const int64_t n = ix->n_rows;
-    const int nb = ix->n_blocks;
-    *declined = false;
     K3SymState *s = ix->sym;
-    if (!s) {
-        s = new K3SymState();
+    if (s) return s->n < 0 ? nullptr : s;
+    s = new K3SymState();
+    s->ctx = ctx;
+    s->n = ix->n_rows;
+    ix->sym = s;      // (freed with the index, whatever happens below)
+    if (getenv("PFZ_K3_SYM_FAIL_ALLOC") || sym_state_alloc(ctx, ix, s) != PFZ_OK) {      // (the knob: tests of this fallback)
+        void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
+        for (void *p : bufs)
+            if (p) pool_free(p);
+        *s = K3SymState();
         s->ctx = ctx;
-        s->n = n;
-        ix->sym = s;      // (freed with the index, whatever happens below)
-        if (getenv("PFZ_K3_SYM_FAIL_ALLOC") || sym_state_alloc(ctx, ix, s) != PFZ_OK) {      // (the knob: tests of this fallback)
-            void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
-            for (void *p : bufs)
-                if (p) pool_free(p);
-            *s = K3SymState();
-            s->ctx = ctx;
-            s->n = -1;
-            (void)hipGetLastError();
-            *declined = true;
-            return PFZ_OK;
-        }
+        s->n = -1;
+        (void)hipGetLastError();
+        return nullptr;
     }
-    s->next_row = -1;     // (no session while this call can still fail)
-    K3SymArgs a;
+    return s;
+}
+
+// the arguments every launch of a job shares
+static void sym_fill_args(K3SymArgs &a, const pfz_index *ix, const pfz_csr *A, K3SymState *s, int32_t ntop, int32_t thr0, float scale,
+                          float inv_scale)
+{
     a.a_indptr = A->indptr;
     a.a_idx = A->indices;
     a.a_val = A->data;
-    a.n = (int32_t)n;
+    a.n = (int32_t)ix->n_rows;
     a.tab = ix->tab;
     a.post = ix->post;
     a.post_sym = s->post_sym;
     a.pblk = ix->pblk;
-    a.nb = nb;
+    a.nb = ix->n_blocks;
     a.n_pieces = ix->n_pieces;
     a.ntop = ntop;
     a.thr0 = thr0;
     a.scale = scale;
     a.inv_scale = inv_scale;
+    a.row_begin = 0;
+    a.row_end = (int32_t)ix->n_rows;
+    a.n_parts = 1;
+    a.my_part = 0;
+    a.per = (int32_t)ix->n_rows;
+    a.keys_out = nullptr;
     a.thrv = s->thrv;
     a.slot4 = s->slot4;
     a.gmin = s->gmin;
@@ -724,6 +739,49 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.ovf_base = 0;
     a.ovf_max = 0;
     a.n_sl = 1;
+    a.out_idx = nullptr;
+    a.out_val = nullptr;
+}
+
+// pass 2 of the rows the merge listed (sent more than their push slots hold): the first kSymSlicedRows in slices of the to-blocks
+// (a whole row is ~100 us of one wave: a handful of rows would cost that much wall time), their partial lists merged; whatever is
+// listed beyond, as whole rows
+static void sym_launch_pass2(pfz_ctx *ctx, K3SymArgs a)
+{
+    const int nb = a.nb;
+    const unsigned grid2 = (unsigned)ctx->prop.multiProcessorCount * 16;
+    const int per = (nb + kSymSlices - 1) / kSymSlices;
+    a.n_mag_items = 0;
+    a.n_parts = 1;         // (the listed rows are recomputed in full, whoever they belong to)
+    a.n_sl = (nb + per - 1) / per;
+    a.ovf_base = 0;
+    a.ovf_max = kSymSlicedRows;
+    if (a.n_sl > 1) {
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k3_sym_merge_slices, dim3(256), dim3(256), 0, ctx->stream, a);
+        a.ovf_base = kSymSlicedRows;
+    }
+    a.n_sl = 1;
+    a.ovf_max = a.n;
+    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
+}
+
+// *declined: the buffers of the session could not be allocated -- nothing was enqueued, the caller runs the row-major kernel
+// (which needs none of them) and this index is not asked again
+int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
+                  int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start, bool *declined)
+{
+    const int64_t n = ix->n_rows;
+    const int nb = ix->n_blocks;
+    *declined = false;
+    K3SymState *s = sym_state_of(ctx, ix);
+    if (!s) {
+        *declined = true;
+        return PFZ_OK;
+    }
+    s->next_row = -1;     // (no session while this call can still fail)
+    K3SymArgs a;
+    sym_fill_args(a, ix, A, s, ntop, thr0, scale, inv_scale);
     a.out_idx = out->idx;
     a.out_val = out->val;
     if (start) {
@@ -754,23 +812,7 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)row_end;
     hipLaunchKernelGGL(k3_sym_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, ctx->stream, a);
-    // pass 2: the first kSymSlicedRows of the listed rows in slices of the to-blocks (a whole row is ~100 us of one wave: a handful
-    // of rows would cost that much wall time), their partial lists merged; whatever is listed beyond, as whole rows
-    {
-        const unsigned grid2 = (unsigned)ctx->prop.multiProcessorCount * 16;
-        const int per = (nb + kSymSlices - 1) / kSymSlices;
-        a.n_sl = (nb + per - 1) / per;
-        a.ovf_base = 0;
-        a.ovf_max = kSymSlicedRows;
-        if (a.n_sl > 1) {
-            hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
-            hipLaunchKernelGGL(k3_sym_merge_slices, dim3(256), dim3(256), 0, ctx->stream, a);
-            a.ovf_base = kSymSlicedRows;
-        }
-        a.n_sl = 1;
-        a.ovf_max = (int32_t)n;
-        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
-    }
+    sym_launch_pass2(ctx, a);
     PFZ_HIP(hipGetLastError());
     s->next_row = row_end;
     s->launches += 1;
@@ -780,6 +822,123 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     s->ntop = ntop;
     s->thr0 = thr0;
     s->scale = scale;
+    return PFZ_OK;
+}
+
+// ---- the self-match cut over several GPUs ----------------------------------------------------------------
+// Every GPU holds the whole list's matrix and index (replicated).  Part p of n_parts works on the rows p, p + n_parts, ...: their
+// pass 0 -- the thresholds of the parts are all-gathered, the re-deal of the slots is the same everywhere --, their pass 1 and
+// their magnet items; every unordered pair of rows is still scored once over all parts.  What a part finds for a row -- its
+// own rows' keys, what its rows handed to ANY row -- it merges into one sorted list of at most ntop keys per row; the parts'
+// lists are all-gathered (n x ntop x 8 bytes per part: 4 MB at 100 000 x 5) and every GPU merges them: the full result on
+// every GPU, bit-identical to one GPU's (the selection is by exact key -- integer sum, column -- on every level; a row that one
+// part recomputes in full brings duplicates of the others' keys, which a selection round removes together).
+__global__ __launch_bounds__(256) void k3_sym_merge_parts(const uint64_t *__restrict__ keys_all, int32_t n_parts, int32_t n,
+                                                           int32_t ntop, float inv_scale, int32_t *__restrict__ out_idx,
+                                                           float *__restrict__ out_val)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    uint64_t *cand = cand_all[wave];
+    TopState st;
+    st.cnt = 0;
+    st.thr = 0;
+    st.pushed = 0;
+    const int total = n_parts * ntop;       // <= 256 (k3_sym_sharded_ok)
+    for (int e0 = 0; e0 < total; e0 += 64) {
+        const int e = e0 + lane;
+        const uint64_t k = e < total ? keys_all[((int64_t)(e / ntop) * n + row) * ntop + e % ntop] : 0ull;
+        const uint64_t mk = __ballot(k != 0ull);
+        if (k) cand[st.cnt + __popcll(mk & ((1ull << lane) - 1ull))] = k;
+        st.cnt += __popcll(mk);
+    }
+    compact<256>(cand, st, ntop, lane);
+    for (int q = lane; q < ntop; q += 64) {
+        const uint64_t key = q < st.cnt ? cand[q] : 0ull;
+        out_idx[(int64_t)row * ntop + q] = key ? (int32_t)(~(uint32_t)key) : -1;
+        out_val[(int64_t)row * ntop + q] = key ? (float)(int32_t)(uint32_t)(key >> 32) * inv_scale : 0.f;
+    }
+}
+
+bool k3_sym_sharded_ok(const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t n_parts)
+{
+    if (A->serial != ix->src_serial || A->n_rows != ix->n_rows) return false;
+    if (ix->block_cols != kSymC || !ix->pblk || ntop > kSymKeep || ix->n_blocks < 2 || ix->n_rows >= ((int64_t)1 << 30)) return false;
+    if (n_parts < 1 || (int64_t)n_parts * ntop > 256 || n_parts > 64) return false;
+    if (ix->sym && ix->sym->n < 0) return false;
+    const int force = sym_env_int("PFZ_K3_SYM", -1);      // 0: never; 1: whenever the arithmetic allows (tests); default: by size, as on one GPU
+    if (force >= 0) return force != 0;
+    return ix->n_rows >= sym_env_int("PFZ_K3_SYM_MIN", 20480) && ix->n_rows <= 250000;
+}
+
+int k3_sym_sharded(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound, pfz_topn *out)
+{
+    const int64_t n = ix->n_rows;
+    const int nb = ix->n_blocks;
+    const int n_parts = comm_world(comm), part = comm_rank(comm);
+    K3SymState *s = sym_state_of(ctx, ix);
+    if (!s) {
+        set_error("pfz_comm_cossim_topn_symmetric: the session buffers of this index could not be allocated");
+        return PFZ_ERR_NOMEM;
+    }
+    float scale, inv_scale;
+    int32_t thr0;
+    k3_fixed_point(A, ix, lower_bound, &scale, &inv_scale, &thr0);
+    s->next_row = -1;
+    struct Tmp {
+        uint64_t *p = nullptr;
+        ~Tmp() { if (p) pool_free(p); }
+    } mine, all;
+    const size_t list_bytes = (size_t)n * ntop * sizeof(uint64_t);
+    PFZ_TRY(pool_alloc(ctx, &mine.p, list_bytes));
+    PFZ_TRY(pool_alloc(ctx, &all.p, list_bytes * n_parts));
+    K3SymArgs a;
+    sym_fill_args(a, ix, A, s, ntop, thr0, scale, inv_scale);
+    a.n_parts = n_parts;
+    a.my_part = part;
+    a.per = (int32_t)((n + n_parts - 1) / n_parts);
+    a.keys_out = mine.p;
+    PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
+    PFZ_HIP(hipMemsetAsync(s->ovf, 0, sizeof(int32_t), ctx->stream));
+    // pass 0 of this part's rows; the parts' thresholds, stretch by stretch, complete thrv on every GPU
+    a.row_begin = part;
+    a.row_end = (int32_t)n;
+    const unsigned mine0 = (unsigned)((n - part + n_parts - 1) / n_parts);
+    if (mine0) hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(mine0), dim3(64), 0, ctx->stream, a);
+    PFZ_HIP(hipGetLastError());
+    if (n_parts > 1) PFZ_TRY(comm_allgather_bytes(comm, s->thrv + (size_t)part * a.per, s->thrv, (size_t)a.per * sizeof(int32_t)));
+    hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
+    const int64_t pairs = ((int64_t)ix->n_pieces + 1) * (kPiece / 2);
+    hipLaunchKernelGGL(k3_sym_repost, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    // pass 1 of this part's rows and magnets
+    const int64_t last_block_row = (int64_t)(nb - 1) * kSymC;
+    a.row_end = (int32_t)(n < last_block_row ? n : last_block_row);
+    const int rows1 = a.row_end > part ? (a.row_end - part + n_parts - 1) / n_parts : 0;
+    if (a.row_end < a.row_begin) a.row_end = a.row_begin;
+    a.mag_b0 = 0;
+    a.mag_row_end = (int32_t)n;
+    a.n_mag_items = (int32_t)(nb * 32 * kSymMag * ((nb - 1 + kSymMagBlocks - 1) / kSymMagBlocks));
+    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(rows1 + a.n_mag_items)), dim3(64), 0, ctx->stream, a);
+    a.n_mag_items = 0;
+    // this part's list of every row; the rows it was sent too much for, in full
+    a.row_begin = 0;
+    a.row_end = (int32_t)n;
+    hipLaunchKernelGGL(k3_sym_merge, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, a);
+    sym_launch_pass2(ctx, a);
+    PFZ_HIP(hipGetLastError());
+    // the parts' lists -> the result, on every GPU
+    const uint64_t *lists = mine.p;
+    if (n_parts > 1) {
+        PFZ_TRY(comm_allgather_bytes(comm, mine.p, all.p, list_bytes));
+        lists = all.p;
+    }
+    hipLaunchKernelGGL(k3_sym_merge_parts, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, lists, n_parts, (int32_t)n, ntop,
+                       inv_scale, out->idx, out->val);
+    PFZ_HIP(hipGetLastError());
+    s->launches += 1;
+    s->rows += n;
     return PFZ_OK;
 }
 
@@ -809,5 +968,30 @@ extern "C" int pfz_index_symmetric_census(const pfz_index *ix, int64_t *magnet_r
     }
     if (magnet_rows) *magnet_rows = mags;
     if (recomputed_rows) *recomputed_rows = rec;
+    return PFZ_OK;
+}
+
+extern "C" int pfz_comm_cossim_topn_symmetric(pfz_comm *c, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound,
+                                              pfz_topn *out)
+{
+    PFZ_REQUIRE(c && ix && A && out, "pfz_comm_cossim_topn_symmetric: NULL argument");
+    PFZ_REQUIRE(ntop >= 1 && lower_bound == lower_bound, "pfz_comm_cossim_topn_symmetric: ntop must be >= 1 and lower_bound a number");
+    PFZ_REQUIRE(out->n_rows >= A->n_rows && out->ntop == ntop, "pfz_comm_cossim_topn_symmetric: result buffer is %lldx%d, need %lldx%d",
+                (long long)out->n_rows, out->ntop, (long long)A->n_rows, ntop);
+    if (!pfz::k3_sym_sharded_ok(ix, A, ntop, pfz::comm_world(c))) {
+        pfz::set_error("pfz_comm_cossim_topn_symmetric: not a job for the symmetric form (the matrix must be the one the index was built "
+                       "from, 2048-row blocks, at least two of them, top_n <= 32, ranks x top_n <= 256): ask pfz_index_symmetric_ok first");
+        return PFZ_ERR_UNSUPPORTED;
+    }
+    pfz_ctx *ctx = ix->ctx;
+    PFZ_HIP(hipSetDevice(ctx->device));
+    pfz::ProfScope ps(ctx, "k3_cossim_topn");
+    return pfz::k3_sym_sharded(ctx, c, ix, A, ntop, lower_bound, out);
+}
+
+extern "C" int pfz_index_symmetric_ok(const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t n_parts, int32_t *yes)
+{
+    PFZ_REQUIRE(ix && A && yes, "pfz_index_symmetric_ok: NULL argument");
+    *yes = pfz::k3_sym_sharded_ok(ix, A, ntop, n_parts) ? 1 : 0;
     return PFZ_OK;
 }

@@ -121,7 +121,9 @@ static int local_allgather(pfz_comm *c, const void *send, void *recv, size_t byt
     g->barrier();                       // every rank has published its buffer and recorded its event
     for (int p = 0; p < c->world; ++p) {
         if (p != c->rank) PFZ_HIP(hipStreamWaitEvent(st, g->ready[p], 0));
-        PFZ_HIP(hipMemcpyAsync((char *)recv + (size_t)p * bytes_per_rank, g->send[p], bytes_per_rank, hipMemcpyDefault, st));
+        char *dst = (char *)recv + (size_t)p * bytes_per_rank;
+        if (dst != (const char *)g->send[p])      // (in place: this rank's stretch is where it belongs already)
+            PFZ_HIP(hipMemcpyAsync(dst, g->send[p], bytes_per_rank, hipMemcpyDefault, st));
     }
     PFZ_HIP(hipEventRecord(g->done[c->rank], st));
     g->barrier();                       // every rank has enqueued its copies

@@ -85,6 +85,12 @@ class HipEngine:
     def allgather_topn(self, comm, local, out):
         return comm.allgather_topn(local, out)
 
+    def symmetric_ok(self, index, csr, ntop, world):
+        return index.symmetric_ok(csr, ntop, world)
+
+    def cossim_topn_symmetric(self, comm, index, csr, ntop, lower_bound, out):
+        return comm.cossim_topn_symmetric(index, csr, ntop, lower_bound, out)
+
 
 class TfidfMatchJob:
     def __init__(self, ctx, from_shard, to_list, top_n=1, min_similarity=0.0, n_gram_range=(3, 3),
@@ -126,6 +132,9 @@ class TfidfMatchJob:
         if comm is not None and comm.world > 1:
             self.gathered = self.eng.alloc_topn(self.rows_per_rank * comm.world, self.top_n)
         self.vec = self.from_csr = self.to_csr = self.index = None
+        # a self-match cut over several GPUs in K3's symmetric form leaves the FULL result (n_to x top_n) on every rank
+        self.full = None
+        self.result_is_full = False
 
     def step(self):
         eng = self.eng
@@ -140,6 +149,19 @@ class TfidfMatchJob:
             self.vec = eng.fit(self.params, self.to_dev, self.from_dev)
         self.to_csr = eng.transform(self.vec, self.to_dev)
         self.index = eng.build_index(self.to_csr)
+        if self.self_match and sharded and self.to_dev is not self.from_dev and eng.symmetric_ok(self.index, self.to_csr, self.top_n,
+                                                                                                  self.comm.world):
+            # One list against itself, cut over the ranks (bench --scaling strong): the symmetric form of K3 scores every
+            # unordered pair of rows ONCE over all ranks -- rank r works on the rows r, r + world, ... of the replicated list,
+            # whatever contiguous shard it was handed (the sorted list's cost is spread evenly that way) -- and the ranks'
+            # per-row candidate lists are all-gathered and merged on every rank: the full result, no second exchange.
+            if self.full is None:
+                self.full = eng.alloc_topn(self.n_to, self.top_n)
+            self.from_csr = self.to_csr
+            eng.cossim_topn_symmetric(self.comm, self.index, self.to_csr, self.top_n, self.min_similarity, self.full)
+            self.result_is_full = True
+            return self.full
+        self.result_is_full = False
         if self.self_match and self.shard_offset == 0 and (self.to_dev is self.from_dev or (not sharded and self.n_from == self.n_to)):
             self.from_csr = self.to_csr            # the same rows: vectorise once (reference _tfidf.py:114-116)
         else:
@@ -149,6 +171,12 @@ class TfidfMatchJob:
         if self.gathered is not None:
             eng.allgather_topn(self.comm, self.local, self.gathered)
         return self.gathered if self.gathered is not None else self.local
+
+    def whole_result(self, idx, val, shard_sizes):
+        """(idx, val) of ALL from-rows out of what the last step() returned and .download() gave"""
+        if self.result_is_full:
+            return idx, val
+        return self.unpad(idx, val, shard_sizes, self.rows_per_rank)
 
     @staticmethod
     def unpad(idx, val, shard_sizes, rows_per_rank):
@@ -162,6 +190,9 @@ class TfidfMatchJob:
                 "with the diagonal excluded (K3)" if self.self_match else
                 "fit vocabulary+idf on to+from (K1/K2), vectorise both lists, build the to-side inverted index, "
                 "fused cosine top-n (K3)")
+        if self.result_is_full:
+            return what + ("; the self-match cut over the ranks in K3's symmetric form (every unordered pair once over all ranks): all-gather "
+                           "of the ranks' pass-0 thresholds and of their per-row candidate lists, merged on every rank")
         return what + ("; all-gather of the per-shard results" if self.gathered else "")
 
     # ---- host-side accounting (never inside the timed region) ---------------------
@@ -375,7 +406,7 @@ def run_sharded_job(ctxs, comms, from_list, to_list, **job_kw):
                             shard_offset=b if self_match else 0, **job_kw)
         out = job.step()
         idx, val = out.download()
-        return TfidfMatchJob.unpad(idx, val, sizes, rpr), job
+        return job.whole_result(idx, val, sizes), job
 
     with cf.ThreadPoolExecutor(world) as ex:
         futs = [ex.submit(rank_fn, r) for r in range(world)]

@@ -121,3 +121,37 @@ class OracleEngine:
         out.idx[:] = torch.cat(gi).numpy()
         out.val[:] = torch.cat(gv).numpy()
         return out
+
+    # ---- the self-match cut over the ranks in K3's symmetric form (polyfuzz_amd/csrc/k3_symmetric.hip, k3_sym_sharded) ----
+    SYM_BLOCK = 16         # to-rows per block of the emulation (the kernel: 2048)
+
+    def symmetric_ok(self, index, csr, ntop, world):
+        return len(csr.triple[0]) - 1 > 2 * self.SYM_BLOCK
+
+    def cossim_topn_symmetric(self, comm, index, csr, ntop, lower_bound, out):
+        """The partition rule of the device job, on oracle scores: rank r works on the rows r, r + world, ...; a pair inside one
+        block is scored by both its rows (each keeps it), a pair of different blocks ONCE, by the row of the lower block, which
+        keeps it and hands it to the other row; every rank cuts what it knows of a row to ntop, the lists are all-gathered and
+        merged by (score desc, index asc)."""
+        n = len(csr.triple[0]) - 1
+        c = self.SYM_BLOCK
+        idx, val = oracle.cossim_topn(csr.triple, csr.triple, csr.n_cols, max(n - 1, 1), lower_bound, exclude_diag=True)
+        lists = [[] for _ in range(n)]
+        for j in range(comm.rank, n, comm.world):
+            for i, s in zip(idx[j], val[j]):
+                if i < 0:
+                    continue
+                if i // c == j // c:
+                    lists[j].append((-s, int(i)))
+                elif i // c > j // c:
+                    lists[j].append((-s, int(i)))
+                    lists[int(i)].append((-s, j))
+        mine = [sorted(lst)[:ntop] for lst in lists]
+        gathered = [None] * comm.world
+        comm.dist.all_gather_object(gathered, mine)
+        out.clear()
+        for i in range(n):
+            best = sorted(set(e for part in gathered for e in part[i]))[:ntop]
+            for r, (ns, j) in enumerate(best):
+                out.idx[i, r], out.val[i, r] = j, -ns
+        return out

@@ -22,20 +22,27 @@ def _bench(*flags):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("scaling", ["weak", "strong", None])
 def test_tfidf_two_local_ranks(scaling):
-    d = _bench("--transport", "local", "--gpus", "2", "--n", "20000", "--steps", "2", "--warmup", "1", "--scaling", scaling,
-               "--no-cpu-baseline", "--no-match-wall")
+    flags = ("--transport", "local", "--gpus", "2", "--n", "24000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-match-wall")
+    d = _bench(*flags, *(("--scaling", scaling) if scaling else ()))
+    scaling = scaling or "strong"                     # the default at N > 1: the one self-match cut over the ranks
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["config"]["transport"] == "local"
     assert "all-gather" in d["config"]["exchange"] and d["config"]["parallelism"].startswith("from-rows sharded x2")
-    n_total = 40000 if scaling == "weak" else 20000
-    # (strong: cost-balanced cuts of the sorted list, pipeline.balanced_bounds -- about half the rows each)
+    n_total = 48000 if scaling == "weak" else 24000
     assert d["config"]["n_from_total"] == n_total
-    assert d["config"]["n_from_this_rank"] == 20000 if scaling == "weak" else 9000 < d["config"]["n_from_this_rank"] < 11000
-    assert abs(d["value"] - n_total * 20000 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
     rf = d["roofline"]
-    assert rf["kernel"] == "k3_cossim_topn" and rf["bound"] == "hbm" and rf["frac"] > 0 and rf["frac"] == rf["frac_hbm_priced"]
-    assert 0 < rf["frac_lds_floor"] <= 1.0 and rf["compulsory_bytes"] > 0 and rf["algorithmic_bytes_per_launch"] > rf["compulsory_bytes"]
+    if scaling == "weak":
+        # every rank: its own batch (the names in a rank-seeded order) against the replicated list -- the row-major kernel
+        assert d["config"]["n_from_this_rank"] == 24000 and not rf["symmetric_form"]
+    else:
+        # K3's symmetric form cut over the ranks (24 000 rows: above the automatic choice's 20 480): rows r, r + 2, ...
+        assert rf["symmetric_form"] and "candidate lists" in d["config"]["exchange"] and "once over all ranks" in d["config"]["parallelism"]
+    assert abs(d["value"] - n_total * 24000 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    # the roofline's top level is the binding resource: a utilisation in (0, 1]; the HBM pricing sits beside it
+    assert rf["kernel"].startswith("k3_cossim_topn") and rf["bound"] == "lds" and 0 < rf["frac"] <= 1.0 and rf["frac"] == rf["frac_lds_floor"]
+    assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-9 and rf["frac_hbm_priced"] > 0 and rf["executed_bytes"] <= rf["algorithmic_bytes_per_launch"]
+    assert rf["compulsory_bytes"] > 0 and rf["algorithmic_bytes_per_launch"] > rf["compulsory_bytes"]
 
 
 @pytest.mark.parametrize("config", ["editdistance", "rapidfuzz", "dense"])

@@ -183,3 +183,37 @@ def test_world2_best_choice_job_edit_distance_and_wratio(oracle_mod):
             np.testing.assert_array_equal(score, np.array(e_score, np.float64))
     for c in comms:
         c.free()
+
+
+@pytest.mark.parametrize("world,top_n", [(2, 5), (3, 1), (4, 8)])
+def test_symmetric_self_match_cut_over_local_ranks(monkeypatch, world, top_n):
+    """the headline's symmetric form (every unordered pair of rows scored once) survives at N > 1.  `world`
+    contexts on ONE device, one host thread per rank, the local transport: rank r works on the rows r, r + world, ... of the
+    replicated list, the ranks' pass-0 thresholds and their per-row candidate lists are all-gathered
+    (pfz_comm_cossim_topn_symmetric), every rank ends with the FULL result -- the single-context result bit for bit (which
+    is the row-major kernel's: tests/test_k3_cossim_gpu.py).  12 000 real names = 6 blocks, the last one partial; odd sizes so
+    that the parts' threshold stretches are uneven."""
+    import polyfuzz_amd
+    from polyfuzz_amd import _lib, datasets, pipeline
+    names = datasets.load_company_names()[:12001]
+    monkeypatch.setenv("PFZ_K3_SYM", "1")               # (the automatic choice starts at 20 480 rows)
+    ctxs = [polyfuzz_amd.Context(0) for _ in range(world)]
+    comms = _lib.Comm.local_group(ctxs)
+    res = pipeline.run_sharded_job(ctxs, comms, names, names, top_n=top_n, min_similarity=0.0, self_match=True)
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    whole = pipeline.TfidfMatchJob(ctxs[0], names, None, top_n=top_n, min_similarity=0.0, self_match=True)
+    w_idx, w_val = whole.step().download()
+    assert whole.index.symmetric_launches()[0] == 0     # the reference run is the row-major kernel's
+    for (idx, val), job in res:
+        assert job.result_is_full and job.index.symmetric_launches() == (1, len(names))
+        np.testing.assert_array_equal(idx, w_idx)
+        np.testing.assert_array_equal(val, w_val)
+    # a second step on the same jobs (buffers re-used) and the row-sharded form of the same job (PFZ_K3_SYM=0) agree too
+    res0 = pipeline.run_sharded_job(ctxs, comms, names, names, top_n=top_n, min_similarity=0.0, self_match=True)
+    for (idx, val), job in res0:
+        assert not job.result_is_full
+        np.testing.assert_array_equal(idx, w_idx)
+        np.testing.assert_array_equal(val, w_val)
+    del res, res0
+    for c in comms:
+        c.free()

@@ -51,7 +51,16 @@ def _worker(rank, port, out_dir):
     sjob = TfidfMatchJob(None, from_list[b:e], from_list, top_n=TOP_N, comm=comm, rows_per_rank=max(sizes), engine=eng,
                          self_match=True, shard_offset=b)
     s_idx, s_val = sjob.step().download()
-    s_idx, s_val = TfidfMatchJob.unpad(s_idx, s_val, sizes, max(sizes))
+    assert sjob.result_is_full          # (the self-match is cut over the ranks in the symmetric form: full result on every rank)
+    s_idx, s_val = sjob.whole_result(s_idx, s_val, sizes)
+    # ... and the row-sharded form of the same self-match (what runs where the symmetric form does not apply)
+    eng.symmetric_ok = lambda *a: False
+    rjob = TfidfMatchJob(None, from_list[b:e], from_list, top_n=TOP_N, comm=comm, rows_per_rank=max(sizes), engine=eng,
+                         self_match=True, shard_offset=b)
+    r_idx, r_val = rjob.step().download()
+    assert not rjob.result_is_full
+    r_idx, r_val = rjob.whole_result(r_idx, r_val, sizes)
+    assert np.array_equal(r_idx, s_idx) and np.array_equal(r_val, s_val)
     np.savez(os.path.join(out_dir, f"sharded{rank}.npz"), idx=idx, val=val, idf=job.vec.v.idf,
              vocab=np.array(job.vec.v.vocabulary), s_idx=s_idx, s_val=s_val, s_ndocs=sjob.vec.v.n_docs)
     dist.barrier()
