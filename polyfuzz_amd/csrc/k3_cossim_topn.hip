@@ -770,7 +770,11 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     // candidate keys: room for ntop kept keys + the 64 one sweep step can add.  LDS per workgroup decides how
     // many from-rows a CU works on at once: 8 KiB of accumulators + 96 keys is 8960 B = 18 workgroups per CU
     const int cap = ntop <= 32 ? 96 : (ntop <= 64 ? 128 : (ntop <= 128 ? 256 : 1152));
-    const int ablate = env_int("PFZ_K3_ABLATE", 0);   // timing experiments only: 1 = no scatter, 2 = no sweep
+#ifdef PFZ_EXPERIMENTS
+    const int ablate = env_int("PFZ_K3_ABLATE", 0);   // timing experiments (variant builds only: tools/build_variant.sh -DPFZ_EXPERIMENTS): 1 = no scatter, 2 = no sweep, 3 = no warm start
+#else
+    const int ablate = 0;                              // (the shipped library has no knob that makes results wrong: tests/test_abi_cpu.py)
+#endif
     {
         ProfScope ps(ctx, "k3_cossim_topn");
 #define PFZ_K3_LAUNCH(CC, CAP)                                                                                  \

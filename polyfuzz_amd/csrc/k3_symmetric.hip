@@ -50,6 +50,7 @@
 // big to-sides (k3_lockstep.hip) -- runs the row-major kernel.
 #include "k3_core.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace pfz {
@@ -88,6 +89,7 @@ struct K3SymArgs {
     float scale, inv_scale;
     int32_t row_begin, row_end;   // the rows of this launch (modes 0 and 1, merge)
     int32_t n_parts, my_part, per;   // the job cut over n_parts GPUs (k3_sym_sharded): this part works on the rows = my_part (mod n_parts); per = ceil(n / n_parts)
+    int32_t thr_by_part;          // thrv is laid out part by part (k3_sym_sharded) -- or by row
     uint64_t *keys_out;           // != NULL: the merge / pass 2 leave every row's sorted keys here ([n][ntop]) instead of (index, score)
     int32_t *thrv;            // [n]              a row's threshold after pass 0 (accept sum > thr)
     uint16_t *slot4;          // [nb * C]         4 * (slot of to-row b * C + r): its accumulator's byte offset in pass 1
@@ -110,7 +112,7 @@ struct K3SymArgs {
 // rows p, p + n_parts, ... are consecutive), so that an in-place all-gather of the parts' stretches completes the array.
 __device__ inline int thr_pos(const K3SymArgs &a, int row)
 {
-    return a.n_parts == 1 ? row : (row % a.n_parts) * a.per + row / a.n_parts;
+    return a.thr_by_part ? (row % a.n_parts) * a.per + row / a.n_parts : row;
 }
 __device__ inline bool row_is_mine(const K3SymArgs &a, int row) { return a.n_parts == 1 || row % a.n_parts == a.my_part; }
 
@@ -721,6 +723,7 @@ static void sym_fill_args(K3SymArgs &a, const pfz_index *ix, const pfz_csr *A, K
     a.n_parts = 1;
     a.my_part = 0;
     a.per = (int32_t)ix->n_rows;
+    a.thr_by_part = 0;
     a.keys_out = nullptr;
     a.thrv = s->thrv;
     a.slot4 = s->slot4;
@@ -805,6 +808,24 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.mag_b0 = (int32_t)(row_begin / kSymC);
     a.mag_row_end = (int32_t)row_end;
     a.n_mag_items = (int32_t)(((row_end - 1) / kSymC - a.mag_b0 + 1) * 32 * kSymMag * ((nb - 1 + kSymMagBlocks - 1) / kSymMagBlocks));
+#ifdef PFZ_EXPERIMENTS
+    // tools/predict_scaling.py: pass 1 of ONE part of a job cut over N GPUs, alone on this GPU ("p/N"; whole jobs only; the result is
+    // that part's share -- wrong on purpose, compiled into variant builds only)
+    if (const char *solo = getenv("PFZ_K3_SYM_SOLO")) {
+        int p = 0, np_ = 1;
+        if (sscanf(solo, "%d/%d", &p, &np_) == 2 && np_ > 1 && p >= 0 && p < np_ && row_begin == 0) {
+            a.n_parts = np_;
+            a.my_part = p;
+            a.row_begin = p;
+        }
+    }
+    const int rows1 = a.row_end > a.row_begin ? (a.row_end - a.row_begin + a.n_parts - 1) / a.n_parts : 0;
+    if (rows1 + a.n_mag_items > 0)
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(rows1 + a.n_mag_items)), dim3(64), 0, ctx->stream, a);
+    a.n_parts = 1;
+    a.my_part = 0;
+    if (false)
+#endif
     if (a.row_end - a.row_begin + a.n_mag_items > 0)      // (one row per one-wave workgroup: 2 / 4 / 22 rows per workgroup measured no faster -- the dispatcher is not what a row waits for)
         hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(a.row_end - a.row_begin + a.n_mag_items)), dim3(64), 0, ctx->stream, a);
     a.n_mag_items = 0;
@@ -899,6 +920,7 @@ int k3_sym_sharded(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix, const pfz_
     a.n_parts = n_parts;
     a.my_part = part;
     a.per = (int32_t)((n + n_parts - 1) / n_parts);
+    a.thr_by_part = 1;
     a.keys_out = mine.p;
     PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
     PFZ_HIP(hipMemsetAsync(s->ovf, 0, sizeof(int32_t), ctx->stream));

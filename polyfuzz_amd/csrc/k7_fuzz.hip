@@ -977,7 +977,9 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         A.row_stats = (unsigned long long *)d_stats.p;
         A.phase_ticks = A.row_stats + (size_t)n_rows * 2;
     }
+#ifdef PFZ_EXPERIMENTS      // (variant builds only, tools/build_variant.sh -DPFZ_EXPERIMENTS: results wrong on purpose)
     if (const char *e = getenv("PFZ_K7_EXP")) A.exp = atoi(e);
+#endif
     const bool side = !cls[0].empty() && (!cls[1].empty() || !cls[2].empty()) && !getenv("PFZ_K7_NO_SIDE_STREAM");
     bool used_side = false;
     if (side) PFZ_TRY(ensure_side_stream(ctx));

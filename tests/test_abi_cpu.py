@@ -59,3 +59,14 @@ def test_product_code_never_imports_the_oracle():
                 # the product never calls scikit-learn either (the name appears only in comments/docstrings
                 # and as the reference's back-end name "sklearn")
                 assert not re.search(r"^\s*(import|from)\s+sklearn\b", src, flags=re.M), f
+
+
+def test_shipped_library_has_no_wrong_on_purpose_knobs():
+    """the timing experiments that make results wrong on purpose (PFZ_K3_ABLATE, PFZ_K3_SYM_EXP,
+    PFZ_K3_SYM_SOLO, PFZ_K7_EXP, the PFZ_K3_EXP what-ifs) exist in variant builds only (tools/build_variant.sh -DPFZ_EXPERIMENTS /
+    -DPFZ_K3_EXP=n): the shipped library does not even contain their names, so no environment can switch them on."""
+    from polyfuzz_amd import _build
+    blob = open(_build.LIB_PATH, "rb").read()
+    for knob in (b"PFZ_K3_ABLATE", b"PFZ_K3_SYM_EXP", b"PFZ_K3_SYM_SOLO", b"PFZ_K7_EXP", b"PFZ_K3_EXP"):
+        assert knob not in blob, knob
+    assert b"PFZ_K3_SYM_MIN" in blob            # (a tuning knob that does not change results is still there: the check reads the right file)

@@ -5,7 +5,13 @@ all-gather of the results, which is PRICED, not measured (ring over xGMI: (N-1)/
 153 GB/s link).  Shards are independent (no data-path collective before the gather), so what bounds
 the curve is the balance of the shards: max / mean of the per-rank times.
 
-usage: python tools/predict_scaling.py [--quick] > profiles/r04_predicted_scaling.json
+Round 5: the headline's strong-scaling job runs K3's symmetric form cut over the ranks (rank r: the rows r, r + N, ...;
+pfz_comm_cossim_topn_symmetric).  Its ranks are NOT independent (two all-gathers), so a rank cannot be run alone through the
+product path; the variant library (tools/build_variant.sh variants/exp.so -DPFZ_EXPERIMENTS) has a knob that runs ONE part's pass 1
+and magnet items alone (PFZ_K3_SYM_SOLO=p/N; pass 0 of all rows, the re-deal, the merge and pass 2 as on one GPU) -- see
+`symmetric_strong` below for what is measured and what is priced.
+
+usage: POLYFUZZ_HIP_LIB=$PWD/variants/exp.so python tools/predict_scaling.py [--quick] > profiles/r05_predicted_scaling.json
 """
 import json
 import os
@@ -84,6 +90,35 @@ for label, bounds_of in (("equal row counts (pipeline.shard_bounds)", lambda w: 
         per[w] = [tfidf_job(names[b:e], names, 5, True, b) for b, e in bounds_of(w)]
     rec = summarise(f"headline 100k x 100k top-5, strong, {label}", t1, per, 5, lambda w: n, "strong")
     rec["bounds_8"] = [list(map(int, be)) for be in bounds_of(8)]
+    out["configs"].append(rec)
+
+# ---- headline, strong scaling, K3's symmetric form cut over the ranks (what bench.py --gpus N runs by default since round 5) ----
+PASS0_MS = 0.199          # k3_sym_kernel<2048, 0> of all 100 000 rows (profiles/experiments/r05_k3_slot_order_steps.txt, run f)
+if os.environ.get("POLYFUZZ_HIP_LIB", "").endswith("exp.so") and n >= 20480:
+    def ring_ms(bytes_per_rank, world):
+        return (world - 1) * bytes_per_rank / (XGMI_LINK_GBS * 1e9) * 1e3
+    job1 = pipeline.TfidfMatchJob(ctx, names, None, top_n=5, min_similarity=0.0, self_match=True)
+    os.environ.pop("PFZ_K3_SYM_SOLO", None)
+    t_sym1 = timed(job1.step)
+    rec = {"config": "headline 100k x 100k top-5, strong, K3's symmetric form cut over the ranks (rows r, r + N, ...)", "scaling": "strong",
+           "single_gpu_ms": t_sym1, "worlds": {},
+           "how": "per rank: the WHOLE step measured on one GPU with only that part's pass 1 + magnet items (variant library, "
+                  "PFZ_K3_SYM_SOLO=p/N) minus the pass-0 time of the other parts' rows (pass 0 is dealt over the ranks in the real "
+                  f"job: {PASS0_MS} ms x (1 - 1/N)); plus, PRICED as rings over one 153 GB/s xGMI link: the in-place all-gather of the "
+                  "thresholds (n x 4 B in all) and the all-gather of the candidate lists (n x top_n x 8 B per rank); plus the merge of "
+                  "the N lists per row (measured once: the world-1 product path's k3_sym_merge_parts is part of single_gpu_ms's sibling "
+                  "below).  fit + vectorise + index are replicated (every rank does the whole list's)."}
+    for w in worlds:
+        ts = []
+        for p in (range(w) if w <= 4 else (0, w // 2, w - 1)):
+            os.environ["PFZ_K3_SYM_SOLO"] = f"{p}/{w}"
+            ts.append(timed(job1.step) - PASS0_MS * (1.0 - 1.0 / w))
+        os.environ.pop("PFZ_K3_SYM_SOLO", None)
+        comm = ring_ms(n * 4 / w, w) + ring_ms(n * 5 * 8, w)
+        job = max(ts) + comm
+        rec["worlds"][str(w)] = {"per_rank_ms": [round(t, 3) for t in ts], "max_over_mean": round(max(ts) / (sum(ts) / len(ts)), 4),
+                                 "allgathers_ms_priced": round(comm, 4), "job_ms_predicted": round(job, 3),
+                                 "efficiency_predicted": round(t_sym1 / (w * job), 4)}
     out["configs"].append(rec)
 
 # ---- config 4: 1M x 1M top-10 on 8 GPUs = 8 shards of 125 000 from-rows against the replicated 1M to-list ---------------
