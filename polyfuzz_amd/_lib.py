@@ -415,13 +415,20 @@ def _pack_threads():
 _PACK_THREADS = _pack_threads()
 
 
-def pack_strings(strings):
+def pack_strings(strings, objects=None):
     """list[str] -> (code units ndarray, offsets int64[n+1], char_width).
 
-    1-byte code units (Latin-1) when every code point is <= 0xFF, UTF-32 otherwise."""
+    1-byte code units (Latin-1) when every code point is <= 0xFF, UTF-32 otherwise.
+    objects: a fresh np.empty(len(strings), object) array that is to become the From column of the result frame -- filled
+    in the same walk over the strings (slot i = strings[i])."""
     if _pack is not None and isinstance(strings, (list, tuple)):
-        raw, off, width = _pack.pack(strings, _PACK_THREADS)
+        if objects is not None:
+            raw, off, width = _pack.pack(strings, _PACK_THREADS, objects.ctypes.data)
+        else:
+            raw, off, width = _pack.pack(strings, _PACK_THREADS)
         return np.frombuffer(raw, np.uint8 if width == 1 else np.uint32), np.frombuffer(off, np.int64), width
+    if objects is not None:
+        objects[:] = strings
     return _pack_strings_py(strings)
 
 

@@ -105,8 +105,10 @@ class EditDistance(BaseMatcher):
         else:
             names = to_list
         # the resident copy stands for the list it was made from and for no other
-        reuse_to = (reuse_to and not self_match and self._to_dev is not None
-                    and (to_list is self._to_names or to_list == self._to_names))
+        # -- compared by CONTENT against a snapshot taken when it was uploaded (the caller's list may have been changed
+        # in place since; an ndarray / Series to-list has no list `==`)
+        snap = None if self_match else tuple(to_list)
+        reuse_to = reuse_to and not self_match and self._to_dev is not None and snap == self._to_names
         held = (self._to_dev, self._to_names)
         self._to_dev = self._to_names = None      # set again below, once this call's to-list is resident
         if len(names) - (1 if self_match else 0) <= 0 and len(from_list) > 0:
@@ -119,7 +121,7 @@ class EditDistance(BaseMatcher):
                 to_dev = held[0]
             else:
                 to_dev = upload_for(ctx, name, names)
-            self._to_dev, self._to_names = to_dev, names
+            self._to_dev, self._to_names = to_dev, snap
         return best_choice_async(ctx, name, from_list, names, skip, self_match, to_dev=to_dev), names
 
     # a matcher is pickled by joblib (reference _distance.py:77, polyfuzz.py:429-457): device handles stay behind

@@ -157,8 +157,10 @@ class RapidFuzz(BaseMatcher):
         ctx = _lib.Context.default()
         self_match = to_list is None
         # the resident copy stands for the list it was made from and for no other
-        reuse = (kwargs.get("re_train", True) is False and not self_match and self._to_dev is not None
-                 and (to_list is self._to_names or to_list == self._to_names))
+        # -- compared by CONTENT against a snapshot taken when it was uploaded (the caller's list may have been changed
+        # in place since; an ndarray / Series to-list has no list `==`)
+        snap = None if self_match else tuple(to_list)
+        reuse = kwargs.get("re_train", True) is False and not self_match and self._to_dev is not None and snap == self._to_names
         held = self._to_dev
         self._to_dev = self._to_names = None      # set again below, once this call's to-list is resident
         names = from_list if self_match else to_list
@@ -179,7 +181,7 @@ class RapidFuzz(BaseMatcher):
             from_col = object_column(from_list)
         else:
             if not self_match:
-                self._to_dev, self._to_names = (held if reuse else upload_for(ctx, self._scorer_name, names)), names
+                self._to_dev, self._to_names = (held if reuse else upload_for(ctx, self._scorer_name, names)), snap
             pending = best_choice_async(ctx, self._scorer_name, from_list, names, skip, self_match,
                                         to_dev=None if self_match else self._to_dev)
             from_col = object_column(from_list)                              # (host work while the device scores)
@@ -195,4 +197,5 @@ class RapidFuzz(BaseMatcher):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.setdefault("reference_self_match", False)      # (a matcher pickled before the attribute existed)
         self._to_dev = self._to_names = None

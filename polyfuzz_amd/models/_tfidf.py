@@ -52,6 +52,9 @@ def _clean_string(string: str) -> str:
     return string
 
 
+_FROM_IN_PACK = os.environ.get("PFZ_FROM_IN_PACK", "1") != "0"      # (A/B knob of tools/match_wall_probe.py; the frames are the same)
+
+
 class HipTfidfVectorizer:
     """What `TFIDF.vectorizer` holds after a fit: the device-resident vocabulary +
     idf, with the read-only parts of sklearn's TfidfVectorizer surface
@@ -153,7 +156,9 @@ class TFIDF(BaseMatcher):
             raise ValueError(f"cosine_method must be one of {_METHODS}")
         ctx = _lib.Context.default()
         t0 = time.perf_counter()
-        from_dev, to_dev = self._extract_tf_idf(from_list, to_list, re_train)
+        # the From column of the frame is filled by the string packer's own walk over from_list (a list): no second pass
+        col = [np.empty(len(from_list), dtype=object)] if isinstance(from_list, list) and len(from_list) >= 1024 and _FROM_IN_PACK else None
+        from_dev, to_dev = self._extract_tf_idf(from_list, to_list, re_train, col)
         top_n = clip_top_n(self.top_n, to_list)                   # _utils.py:54-56
         self_match = to_list is None
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
@@ -178,7 +183,7 @@ class TFIDF(BaseMatcher):
         else:
             res = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=self_match)
         t1 = time.perf_counter()
-        from_col = object_column(from_list)        # host work while the device runs K3
+        from_col = col[0] if col and col[0] is not None else object_column(from_list)        # (host work while the device runs K3)
         t2 = time.perf_counter()
         if split:
             fb = FrameBuilder(from_list, names, top_n, from_col)
@@ -221,22 +226,30 @@ class TFIDF(BaseMatcher):
         lo, hi = int(self.n_gram_range[0]), int(self.n_gram_range[1])
         return _lib.TfidfParams(lo, hi, int(bool(self.clean_string)), int(bool(self.remove_space_ngrams)))
 
-    def _upload(self, strings):
+    def _upload(self, strings, objects=None):
+        """objects: see _lib.pack_strings (the From column, filled in the packer's walk over the strings)"""
         ctx = _lib.Context.default()
-        packed = _lib.pack_strings(strings)
+        packed = _lib.pack_strings(strings, objects)
         if self.clean_string and packed[2] != 1:
             # code points > 0xFF: clean on the host (str.lower() can map into ASCII); cleaning is idempotent,
             # so the device's clean pass leaves these untouched
             packed = _lib.pack_strings([_clean_string(s) for s in strings])
         return _lib.DeviceStrings.upload_packed(ctx, *packed)
 
-    def _extract_tf_idf(self, from_list, to_list=None, re_train=True):
+    def _extract_tf_idf(self, from_list, to_list=None, re_train=True, from_objects=None):
         """ reference _tfidf.py:102-118: fit on to_list + from_list (or from_list alone), keep the
-        to-side matrix; with re_train=False reuse the fitted vocabulary and to-side """
+        to-side matrix; with re_train=False reuse the fitted vocabulary and to-side.
+        from_objects: a one-element list holding a fresh object array -- the frame's From column, filled while from_list
+        is packed for its upload; left None in the list when from_list was not uploaded by this call """
         ctx = _lib.Context.default()
         self._restore()
+        objs = from_objects[0] if from_objects else None
+        if from_objects:
+            from_objects[0] = None
         if to_list:
-            from_s = self._upload(from_list)
+            from_s = self._upload(from_list, objs)
+            if from_objects:
+                from_objects[0] = objs
             if re_train:
                 to_s = self._upload(to_list)
                 self._fit(ctx, to_s, from_s)
@@ -244,7 +257,9 @@ class TFIDF(BaseMatcher):
             self._require_fitted()
             return self._dev_vec.transform(from_s), self._dev_to
         if re_train:
-            from_s = self._upload(from_list)
+            from_s = self._upload(from_list, objs)
+            if from_objects:
+                from_objects[0] = objs
             self._fit(ctx, from_s, None)
             self._set_to_side(ctx, self._dev_vec.transform(from_s))
         self._require_fitted()

@@ -333,11 +333,26 @@ def test_re_train_false_scores_against_the_list_it_is_given(ctx):
         m.match(a)                                            # a fit on one list: self-match, leaves nothing of B behind
         assert m._to_dev is None and m._to_names is None
         assert m.match(e, a, re_train=False).equals(fresh)
-        assert m._to_names is a
+        assert m._to_names == tuple(a)                        # (a snapshot of the contents, not the caller's object: ADVICE r4)
         held = m._to_dev
         assert m.match(x, a, re_train=False).equals(make().match(x, a)) and m._to_dev is held      # same object: resident copy
         assert m.match(x, list(a), re_train=False).equals(make().match(x, a)) and m._to_dev is held  # an equal list: too
         assert m.match(x, b, re_train=False).equals(make().match(x, b)) and m._to_dev is not held  # another list: uploaded
+        # the caller changes its list IN PLACE and hands the same object over again: the resident copy is stale
+        c = list(a)
+        m.match(x, c, re_train=False)
+        held = m._to_dev
+        c[3] = x[0]
+        assert m.match(x, c, re_train=False).equals(make().match(x, c)) and m._to_dev is not held
+        import numpy as np_
+        assert m.match(x, np_.array(c, dtype=object), re_train=False).equals(make().match(x, c))   # an ndarray to-list: no ambiguous `==`
+    # a matcher pickled before `reference_self_match` existed
+    m = RapidFuzz()
+    state = m.__getstate__()
+    state.pop("reference_self_match")
+    m2 = RapidFuzz.__new__(RapidFuzz)
+    m2.__setstate__(state)
+    assert m2.reference_self_match is False and m2.match(e, a).equals(RapidFuzz().match(e, a))
 
 
 def test_rapidfuzz_pin_fixture(ctx):

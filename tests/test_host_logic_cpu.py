@@ -207,3 +207,34 @@ def test_frame_beyond_1024_match_columns():
     a = topn_to_frame(idx, val, names[:n], names, top)
     b = _topn_to_frame_numpy(idx, val, names[:n], names, top)
     assert a.shape == (n, 1 + 2 * top) and a.equals(b)
+
+
+@pytest.mark.parametrize("threads", [1, 4, -4])        # (negative: the general two-pass path also for 1-byte lists)
+def test_packer_fills_the_from_column_in_its_own_walk(threads, monkeypatch):
+    """_pack.pack(strings, n_threads, obj_addr): the frame's From column (a fresh object array) is filled while the strings
+    are packed for their upload -- same strings, one new reference each, nothing else changed; wide (UTF-32) lists, lists
+    that need a second start (not-ready strings cannot be made here, a non-str item can) and a used array are refused."""
+    import sys
+    from polyfuzz_amd import _lib
+    if _lib._pack is None:
+        pytest.skip("_pack.so not built")
+    monkeypatch.setattr(_lib, "_PACK_THREADS", threads)
+    for names in ([f"name {i} inc" for i in range(40000)] + ["dup"] * 50, ["é", "日本語", "x" * 300] + [f"n{i}" for i in range(20000)]):
+        rc0 = [sys.getrefcount(s) for s in names[:5]]
+        last = names[-1]
+        last0 = sys.getrefcount(last)
+        col = np.empty(len(names), dtype=object)
+        a = _lib.pack_strings(names, col)
+        b = _lib.pack_strings(names)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        assert all(col[i] is names[i] for i in range(len(names)))
+        assert [sys.getrefcount(s) for s in names[:5]] == [r + 1 for r in rc0]
+        assert sys.getrefcount(last) - last0 == names.count(last)     # ("dup": one object in 50 slots, atomic adds across the workers)
+        del col
+        assert [sys.getrefcount(s) for s in names[:5]] == rc0 and sys.getrefcount(last) == last0
+    used = np.empty(3, dtype=object)
+    used[1] = "x"
+    with pytest.raises(ValueError):
+        _lib.pack_strings(["a", "b", "c"], used)
+    with pytest.raises(TypeError):
+        _lib.pack_strings(["a", 5, "c"], np.empty(3, dtype=object))
