@@ -32,6 +32,8 @@
 // All of it is HBM-streaming work over a few MB; none of it is MFMA-shaped.
 #include "pfz_internal.h"
 
+#include <string.h>
+
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
@@ -919,16 +921,24 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df)
     return PFZ_OK;
 }
 
-static int build_prefix(pfz_ctx *ctx, pfz_tfidf *v)
+// rank prefix of the vocabulary bitmap; the vocabulary's size starts its way to the host (*size: lazy_get it when needed)
+static int build_prefix(pfz_ctx *ctx, pfz_tfidf *v, LazyI32 *size)
 {
     hipLaunchKernelGGL(k_group_popc, dim3(grid_for(v->n_groups)), dim3(256), 0, ctx->stream, v->bitmap, v->n_groups,
                        v->prefix);
-    PFZ_TRY(exclusive_scan_i32(ctx, v->prefix, v->n_groups));
-    int32_t total = 0;
-    PFZ_HIP(hipMemcpyAsync(&total, v->prefix + v->n_groups, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PFZ_HIP(hipStreamSynchronize(ctx->stream));
-    v->vocab = total;
-    return PFZ_OK;
+    return exclusive_scan_i32(ctx, v->prefix, v->n_groups, size);
+}
+
+// an upper bound of the vocabulary known before anything ran: the n-grams an alphabet of `a` symbols can form
+static int64_t vocab_bound(int64_t a, int lo, int hi)
+{
+    int64_t total = 0, p = 1;
+    for (int n = 1; n <= hi; ++n) {
+        if (p > ((int64_t)1 << 40) / (a > 0 ? a : 1)) return (int64_t)1 << 40;
+        p *= a;
+        if (n >= lo) total += p;
+    }
+    return total;
 }
 
 // Sorted-vocabulary mode (codes wider than kBitmapMaxBits): gather the codes k_extract left in the slot
@@ -1120,10 +1130,24 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
     s->char_width = char_width;
     s->max_len = max_len;
     s->h_off.assign(offsets, offsets + n + 1);
-    PFZ_TRY(pool_alloc(ctx, &s->chars, (size_t)(n_units > 0 ? n_units : 1) * (size_t)char_width + 16));
-    PFZ_TRY(pool_alloc(ctx, &s->offsets, (size_t)(n + 1) * sizeof(int64_t)));
-    if (n_units > 0) PFZ_TRY(copy_h2d(ctx, s->chars, chars, (size_t)n_units * (size_t)char_width));
-    PFZ_TRY(copy_h2d(ctx, s->offsets, offsets, (size_t)(n + 1) * sizeof(int64_t)));
+    const size_t char_bytes = (size_t)n_units * (size_t)char_width, off_bytes = (size_t)(n + 1) * sizeof(int64_t);
+    if (char_bytes + off_bytes <= (48u << 10)) {
+        // a query batch: offsets and code units in ONE block and one host-to-device copy (every copy is ~10 us of a 150-us
+        // single-query match); `offsets` is the block, `chars` points into it
+        const size_t off_pad = (off_bytes + 255) & ~(size_t)255;
+        PFZ_TRY(pool_alloc(ctx, &s->offsets, off_pad + char_bytes + 16));
+        s->chars = (char *)s->offsets + off_pad;
+        s->chars_in_offsets = true;
+        std::vector<char> both(off_pad + char_bytes);
+        memcpy(both.data(), offsets, off_bytes);
+        if (char_bytes) memcpy(both.data() + off_pad, chars, char_bytes);
+        PFZ_TRY(copy_h2d(ctx, s->offsets, both.data(), both.size()));
+    } else {
+        PFZ_TRY(pool_alloc(ctx, &s->chars, (size_t)(n_units > 0 ? n_units : 1) * (size_t)char_width + 16));
+        PFZ_TRY(pool_alloc(ctx, &s->offsets, off_bytes));
+        if (n_units > 0) PFZ_TRY(copy_h2d(ctx, s->chars, chars, char_bytes));
+        PFZ_TRY(copy_h2d(ctx, s->offsets, offsets, off_bytes));
+    }
     *out = s.release();
     return PFZ_OK;
 }
@@ -1132,7 +1156,7 @@ void pfz_strings_free(pfz_strings *s)
 {
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
-    if (s->chars) pool_free(s->chars);
+    if (s->chars && !s->chars_in_offsets) pool_free(s->chars);
     if (s->offsets) pool_free(s->offsets);
     if (s->slots) pool_free(s->slots);
     if (s->indel_plan) pfz_indel_plan_free(s->indel_plan);
@@ -1259,7 +1283,27 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         const unsigned grid = (unsigned)std::min<int64_t>((n_words + 255) / 256, 4096);
         hipLaunchKernelGGL(k_or_reduce, dim3(grid), dim3(256), 0, ctx->stream, gathered, n_words, world, v->bitmap);
     }
-    if (!sorted_vocab) PFZ_TRY(build_prefix(ctx, v));
+    // The vocabulary's size is needed on the host (allocation sizes below), but not by the row kernels: where the alphabet bounds
+    // it inside what one LDS histogram holds -- cleaned 3-grams: 37^3 -- the rows of the fitted lists are sorted and counted
+    // (k_rows_*) while the size is on its way, instead of after a synchronising read-back (45 us of idle device per fit).
+    LazyI32 vsize;
+    bool rows_done = false;
+    if (!sorted_vocab) {
+        PFZ_TRY(build_prefix(ctx, v, &vsize));
+        const int64_t a_syms = params->clean ? 37 : (int64_t)v->alphabet.size() + 1;
+        const bool small = vocab_bound(a_syms, params->ngram_lo, params->ngram_hi) <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST");
+        int rc = PFZ_OK;
+        if (small && world == 1) {
+            for (pfz_strings *s : lists)
+                if (s && rc == PFZ_OK) rc = run_rows(ctx, v, s, DfSink{nullptr, 0});
+            rows_done = true;
+        }
+        int32_t total = 0;
+        const int rc2 = lazy_get(ctx, &vsize, &total);      // (also on the error path: the slot goes back to the pool)
+        PFZ_TRY(rc);
+        PFZ_TRY(rc2);
+        v->vocab = total;
+    }
     if (v->vocab == 0) {
         // sklearn text.py:1282-1285
         set_error("empty vocabulary; perhaps the documents only contain stop words");
@@ -1293,7 +1337,7 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         if (!s) continue;
         // the replicated list (docs_a) is counted by rank 0 only
         const bool counts = (li == 1) || rank == 0 || world == 1;
-        PFZ_TRY(run_rows(ctx, v, s, DfSink{counts && !lds_hist ? df_sh : nullptr, df_shift}));
+        if (!rows_done) PFZ_TRY(run_rows(ctx, v, s, DfSink{counts && !lds_hist ? df_sh : nullptr, df_shift}));
         s->cache_gen = v->gen;
         if (counts) local_docs += s->n;
         if (counts && lds_hist && s->n > 0) {
@@ -1380,23 +1424,24 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
     m->n_rows = s->n;
     m->n_cols = v->vocab;
     PFZ_TRY(pool_alloc(ctx, &m->indptr, (size_t)(s->n + 1) * sizeof(int32_t)));
-    int32_t nnz = 0;
+    // No read-back of the number of non-zeros: every entry is a distinct n-gram of its string, so the n-gram slots the list
+    // owns (R per code unit) bound it -- indices / data are sized by the bound, the count itself travels to the host behind
+    // the scan and is waited for only by whoever asks (csr_nnz: pfz_csr_shape, a download).  A synchronising read-back here
+    // idles the device until the host has enqueued the next launch: 35 - 45 us per transform in a 0.37-ms step of 10k x 10k.
+    const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(s->n_units * (int64_t)R, ((int64_t)1 << 31) - 1));
+    m->nnz_cap = cap;
+    PFZ_TRY(pool_alloc(ctx, &m->indices, (size_t)cap * sizeof(int32_t)));
+    PFZ_TRY(pool_alloc(ctx, &m->data, (size_t)cap * sizeof(float)));
     if (s->n > 0) {
         const int32_t *row_nnz = s->row_cnt + (s->n + 1);
         hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, row_nnz, s->n, m->indptr);
-        PFZ_TRY(exclusive_scan_i32(ctx, m->indptr, s->n));
-        PFZ_HIP(hipMemcpyAsync(&nnz, m->indptr + s->n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PFZ_HIP(hipStreamSynchronize(ctx->stream));
-    } else {
-        PFZ_HIP(hipMemsetAsync(m->indptr, 0, sizeof(int32_t), ctx->stream));
-    }
-    m->nnz = nnz;
-    PFZ_TRY(pool_alloc(ctx, &m->indices, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
-    PFZ_TRY(pool_alloc(ctx, &m->data, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float)));
-    if (s->n > 0 && nnz > 0) {
+        PFZ_TRY(exclusive_scan_i32(ctx, m->indptr, s->n, &m->nnz_lazy));
         ProfScope ps(ctx, "k2_finalize");
         hipLaunchKernelGGL(k_finalize, dim3(grid_for(s->n, 16)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
                            m->indptr, v->idf, m->indices, m->data);
+    } else {
+        PFZ_HIP(hipMemsetAsync(m->indptr, 0, sizeof(int32_t), ctx->stream));
+        m->nnz = 0;
     }
     PFZ_HIP(hipGetLastError());
     *out = m.release();
@@ -1509,7 +1554,11 @@ int pfz_tfidf_import(pfz_ctx *ctx, const pfz_tfidf_params *params, int64_t vocab
         }
         pool_free(d_codes);
         PFZ_HIP(e);
-        PFZ_TRY(build_prefix(ctx, v));
+        LazyI32 vsize;
+        PFZ_TRY(build_prefix(ctx, v, &vsize));
+        int32_t total = 0;
+        PFZ_TRY(lazy_get(ctx, &vsize, &total));
+        v->vocab = total;
     }
     PFZ_REQUIRE(v->vocab == vocab, "pfz_tfidf_import: %lld distinct n-grams, expected %lld", (long long)v->vocab, (long long)vocab);
     PFZ_TRY(pool_alloc(ctx, &v->df, (size_t)vocab * sizeof(int32_t)));

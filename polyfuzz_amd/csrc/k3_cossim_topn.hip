@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void k_index_pieces(int32_t *__restrict__ cnt,
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int c = 0;
+    if (i == 0) tab[-1] = 1;           // piece 0, in front of every list: the all-zero dummy (the scan runs from there)
     if (i < slots) {
         if (sub) {
             int4 v = ((const int4 *)sub)[i];
@@ -134,17 +135,19 @@ __global__ __launch_bounds__(256) void k_index_pieces(int32_t *__restrict__ cnt,
     }
 }
 
-// Padding entries of every list (positions count .. 16*pieces) and the dummy piece at n_pieces: value 0
+// Padding entries of every list (positions count .. 16*pieces) and the dummy piece (piece 0): value 0
 // -- they add nothing -- at accumulator offsets spread over 64 cells, so the padding lanes of one
 // ds_add_u32 do not pile up on one LDS address.
 // pblk != NULL: the to-block of every piece of the list is noted as well (slot i = n-gram * nb + block)
 __global__ __launch_bounds__(256) void k_index_pad(const int32_t *__restrict__ cnt, const int32_t *__restrict__ tab,
-                                                    int64_t slots, int32_t n_pieces, int2 *__restrict__ post,
-                                                    uint16_t *__restrict__ pblk, int32_t nb)
+                                                    int64_t slots, int2 *__restrict__ post,
+                                                    uint16_t *__restrict__ pblk, int32_t nb, const int32_t *__restrict__ nnz_dev,
+                                                    int32_t *__restrict__ nnz_host)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < kPiece) post[(int64_t)n_pieces * kPiece + i] = make_int2((int)i * 4, 0);
-    if (i == 0 && pblk) pblk[n_pieces] = 0;
+    if (i == 0) __hip_atomic_store(nnz_host, *nnz_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the postings' count, for whoever asks the host)
+    if (i < kPiece) post[i] = make_int2((int)i * 4, 0);      // piece 0: the dummy
+    if (i == 0 && pblk) pblk[0] = 0;
     if (i >= slots) return;
     const int c = cnt[i];
     if (c == 0) return;
@@ -311,7 +314,8 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
     const char *post_bytes = (const char *)post;
     const int src4 = (4 * (lane & 15) + (lane >> 4)) * 4;   // bpermute index of the window position this lane processes
     const int sub8 = (lane & 15) * 8;                       // byte offset of this lane's posting inside its piece
-    const int dummy_addr = n_pieces << 7;                   // the all-zero piece
+    const int dummy_addr = 0;                               // the all-zero piece is piece 0
+    (void)n_pieces;
 
     // Work item = (from-row, to-slice).  The to-blocks are cut into n_slices contiguous
     // ranges and item i works on slice i % n_slices (small query batches: fill the chip).
@@ -480,16 +484,16 @@ __global__ __launch_bounds__(256) void k3_merge_slices(const uint64_t *__restric
     TopState st;
     st.cnt = 0;
     st.thr = 0;
-    for (int sl = 0; sl < n_slices; ++sl) {
-        const uint64_t *src = part_keys + ((int64_t)row * n_slices + sl) * ntop;
-        for (int r0 = 0; r0 < ntop; r0 += 64) {     // keys are sorted, zeros (= no entry) at the end
-            const int r = r0 + lane;
-            const uint64_t key = r < ntop ? src[r] : 0ull;
-            const uint64_t mk = __ballot(key != 0ull);
-            if (key) cand[st.cnt + __popcll(mk & ((1ull << lane) - 1ull))] = key;
-            st.cnt += __popcll(mk);
-            if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane, false);
-        }
+    // the row's n_slices x ntop keys lie back to back (zeros = no entry): 64 per load, whatever slice they belong to -- a loop
+    // over the slices made a single query wait for 49 dependent loads (11 us of its 35 us of kernels)
+    const uint64_t *src = part_keys + (int64_t)row * n_slices * ntop;
+    const int total = n_slices * ntop;
+    for (int e0 = 0; e0 < total; e0 += 64) {
+        const uint64_t key = e0 + lane < total ? src[e0 + lane] : 0ull;
+        const uint64_t mk = __ballot(key != 0ull);
+        if (key) cand[st.cnt + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+        st.cnt += __popcll(mk);
+        if (st.cnt > kCap - 64) compact<kCap>(cand, st, ntop, lane, false);
     }
     compact<kCap>(cand, st, ntop, lane);
     for (int r = lane; r < ntop; r += 64) {
@@ -516,6 +520,20 @@ static int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
     return v && *v ? atoi(v) : dflt;
+}
+
+int index_ready(const pfz_index *ix)
+{
+    int32_t v = 0;
+    if (ix->pieces_lazy.pending) {
+        PFZ_TRY(lazy_get(ix->ctx, &ix->pieces_lazy, &v));
+        ix->n_pieces = v - 1;           // (the count includes the dummy)
+    }
+    if (ix->nnz_lazy.pending) {
+        PFZ_TRY(lazy_get(ix->ctx, &ix->nnz_lazy, &v));
+        ix->nnz = v;
+    }
+    return PFZ_OK;
 }
 
 }  // namespace pfz
@@ -546,7 +564,6 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     ix->ctx = ctx;
     ix->n_rows = B->n_rows;
     ix->n_cols = B->n_cols;
-    ix->nnz = B->nnz;
     ix->block_cols = block;
     ix->n_blocks = (int32_t)nb;
     ix->max_norm = B->max_norm;
@@ -555,13 +572,18 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
         int32_t *p = nullptr;
         ~Tmp() { if (p) pool_free(p); }
     } cnt, sub;
-    const bool any = B->n_rows > 0 && B->nnz > 0;
+    // (a device-vectorised matrix does not know its number of non-zeros on the host yet -- csr_nnz() would wait for it; the
+    // build runs on whatever it is, zero included)
+    const bool any = B->n_rows > 0;
     // per-block LDS histograms when the vocabulary fits (PFZ_NO_LDS_HIST=1 forces the global-atomics
     // path of huge vocabularies: tests)
     const bool lds_hist = B->n_cols <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST");
-    PFZ_TRY(pool_alloc(ctx, &ix->tab, (size_t)(slots + 2) * sizeof(int32_t)));
+    // tab_base[0] = 1 (the dummy piece), tab_base[1 + i] = pieces of list i; after the scan tab = tab_base + 1 holds every
+    // list's first piece and tab[slots] the number of pieces, dummy included
+    PFZ_TRY(pool_alloc(ctx, &ix->tab_base, (size_t)(slots + 3) * sizeof(int32_t)));
+    ix->tab = ix->tab_base + 1;
     PFZ_TRY(pool_alloc(ctx, &cnt.p, (size_t)(slots + 2) * sizeof(int32_t)));
-    PFZ_HIP(hipMemsetAsync(ix->tab, 0, (size_t)(slots + 2) * sizeof(int32_t), ctx->stream));
+    PFZ_HIP(hipMemsetAsync(ix->tab_base, 0, (size_t)(slots + 3) * sizeof(int32_t), ctx->stream));
     if (lds_hist && any) {      // counts per (list, sub-block); cnt itself is written by k_index_pieces
         PFZ_TRY(pool_alloc(ctx, &sub.p, (size_t)(slots + 1) * kSub * sizeof(int32_t)));
         PFZ_HIP(hipMemsetAsync(sub.p, 0, (size_t)slots * kSub * sizeof(int32_t), ctx->stream));
@@ -584,37 +606,45 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     const int32_t words = (int32_t)((B->n_cols + 1) / 2);
     const unsigned row_grid = (unsigned)((B->n_rows * 16 + 255) / 256);
     const unsigned slot_grid = (unsigned)((slots + kPiece + 255) / 256);
-    int32_t n_pieces = 0;
-    if (any) {
-        {
-            ProfScope ps(ctx, "k_index_count");
-            if (lds_hist)
-                hipLaunchKernelGGL(k_index_count_lds, dim3((unsigned)nb * kSub), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
-                                   (int32_t)B->n_rows, (int32_t)nb, block, words, sub.p);
-            else
-                hipLaunchKernelGGL(k_index_count, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
-                                   (int32_t)B->n_rows, (int32_t)nb, block, cnt.p);
-            hipLaunchKernelGGL(k_index_pieces, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, lds_hist ? sub.p : nullptr, slots,
-                               ix->tab, heavy.p, heavy_cap, bank_min);
+    {
+        ProfScope ps(ctx, "k_index_count");
+        if (any && lds_hist)
+            hipLaunchKernelGGL(k_index_count_lds, dim3((unsigned)nb * kSub), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
+                               (int32_t)B->n_rows, (int32_t)nb, block, words, sub.p);
+        else if (any)
+            hipLaunchKernelGGL(k_index_count, dim3(row_grid), dim3(256), 0, ctx->stream, B->indptr, B->indices,
+                               (int32_t)B->n_rows, (int32_t)nb, block, cnt.p);
+        hipLaunchKernelGGL(k_index_pieces, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, lds_hist && any ? sub.p : nullptr, slots,
+                           ix->tab, heavy.p, heavy_cap, bank_min);
+    }
+    PFZ_TRY(exclusive_scan_i32(ctx, ix->tab_base, slots + 1, &ix->pieces_lazy));   // tab[i] = first piece of list i, tab[slots] = pieces + the dummy
+    // The postings are allocated by a BOUND of the number of pieces (a list of c postings has ceil(c / 16) pieces: at most nnz / 16
+    // + one per non-empty list), not by the count itself: waiting for it here idles the device until the host has enqueued the fill
+    // (50 us of a 0.37-ms step at 10k x 10k).  Only where the bound leaves the 4 GiB the kernels address with 32-bit byte offsets
+    // is the count waited for and checked.
+    const int64_t nnz_bound = B->nnz_lazy.pending ? B->nnz_cap : B->nnz;
+    int64_t piece_cap = nnz_bound / kPiece + std::min<int64_t>(slots, nnz_bound) + 1;
+    if (piece_cap >= (1 << 25) - 1) {
+        int32_t total = 0;
+        PFZ_TRY(lazy_get(ctx, &ix->pieces_lazy, &total));
+        if (total - 1 >= (1 << 25) - 1) {
+            set_error("pfz_index_build: %d index pieces (%lld postings padded to 16 per list and block) exceed the 4 GiB "
+                      "the kernel addresses with 32-bit byte offsets", total - 1, (long long)csr_nnz(B));
+            return PFZ_ERR_UNSUPPORTED;
         }
-        PFZ_TRY(exclusive_scan_i32(ctx, ix->tab, slots));   // tab[i] = first piece of list i, tab[slots] = pieces
-        PFZ_HIP(hipMemcpyAsync(&n_pieces, ix->tab + slots, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        piece_cap = total;
     }
-    if (n_pieces >= (1 << 25) - 1) {
-        set_error("pfz_index_build: %d index pieces (%lld postings padded to 16 per list and block) exceed the 4 GiB "
-                  "the kernel addresses with 32-bit byte offsets", n_pieces, (long long)B->nnz);
-        return PFZ_ERR_UNSUPPORTED;
-    }
-    ix->n_pieces = n_pieces;
-    PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)(n_pieces + 1) * kPiece * sizeof(int2)));
+    ix->piece_cap = piece_cap;
+    PFZ_TRY(lazy_acquire(ctx, &ix->nnz_lazy));      // (written by k_index_pad: the matrix' last row bound, wherever the host stands with B's own count)
+    PFZ_TRY(pool_alloc(ctx, &ix->post, (size_t)piece_cap * kPiece * sizeof(int2)));
     if (block == 2048 && nb >= 2 && nb < 65536)      // (what the symmetric form of a self-match reads: k3_symmetric.hip)
-        PFZ_TRY(pool_alloc(ctx, &ix->pblk, (size_t)(n_pieces + 1) * sizeof(uint16_t)));
+        PFZ_TRY(pool_alloc(ctx, &ix->pblk, (size_t)piece_cap * sizeof(uint16_t)));
     {
         ProfScope ps(ctx, "k_index_fill");
         // (before the fill: the global-atomics fill counts cnt down)
-        hipLaunchKernelGGL(k_index_pad, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, ix->tab, any ? slots : 0, n_pieces,
-                           ix->post, ix->pblk, (int32_t)nb);
+        hipLaunchKernelGGL(k_index_pad, dim3(slot_grid), dim3(256), 0, ctx->stream, cnt.p, ix->tab, slots, ix->post, ix->pblk, (int32_t)nb,
+                           B->indptr + B->n_rows, ix->nnz_lazy.slot);
+        PFZ_TRY(lazy_mark(ctx, &ix->nnz_lazy));
         if (any && lds_hist)
             hipLaunchKernelGGL(k_index_fill_lds, dim3((unsigned)nb * kSub), dim3(1024), 0, ctx->stream, B->indptr, B->indices,
                                B->data, (int32_t)B->n_rows, (int32_t)nb, block, words, ix->tab, sub.p, ix->post);
@@ -637,7 +667,12 @@ void pfz_index_free(pfz_index *ix)
     if (!ix) return;
     if (ix->ctx) (void)hipSetDevice(ix->ctx->device);
     k3_sym_free(ix);
-    if (ix->tab) pool_free(ix->tab);
+    for (LazyI32 *z : {&ix->pieces_lazy, &ix->nnz_lazy})
+        if (z->pending || z->slot) {      // (the copy into the slot may still be in flight)
+            if (z->ev) (void)hipEventSynchronize(z->ev);
+            lazy_release(ix->ctx, z);
+        }
+    if (ix->tab_base) pool_free(ix->tab_base);
     if (ix->post) pool_free(ix->post);
     if (ix->pblk) pool_free(ix->pblk);
     delete ix;
@@ -647,6 +682,7 @@ int pfz_index_info(const pfz_index *ix, int64_t *n_rows, int64_t *n_cols, int64_
                    int64_t *n_blocks, int64_t *table_bytes)
 {
     PFZ_REQUIRE(ix, "pfz_index_info: NULL index");
+    PFZ_TRY(index_ready(ix));
     if (n_rows) *n_rows = ix->n_rows;
     if (n_cols) *n_cols = ix->n_cols;
     if (nnz) *nnz = ix->nnz;
@@ -659,6 +695,7 @@ int pfz_index_info(const pfz_index *ix, int64_t *n_rows, int64_t *n_cols, int64_
 int pfz_index_pieces(const pfz_index *ix, int64_t *n_pieces, int64_t *piece_postings)
 {
     PFZ_REQUIRE(ix, "pfz_index_pieces: NULL index");
+    PFZ_TRY(index_ready(ix));
     if (n_pieces) *n_pieces = ix->n_pieces;
     if (piece_postings) *piece_postings = kPiece;
     return PFZ_OK;
@@ -709,7 +746,7 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
             const int32_t w = ntop - col0 < kMaxTop ? ntop - col0 : kMaxTop;
 #define PFZ_K3_DEEP(CC)                                                                                                   \
     hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, 1152, true>), dim3(grid), dim3(64), 0, ctx->stream, A->indptr + row_begin,     \
-                       A->indices, A->data, (int32_t)n_rows, ix->tab, ix->post, ix->n_blocks, ix->n_pieces, w, thr0, scale,      \
+                       A->indices, A->data, (int32_t)n_rows, ix->tab, ix->post, ix->n_blocks, 0, w, thr0, scale,      \
                        inv_scale, exclude_diag, diag_offset + row_begin, (int32_t *)t_idx.p, (float *)t_val.p, 0, 1,              \
                        (uint64_t *)nullptr, (uint64_t *)ub.p)
             switch (ix->block_cols) {
@@ -780,7 +817,7 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
 #define PFZ_K3_LAUNCH(CC, CAP)                                                                                  \
     hipLaunchKernelGGL((k3_cossim_topn_kernel<CC, CAP>), dim3(grid), dim3(64), 0, ctx->stream,                  \
                        A->indptr + row_begin, A->indices, A->data, (int32_t)n_rows, ix->tab, ix->post,          \
-                       ix->n_blocks, ix->n_pieces, ntop, thr0, scale, inv_scale, exclude_diag,                  \
+                       ix->n_blocks, 0, ntop, thr0, scale, inv_scale, exclude_diag,                  \
                        diag_offset + row_begin, out->idx + row_begin * ntop, out->val + row_begin * ntop,       \
                        ablate, n_slices, part)
 #define PFZ_K3_CASE(CC)                              \

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void k3_lockstep_kernel(const K3LsArgs a)
     const char *post_bytes = (const char *)a.post;
     const int src4 = (4 * (lane & 15) + (lane >> 4)) * 4;
     const int sub8 = (lane & 15) * 8;
-    const int dummy_addr = a.n_pieces << 7;
+    const int dummy_addr = 0;      // (piece 0 is the all-zero dummy)
     const int nb = a.nb, ntop = a.ntop;
 
     // hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits): which XCD this wave runs on (a speed hint only: any value works)
@@ -351,7 +351,7 @@ int k3_lockstep_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int6
     a.tab = ix->tab;
     a.post = ix->post;
     a.nb = ix->n_blocks;
-    a.n_pieces = ix->n_pieces;
+    a.n_pieces = 0;                // (not needed any more: the dummy piece is piece 0)
     a.ntop = ntop;
     a.thr0 = thr0;
     a.scale = scale;

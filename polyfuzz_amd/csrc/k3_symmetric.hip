@@ -84,8 +84,9 @@ struct K3SymArgs {
     const int32_t *tab;
     const int2 *post;         // the index' postings: passes 0 and 2
     const int2 *post_sym;     // the same pieces with the slot fields re-dealt by threshold: pass 1
-    const uint16_t *pblk;     // [n_pieces + 1] to-block of every piece
-    int32_t nb, n_pieces, ntop, thr0;
+    const uint16_t *pblk;     // to-block of every piece
+    const int32_t *n_pieces1; // (device) pieces of the index, the dummy piece 0 included
+    int32_t nb, ntop, thr0;
     float scale, inv_scale;
     int32_t row_begin, row_end;   // the rows of this launch (modes 0 and 1, merge)
     int32_t n_parts, my_part, per;   // the job cut over n_parts GPUs (k3_sym_sharded): this part works on the rows = my_part (mod n_parts); per = ceil(n / n_parts)
@@ -183,12 +184,12 @@ __global__ __launch_bounds__(1024) void k3_sym_order(const K3SymArgs a)
 __global__ __launch_bounds__(256) void k3_sym_repost(const K3SymArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // pair of postings
-    if (i >= ((int64_t)a.n_pieces + 1) * (kPiece / 2)) return;
+    if (i >= (int64_t)*a.n_pieces1 * (kPiece / 2)) return;        // (the grid covers the index' piece CAPACITY)
     const int piece = (int)(i >> 3);
     const int b = a.pblk[piece];
     int4 e = ((const int4 *)a.post)[i];
     const uint16_t *s4 = a.slot4 + (int64_t)b * kSymC;
-    if (piece < a.n_pieces) {           // (the all-zero dummy piece stays as it is)
+    if (piece > 0) {                    // (the all-zero dummy, piece 0, stays as it is)
         e.x = s4[e.x >> 2];
         e.z = s4[e.z >> 2];
     }
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     const char *post_bytes = (const char *)(mode == 1 ? a.post_sym : a.post);
     const int src4 = (4 * (lane & 15) + (lane >> 4)) * 4;
     const int sub8 = (lane & 15) * 8;
-    const int dummy_addr = a.n_pieces << 7;
+    const int dummy_addr = 0;          // (piece 0 is the all-zero dummy)
     const int nb = a.nb, ntop = a.ntop;
 
     int n_items = (a.row_end - a.row_begin + a.n_parts - 1) / a.n_parts + (mode == 1 ? a.n_mag_items : 0);      // (every n_parts-th row)
@@ -668,7 +669,7 @@ static int sym_state_alloc(pfz_ctx *ctx, const pfz_index *ix, K3SymState *s)
     PFZ_TRY(pool_alloc(ctx, &s->thr_slot, cells * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->row_slot, cells * sizeof(uint16_t)));
     PFZ_TRY(pool_alloc(ctx, &s->mag, (size_t)ix->n_blocks * 32 * kSymMag * sizeof(int32_t)));
-    PFZ_TRY(pool_alloc(ctx, &s->post_sym, (size_t)(ix->n_pieces + 1) * kPiece * sizeof(int2)));
+    PFZ_TRY(pool_alloc(ctx, &s->post_sym, (size_t)ix->piece_cap * kPiece * sizeof(int2)));
     PFZ_TRY(pool_alloc(ctx, &s->keys, (size_t)n * kSymKeep * sizeof(uint64_t)));
     PFZ_TRY(pool_alloc(ctx, &s->push_cnt, (size_t)n * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->push_buf, (size_t)n * kSymPush * sizeof(uint64_t)));
@@ -700,6 +701,15 @@ static K3SymState *sym_state_of(pfz_ctx *ctx, const pfz_index *ix)
     return s;
 }
 
+// pairs of postings k3_sym_repost has to look at: the index' pieces if the host knows them by now (the build enqueued their count
+// a pass 0 ago: asking does not wait), its piece capacity otherwise (the kernel checks against the device's count)
+static int64_t sym_repost_pairs(const pfz_index *ix)
+{
+    if (ix->pieces_lazy.pending && hipEventQuery(ix->pieces_lazy.ev) == hipSuccess) (void)index_ready(ix);
+    (void)hipGetLastError();      // (hipErrorNotReady is not an error)
+    return (ix->pieces_lazy.pending ? ix->piece_cap : (int64_t)ix->n_pieces + 1) * (kPiece / 2);
+}
+
 // the arguments every launch of a job shares
 static void sym_fill_args(K3SymArgs &a, const pfz_index *ix, const pfz_csr *A, K3SymState *s, int32_t ntop, int32_t thr0, float scale,
                           float inv_scale)
@@ -713,7 +723,7 @@ static void sym_fill_args(K3SymArgs &a, const pfz_index *ix, const pfz_csr *A, K
     a.post_sym = s->post_sym;
     a.pblk = ix->pblk;
     a.nb = ix->n_blocks;
-    a.n_pieces = ix->n_pieces;
+    a.n_pieces1 = ix->tab + ix->n_cols * ix->n_blocks;
     a.ntop = ntop;
     a.thr0 = thr0;
     a.scale = scale;
@@ -795,7 +805,7 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
         a.row_end = (int32_t)n;
         hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3((unsigned)n), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
-        const int64_t pairs = ((int64_t)ix->n_pieces + 1) * (kPiece / 2);
+        const int64_t pairs = sym_repost_pairs(ix);
         hipLaunchKernelGGL(k3_sym_repost, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, a);
     }
     PFZ_HIP(hipMemsetAsync(s->ovf, 0, sizeof(int32_t), ctx->stream));
@@ -932,7 +942,7 @@ int k3_sym_sharded(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix, const pfz_
     PFZ_HIP(hipGetLastError());
     if (n_parts > 1) PFZ_TRY(comm_allgather_bytes(comm, s->thrv + (size_t)part * a.per, s->thrv, (size_t)a.per * sizeof(int32_t)));
     hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
-    const int64_t pairs = ((int64_t)ix->n_pieces + 1) * (kPiece / 2);
+    const int64_t pairs = sym_repost_pairs(ix);
     hipLaunchKernelGGL(k3_sym_repost, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, a);
     // pass 1 of this part's rows and magnets
     const int64_t last_block_row = (int64_t)(nb - 1) * kSymC;

@@ -30,6 +30,71 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     return PFZ_ERR_HIP;
 }
 
+int lazy_acquire(pfz_ctx *ctx, LazyI32 *z)
+{
+    if (ctx->lazy_slots.empty()) {
+        int32_t *chunk = nullptr;
+        PFZ_HIP(hipHostMalloc((void **)&chunk, 64 * sizeof(int32_t), hipHostMallocDefault));      // (pinned, mapped: kernels may write it)
+        ctx->lazy_chunks.push_back(chunk);
+        for (int i = 0; i < 64; ++i) ctx->lazy_slots.push_back(chunk + i);
+    }
+    if (ctx->lazy_events.empty()) {
+        hipEvent_t ev;
+        PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->lazy_events.push_back(ev);
+    }
+    z->slot = ctx->lazy_slots.back();
+    ctx->lazy_slots.pop_back();
+    z->ev = ctx->lazy_events.back();
+    ctx->lazy_events.pop_back();
+    z->pending = false;
+    return PFZ_OK;
+}
+
+int lazy_mark(pfz_ctx *ctx, LazyI32 *z)
+{
+    PFZ_HIP(hipEventRecord(z->ev, ctx->stream));
+    z->pending = true;
+    return PFZ_OK;
+}
+
+int lazy_begin(pfz_ctx *ctx, LazyI32 *z, const int32_t *dev)
+{
+    PFZ_TRY(lazy_acquire(ctx, z));
+    PFZ_HIP(hipMemcpyAsync(z->slot, dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return lazy_mark(ctx, z);
+}
+
+int lazy_get(pfz_ctx *ctx, LazyI32 *z, int32_t *out)
+{
+    if (z->pending) {
+        PFZ_HIP(hipEventSynchronize(z->ev));
+        z->value = *z->slot;
+        lazy_release(ctx, z);
+    }
+    *out = z->value;
+    return PFZ_OK;
+}
+
+void lazy_release(pfz_ctx *ctx, LazyI32 *z)
+{
+    if (z->slot) ctx->lazy_slots.push_back(z->slot);
+    if (z->ev) ctx->lazy_events.push_back(z->ev);
+    z->slot = nullptr;
+    z->ev = nullptr;
+    z->pending = false;
+}
+
+int64_t csr_nnz(const pfz_csr *m)
+{
+    if (m->nnz_lazy.pending) {
+        int32_t v = 0;
+        if (lazy_get(m->ctx, &m->nnz_lazy, &v) != PFZ_OK) return -1;
+        m->nnz = v;
+    }
+    return m->nnz;
+}
+
 int ensure_scratch(pfz_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->scratch_bytes) return PFZ_OK;
@@ -345,7 +410,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(int32_t *__restrict
 // (Three launches -- ~15 us on a 10 000-string list whose whole fit + transform + index + match is 0.4 ms -- were the price of
 // the version above, which stays for PFZ_SCAN3=1.)
 __global__ __launch_bounds__(kScanThreads) void k_scan_lookback(int32_t *__restrict__ data, int64_t n, uint64_t *__restrict__ state,
-                                                                uint32_t *__restrict__ ticket, uint32_t epoch4, int32_t n_tiles)
+                                                                uint32_t *__restrict__ ticket, uint32_t epoch4, int32_t n_tiles,
+                                                                int32_t *__restrict__ host_total)
 {
     __shared__ int32_t lds4[kScanThreads / 64];
     __shared__ int32_t s_tile, s_prefix;
@@ -384,6 +450,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_lookback(int32_t *__restr
         s_prefix = prefix;
         if (tile == n_tiles - 1) {
             data[n] = prefix + tot;      // the grand total
+            // ... and straight into a pinned word of the host's when it wants it (LazyI32): no copy kernel behind the scan
+            if (host_total) __hip_atomic_store(host_total, prefix + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             *ticket = 0u;                // (every ticket has been taken: this tile holds the last one)
         }
     }
@@ -397,11 +465,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_lookback(int32_t *__restr
     }
 }
 
-int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n)
+int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n, LazyI32 *total)
 {
     if (n <= 0) {
         PFZ_HIP(hipMemsetAsync(data, 0, sizeof(int32_t), ctx->stream));
-        return PFZ_OK;
+        return total ? lazy_begin(ctx, total, data) : PFZ_OK;
     }
     const int64_t n_tiles = (n + kScanTile - 1) / kScanTile;
     static const bool three = getenv("PFZ_SCAN3") != nullptr;
@@ -423,10 +491,11 @@ int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n)
             ctx->scan_epoch = 0;
         }
         const uint32_t epoch4 = ++ctx->scan_epoch * 4u;
+        if (total) PFZ_TRY(lazy_acquire(ctx, total));
         hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)n_tiles), dim3(kScanThreads), 0, ctx->stream, data, n, ctx->scan_state,
-                           (uint32_t *)(ctx->scan_state + ctx->scan_tiles), epoch4, (int32_t)n_tiles);
+                           (uint32_t *)(ctx->scan_state + ctx->scan_tiles), epoch4, (int32_t)n_tiles, total ? total->slot : nullptr);
         PFZ_HIP(hipGetLastError());
-        return PFZ_OK;
+        return total ? lazy_mark(ctx, total) : PFZ_OK;
     }
     PFZ_TRY(ensure_scratch(ctx, (size_t)n_tiles * sizeof(int32_t)));
     int32_t *tile_sums = (int32_t *)ctx->scratch;
@@ -434,7 +503,7 @@ int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n)
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, ctx->stream, tile_sums, n_tiles, data + n);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(kScanThreads), 0, ctx->stream, data, n, tile_sums);
     PFZ_HIP(hipGetLastError());
-    return PFZ_OK;
+    return total ? lazy_begin(ctx, total, data + n) : PFZ_OK;
 }
 
 }  // namespace pfz
@@ -489,6 +558,8 @@ void pfz_ctx_destroy(pfz_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->prof_entries) prof_fold(ctx, kv.second);
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->lazy_events) (void)hipEventDestroy(ev);
+    for (int32_t *c : ctx->lazy_chunks) (void)hipHostFree(c);
     for (int i = 0; i < kEventSlots; ++i)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -603,6 +674,7 @@ int pfz_csr_upload(pfz_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *
     m->n_rows = n_rows;
     m->n_cols = n_cols;
     m->nnz = nnz;
+    m->nnz_cap = nnz;
     std::vector<int32_t> ip32((size_t)n_rows + 1);
     for (int64_t i = 0; i <= n_rows; ++i) {
         if (i > 0 && indptr[i] < indptr[i - 1]) {
@@ -649,7 +721,10 @@ int pfz_csr_shape(const pfz_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *n
     PFZ_REQUIRE(m, "pfz_csr_shape: NULL matrix");
     if (n_rows) *n_rows = m->n_rows;
     if (n_cols) *n_cols = m->n_cols;
-    if (nnz) *nnz = m->nnz;
+    if (nnz) {
+        *nnz = csr_nnz(m);
+        if (*nnz < 0) return PFZ_ERR_HIP;
+    }
     return PFZ_OK;
 }
 
@@ -663,8 +738,10 @@ int pfz_csr_download(pfz_ctx *ctx, const pfz_csr *m, int64_t *indptr, int32_t *i
         PFZ_TRY(copy_d2h(ctx, ip32.data(), m->indptr, ip32.size() * sizeof(int32_t)));
         for (size_t i = 0; i < ip32.size(); ++i) indptr[i] = ip32[i];
     }
-    if (indices && m->nnz > 0) PFZ_TRY(copy_d2h(ctx, indices, m->indices, (size_t)m->nnz * sizeof(int32_t)));
-    if (data && m->nnz > 0) PFZ_TRY(copy_d2h(ctx, data, m->data, (size_t)m->nnz * sizeof(float)));
+    const int64_t nnz = csr_nnz(m);
+    if (nnz < 0) return PFZ_ERR_HIP;
+    if (indices && nnz > 0) PFZ_TRY(copy_d2h(ctx, indices, m->indices, (size_t)nnz * sizeof(int32_t)));
+    if (data && nnz > 0) PFZ_TRY(copy_d2h(ctx, data, m->data, (size_t)nnz * sizeof(float)));
     return PFZ_OK;
 }
 
@@ -672,6 +749,11 @@ void pfz_csr_free(pfz_csr *m)
 {
     if (!m) return;
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->nnz_lazy.pending || m->nnz_lazy.slot) {
+        // the copy into the slot may still be in flight: the slot goes back to the pool only behind it
+        if (m->nnz_lazy.ev) (void)hipEventSynchronize(m->nnz_lazy.ev);
+        pfz::lazy_release(m->ctx, &m->nnz_lazy);
+    }
     if (m->indptr) pool_free(m->indptr);
     if (m->indices) pool_free(m->indices);
     if (m->data) pool_free(m->data);
@@ -688,9 +770,11 @@ int pfz_topn_alloc(pfz_ctx *ctx, int64_t n_rows, int32_t ntop, pfz_topn **out)
     t->ctx = ctx;
     t->n_rows = n_rows;
     t->ntop = ntop;
+    // one block: the indices, then (256-byte aligned) the scores -- a small result comes back in ONE device-to-host copy
     size_t n = (size_t)(n_rows > 0 ? n_rows : 1) * (size_t)ntop;
-    PFZ_TRY(pool_alloc(ctx, &t->idx, n * sizeof(int32_t)));
-    PFZ_TRY(pool_alloc(ctx, &t->val, n * sizeof(float)));
+    const size_t idx_bytes = (n * sizeof(int32_t) + 255) & ~(size_t)255;
+    PFZ_TRY(pool_alloc(ctx, &t->idx, idx_bytes + n * sizeof(float)));
+    t->val = (float *)((char *)t->idx + idx_bytes);
     *out = t.release();
     return PFZ_OK;
 }
@@ -699,8 +783,7 @@ void pfz_topn_free(pfz_topn *t)
 {
     if (!t) return;
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
-    if (t->idx) pool_free(t->idx);
-    if (t->val) pool_free(t->val);
+    if (t->idx) pool_free(t->idx);      // (val lives in the same block)
     delete t;
 }
 
@@ -719,9 +802,24 @@ int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *
 {
     PFZ_REQUIRE(ctx && t, "pfz_topn_download: NULL argument");
     PFZ_HIP(hipSetDevice(ctx->device));
-    PFZ_HIP(hipStreamSynchronize(ctx->stream));
     size_t n = (size_t)t->n_rows * (size_t)t->ntop;
-    if (n == 0) return PFZ_OK;
+    if (n == 0) {
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        return PFZ_OK;
+    }
+    const size_t span = (size_t)((const char *)t->val - (const char *)t->idx) + n * sizeof(float);
+    if (out_idx && out_val && span <= (64u << 10)) {
+        // a small result (a query batch): indices and scores lie in one block -- one copy, one wait (stream order puts it
+        // behind the kernels: no synchronise of its own in front)
+        char *st = nullptr;
+        PFZ_TRY(stage_take(ctx, span, &st));
+        PFZ_HIP(hipMemcpyAsync(st, t->idx, span, hipMemcpyDeviceToHost, ctx->stream));
+        PFZ_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(out_idx, st, n * sizeof(int32_t));
+        memcpy(out_val, st + ((const char *)t->val - (const char *)t->idx), n * sizeof(float));
+        ctx->stage_off = 0;
+        return PFZ_OK;
+    }
     if (out_idx) PFZ_TRY(copy_d2h(ctx, out_idx, t->idx, n * sizeof(int32_t)));
     if (out_val) PFZ_TRY(copy_d2h(ctx, out_val, t->val, n * sizeof(float)));
     return PFZ_OK;

@@ -51,6 +51,18 @@ inline uint64_t next_serial()
 }
 struct K3SymState;   // k3_symmetric.hip: the exchange buffers and the running session of a symmetric self-match
 
+// A 32-bit scalar the device computes and the host wants LATER (a matrix' number of non-zeros, a vocabulary's size): the
+// copy into a pinned slot and an event are enqueued where the value is ready on the device; the host waits for the event
+// only when (if) it reads the value -- by then usually long past.  A hipStreamSynchronize at that point instead idles the
+// device until the host has woken up and enqueued the next launch: 25 - 50 us per read-back, four of them in a 0.37-ms
+// TF-IDF step of 10 000 x 10 000 names.
+struct LazyI32 {
+    hipEvent_t ev = nullptr;
+    int32_t *slot = nullptr;     // pinned, owned by the context's slot pool
+    bool pending = false;
+    int32_t value = 0;
+};
+
 struct ProfEntry {
     std::vector<hipEvent_t> begin, end;  // recorded pairs not yet folded in
     double total_ms = 0.0;
@@ -82,6 +94,10 @@ struct pfz_ctx {
     uint64_t *scan_state = nullptr;
     size_t scan_tiles = 0;
     uint32_t scan_epoch = 0;
+    // LazyI32 slots: pinned words + events, recycled
+    std::vector<int32_t *> lazy_slots;
+    std::vector<hipEvent_t> lazy_events;
+    std::vector<int32_t *> lazy_chunks;   // the hipHostMalloc'ed chunks the slots are cut from
     // caching allocator state: size class -> free blocks
     std::map<size_t, std::vector<void *>> pool_free_lists;
     size_t pool_cached_bytes = 0, pool_live_bytes = 0;
@@ -89,7 +105,10 @@ struct pfz_ctx {
 
 struct pfz_csr {
     pfz_ctx *ctx = nullptr;
-    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int64_t n_rows = 0, n_cols = 0;
+    mutable int64_t nnz = 0;     // (device-vectorised matrices: resolved on first use, see nnz_lazy -- read it through csr_nnz())
+    mutable pfz::LazyI32 nnz_lazy;
+    int64_t nnz_cap = 0;         // entries indices / data have room for (>= nnz)
     int32_t *indptr = nullptr;   // [n_rows + 1], nnz < 2^31
     int32_t *indices = nullptr;  // [nnz]
     float *data = nullptr;       // [nnz]
@@ -100,15 +119,21 @@ struct pfz_csr {
 // Inverted index of the to-side: for n-gram id k and to-row block b (block =
 // block_cols consecutive to-rows) the postings (local_row, value), padded with
 // zero-valued entries to whole 16-posting pieces, are pieces
-// tab[k * n_blocks + b] .. tab[k * n_blocks + b + 1) of post; piece n_pieces is all zero.
+// tab[k * n_blocks + b] .. tab[k * n_blocks + b + 1) of post; piece 0 is all zero.
 struct pfz_index {
     pfz_ctx *ctx = nullptr;
-    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int64_t n_rows = 0, n_cols = 0;
     int32_t block_cols = 0, n_blocks = 0;
-    int32_t n_pieces = 0;
-    int32_t *tab = nullptr;  // [n_cols * n_blocks + 2] first piece of every list
-    int2 *post = nullptr;    // [(n_pieces + 1) * 16]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
-    uint16_t *pblk = nullptr; // [n_pieces + 1]  the to-block of every piece (k3_symmetric.hip re-deals a block's rows to its accumulator slots)
+    // Pieces are numbered from 1: piece 0 is the all-zero dummy every kernel pads its rounds with.  The number of pieces and of
+    // postings are known on the DEVICE when the build is enqueued; the host learns them when somebody asks (index_ready()).
+    mutable int32_t n_pieces = 0;       // real pieces (after index_ready())
+    mutable int64_t nnz = 0;            // postings (after index_ready())
+    mutable pfz::LazyI32 pieces_lazy, nnz_lazy;
+    int64_t piece_cap = 0;              // pieces `post` / `pblk` have room for (dummy included): a bound, see pfz_index_build
+    int32_t *tab_base = nullptr;        // the allocation behind tab
+    int32_t *tab = nullptr;  // = tab_base + 1: [n_cols * n_blocks + 1] first piece of every list; tab[n_cols * n_blocks] = pieces incl. the dummy
+    int2 *post = nullptr;    // [piece_cap * 16]  .x = 4 * (to-row - b*block_cols), .y = fp32 bits
+    uint16_t *pblk = nullptr; // [piece_cap]  the to-block of every piece (k3_symmetric.hip re-deals a block's rows to its accumulator slots)
     float max_norm = 1.f;    // of the indexed matrix' rows
     uint64_t src_serial = 0; // pfz_csr::serial of the matrix it was built from
     mutable pfz::K3SymState *sym = nullptr;   // k3_symmetric.hip, allocated by the first symmetric self-match on this index
@@ -127,6 +152,7 @@ struct pfz_strings {
     int64_t n = 0, n_units = 0;
     int32_t char_width = 1;      // bytes per code unit: 1 or 4
     void *chars = nullptr;       // device [n_units]
+    bool chars_in_offsets = false;   // small lists: chars points into the block of `offsets` (one upload)
     int64_t *offsets = nullptr;  // device [n+1], in code units
     int64_t max_len = 0;
     // host mirror of the offsets: string lengths for the host-side planning of K4
@@ -205,6 +231,17 @@ template <typename T, void (*Free)(T *)> struct Owner {
 };
 
 int ensure_scratch(pfz_ctx *ctx, size_t bytes);
+// LazyI32: enqueue the copy of *dev (+ event) on ctx->stream; read the value (waits for the event if it has not been read yet);
+// give the slot back
+int lazy_begin(pfz_ctx *ctx, LazyI32 *z, const int32_t *dev);
+int lazy_acquire(pfz_ctx *ctx, LazyI32 *z);      // a slot a kernel writes itself (z->slot is device-visible) ...
+int lazy_mark(pfz_ctx *ctx, LazyI32 *z);         // ... and the event behind that kernel
+int lazy_get(pfz_ctx *ctx, LazyI32 *z, int32_t *out);
+void lazy_release(pfz_ctx *ctx, LazyI32 *z);
+// a matrix' number of non-zeros (waits for the vectoriser's count if nobody has asked before); < 0: a HIP error
+int64_t csr_nnz(const pfz_csr *m);
+// what the host has not been told about an index yet -- its numbers of pieces and postings -- is fetched (k3_cossim_topn.hip)
+int index_ready(const pfz_index *ix);
 // the context's side stream (ctx->stream2) and its four events (ctx->side_events), created on first use
 int ensure_side_stream(pfz_ctx *ctx);
 // Host <-> device copies of caller-owned (pageable) buffers through the context's pinned staging buffer.
@@ -245,7 +282,8 @@ int comm_allreduce_sum_i64(pfz_comm *c, int64_t *buf, size_t n);
 
 // exclusive scan of n int32 counters in place, total written to in[n]
 // (array must have n+1 slots).  Enqueues on ctx->stream.
-int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n);
+// total != NULL: the grand total also starts its way to the host (written by the scan itself into the LazyI32's pinned word)
+int exclusive_scan_i32(pfz_ctx *ctx, int32_t *data, int64_t n, LazyI32 *total = nullptr);
 
 // ascending sort of n-gram codes (sort_u64.hip: bitonic network, LDS tiles + streaming passes);
 // `out` must hold sort_codes_capacity(n) keys
