@@ -592,6 +592,13 @@ def headline(world, ctx, args):
                                "to DataFrame -- is match_pairs_per_s.")
     if size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline_arms"].append(reference_backend_arm(names, args.top_n))
+        # the library pins, armed: this box may have what the build container lacks
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+            from live_pins import live_pins
+            out["library_pins"] = live_pins()
+        except Exception as e:
+            out["library_pins"] = {"error": f"{type(e).__name__}: {e}"}
     if size == 1 and not args.no_match_wall:
         mw = match_wall(names, args.top_n, res[0])       # (profiling is off again: these launches do not enter the K3 average)
         lat = top1_latency(names)

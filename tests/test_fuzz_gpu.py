@@ -408,3 +408,23 @@ def test_rapidfuzz_reference_self_match(ctx):
         df = RapidFuzz(score_cutoff=cutoff, scorer=scorer).match(list(names), reference_self_match=True)
         assert df["To"].tolist() == to
         assert df["Similarity"].tolist() == sim
+
+
+def test_partial_ratio_windows_vs_third_party_lcs_on_the_device(ctx):
+    """K7's window sweep against tests/golden/windows_golden.json directly -- `textdistance.lcsseq` on every window of 388
+    (needle, haystack) pairs, no oracle in between: partial_ratio(needle, haystack) must be the maximum over the library's
+    window LCS values of the published formula (needle strictly shorter: with equal lengths the roles are also swapped)."""
+    from oracle import fuzz_scorers as f
+    from polyfuzz_amd import _lib
+    from tests.test_fuzz_oracle_cpu import _window_pin
+    pairs, windows = _window_pin()
+    checked = 0
+    for a, b, lcs in pairs:
+        if len(a) >= len(b):
+            continue
+        want = max(f._ratio_of(len(a) + len(w) - 2 * k, len(a) + len(w)) for w, k in zip(windows(a, b), lcs))
+        for frm, to in (([a], [b]), ([b], [a])):                      # either string may be the from-string
+            idx, score = _lib.fuzz_extract_one(ctx, frm, to, "partial_ratio")
+            assert idx[0] == 0 and score[0] == want, (a, b, score[0], want)
+        checked += 1
+    assert checked > 300

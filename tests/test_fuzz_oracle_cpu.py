@@ -154,3 +154,38 @@ def test_shared_list_self_match_restatement_equals_the_reference_class():
             assert to == case["To"], (case["scorer"], case["score_cutoff"])
             assert sim == case["Similarity"]
         assert to[-1] is None and sim[-1] == 0.0          # the last row has nothing left to match
+
+
+def _window_pin():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "windows_golden.json")
+    fix = json.load(open(path, encoding="utf-8"))
+    assert fix["textdistance"] and len(fix["pairs"]) > 300
+
+    def windows(s1, s2):          # the order the published algorithm walks them (fuzz_py._partial_ratio_impl)
+        m, n = len(s1), len(s2)
+        return [s2[:k] for k in range(1, m)] + [s2[i:i + m] for i in range(0, n - m + 1)] + [s2[i:] for i in range(n - m + 1, n)]
+    return fix["pairs"], windows
+
+
+def test_partial_ratio_windows_vs_third_party_lcs(oracle_mod):
+    """the integer core of partial_ratio's window sweep held to a LIBRARY, window by window --
+    tests/golden/windows_golden.json is `textdistance.lcsseq` on every window of 388 (needle, haystack) pairs (13 859
+    windows; made by tests/golden/make_golden_windows.py under the container's conda interpreter).  Both restatements must
+    give every window's LCS and, from those integers by the one published formula, the pair's score."""
+    from oracle import fuzz_scorers as f
+    pairs, windows = _window_pin()
+    n_win = 0
+    for a, b, lcs in pairs:
+        ws = windows(a, b)
+        assert len(ws) == len(lcs)
+        for w, k in zip(ws, lcs):
+            assert f.lcs_len(a, w) == k and f.lcs_len_dp(a, w) == k, (a, w, k)
+            assert oracle_mod.fuzz_score(a, w, "ratio") == f._ratio_of(len(a) + len(w) - 2 * k, len(a) + len(w)), (a, w)      # (oracle/fuzz_scorers.c)
+        n_win += len(ws)
+        want = max([f._ratio_of(len(a) + len(w) - 2 * k, len(a) + len(w)) for w, k in zip(ws, lcs)] + [0.0])
+        assert f._partial_ratio_impl(a, b) == want, (a, b)
+        if len(a) < len(b):          # (equal lengths: partial_ratio also runs with the roles swapped)
+            assert f.partial_ratio(a, b) == want and oracle_mod.fuzz_score(a, b, "partial_ratio") == want, (a, b)
+    assert n_win > 13000
