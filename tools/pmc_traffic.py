@@ -14,14 +14,14 @@ WHAT = {"tfidf": "company_names[:100000] self-match top-5", "c2": "config 2: 10 
 def avg(db_path, counter):
     """(kernel name, K3 launches, average per K3 launch) of the K3 form that ran: the row-major or the lock-step kernel (one
     dispatch per launch), or -- a list against itself -- the symmetric form, whose launch is four dispatches (k3_sym_kernel
-    in its three passes + k3_sym_merge: summed, per dispatch of the merge)"""
+    in its three passes + k3_sym_order / repost / merge / merge_slices: summed, per dispatch of the merge)"""
     db = sqlite3.connect(db_path)
     sym = db.execute("select count(*) from counters_collection where counter_name = ? and kernel_name like '%k3_sym_merge(%'",
                      (counter,)).fetchone()[0]
     if sym:
-        total = db.execute("select sum(value) from counters_collection where counter_name = ? and "
-                           "(kernel_name like '%k3_sym_kernel%' or kernel_name like '%k3_sym_merge%')", (counter,)).fetchone()[0]
-        return ("pfz::k3_sym_kernel<2048> x3 passes + pfz::k3_sym_merge", sym, total / sym)
+        total = db.execute("select sum(value) from counters_collection where counter_name = ? and kernel_name like '%k3_sym_%'",
+                           (counter,)).fetchone()[0]
+        return ("pfz::k3_sym_kernel<2048> x3 passes + k3_sym_order / repost / merge / merge_slices", sym, total / sym)
     rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? and "
                       "(kernel_name like '%k3_cossim_topn_kernel%' or kernel_name like '%k3_lockstep_kernel%') group by kernel_name order by sum(value) desc", (counter,)).fetchall()
     return rows[0] if rows else (None, 0, None)
