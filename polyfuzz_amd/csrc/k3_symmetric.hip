@@ -459,7 +459,11 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             // scatter has its whole latency exposed there (measured: a tenth of pass 1)
             const uint32_t tq = tq_next;
             bool touched = __ballot(e > s) != 0;
+#if PFZ_K3_SYM_EXP == 13     // (what-if 13: pass 0 without its scatter)
+            if (touched && mode != 0) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
+#else
             if (touched) scatter_pieces(acc, post_bytes, mark, e - s, s, as0, lane, src4, sub8, dummy_addr);
+#endif
             if (have0 && it + 1 < n_blk) {
                 cur0 = trow[b_next];
                 nxt0 = trow[b_next + 1];
@@ -485,14 +489,20 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                 wave_sync();
                 if (!warmed) {
                     warmed = true;
+#if PFZ_K3_SYM_EXP != 10     // (what-if 10: no warm start)
                     if (ntop <= kWarmMaxTop) {
                         const int t = warm_threshold<N4>(acc4, 0, ntop + 1, lane);
                         st.thr = t > st.thr ? t : st.thr;
                     }
+#endif
                 }
                 if (mode == 1)
                     sweep_block_handover<N4, kSymCap>(acc4, cand, st, b, ntop, lane, zero, tq, fbuf, fcnt, a, inv_row);
+#if PFZ_K3_SYM_EXP == 12     // (what-if 12: pass 0 without its sweep)
+                else if (mode != 0)
+#else
                 else
+#endif
                     sweep_block<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero);
                 wave_sync();
             }
@@ -500,6 +510,9 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         }
 
         if (mode == 1 && fcnt) drain_stage<kSymCap>(cand, st, fbuf, fcnt, ntop, lane, a, inv_row);
+#if PFZ_K3_SYM_EXP == 11     // (what-if 11: pass 0 without its final compaction)
+        if (mode != 0)
+#endif
         compact<kSymCap>(cand, st, ntop, lane);
         if (mode == 1 && magnet) {
             // what the row found below its own block, to its own push slots (the merge joins them with the row's keys)
