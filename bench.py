@@ -296,38 +296,50 @@ def k3_parity(job, idx, val, rows, e_idx, e_val, a3, b3, n_col):
             "ok": bool(max_err <= 1e-5 and hard == 0)}
 
 
-ORACLE_VECTORISE_MAX_STRINGS = 250_000     # the Python restatement of the vectoriser does ~20 us per string and pass
+ORACLE_VECTORISE_PY_MAX = 250_000     # the Python restatement of the vectoriser does ~20 us per string and pass; longer
+#                                       lists go through its numpy twin (oracle/tfidf_numpy.py, pinned on it bit for bit)
 
 
 def oracle_matrices(job, from_strings, to_strings):
-    """The lists vectorised by the ORACLE (oracle/tfidf_oracle.py == scikit-learn bit for bit; reference _tfidf.py:102-118:
-    fit on to + from, or on the one list of a self-match) and the device's K1 / K2 output held against it: CSR structure
-    equal, values within one fp32 rounding.  Returns (a3, b3, n_col, record) or None when the lists are too long for the
-    Python restatement to stay inside the bench's time budget."""
+    """The lists vectorised by the ORACLE (oracle/tfidf_oracle.py == scikit-learn bit for bit, or its numpy twin for lists
+    of more than ORACLE_VECTORISE_PY_MAX strings; reference _tfidf.py:102-118: fit on to + from, or on the one list of a
+    self-match) and the device's K1 / K2 output held against it: CSR structure equal, values within one fp32 rounding.
+    Returns (a3, b3, n_col, record)."""
     import oracle
     n = len(from_strings) + (0 if to_strings is None else len(to_strings))
-    if n > ORACLE_VECTORISE_MAX_STRINGS:
-        return None
     t0 = time.perf_counter()
-    o = oracle.TfidfOracle()
-    if to_strings is None:
-        o.fit(from_strings)
-        a3 = b3 = o.transform(from_strings)
+    if n > ORACLE_VECTORISE_PY_MAX:
+        which = "oracle/tfidf_numpy.py (== oracle/tfidf_oracle.py == sklearn TfidfVectorizer bit for bit)"
+        o = oracle.TfidfNumpyOracle()
+        if to_strings is None:
+            o.fit(from_strings)
+            a3 = b3 = o.transform_fitted(0, n)
+        else:
+            o.fit(list(to_strings) + list(from_strings))
+            b3, a3 = o.transform_fitted(0, len(to_strings)), o.transform_fitted(len(to_strings), n)
+        n_vocab = len(o.codes)
     else:
-        o.fit(list(to_strings) + list(from_strings))
-        a3, b3 = o.transform(from_strings), o.transform(to_strings)
+        which = "oracle/tfidf_oracle.py (== sklearn TfidfVectorizer bit for bit)"
+        o = oracle.TfidfOracle()
+        if to_strings is None:
+            o.fit(from_strings)
+            a3 = b3 = o.transform(from_strings)
+        else:
+            o.fit(list(to_strings) + list(from_strings))
+            a3, b3 = o.transform(from_strings), o.transform(to_strings)
+        n_vocab = len(o.vocabulary)
     dt = time.perf_counter() - t0
     d_a, d_b, n_col = job.host_matrices()
-    rec = {"what": "device CSR (K1/K2) vs oracle/tfidf_oracle.py (== sklearn TfidfVectorizer bit for bit) on the same lists",
-           "strings": n, "vocab_device": int(n_col), "vocab_oracle": len(o.vocabulary), "oracle_seconds": round(dt, 2)}
-    ok = n_col == len(o.vocabulary)
+    rec = {"what": f"device CSR (K1/K2) vs {which} on the same lists",
+           "strings": n, "vocab_device": int(n_col), "vocab_oracle": n_vocab, "oracle_seconds": round(dt, 2)}
+    ok = n_col == n_vocab
     err = 0.0
     for dev, orc in ((d_a, a3), (d_b, b3)):
         ok = ok and np.array_equal(dev[0], orc[0]) and np.array_equal(dev[1], orc[1])
         if ok and len(orc[2]):
             err = max(err, float(np.abs(dev[2] - orc[2]).max()))
     rec.update({"indptr_and_indices_equal": bool(ok), "max_abs_value_err": err if ok else None, "ok": bool(ok and err <= 2e-7)})
-    return a3, b3, len(o.vocabulary), rec
+    return a3, b3, n_vocab, rec
 
 
 def k3_cpu_and_parity(job, idx, val, seconds, all_cores=True, min_rows=0, lists=None):
@@ -336,12 +348,11 @@ def k3_cpu_and_parity(job, idx, val, seconds, all_cores=True, min_rows=0, lists=
     ranges on threads; ctypes releases the GIL).  The sample's results are also the parity check of the GPU result.
     lists = (from strings, to strings or None): the CPU side then starts from the STRINGS -- the oracle vectoriser builds the
     float64 matrices the oracle product runs on, and the device's CSR is checked against them (`parity_check.vectoriser`);
-    without them (lists too long for the Python vectoriser) the oracle product runs on the device-built CSR."""
+    without them the oracle product runs on the device-built CSR."""
     import concurrent.futures as cf
     import oracle
     oracle.build_native()
-    vec_rec = {"ok": None, "what": "not run: the oracle product ran on the device-built CSR (lists too long for the Python "
-                                   "restatement of the vectoriser inside the bench's time budget)"}
+    vec_rec = {"ok": None, "what": "not run: no strings handed over, the oracle product ran on the device-built CSR"}
     om = oracle_matrices(job, *lists) if lists is not None else None
     if om is not None:
         a3, b3, n_col, vec_rec = om

@@ -36,6 +36,7 @@ Pinning status (see DESIGN.md "Oracle"):
   itself (tests/golden/make_golden_group.py).
 """
 from .tfidf_oracle import (clean_string, create_ngrams, TfidfOracle)      # noqa: F401
+from .tfidf_numpy import TfidfNumpyOracle      # noqa: F401
 from .dense import dense_cossim, dense_cossim_topn   # noqa: F401
 from .native import (cossim_topn, cossim_dense, indel_ratio, indel_argmax, fuzz_score, fuzz_extract_one, fuzz_matrix,  # noqa: F401
                      build as build_native)
