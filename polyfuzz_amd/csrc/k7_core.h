@@ -694,6 +694,16 @@ PFZ_HD float fz_r32(int lcs, int lensum)
 #endif
 }
 
+// (the same where the caller knows lensum > 0)
+PFZ_HD float fz_r32_nz(int lcs, int lensum)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 200.0f * (float)lcs * __builtin_amdgcn_rcpf((float)lensum);
+#else
+    return 200.0f * (float)lcs / (float)lensum;
+#endif
+}
+
 // token_set_ratio's bound once the common tokens of the from-string are known (bit i of ca; lb2 / tb: the to-string's
 // form-2 length and distinct tokens): the two "sect" ratios are length arithmetic -- exact -- and the LCS of the joined
 // differences is at most the shorter difference and at most u minus the characters of the common tokens (they sit in both
@@ -764,14 +774,44 @@ PFZ_HD float fz_upper_bound(const FuzzSummary &a, const FuzzSummary &b, int mode
     };
     switch (mode) {
     case kWRatio: {
+        // Sweep 1 runs this for every pair and the kernel is bound by its vector instruction rate, so what cannot change the
+        // result is left out: (i) WRatio is 0 when either string is empty, so form 0's length sum and minimum are not 0 where
+        // the result counts -- its fz_r32 / partial_ub guards go (lanes with an empty string compute garbage that the last
+        // select discards; forms 1 and 2 keep theirs: a string of spaces has no token); (ii) the sorted form (1) and the
+        // distinct-token form (2) of a title are, nearly always, as long as the title itself: a ratio or partial bound over
+        // forms of the SAME lengths as form 0 equals form 0's, enters scaled by 0.95 and is dominated by it -- computed
+        // only where a length differs (a divergent branch: whole waves skip it).
         const int la = a.len[0], lb = b.len[0];
         const int lmax = fz_max(la, lb), lmin = fz_min(la, lb);
-        const float r0 = ratio_ub(0);
+        auto r_ub = [&](int v) { return v == 0 ? fz_r32_nz(fz_min(u, fz_min(la - miss_a, lb - miss_b)), la + lb) : ratio_ub(v); };
+        auto p_ub = [&](int v) -> float {
+            if (v != 0) return partial_ub(v);
+            const int miss = la < lb ? miss_a : (lb < la ? miss_b : fz_min(miss_a, miss_b));
+            const int m = fz_min(u, lmin - miss);
+            return fz_r32_nz(m, lmin + m);
+        };
+        const bool same1 = a.len[1] == la && b.len[1] == lb, same2 = a.len[2] == la && b.len[2] == lb;
+        const float r0 = r_ub(0);
         float ub;
-        if (2 * lmax < 3 * lmin) ub = fmx(r0, 0.95f * fmx(ratio_ub(1), token_set_ub()));       // (groups are sorted by length: mostly one side per wave)
-        else {
+        if (2 * lmax < 3 * lmin) {                       // (groups are sorted by length: mostly one side per wave)
+            float r1 = 0.0f, ts = 0.0f;
+            if (!same1) r1 = r_ub(1);
+            if (toks) {
+                if (common != 0) ts = tset >= 0.0f ? tset : 100.0f;
+                else if (!same2) ts = r_ub(2);
+            }
+            ub = fmx(r0, 0.95f * fmx(r1, ts));
+        } else {
             const float scale = lmax < 8 * lmin ? 0.9f : 0.6f;
-            ub = fmx(r0, fmx(scale * partial_ub(0), 0.95f * scale * ptoken_ub()));
+            float pt = 0.0f;
+            if (toks) {
+                if (common != 0) pt = 100.0f;
+                else {
+                    if (!same1) pt = p_ub(1);
+                    if (!same2) pt = fmx(pt, p_ub(2));
+                }
+            }
+            ub = fmx(r0, fmx(scale * p_ub(0), 0.95f * scale * pt));
         }
         return lmin != 0 ? ub : 0.0f;
     }

@@ -67,6 +67,9 @@ namespace pfz {
 // batch of seeds, a last partial batch -- is paid per wave that works on it, and four waves sharing one from-string paid
 // it four times over (the 100 000-name self-match: 0.79 -> 0.49 s).  More waves per workgroup = fewer from-strings in flight.
 constexpr int kK7Waves = 1, kK7Threads = 64 * kK7Waves;
+#ifndef PFZ_K7_OCC
+#define PFZ_K7_OCC 4          // one-word rows: waves per SIMD the compiler budgets registers for (tuning builds: 3 = no spills)
+#endif
 constexpr float kBoundSlack = 0.05f;
 // log2 of the windows per run of a window sweep: 16, more for long forms -- at most 8 runs (forms are <= 256 symbols here)
 #ifndef PFZ_K7_SHARE_LOG2
@@ -108,6 +111,20 @@ __device__ inline void wave_best(RowBest &b)
     }
 }
 
+// v where any of m's four components equals id (a wave-uniform value, in a scalar register), else 0
+__device__ inline int select_if_any_eq(const int4 &m, int id, int v)
+{
+    uint64_t e0, e1, e2, e3;
+    int r;
+    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(e0) : "s"(id), "v"(m.x));
+    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(e1) : "s"(id), "v"(m.y));
+    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(e2) : "s"(id), "v"(m.z));
+    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(e3) : "s"(id), "v"(m.w));
+    const uint64_t any = (e0 | e1) | (e2 | e3);
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(any));
+    return r;
+}
+
 __device__ inline bool mode_uses_tokens(int mode) { return mode != kPartialRatio && mode != kPartialTokenSortRatio; }
 
 // 64-bit word-steps a scored pair costs at most (work accounting for the roofline; an estimate from the lengths: one
@@ -119,8 +136,8 @@ __device__ inline int work_estimate(const Fz3<int> &la, const int4 &m, int mode,
     return (pass + fz_min(la[0], m.x) * fz_max(la[0], m.x) / 4) * W;
 }
 
-template <int W>
-__global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_fuzz_kernel(FuzzArgs A)
+template <int W, int MODE = -1>
+__global__ __launch_bounds__(kK7Threads, W == 1 ? PFZ_K7_OCC : (W == 2 ? 3 : 2)) void k7_fuzz_kernel(FuzzArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // dynamic part: the from-string's match table [symbol][form][word]; the scratch columns of the window sweeps
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
     __shared__ int s_queue[kK7Waves][128];
     __shared__ int s_sweeps[kK7Waves][3][64];     // runs of windows waiting for a lane (see sweep_rounds): item, lengths, symbols
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mode = A.mode, parts = A.parts;
+    const int mode = MODE >= 0 ? MODE : A.mode, parts = A.parts;      // (MODE >= 0: the scorer a compile-time constant)
     const bool use_tokens = mode_uses_tokens(mode);
     const bool use_pres = mode != kTokenSetRatio && mode != kTokenRatio;      // the symbol-presence term of the bound (see bound_of)
 
@@ -309,6 +326,10 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         const uint32_t pres_a0 = s_pres[0], pres_a1 = s_pres[1];
         const int n_pres_a = __popc(pres_a0) + __popc(pres_a1);
         const int skip = A.skip_idx ? A.skip_idx[row] : -1;
+        // choice_left_out(w, skip, up_to) for w >= 0 as ONE unsigned range test (sweep 1 runs it for every pair): the choices
+        // skip_lo .. skip_lo + skip_span are left out -- "equal": skip alone; "up to": 0 .. skip; none (-1): the empty range at -1
+        const int skip_lo = A.skip_up_to && skip >= 0 ? 0 : skip;
+        const unsigned skip_span = (unsigned)(skip - skip_lo);
 
         auto cur_now = [&]() {
             return __longlong_as_double((long long)__hip_atomic_load(&s_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -334,15 +355,18 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
             uint4 h0, h1;
             uint2 p;
         };
+        // (byte offsets in 32 bits: a scalar base + one vector offset per load instead of 64-bit address arithmetic per lane
+        // and array -- the to-side holds at most 2^26 strings, 2^30 B of its widest array)
         auto load_meta = [&](int g) {
-            const int slot = g * 64 + lane;
+            const uint32_t off = ((uint32_t)g * 64u + (uint32_t)lane) * 16u;
             Meta x;
-            x.m = A.b_meta[slot];
-            x.m2 = A.b_meta2[slot];
-            x.m4 = A.b_meta4[slot];
-            x.h0 = A.b_hist[(g * 2 + 0) * 64 + lane];
-            x.h1 = A.b_hist[(g * 2 + 1) * 64 + lane];
-            x.p = use_pres ? A.b_pres[slot] : make_uint2(0u, 0u);
+            x.m = *(const int4 *)((const char *)A.b_meta + off);
+            x.m2 = *(const int4 *)((const char *)A.b_meta2 + off);
+            x.m4 = *(const int4 *)((const char *)A.b_meta4 + off);
+            const uint32_t hoff = ((uint32_t)g * 128u + (uint32_t)lane) * 16u;
+            x.h0 = *(const uint4 *)((const char *)A.b_hist + hoff);
+            x.h1 = *(const uint4 *)((const char *)A.b_hist + hoff + 1024u);
+            x.p = use_pres ? *(const uint2 *)((const char *)A.b_pres + (off >> 1)) : make_uint2(0u, 0u);
             return x;
         };
         // float32 upper bound of the pair (from-string, to-string x) FROM REGISTERS ONLY; valid = a real candidate of this
@@ -369,22 +393,26 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         };
         auto bound_of = [&](const Meta &x, bool &valid, bool &coarse) -> float {
             const int4 m = x.m;
-            valid = x.m2.w >= 0 && !choice_left_out(x.m2.w, skip, A.skip_up_to) && m.w <= kFuzzMaxTokens;
+            valid = x.m2.w >= 0 && (unsigned)(x.m2.w - skip_lo) > skip_span && m.w <= kFuzzMaxTokens;
             const FuzzSummary sb = summary_of(x);
             const int uu = fz_common_chars(sa, sb);
             const bool maybe = use_tokens && (sa.sig & sb.sig) != 0ull;
             coarse = maybe && m.w > 4;
             // the common tokens: every lane compares its (up to four) to-token ids with the from-string's, which sit in
             // scalar registers -- one pass, no branch (disjoint signatures simply find nothing)
+            // (the four compares leave lane masks in scalar registers, or-ed there; one select and one add per from-token carry
+            // both sums -- common tokens << 16 | their characters, a form is shorter than 2^16: 8 vector instructions per token
+            // where the compiler's own rendering of `hit ? .. : ..` took 18, and the kernel is bound by its vector issue rate)
             int nc = 0, sect_chars = 0;
-            if (use_tokens)
+            if (use_tokens) {
+                int acc = 0;
                 for (int i = 0; i < F.ta; ++i) {
                     const int ida = __builtin_amdgcn_readfirstlane(s_tid[i]);          // (absent to-tokens are -1, unknown from-tokens <= -2)
-                    const int len = __builtin_amdgcn_readfirstlane(s_tlen[i]);
-                    const bool hit = (x.m4.x == ida) | (x.m4.y == ida) | (x.m4.z == ida) | (x.m4.w == ida);
-                    nc += hit ? 1 : 0;
-                    sect_chars += hit ? len : 0;
+                    acc += select_if_any_eq(x.m4, ida, s_tlen[i] | 0x10000);
                 }
+                nc = acc >> 16;
+                sect_chars = acc & 0xffff;
+            }
             // symbols of the one string that the other lacks (fz_presence_miss, the from-side's bits in scalar registers)
             // (only where it pays: the scorers that sweep windows, WRatio included -- 20k x 20k titles, WRatio 8.38 -> 8.04 ms
             // with 3.8 % of the pairs scored instead of 6.0 %; token_ratio, which sweeps none, 5.33 -> 5.86 ms for 2.5 %
@@ -395,7 +423,11 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                 miss_a = n_pres_a - pres_common;
                 miss_b = __popc(x.p.x) + __popc(x.p.y) - pres_common;
             }
-            const float tset = nc != 0 ? fz_token_set_bound_n(F.la[2], F.ta, m.z, m.w, uu, nc, sect_chars, miss_a, miss_b) : -1.0f;
+            // (WRatio reads the token-set bound in one of its two families only -- fz_upper_bound; groups are sorted by length,
+            // so whole waves skip it)
+            const bool wants_tset = mode == kTokenSetRatio || mode == kTokenRatio ||
+                                    (mode == kWRatio && 2 * max(sa.len[0], m.x) < 3 * min(sa.len[0], m.x));
+            const float tset = nc != 0 && wants_tset ? fz_token_set_bound_n(F.la[2], F.ta, m.z, m.w, uu, nc, sect_chars, miss_a, miss_b) : -1.0f;
             return fz_upper_bound(sa, sb, mode, uu, coarse ? -1 : (nc != 0 ? 1 : 0), coarse ? -1.0f : tset, miss_a, miss_b);
         };
         RowBest best = {-1.0, INT_MAX};
@@ -582,12 +614,11 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
         float seed_ub = -1.0f;
         int seed_slot = -1;
         const int row_region = is_cont ? __builtin_amdgcn_readfirstlane(A.cont_region[cont_rec]) : -1;      // (a continuation unit: its row's bytes)
-        uint8_t *ubc = A.ub_cache + (int64_t)(row_region >= 0 ? row_region : my_region) * A.n_groups * 64 + lane;
+        // (the region's base is wave-uniform -- a scalar register pair --, a pair's byte a 32-bit offset from it: n_groups * 64 <= 2^26)
+        uint8_t *const ubc_row = A.ub_cache + (int64_t)(row_region >= 0 ? row_region : my_region) * A.n_groups * 64;
+        auto ubc_at = [&](int g) -> uint8_t & { return ubc_row[(uint32_t)g * 64u + (uint32_t)lane]; };
         if (row_region < 0) {
-            Meta nxt = load_meta(min(g_first, A.n_groups - 1));
-            for (int g = g_first; g < A.n_groups; g += g_step) {
-                const Meta x = nxt;
-                nxt = load_meta(min(g + g_step, A.n_groups - 1));         // (the last trip re-reads a group: harmless)
+            auto bound_group = [&](const Meta &x, int g) {
                 bool valid, coarse;
                 const float ub = bound_of(x, valid, coarse);
                 n_bounded += 1;
@@ -595,7 +626,16 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     seed_ub = ub;
                     seed_slot = g * 64 + lane;
                 }
-                ubc[(int64_t)g * 64] = valid ? (uint8_t)(min(127, (int)(fmaxf(ub, 0.0f) * 1.27f) + 1) | (coarse ? 128 : 0)) : (uint8_t)0;
+                ubc_at(g) = valid ? (uint8_t)(min(127, (int)(fmaxf(ub, 0.0f) * 1.27f) + 1) | (coarse ? 128 : 0)) : (uint8_t)0;
+            };
+            // two groups per trip, each record fetched a group ahead into registers of its own (one record handed from trip
+            // to trip cost seventeen register moves per group; the last trips re-read a group: harmless)
+            Meta xa = load_meta(min(g_first, A.n_groups - 1));
+            for (int g = g_first; g < A.n_groups; g += 2 * g_step) {
+                const Meta xb = load_meta(min(g + g_step, A.n_groups - 1));
+                bound_group(xa, g);
+                xa = load_meta(min(g + 2 * g_step, A.n_groups - 1));
+                if (g + g_step < A.n_groups) bound_group(xb, g + g_step);
             }
         }
         tick(1);
@@ -624,7 +664,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
                     // read again later
                     int q4[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) q4[k] = ubc[(int64_t)min(g + k * g_step, A.n_groups - 1) * 64];
+                    for (int k = 0; k < 4; ++k) q4[k] = ubc_at(min(g + k * g_step, A.n_groups - 1));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (g < A.n_groups && q_tail - q_head < 64) {
@@ -663,7 +703,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? 4 : (W == 2 ? 3 : 2)) void k7_
             int survivors = 0;
             {
                 const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;
-                for (int gg = g; gg < A.n_groups; gg += g_step) survivors += !((float)(ubc[(int64_t)gg * 64] & 127) < thr) ? 1 : 0;
+                for (int gg = g; gg < A.n_groups; gg += g_step) survivors += !((float)(ubc_at(gg) & 127) < thr) ? 1 : 0;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) survivors += __shfl_xor(survivors, d, 64);
             }
@@ -911,7 +951,7 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
 
     // how many workgroups share a from-string's to-groups (few from-strings: split, as K4 does), per class; then one slot for
     // the general kernel's "to-strings with more than 32 tokens" pass and one for its own rows
-    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * (16 / kK7Waves);      // (persistent workgroups: units are handed out)
+    const int64_t max_grid = (int64_t)ctx->prop.multiProcessorCount * (4 * PFZ_K7_OCC / kK7Waves);      // (persistent workgroups: units are handed out)
     int32_t parts_of[3] = {1, 1, 1}, max_parts = 1;
     for (int c = 0; c < 3; ++c) {
         if (cls[c].empty()) continue;
@@ -1045,7 +1085,13 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
             else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k7_fuzz_kernel<4>, kK7Threads, lds);
             fprintf(stderr, "k7 class %d: rows %d parts %d grid %u dynamic LDS %zu B, workgroups per CU %d\n", c, A.n_rows, A.parts, grid, lds, occ);
         }
-        if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, st, L);
+        // WRatio -- what PolyFuzz("EditDistance") and RapidFuzz() run by default -- has instances of its own: the scorer a
+        // compile-time constant (no scalar dispatch inside the sweeps, only that scorer's values live)
+        if (scorer == kWRatio) {
+            if (c == 0) hipLaunchKernelGGL((k7_fuzz_kernel<1, kWRatio>), dim3(grid), dim3(kK7Threads), lds, st, L);
+            else if (c == 1) hipLaunchKernelGGL((k7_fuzz_kernel<2, kWRatio>), dim3(grid), dim3(kK7Threads), lds, st, L);
+            else hipLaunchKernelGGL((k7_fuzz_kernel<4, kWRatio>), dim3(grid), dim3(kK7Threads), lds, st, L);
+        } else if (c == 0) hipLaunchKernelGGL(k7_fuzz_kernel<1>, dim3(grid), dim3(kK7Threads), lds, st, L);
         else if (c == 1) hipLaunchKernelGGL(k7_fuzz_kernel<2>, dim3(grid), dim3(kK7Threads), lds, st, L);
         else hipLaunchKernelGGL(k7_fuzz_kernel<4>, dim3(grid), dim3(kK7Threads), lds, st, L);
         PFZ_HIP(hipGetLastError());

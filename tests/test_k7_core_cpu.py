@@ -81,8 +81,9 @@ def test_score_and_bound_vs_oracle(host, oracle_mod, mode, W, seed, long_words):
     from polyfuzz_amd import datasets
     fl, tl = _lists(seed, 40, 90, long_words)
     titles_f, titles_t = datasets.c3_lists(60)
-    fl += titles_f[:25] + ["this is a test", "fuzzy was a bear", "", "a", "mets mets mets new", "zzz"]
-    tl += titles_t[:50] + ["this is a new test!!!", "fuzzy fuzzy was a bear", "", "this is a test!", "new mets", "a\tb  a"]
+    # (strings of spaces: not empty, yet without a token -- their sorted and distinct-token forms ARE empty)
+    fl += titles_f[:25] + ["this is a test", "fuzzy was a bear", "", "a", "mets mets mets new", "zzz", "  ", " "]
+    tl += titles_t[:50] + ["this is a new test!!!", "fuzzy fuzzy was a bear", "", "this is a test!", "new mets", "a\tb  a", " ", "   ", "\t "]
     if W == 1:
         fl = [s for s in fl if len(s) <= 64]
     fl = [s for s in fl if len(s) <= 64 * W and len(set(s.split())) <= 32]
