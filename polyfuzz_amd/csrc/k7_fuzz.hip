@@ -56,7 +56,9 @@
         (T).t0 = now_;                                                \
     } while (0)
 #endif
-#define FZ_ANY(x) (__ballot(x) != 0ull)
+// (the builtin takes the condition as it is: __ballot() compares an integer copy of it with 0 -- a select and a compare more)
+#define FZ_BALLOT(x) __builtin_amdgcn_ballot_w64(x)
+#define FZ_ANY(x) (FZ_BALLOT(x) != 0ull)
 #include "k7_core.h"
 #include "k7_args.h"
 #include "k7_plan.h"
@@ -109,6 +111,12 @@ __device__ inline void wave_best(RowBest &b)
         const int oi = __shfl_xor(b.idx, d, 64);
         b.take(os, oi);
     }
+}
+
+// how many of the lanes below this one are set in a wave mask (v_mbcnt: two instructions)
+__device__ inline int lanes_below(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
 // v where any of m's four components equals id (a wave-uniform value, in a scalar register), else 0
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? PFZ_K7_OCC : (W == 2 ? 3 : 2))
         int sq_head = 0, sq_tail = 0;
         auto sweep_rounds = [&](bool flush) {
             for (;;) {
-                const unsigned long long idle = __ballot(sw_item < 0);
+                const unsigned long long idle = FZ_BALLOT(sw_item < 0);
                 const int n_take = min((int)__popcll(idle), sq_tail - sq_head);
                 const int n_busy = 64 - (int)__popcll(idle) + n_take;
                 // (the lane's column: [position][lane] elements of 1 or 2 bytes)
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? PFZ_K7_OCC : (W == 2 ? 3 : 2))
                 // every waiting run is taken whenever the lanes are not all busy (the ring holds 64): a round is held only
                 // when all of them are, or at the end
                 if (sw_item < 0) {
-                    const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    const int rank = lanes_below(idle);
                     if (rank < n_take) {
                         // (the pair's scoring lane left lengths and the form's place beside the item: the lane goes to memory
                         // once, for the symbols)
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? PFZ_K7_OCC : (W == 2 ? 3 : 2))
             if (A.phase_ticks) {
                 // 8 batches, 9 lanes with a pair, 10 lanes scored, 11 lanes that swept windows, 12 windows swept,
                 // 13 64 x the most windows any lane swept (what the wave paid for)
-                const int n_act = __popcll(__ballot(active)), n_go = __popcll(__ballot(did_score)), n_sw = __popcll(__ballot(want_p != 0));
+                const int n_act = __popcll(FZ_BALLOT(active)), n_go = __popcll(FZ_BALLOT(did_score)), n_sw = __popcll(FZ_BALLOT(want_p != 0));
 #ifdef PFZ_K7_PROFILE
                 // 16..21: the slowest lane's ticks by sub-phase -- tokens / set-up, LCS passes, token-set pass, window
                 // sweeps, metadata + refined bound, the rest
@@ -591,11 +599,11 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? PFZ_K7_OCC : (W == 2 ? 3 : 2))
             const int runs0 = runs_of(1, F.la[0], lens.x), runs1 = runs_of(2, F.la[1], lens.y), runs2 = runs_of(4, F.la[2], lens.z);
             for (int it = 0;; ++it) {
                 const bool has = it < runs0 + runs1 + runs2;
-                const unsigned long long bal = __ballot(has);
+                const unsigned long long bal = FZ_BALLOT(has);
                 if (has) {
                     const int v = it < runs0 ? 0 : (it < runs0 + runs1 ? 1 : 2);
                     const int run = it - (v == 0 ? 0 : (v == 1 ? runs0 : runs0 + runs1));
-                    const int at = (sq_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 63;
+                    const int at = (sq_tail + lanes_below(bal)) & 63;
                     sweeps[0][at] = slot_of | v << 26 | run << 28;
                     sweeps[1][at] = (v == 0 ? lens.x : (v == 1 ? lens.y : lens.z)) | lens.x << 16;
                     sweeps[2][at] = sym_at + v * sym_step;
@@ -650,34 +658,48 @@ __global__ __launch_bounds__(kK7Threads, W == 1 ? PFZ_K7_OCC : (W == 2 ? 3 : 2))
         bool swept_out = false;
         bool drain = !is_cont;                  // (the seeds: scored before anything else)
         if (drain) {
-            const unsigned long long bal = __ballot(seed_slot >= 0);
-            if (seed_slot >= 0) queue[__popcll(bal & ((1ull << lane) - 1ull))] = seed_slot;
+            const unsigned long long bal = FZ_BALLOT(seed_slot >= 0);
+            if (seed_slot >= 0) queue[lanes_below(bal)] = seed_slot;
             q_tail = __popcll(bal);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         for (int g = g_first;;) {
             if (!drain && g < A.n_groups) {
+                // (a byte b passes unless (float)b < thr: b >= ceil(thr), in integers -- and b != 0, the byte of a pair that is no candidate)
                 const float thr = ((float)cur_now() - kBoundSlack) * 1.27f;       // (the best score moves only where pairs are scored)
+                const int thr_i = __builtin_amdgcn_readfirstlane(max(1, (int)ceilf(fminf(thr, 1000.0f))));
+                // (the walk's counters are wave-uniform; told so, the compiler keeps them -- and the loop's control -- in
+                // scalar registers: the walk is a load, a compare and a push per group and was half bookkeeping)
+                int gs = __builtin_amdgcn_readfirstlane(g), qt = __builtin_amdgcn_readfirstlane(q_tail);
+                const int qh = __builtin_amdgcn_readfirstlane(q_head), gstep = __builtin_amdgcn_readfirstlane(g_step);
+                // four groups' bytes per trip, the next trip's four already in flight (a group is no more than a compare and a
+                // push: a load's latency per trip is all there is to this walk); when the queue fills up in between, the rest
+                // are read again later
+                int nx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nx[k] = ubc_at(min(gs + k * gstep, A.n_groups - 1));
                 do {
-                    // four groups' bytes in flight at a time (a group is no more than a compare and a push: one load's
-                    // latency per group would be all there is to it); when the queue fills up in between, the rest are
-                    // read again later
                     int q4[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) q4[k] = ubc_at(min(g + k * g_step, A.n_groups - 1));
+                    for (int k = 0; k < 4; ++k) q4[k] = nx[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nx[k] = ubc_at(min(gs + (4 + k) * gstep, A.n_groups - 1));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if (g < A.n_groups && q_tail - q_head < 64) {
-                            const int q = q4[k], slot = g * 64 + lane;
-                            const bool want = (q & 127) != 0 && slot != seed_slot && !((float)(q & 127) < thr);
-                            const unsigned long long bal = __ballot(want);
-                            if (want) queue[(q_tail + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = slot | ((q & 128) ? (int)0x80000000 : 0);
-                            q_tail += __popcll(bal);
+                        if (gs < A.n_groups && qt - qh < 64) {
+                            const int q = q4[k], slot = gs * 64 + lane;
+                            const bool want = (q & 127) >= thr_i && slot != seed_slot;
+                            // (one ballot per compare: the ballot of a conjunction is rendered as a select and a compare more)
+                            const unsigned long long bal = FZ_BALLOT((q & 127) >= thr_i) & FZ_BALLOT(slot != seed_slot);
+                            if (want) queue[(qt + lanes_below(bal)) & 127] = slot | ((q & 128) ? (int)0x80000000 : 0);
+                            qt += __popcll(bal);
                             n_bounded += 1;
-                            g += g_step;
+                            gs += gstep;
                         }
                     }
-                } while (g < A.n_groups && q_tail - q_head < 64);
+                } while (gs < A.n_groups && qt - qh < 64);
+                g = gs;
+                q_tail = qt;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             tick(2);
