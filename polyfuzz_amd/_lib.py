@@ -266,6 +266,14 @@ class DeviceCSR(_Handle):
         check(self.ctx.lib.pfz_csr_shape(self.h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(z)))
         return r.value, c.value, z.value
 
+    @property
+    def n_rows(self):
+        """rows alone: known when the matrix is enqueued -- `shape` also asks for the count of non-zeros, which waits for the
+        kernels that produce it (a transform's count travels to the host behind its last kernel)"""
+        r = c_i64()
+        check(self.ctx.lib.pfz_csr_shape(self.h, ctypes.byref(r), None, None))
+        return r.value
+
     def download(self):
         n_rows, n_cols, nnz = self.shape
         indptr = np.empty(n_rows + 1, np.int64)
@@ -366,7 +374,7 @@ class DeviceTopN(_Handle):
 def cossim_topn(ctx, index, from_csr, ntop, lower_bound, exclude_diag=False, diag_offset=0, out=None, rows=None):
     """Enqueue K3 (for from-rows `rows` = (begin, end) only, if given); returns the (device-resident) DeviceTopN."""
     if out is None:
-        out = DeviceTopN.alloc(ctx, from_csr.shape[0], ntop)
+        out = DeviceTopN.alloc(ctx, from_csr.n_rows, ntop)      # (not .shape: that would wait for the transform)
     if rows is None:
         check(ctx.lib.pfz_cossim_topn(ctx.h, index.h, from_csr.h, int(ntop), float(lower_bound),
                                       int(bool(exclude_diag)), int(diag_offset), out.h))

@@ -216,6 +216,101 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
     }
 }
 
+// Document-frequency counters.  A hot n-gram ('inc': 20 % of all names) would
+// serialise tens of thousands of atomics on ONE address, so every n-gram has
+// 2^shift counters selected by a salt (the row); k_df_reduce adds them up.
+struct DfSink {
+    int32_t *p;   // [vocab << shift], or NULL: do not count
+    int shift;
+    __device__ inline void add(uint32_t key, int64_t salt) const
+    {
+        if (p) atomicAdd(&p[((int64_t)key << shift) + (salt & ((1 << shift) - 1))], 1);
+    }
+};
+
+// One string of 1 .. kShortMax (128) n-gram codes in its slots -> the (column id, count) pairs of its distinct known n-grams,
+// ascending, in the same slots; one WAVE, no barrier (k_rows_short runs it on a wave per string; k_extract_wave<.., ROWS>
+// right behind the extraction of the string, by the wave that extracted it).
+__device__ inline void rows_short_row(const VocabView &V, uint64_t *base, int cnt, int lane, int32_t *row_nnz_at, int64_t row, DfSink df)
+{
+    if (cnt > 64) {
+        // 65 .. 128 n-grams: two keys per lane (elements lane and lane + 64 of a 128-key bitonic network), still one wave and
+        // no barrier.  (k_rows_long sorts in LDS with a workgroup barrier per stage: ~30 us for ONE such string, and a list of
+        // names has a few -- 21 of the 100 000 company names, none beyond 87 n-grams -- so that launch was pure latency.)
+        uint32_t k0 = vocab_rank(V, base[lane]);
+        uint32_t k1 = lane + 64 < cnt ? vocab_rank(V, base[lane + 64]) : kInvalid;
+#pragma unroll
+        for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j == 64) {                      // (k == 128) the partner is the lane's other key; the last merge ascends
+                    const uint32_t mn = k0 < k1 ? k0 : k1, mx = k0 < k1 ? k1 : k0;
+                    k0 = mn;
+                    k1 = mx;
+                } else {
+                    const uint32_t o0 = __shfl_xor(k0, j, 64), o1 = __shfl_xor(k1, j, 64);
+                    const bool lower = (lane & j) == 0;
+                    const bool asc0 = (lane & k) == 0, asc1 = ((lane + 64) & k) == 0;     // element index & k
+                    const uint32_t mn0 = k0 < o0 ? k0 : o0, mx0 = k0 < o0 ? o0 : k0;
+                    const uint32_t mn1 = k1 < o1 ? k1 : o1, mx1 = k1 < o1 ? o1 : k1;
+                    k0 = (lower == asc0) ? mn0 : mx0;
+                    k1 = (lower == asc1) ? mn1 : mx1;
+                }
+            }
+        }
+        // run lengths over the 128 sorted keys (element e = lane + 64 r)
+        const uint32_t p0 = __shfl_up(k0, 1, 64), last0 = __shfl(k0, 63, 64);
+        uint32_t p1 = __shfl_up(k1, 1, 64);
+        if (lane == 0) p1 = last0;
+        const bool v0 = k0 != kInvalid, v1 = k1 != kInvalid;
+        const bool h0 = v0 && (lane == 0 || k0 != p0), h1 = v1 && k1 != p1;
+        const uint64_t H0 = __ballot(h0), H1 = __ballot(h1);
+        const int nvalid = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+        const uint64_t below = (1ull << lane) - 1ull;
+        const uint64_t above0 = lane == 63 ? 0ull : (H0 >> (lane + 1)), above1 = lane == 63 ? 0ull : (H1 >> (lane + 1));
+        if (h0) {
+            const int next = above0 ? lane + 1 + __builtin_ctzll(above0) : (H1 ? 64 + __builtin_ctzll(H1) : nvalid);
+            base[__popcll(H0 & below)] = ((uint64_t)(uint32_t)(next - lane) << 32) | k0;
+            df.add(k0, row);
+        }
+        if (h1) {
+            const int e = lane + 64;
+            const int next = above1 ? e + 1 + __builtin_ctzll(above1) : nvalid;
+            base[__popcll(H0) + __popcll(H1 & below)] = ((uint64_t)(uint32_t)(next - e) << 32) | k1;
+            df.add(k1, row);
+        }
+        if (lane == 0) *row_nnz_at = __popcll(H0) + __popcll(H1);
+        return;
+    }
+    uint32_t key = kInvalid;
+    if (lane < cnt) key = vocab_rank(V, base[lane]);
+    // 64-lane bitonic sort, ascending
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t o = __shfl_xor(key, j, 64);
+            const bool asc = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            const uint32_t mn = key < o ? key : o, mx = key < o ? o : key;
+            key = (lower == asc) ? mn : mx;
+        }
+    }
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool valid = key != kInvalid;
+    const bool head = valid && (lane == 0 || key != prev);
+    const uint64_t H = __ballot(head);
+    const int nvalid = __popcll(__ballot(valid));
+    if (head) {
+        const int pos = __popcll(H & ((1ull << lane) - 1ull));
+        const uint64_t above = lane == 63 ? 0ull : (H >> (lane + 1));
+        const int next = above ? lane + 1 + __builtin_ctzll(above) : nvalid;
+        base[pos] = ((uint64_t)(uint32_t)(next - lane) << 32) | key;   // (.x = id, .y = tf) little-endian
+        df.add(key, row);
+    }
+    if (lane == 0) *row_nnz_at = __popcll(H);
+}
+
 // ---------------------------------------------------------------------------
 // k_extract_wave: one WAVE per string, one LANE per character (round 4).
 // ---------------------------------------------------------------------------
@@ -230,11 +325,15 @@ __global__ __launch_bounds__(256) void k_extract(const void *__restrict__ chars_
 constexpr int kWaveMaxLen = 256;
 constexpr int kWaveStringsMax = 128;       // strings per workgroup at most: one LDS bitmap, one staged stretch of characters
 
-template <int CW, bool LB, typename CODE>
+// ROWS (a transform: the vocabulary is there): the wave goes on to sort, look up and count the string's n-grams itself
+// (rows_short_row; strings of more than kShortMax n-grams are left to k_rows_long) -- a launch less in a chain whose cost on
+// short lists IS the number of its launches.
+template <int CW, bool LB, typename CODE, bool ROWS = false>
 __global__ __launch_bounds__(256) void k_extract_wave(const void *__restrict__ chars_v, const int64_t *__restrict__ off,
                                                        int64_t n, ExtractParams P, const uint32_t *__restrict__ alpha_map,
                                                        uint64_t *__restrict__ slots, int32_t *__restrict__ row_cnt,
-                                                       uint32_t *__restrict__ bitmap, int32_t per_wg)
+                                                       uint32_t *__restrict__ bitmap, int32_t per_wg, VocabView V = VocabView{},
+                                                       int32_t *__restrict__ row_nnz = nullptr)
 {
     constexpr int kStageBytes = 24 * 1024;
     __shared__ uint32_t stage[kStageBytes / 4];
@@ -346,6 +445,16 @@ __global__ __launch_bounds__(256) void k_extract_wave(const void *__restrict__ c
             }
         }
         if (lane == 0) row_cnt[i] = cnt;
+        if (ROWS) {
+            // (the codes the wave's lanes just stored are read back by other lanes of the same wave)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (cnt == 0) {
+                if (lane == 0) row_nnz[i] = 0;
+            } else if (cnt <= kShortMax) {
+                rows_short_row(V, out, cnt, lane, row_nnz + i, i, DfSink{nullptr, 0});
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();               // the symbol line is reused by the wave's next string
     }
@@ -460,18 +569,6 @@ __global__ __launch_bounds__(256) void k_export_codes(const uint32_t *__restrict
 // ---------------------------------------------------------------------------
 // k_rows_short: one wave per string with <= 64 n-grams.
 // ---------------------------------------------------------------------------
-// Document-frequency counters.  A hot n-gram ('inc': 20 % of all names) would
-// serialise tens of thousands of atomics on ONE address, so every n-gram has
-// 2^shift counters selected by a salt (the row); k_df_reduce adds them up.
-struct DfSink {
-    int32_t *p;   // [vocab << shift], or NULL: do not count
-    int shift;
-    __device__ inline void add(uint32_t key, int64_t salt) const
-    {
-        if (p) atomicAdd(&p[((int64_t)key << shift) + (salt & ((1 << shift) - 1))], 1);
-    }
-};
-
 __global__ __launch_bounds__(256) void k_df_reduce(const int32_t *__restrict__ sharded, int64_t vocab, int shift,
                                                     int32_t *__restrict__ df)
 {
@@ -571,83 +668,7 @@ __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ 
         if (lane == 0) row_nnz[row] = 0;
         return;
     }
-    uint64_t *base = slots + off[row] * R;
-    if (cnt > 64) {
-        // 65 .. 128 n-grams: two keys per lane (elements lane and lane + 64 of a 128-key bitonic network), still one wave and
-        // no barrier.  (k_rows_long sorts in LDS with a workgroup barrier per stage: ~30 us for ONE such string, and a list of
-        // names has a few -- 21 of the 100 000 company names, none beyond 87 n-grams -- so that launch was pure latency.)
-        uint32_t k0 = vocab_rank(V, base[lane]);
-        uint32_t k1 = lane + 64 < cnt ? vocab_rank(V, base[lane + 64]) : kInvalid;
-#pragma unroll
-        for (int k = 2; k <= 128; k <<= 1) {
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                if (j == 64) {                      // (k == 128) the partner is the lane's other key; the last merge ascends
-                    const uint32_t mn = k0 < k1 ? k0 : k1, mx = k0 < k1 ? k1 : k0;
-                    k0 = mn;
-                    k1 = mx;
-                } else {
-                    const uint32_t o0 = __shfl_xor(k0, j, 64), o1 = __shfl_xor(k1, j, 64);
-                    const bool lower = (lane & j) == 0;
-                    const bool asc0 = (lane & k) == 0, asc1 = ((lane + 64) & k) == 0;     // element index & k
-                    const uint32_t mn0 = k0 < o0 ? k0 : o0, mx0 = k0 < o0 ? o0 : k0;
-                    const uint32_t mn1 = k1 < o1 ? k1 : o1, mx1 = k1 < o1 ? o1 : k1;
-                    k0 = (lower == asc0) ? mn0 : mx0;
-                    k1 = (lower == asc1) ? mn1 : mx1;
-                }
-            }
-        }
-        // run lengths over the 128 sorted keys (element e = lane + 64 r)
-        const uint32_t p0 = __shfl_up(k0, 1, 64), last0 = __shfl(k0, 63, 64);
-        uint32_t p1 = __shfl_up(k1, 1, 64);
-        if (lane == 0) p1 = last0;
-        const bool v0 = k0 != kInvalid, v1 = k1 != kInvalid;
-        const bool h0 = v0 && (lane == 0 || k0 != p0), h1 = v1 && k1 != p1;
-        const uint64_t H0 = __ballot(h0), H1 = __ballot(h1);
-        const int nvalid = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-        const uint64_t below = (1ull << lane) - 1ull;
-        const uint64_t above0 = lane == 63 ? 0ull : (H0 >> (lane + 1)), above1 = lane == 63 ? 0ull : (H1 >> (lane + 1));
-        if (h0) {
-            const int next = above0 ? lane + 1 + __builtin_ctzll(above0) : (H1 ? 64 + __builtin_ctzll(H1) : nvalid);
-            base[__popcll(H0 & below)] = ((uint64_t)(uint32_t)(next - lane) << 32) | k0;
-            df.add(k0, row);
-        }
-        if (h1) {
-            const int e = lane + 64;
-            const int next = above1 ? e + 1 + __builtin_ctzll(above1) : nvalid;
-            base[__popcll(H0) + __popcll(H1 & below)] = ((uint64_t)(uint32_t)(next - e) << 32) | k1;
-            df.add(k1, row);
-        }
-        if (lane == 0) row_nnz[row] = __popcll(H0) + __popcll(H1);
-        return;
-    }
-    uint32_t key = kInvalid;
-    if (lane < cnt) key = vocab_rank(V, base[lane]);
-    // 64-lane bitonic sort, ascending
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t o = __shfl_xor(key, j, 64);
-            const bool asc = (lane & k) == 0;
-            const bool lower = (lane & j) == 0;
-            const uint32_t mn = key < o ? key : o, mx = key < o ? o : key;
-            key = (lower == asc) ? mn : mx;
-        }
-    }
-    const uint32_t prev = __shfl_up(key, 1, 64);
-    const bool valid = key != kInvalid;
-    const bool head = valid && (lane == 0 || key != prev);
-    const uint64_t H = __ballot(head);
-    const int nvalid = __popcll(__ballot(valid));
-    if (head) {
-        const int pos = __popcll(H & ((1ull << lane) - 1ull));
-        const uint64_t above = lane == 63 ? 0ull : (H >> (lane + 1));
-        const int next = above ? lane + 1 + __builtin_ctzll(above) : nvalid;
-        base[pos] = ((uint64_t)(uint32_t)(next - lane) << 32) | key;   // (.x = id, .y = tf) little-endian
-        df.add(key, row);
-    }
-    if (lane == 0) row_nnz[row] = __popcll(H);
+    rows_short_row(V, slots + off[row] * R, cnt, lane, row_nnz + row, row, df);
 }
 
 // ---------------------------------------------------------------------------
@@ -774,17 +795,46 @@ __device__ inline double shfl_f64(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
+// SELF_SCAN (lists of up to kSelfScanRows strings): the row offsets are not there yet -- every workgroup adds up the counts of
+// the rows before its own (a few KB from L2), writes the offsets of its 16 rows, the last one the total (to indptr[n] and to
+// the host's pinned word, LazyI32) -- one launch where a copy, a scan and this kernel were three: a transform of a short list
+// is a chain of short dependent launches, and what it costs is their number (5 - 7 us each).
+constexpr int64_t kSelfScanRows = 16384;
+template <bool SELF_SCAN>
 __global__ __launch_bounds__(256) void k_finalize(const int64_t *__restrict__ off, int64_t n, int32_t R,
                                                    const uint64_t *__restrict__ slots,
-                                                   const int32_t *__restrict__ indptr, const double *__restrict__ idf,
-                                                   int32_t *__restrict__ indices, float *__restrict__ data)
+                                                   int32_t *__restrict__ indptr, const double *__restrict__ idf,
+                                                   int32_t *__restrict__ indices, float *__restrict__ data,
+                                                   const int32_t *__restrict__ row_nnz, int32_t *__restrict__ host_total)
 {
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
     const int lane0 = (threadIdx.x & 63) & ~15;    // first lane of this row's group inside the wave
     const bool live = row < n;
     const uint2 *in = live ? (const uint2 *)(slots + off[row] * R) : nullptr;
-    const int o = live ? indptr[row] : 0, nn = live ? indptr[row + 1] - o : 0;
+    int o, nn;
+    if (SELF_SCAN) {
+        __shared__ int32_t s_part[4], s_cnt[16];
+        const int64_t row0 = (int64_t)blockIdx.x * 16;
+        int32_t acc = 0;
+        for (int64_t t = threadIdx.x; t < row0; t += 256) acc += row_nnz[t];
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+        if (threadIdx.x < 16) s_cnt[threadIdx.x] = row0 + threadIdx.x < n ? row_nnz[row0 + threadIdx.x] : 0;
+        __syncthreads();
+        o = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const int mine = (int)(row - row0);
+        for (int k = 0; k < mine; ++k) o += s_cnt[k];
+        nn = live ? s_cnt[mine] : 0;
+        if (live && sub == 0) indptr[row] = o;
+        if (row == n - 1 && sub == 0) {
+            indptr[n] = o + nn;
+            if (host_total) __hip_atomic_store(host_total, o + nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    } else {
+        o = live ? indptr[row] : 0;
+        nn = live ? indptr[row + 1] - o : 0;
+    }
     // rows of one wave may differ in length: every lane runs the longest row's trip count so that the
     // shuffles stay convergent
     int nn_max = nn;
@@ -832,7 +882,7 @@ static int bits_for(uint64_t max_value)
     return b;
 }
 
-static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool mark)
+static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool mark, bool *rows_done = nullptr)
 {
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
     const size_t need = (size_t)(s->n_units > 0 ? s->n_units : 1) * (size_t)R;
@@ -858,6 +908,27 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     // a wave's strings are a chain of dependent LDS round trips, and there the chip is full of threads anyway)
     int per_wg = 32;
     if (const char *e = getenv("PFZ_K1_WAVE_STRINGS")) per_wg = std::max(4, std::min(kWaveStringsMax, atoi(e)));
+    // a transform of a list the wave kernel takes: extraction and the short rows in ONE launch (see k_extract_wave<.., ROWS>)
+    const char *fuse_knob = getenv("PFZ_K1_FUSE_ROWS");      // (tests: 0 = two launches)
+    if (rows_done) *rows_done = false;
+    if (rows_done && !mark && wave && !(fuse_knob && atoi(fuse_knob) == 0)) {
+        VocabView V{v->bitmap, v->prefix, v->vcodes, v->vocab};
+        int32_t *row_nnz = s->row_cnt + (s->n + 1);
+#define PFZ_EXTRACT_ROWS(CW, CODE)                                                                                   \
+        hipLaunchKernelGGL((k_extract_wave<CW, false, CODE, true>), dim3(grid_for(s->n, per_wg)), dim3(256), 0, ctx->stream,      \
+                           s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt, nullptr, per_wg, V, row_nnz)
+        if (s->char_width == 1) {
+            if (v->code_bits <= 32) PFZ_EXTRACT_ROWS(1, uint32_t);
+            else PFZ_EXTRACT_ROWS(1, uint64_t);
+        } else {
+            if (v->code_bits <= 32) PFZ_EXTRACT_ROWS(4, uint32_t);
+            else PFZ_EXTRACT_ROWS(4, uint64_t);
+        }
+#undef PFZ_EXTRACT_ROWS
+        PFZ_HIP(hipGetLastError());
+        *rows_done = true;
+        return PFZ_OK;
+    }
 #define PFZ_EXTRACT(CW, LB)                                                                                          \
     do {                                                                                                             \
         if (wave && v->code_bits <= 32)                                                                              \
@@ -889,13 +960,13 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     return PFZ_OK;
 }
 
-static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df)
+static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df, bool short_done = false)
 {
     if (s->n == 0) return PFZ_OK;
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
     VocabView V{v->bitmap, v->prefix, v->vcodes, v->vocab};
     int32_t *row_nnz = s->row_cnt + (s->n + 1);
-    {
+    if (!short_done) {
         ProfScope ps(ctx, "k2_rows_short");
         hipLaunchKernelGGL(k_rows_short, dim3(grid_for(s->n, 4)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, V,
                            s->slots, s->row_cnt, row_nnz, df);
@@ -1414,8 +1485,9 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
         return PFZ_ERR_INVALID;
     }
     if (s->cache_gen != v->gen) {
-        PFZ_TRY(run_extract(ctx, v, s, false));
-        PFZ_TRY(run_rows(ctx, v, s, DfSink{nullptr, 0}));
+        bool rows_done = false;
+        PFZ_TRY(run_extract(ctx, v, s, false, &rows_done));
+        PFZ_TRY(run_rows(ctx, v, s, DfSink{nullptr, 0}, rows_done));
         s->cache_gen = v->gen;
     }
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
@@ -1434,11 +1506,23 @@ int pfz_tfidf_transform(pfz_ctx *ctx, const pfz_tfidf *v, const pfz_strings *doc
     PFZ_TRY(pool_alloc(ctx, &m->data, (size_t)cap * sizeof(float)));
     if (s->n > 0) {
         const int32_t *row_nnz = s->row_cnt + (s->n + 1);
-        hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, row_nnz, s->n, m->indptr);
-        PFZ_TRY(exclusive_scan_i32(ctx, m->indptr, s->n, &m->nnz_lazy));
-        ProfScope ps(ctx, "k2_finalize");
-        hipLaunchKernelGGL(k_finalize, dim3(grid_for(s->n, 16)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
-                           m->indptr, v->idf, m->indices, m->data);
+        const char *knob = getenv("PFZ_K2_SELF_SCAN");      // (tests: 0 = the long-list path on short lists too)
+        const bool no_self_scan = knob && atoi(knob) == 0;
+        if (s->n <= kSelfScanRows && !no_self_scan) {
+            PFZ_TRY(lazy_acquire(ctx, &m->nnz_lazy));
+            {
+                ProfScope ps(ctx, "k2_finalize");
+                hipLaunchKernelGGL(k_finalize<true>, dim3(grid_for(s->n, 16)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
+                                   m->indptr, v->idf, m->indices, m->data, row_nnz, m->nnz_lazy.slot);
+            }
+            PFZ_TRY(lazy_mark(ctx, &m->nnz_lazy));
+        } else {
+            hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(s->n)), dim3(256), 0, ctx->stream, row_nnz, s->n, m->indptr);
+            PFZ_TRY(exclusive_scan_i32(ctx, m->indptr, s->n, &m->nnz_lazy));
+            ProfScope ps(ctx, "k2_finalize");
+            hipLaunchKernelGGL(k_finalize<false>, dim3(grid_for(s->n, 16)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, s->slots,
+                               m->indptr, v->idf, m->indices, m->data, nullptr, nullptr);
+        }
     } else {
         PFZ_HIP(hipMemsetAsync(m->indptr, 0, sizeof(int32_t), ctx->stream));
         m->nnz = 0;

@@ -238,3 +238,42 @@ def test_packer_fills_the_from_column_in_its_own_walk(threads, monkeypatch):
         _lib.pack_strings(["a", "b", "c"], used)
     with pytest.raises(TypeError):
         _lib.pack_strings(["a", 5, "c"], np.empty(3, dtype=object))
+
+
+@pytest.mark.parametrize("n,top_n", [(0, 1), (1, 1), (1, 3), (5, 2), (300, 4)])
+def test_small_frames_put_together_from_their_blocks_equal_the_constructor_s(n, top_n, monkeypatch):
+    """frames of fewer than 8 192 rows skip pd.DataFrame(dict) (a third of a single query's wall time): one object block, one
+    float64 block, a RangeIndex, from pandas' own parts -- checked against the constructor once per process, and here:
+    equal frames (values, dtypes, columns, index type), ordinary behaviour afterwards (assignment, a new column, to_dict),
+    reference counts of the names balanced; PFZ_FAST_FRAME=0 is the constructor's frame."""
+    import sys
+    import pandas as pd
+    from polyfuzz_amd import _lib
+    from polyfuzz_amd.models import _utils
+    if _lib._pack is None:
+        pytest.skip("_pack.so not built")
+    rng = np.random.default_rng(n * 7 + top_n)
+    to_list = [f"name {i}" for i in range(50)]
+    from_list = [f"q{i}" for i in range(n)]
+    idx = rng.integers(-1, len(to_list) + 1, (n, top_n)).astype(np.int32)
+    val = rng.random((n, top_n)).astype(np.float32)
+    val[rng.random((n, top_n)) < 0.3] = np.float32(0.0004)
+    monkeypatch.setitem(_utils._FAST_FRAME, "ok", None)
+    assert _utils._fast_frame_ok()
+    before = sys.getrefcount(to_list[7])
+    fast = _utils.topn_to_frame(idx, val, from_list, to_list, top_n)
+    monkeypatch.setenv("PFZ_FAST_FRAME", "0")
+    monkeypatch.setitem(_utils._FAST_FRAME, "ok", None)
+    slow = _utils.topn_to_frame(idx, val, from_list, to_list, top_n)
+    assert not _utils._FAST_FRAME["ok"]
+    pd.testing.assert_frame_equal(fast, slow)
+    assert isinstance(fast.index, pd.RangeIndex) and fast.dtypes.tolist() == slow.dtypes.tolist()
+    assert fast.to_dict() == slow.to_dict()
+    if n:
+        fast.loc[0, "Similarity"] = 0.125
+        fast["extra"] = np.arange(n)
+        assert fast["Similarity"].iloc[0] == 0.125 and list(fast.columns)[-1] == "extra" and len(fast.columns) == 2 + 2 * top_n
+        assert pd.concat([fast, fast]).shape == (2 * n, 2 + 2 * top_n)
+    del fast, slow
+    after = sys.getrefcount(to_list[7])          # (outside the assert: pytest's rewriting keeps the operand alive)
+    assert after == before

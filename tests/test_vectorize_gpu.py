@@ -207,3 +207,37 @@ def test_rows_of_65_to_128_ngrams(ctx, oracle_mod, clean):
     got = vec2.transform(_lib.DeviceStrings.upload(ctx, new)).download()
     o2 = oracle_mod.TfidfOracle(n_gram_range=(2, 3), clean=clean).fit(fit_docs)
     _check_csr(got, o2.transform(new), len(o2.vocabulary))
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 255, 4097, 16384, 16385])
+def test_fused_launches_of_a_transform(ctx, oracle_mod, monkeypatch, n):
+    """A transform's launches, fused where the list is short: (i) k_extract_wave<.., ROWS> sorts and counts a string's n-grams
+    right behind their extraction (PFZ_K1_FUSE_ROWS=0: the k_rows_short launch); (ii) lists of up to 16 384 strings:
+    k_finalize<true> adds up the row counts itself (PFZ_K2_SELF_SCAN=0: copy + scan + finalize).  Same CSR bit for bit whichever
+    way, the count of non-zeros (the host's pinned word) included; empty rows at either end and in between, strings of 65 .. 128
+    and of more than 128 n-grams (k_rows_long's) in the list; the oracle on the short lists."""
+    from polyfuzz_amd import _lib, datasets
+    names = datasets.load_company_names()
+    if n > 8:
+        docs = ["", "!!", " ".join(names[:5]), " ".join(names[5:30])] + names[:n - 7] + ["", "zz", ""]
+    else:
+        docs = (names[:1] + ["", "ab", "", "x y z"])[:n]
+    assert len(docs) == n
+    params = _lib.TfidfParams(3, 3, 1, 1)
+    vec = _lib.DeviceTfidf.fit(ctx, params, _lib.DeviceStrings.upload(ctx, names[:30000]), None)
+    got = {}
+    for fuse in ("1", "0"):
+        for scan in ("1", "0"):
+            monkeypatch.setenv("PFZ_K1_FUSE_ROWS", fuse)
+            monkeypatch.setenv("PFZ_K2_SELF_SCAN", scan)
+            m = vec.transform(_lib.DeviceStrings.upload(ctx, docs))
+            got[fuse + scan] = (m.shape, m.download())
+    for key in ("10", "01", "00"):
+        assert got[key][0] == got["11"][0], key
+        for x, y in zip(got[key][1], got["11"][1]):
+            np.testing.assert_array_equal(x, y, err_msg=key)
+    indptr = got["11"][1][0]
+    assert len(indptr) == n + 1 and got["11"][0][2] == indptr[-1]
+    if n <= 4097:
+        o = oracle_mod.TfidfOracle().fit(names[:30000])
+        _check_csr(got["11"][1], o.transform(docs), len(o.vocabulary))
