@@ -32,15 +32,17 @@ def _one(kernels, prefix):
 def test_k7_one_word_class_keeps_16_workgroups_per_cu(kernels):
     """64-lane workgroups: 128 VGPRs = 4 waves per SIMD; LDS per workgroup = static + the match table (143 symbols of config
     3's titles: 3432 B) + the byte scratch columns (4096 B) must stay within 9872 B (the most that was measured to hold 16)."""
-    k = _one(kernels, "void pfz::k7_fuzz_kernel<1>(")
-    assert k["vgpr"] <= 128, k
-    assert k["lds"] + 3432 + 4096 <= 9872, k
-    assert k["scratch"] <= 128, k                      # (a few spilled dwords, none in a hot loop: DESIGN.md)
+    for scorer in ("-1", "0"):                            # (the scorer at run time; WRatio's own instance)
+        k = _one(kernels, f"void pfz::k7_fuzz_kernel<1, {scorer}>(")
+        assert k["vgpr"] <= 128, k
+        assert k["lds"] + 3432 + 4096 <= 9872, k
+        assert k["scratch"] <= 128, k                  # (a few spilled dwords, none in a hot loop: DESIGN.md)
 
 
 def test_k7_longer_classes(kernels):
-    assert _one(kernels, "void pfz::k7_fuzz_kernel<2>(")["vgpr"] <= 170          # 3 waves per SIMD
-    assert _one(kernels, "void pfz::k7_fuzz_kernel<4>(")["vgpr"] <= 256          # 2
+    for scorer in ("-1", "0"):
+        assert _one(kernels, f"void pfz::k7_fuzz_kernel<2, {scorer}>(")["vgpr"] <= 170          # 3 waves per SIMD
+        assert _one(kernels, f"void pfz::k7_fuzz_kernel<4, {scorer}>(")["vgpr"] <= 256          # 2
 
 
 def test_k3_headline_kernel_keeps_18_workgroups_per_cu(kernels):
