@@ -43,6 +43,15 @@
 
 namespace pfz {
 
+// s | (v & ~u) -- = s | (v ^ u) where u is a subset of v -- as ONE v_bitop3_b32 per 32 bits (truth table 0xF4): the kernels of
+// this file are bound by their vector instruction rate (SQ counters: 85 % of the issue slots), and the compiler renders the
+// xor and the or as two instructions
+__device__ inline uint32_t or_andnot(uint32_t s, uint32_t v, uint32_t u) { return __builtin_amdgcn_bitop3_b32(s, v, u, 0xF4); }
+__device__ inline uint64_t or_andnot(uint64_t s, uint64_t v, uint64_t u)
+{
+    return (uint64_t)or_andnot((uint32_t)(s >> 32), (uint32_t)(v >> 32), (uint32_t)(u >> 32)) << 32 | or_andnot((uint32_t)s, (uint32_t)v, (uint32_t)u);
+}
+
 template <typename WORD, int W>
 __device__ inline void lcs_step(WORD (&V)[W], const WORD *__restrict__ pmc)
 {
@@ -57,7 +66,7 @@ __device__ inline void lcs_step(WORD (&V)[W], const WORD *__restrict__ pmc)
         sum += carry;
         const WORD c2 = sum < carry ? 1 : 0;
         carry = c1 | c2;
-        V[w] = sum | (s ^ u);
+        V[w] = or_andnot(sum, s, u);
     }
 }
 
@@ -305,12 +314,12 @@ __global__ __launch_bounds__(256, NS == 8 ? 6 : 7) void k4_indel_quad_kernel(Ind
             // instruction against 2.6, tools/ubench/valu_rate.hip; no gain, tried.)
             auto rec = [](uint32_t &V, uint32_t mask) {
                 const uint32_t u = V & mask;
-                if (NS == 8) {
-                    const u16x2 sum = __builtin_bit_cast(u16x2, V) + __builtin_bit_cast(u16x2, u);
-                    V = __builtin_bit_cast(uint32_t, sum) | (V ^ u);
-                }
-                else
-                    V = (V + u) | (V ^ u);
+                // three operations: the or of the sum with V & ~PM is ONE v_bitop3_b32 (or_andnot above); 20k x 20k titles 1.036 ->
+                // 0.972 ms against the four two-operand operations the compiler makes of (V + u) | (V ^ u)
+                uint32_t s;
+                if (NS == 8) s = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, V) + __builtin_bit_cast(u16x2, u)));
+                else s = V + u;
+                V = or_andnot(s, V, u);
             };
             // The packed to-characters are fetched two steps ahead of their use; the to-string's length and original
             // index (needed after the character loop) are requested before it.

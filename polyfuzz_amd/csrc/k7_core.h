@@ -177,16 +177,60 @@ PFZ_HD int fz_min(int a, int b) { return a < b ? a : b; }
 PFZ_HD int fz_max(int a, int b) { return a > b ? a : b; }
 PFZ_HD double fz_fmax(double a, double b) { return a > b ? a : b; }      // (no NaNs here)
 
+// three-input boolean functions of 64-bit words: one v_bitop3_b32 per half on the device (the compiler renders a & b & c and
+// s | (v ^ u) as two two-input operations each -- four of a recurrence step's seven vector instructions per word; the kernels
+// built on this step are bound by their vector instruction rate)
+PFZ_HD uint64_t fz_and3(uint64_t a, uint64_t b, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0x80);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0x80);
+    return (uint64_t)hi << 32 | lo;
+#else
+    return a & b & c;
+#endif
+}
+
+// s | (v & ~u)  (= s | (v ^ u) where u is a subset of v)
+PFZ_HD uint64_t fz_or_andnot(uint64_t s, uint64_t v, uint64_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)s, (uint32_t)v, (uint32_t)u, 0xF4);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(s >> 32), (uint32_t)(v >> 32), (uint32_t)(u >> 32), 0xF4);
+    return (uint64_t)hi << 32 | lo;
+#else
+    return s | (v & ~u);
+#endif
+}
+
+// (the 64-bit sum as ONE instruction: once its operands and users are 32-bit halves the compiler splits it into an add and
+// an add-with-carry)
+PFZ_HD uint64_t fz_add64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    return a + b;
+#endif
+}
+
 template <int W>
 PFZ_HD void fz_step(uint64_t (&V)[W], const uint64_t *pm, const uint64_t (&mask)[W])
 {
+    if (W == 1) {           // (no carry to pass on)
+        const uint64_t u = V[0] & pm[0] & mask[0];
+        V[0] = fz_or_andnot(fz_add64(V[0], u), V[0], u);
+        return;
+    }
     uint64_t carry = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
         const uint64_t u = V[w] & pm[w] & mask[w];
         const uint64_t sum = V[w] + u + carry;
         carry = (sum < V[w]) | (carry & (sum == V[w]));
-        V[w] = sum | (V[w] ^ u);
+        V[w] = fz_or_andnot(sum, V[w], u);
     }
 }
 
@@ -217,6 +261,9 @@ PFZ_HD void fz_range_mask(uint64_t (&m)[W], int lo, int hi)      // bits [lo, hi
 
 // LCS state of the from-form v (restricted to `amask`) against the to-form v; with `tagged` only the to-tokens whose bit
 // is set in `rb` are fed (form 2), the space after the last of them (`last_rb`) left out
+#ifndef PFZ_K7_PASS_PRELOAD
+#define PFZ_K7_PASS_PRELOAD 1          // (0: a branch per position, the table reads one behind the other -- A/B builds)
+#endif
 template <int W>
 PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint64_t (&amask)[W], bool tagged, uint32_t rb,
                         int last_rb, uint64_t (&V)[W])
@@ -238,9 +285,26 @@ PFZ_HD void fz_lcs_pass(const FuzzFrom<W> &F, const FuzzTo &T, int v, const uint
                 sy[q] = keep ? sy[q] : 0;
             }
         }
+        // (no branch per position: beyond the form's end the symbol is 0, "unknown" -- its table row is empty and the step
+        // leaves V as it is -- so the eight table reads go out together instead of each behind the step before it)
+#if !PFZ_K7_PASS_PRELOAD
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (p0 + q < lb) fz_step<W>(V, F.pm + (sy[q] * 3 + v) * W, amask);
+#else
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sy[q] = p0 + q < lb ? sy[q] : 0;
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+            uint64_t pmv[4][W];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int w = 0; w < W; ++w) pmv[q][w] = F.pm[(sy[h + q] * 3 + v) * W + w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fz_step<W>(V, pmv[q], amask);
+        }
+#endif
     }
 }
 
