@@ -366,7 +366,9 @@ __global__ __launch_bounds__(256, NS == 8 ? 6 : 7) void k4_indel_quad_kernel(Ind
                     // (the initial best 0 / 1 with index INT_MAX loses to every candidate -- equal products, lower
                     // index -- so "nothing yet" needs no test; slots beyond the last row are never written out)
                     int l_a = lcs, m_a = m[k] + lb;
-                    if (m[k] == 0) {                      // (uniform) an empty from-string: "" vs "" is 1 / 1 = ratio 100
+                    // (an empty from-string: "" vs "" is 1 / 1 = ratio 100.  Wave-uniform, and said so: as a select it was two
+                    // vector instructions per pair in a kernel that is bound by their rate)
+                    if (__builtin_amdgcn_readfirstlane(m[k]) == 0) {
                         l_a = lb == 0 ? 1 : 0;
                         m_a = lb == 0 ? 1 : lb;
                     }
