@@ -325,6 +325,22 @@ __device__ inline void run_steps(int *acc, const char *__restrict__ post_bytes, 
     run_steps_seq(acc, post_bytes, addr_t, as_t, sub8, std::make_integer_sequence<int, NS>{});
 }
 
+// inclusive prefix sum over the 64 lanes: six v_add_u32_dpp (row_shr 1, 2, 4, 8 inside each 16-lane row, then row_bcast 15 / 31
+// across the rows).  Written out: from `x += update_dpp(0, x, ..)` the compiler made a move of the identity, a DPP move and an add
+// per step, and kept the moved partials alive to re-derive the exclusive sum from them -- 26 vector instructions per (row, block)
+// of a kernel that issues them in 60 % of its slots.  (s_nop 1: a DPP operand written by the instruction before needs two wait
+// states, and the hazard is not looked for between inline statements.)
+__device__ inline int dpp_add_scan(int v)
+{
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return v;
+}
+
 // Scatter the (k,b) lists of up to 64 n-grams of one from-row into the accumulators.
 //   np, st : per lane, number of pieces and first piece of the lane's list in this block (np == 0: nothing)
 //   as     : per lane, the row's value for the lane's n-gram times the fixed-point scale
@@ -337,13 +353,7 @@ __device__ inline void scatter_pieces(int *acc, const char *__restrict__ post_by
                                       int lane, int src4, int sub8, int dummy_addr)
 {
     // inclusive scan over the 64 lanes with DPP adds (no LDS traffic, unlike __shfl_up/ds_bpermute)
-    int pin = np;
-    pin += __builtin_amdgcn_update_dpp(0, pin, 0x111, 0xf, 0xf, false);
-    pin += __builtin_amdgcn_update_dpp(0, pin, 0x112, 0xf, 0xf, false);
-    pin += __builtin_amdgcn_update_dpp(0, pin, 0x114, 0xf, 0xf, false);
-    pin += __builtin_amdgcn_update_dpp(0, pin, 0x118, 0xf, 0xf, false);
-    pin += __builtin_amdgcn_update_dpp(0, pin, 0x142, 0xa, 0xf, false);
-    pin += __builtin_amdgcn_update_dpp(0, pin, 0x143, 0xc, 0xf, false);
+    const int pin = dpp_add_scan(np);
     const int total = __builtin_amdgcn_readlane(pin, 63);
     const int excl = pin - np;
     const int base = st - excl;            // piece P of this list is index piece base + P
