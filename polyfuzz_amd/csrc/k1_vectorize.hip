@@ -92,6 +92,17 @@ struct ExtractParams {
     int64_t alpha_len;
 };
 
+// A second list riding in the same launch (a fit over to + from: both lists' extraction / rows / histograms are short,
+// latency-bound launches -- one launch over both instead of two in a row; workgroups from grid0 on belong to it).
+struct ListB {
+    const void *chars = nullptr;
+    const int64_t *off = nullptr;
+    int64_t n = 0;
+    uint64_t *slots = nullptr;
+    int32_t *row_cnt = nullptr;       // (row_nnz follows it: row_cnt + n + 1)
+    unsigned grid0 = 0xffffffffu;     // workgroups of the first list (0xffffffff: there is no second one)
+};
+
 constexpr int kLdsBitmapWords = 8192;   // code spaces of up to 18 bits (cleaned 3-grams) fit a 32 KiB LDS bitmap
 
 // ---------------------------------------------------------------------------
@@ -333,8 +344,17 @@ __global__ __launch_bounds__(256) void k_extract_wave(const void *__restrict__ c
                                                        int64_t n, ExtractParams P, const uint32_t *__restrict__ alpha_map,
                                                        uint64_t *__restrict__ slots, int32_t *__restrict__ row_cnt,
                                                        uint32_t *__restrict__ bitmap, int32_t per_wg, VocabView V = VocabView{},
-                                                       int32_t *__restrict__ row_nnz = nullptr)
+                                                       int32_t *__restrict__ row_nnz = nullptr, ListB B = ListB{})
 {
+    unsigned bx = blockIdx.x;
+    if (bx >= B.grid0) {           // (a workgroup of the second list)
+        bx -= B.grid0;
+        chars_v = B.chars;
+        off = B.off;
+        n = B.n;
+        slots = B.slots;
+        row_cnt = B.row_cnt;
+    }
     constexpr int kStageBytes = 24 * 1024;
     __shared__ uint32_t stage[kStageBytes / 4];
     __shared__ uint32_t lbm[LB ? kLdsBitmapWords : 1];
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(256) void k_extract_wave(const void *__restrict__ c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (LB)
         for (int t = threadIdx.x; t < P.bitmap_words; t += 256) lbm[t] = 0u;
-    const int64_t i0 = (int64_t)blockIdx.x * per_wg;
+    const int64_t i0 = (int64_t)bx * per_wg;
     const int64_t i_end = i0 + per_wg < n ? i0 + per_wg : n;
     const int64_t byte0 = off[i0] * CW, byte1 = off[i_end] * CW;
     const int64_t base4 = byte0 & ~(int64_t)3;
@@ -589,12 +609,20 @@ constexpr int kHistRows = 1024;   // <= 65 535, the range of a 16-bit counter; s
 __global__ __launch_bounds__(1024) void k_df_hist(const int64_t *__restrict__ off, int64_t n, int32_t R,
                                                    const uint64_t *__restrict__ slots,
                                                    const int32_t *__restrict__ row_nnz, int32_t words,
-                                                   uint32_t *__restrict__ partial)
+                                                   uint32_t *__restrict__ partial, ListB B = ListB{})
 {
     __shared__ uint32_t h[kHistWords];
     for (int t = threadIdx.x; t < words; t += 1024) h[t] = 0u;
     __syncthreads();
-    const int64_t r0 = (int64_t)blockIdx.x * kHistRows;
+    unsigned bx = blockIdx.x;
+    if (bx >= B.grid0) {           // (the second list's chunks follow the first's in `partial`: blockIdx.x numbers them all)
+        bx -= B.grid0;
+        off = B.off;
+        n = B.n;
+        slots = B.slots;
+        row_nnz = B.row_cnt + (B.n + 1);
+    }
+    const int64_t r0 = (int64_t)bx * kHistRows;
     const int64_t r1 = r0 + kHistRows < n ? r0 + kHistRows : n;
     // a 16-lane group takes 16 consecutive strings at a time: the lanes fetch the 16 strings' lengths
     // and slot addresses in parallel, then the first 16 entries of all 16 strings are loaded back to back
@@ -657,10 +685,19 @@ __global__ __launch_bounds__(256) void k_df_hist_reduce(const uint32_t *__restri
 __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ off, int64_t n, int32_t R,
                                                      VocabView V, uint64_t *__restrict__ slots,
                                                      const int32_t *__restrict__ row_cnt,
-                                                     int32_t *__restrict__ row_nnz, DfSink df)
+                                                     int32_t *__restrict__ row_nnz, DfSink df, ListB B = ListB{})
 {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned bx = blockIdx.x;
+    if (bx >= B.grid0) {
+        bx -= B.grid0;
+        off = B.off;
+        n = B.n;
+        slots = B.slots;
+        row_cnt = B.row_cnt;
+        row_nnz = B.row_cnt + (B.n + 1);
+    }
+    const int64_t row = (int64_t)bx * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const int cnt = row_cnt[row];
     if (cnt > kShortMax) return;  // k_rows_long
@@ -882,7 +919,7 @@ static int bits_for(uint64_t max_value)
     return b;
 }
 
-static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool mark, bool *rows_done = nullptr)
+static int prepare_slots(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s)
 {
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
     const size_t need = (size_t)(s->n_units > 0 ? s->n_units : 1) * (size_t)R;
@@ -893,6 +930,16 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
         s->slots_cap = need;
     }
     if (!s->row_cnt) PFZ_TRY(pool_alloc(ctx, &s->row_cnt, (size_t)(s->n + 1) * 2 * sizeof(int32_t)));
+    return PFZ_OK;
+}
+
+// sb (a fit over two lists): its strings are extracted by the same launch when both lists take the wave kernel and share a
+// character width; *sb_done says whether that happened (else the caller extracts it on its own).
+static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool mark, bool *rows_done = nullptr,
+                       pfz_strings *sb = nullptr, bool *sb_done = nullptr)
+{
+    if (sb_done) *sb_done = false;
+    PFZ_TRY(prepare_slots(ctx, v, s));
     if (s->n == 0) return PFZ_OK;
     const int64_t bitmap_words = v->n_groups * 8;
     ExtractParams P{v->params.ngram_lo, v->params.ngram_hi, v->params.clean, v->params.remove_space_ngrams,
@@ -908,6 +955,22 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     // a wave's strings are a chain of dependent LDS round trips, and there the chip is full of threads anyway)
     int per_wg = 32;
     if (const char *e = getenv("PFZ_K1_WAVE_STRINGS")) per_wg = std::max(4, std::min(kWaveStringsMax, atoi(e)));
+    // the second list in the same launch (PFZ_K1_TWO_LISTS=0: never -- tests, A/B)
+    ListB B;
+    unsigned grid_b = 0;
+    const char *two_knob = getenv("PFZ_K1_TWO_LISTS");
+    if (sb && sb_done && wave && sb->n > 0 && sb->n <= 32768 && sb->max_len <= kWaveMaxLen && sb->char_width == s->char_width &&
+        !(which && which[0] != 'w') && !(two_knob && atoi(two_knob) == 0)) {
+        PFZ_TRY(prepare_slots(ctx, v, sb));
+        B.chars = sb->chars;
+        B.off = sb->offsets;
+        B.n = sb->n;
+        B.slots = sb->slots;
+        B.row_cnt = sb->row_cnt;
+        B.grid0 = grid_for(s->n, per_wg);
+        grid_b = grid_for(sb->n, per_wg);
+        *sb_done = true;
+    }
     // a transform of a list the wave kernel takes: extraction and the short rows in ONE launch (see k_extract_wave<.., ROWS>)
     const char *fuse_knob = getenv("PFZ_K1_FUSE_ROWS");      // (tests: 0 = two launches)
     if (rows_done) *rows_done = false;
@@ -932,13 +995,13 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
 #define PFZ_EXTRACT(CW, LB)                                                                                          \
     do {                                                                                                             \
         if (wave && v->code_bits <= 32)                                                                              \
-            hipLaunchKernelGGL((k_extract_wave<CW, LB, uint32_t>), dim3(grid_for(s->n, per_wg)), dim3(256), 0,       \
+            hipLaunchKernelGGL((k_extract_wave<CW, LB, uint32_t>), dim3(grid_for(s->n, per_wg) + grid_b), dim3(256), 0,       \
                                ctx->stream, s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,       \
-                               mark ? v->bitmap : nullptr, per_wg);                                                  \
+                               mark ? v->bitmap : nullptr, per_wg, VocabView{}, nullptr, B);                         \
         else if (wave)                                                                                               \
-            hipLaunchKernelGGL((k_extract_wave<CW, LB, uint64_t>), dim3(grid_for(s->n, per_wg)), dim3(256), 0,       \
+            hipLaunchKernelGGL((k_extract_wave<CW, LB, uint64_t>), dim3(grid_for(s->n, per_wg) + grid_b), dim3(256), 0,       \
                                ctx->stream, s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,       \
-                               mark ? v->bitmap : nullptr, per_wg);                                                  \
+                               mark ? v->bitmap : nullptr, per_wg, VocabView{}, nullptr, B);                         \
         else if (v->code_bits <= 32)                                                                                 \
             hipLaunchKernelGGL((k_extract<CW, LB, uint32_t>), dim3(grid_for(s->n)), dim3(256), 0, ctx->stream,       \
                                s->chars, s->offsets, s->n, P, v->alpha_map, s->slots, s->row_cnt,                    \
@@ -960,16 +1023,28 @@ static int run_extract(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, bool ma
     return PFZ_OK;
 }
 
-static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df, bool short_done = false)
+// sb: a second list whose SHORT rows ride in the same launch (df must not count: the LDS-histogram path); its long rows, if
+// any, are the caller's (run_rows(sb, .., short_done = true)).
+static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df, bool short_done = false, pfz_strings *sb = nullptr)
 {
-    if (s->n == 0) return PFZ_OK;
+    if (s->n == 0) return sb ? run_rows(ctx, v, sb, df) : PFZ_OK;
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
     VocabView V{v->bitmap, v->prefix, v->vcodes, v->vocab};
     int32_t *row_nnz = s->row_cnt + (s->n + 1);
     if (!short_done) {
+        ListB B;
+        unsigned grid_b = 0;
+        if (sb && sb->n > 0) {
+            B.off = sb->offsets;
+            B.n = sb->n;
+            B.slots = sb->slots;
+            B.row_cnt = sb->row_cnt;
+            B.grid0 = grid_for(s->n, 4);
+            grid_b = grid_for(sb->n, 4);
+        }
         ProfScope ps(ctx, "k2_rows_short");
-        hipLaunchKernelGGL(k_rows_short, dim3(grid_for(s->n, 4)), dim3(256), 0, ctx->stream, s->offsets, s->n, R, V,
-                           s->slots, s->row_cnt, row_nnz, df);
+        hipLaunchKernelGGL(k_rows_short, dim3(grid_for(s->n, 4) + grid_b), dim3(256), 0, ctx->stream, s->offsets, s->n, R, V,
+                           s->slots, s->row_cnt, row_nnz, df, B);
     }
     if (s->max_len * R > kShortMax) {
         const int64_t max_cnt = s->max_len * R;
@@ -989,6 +1064,7 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df,
                            s->row_cnt, row_nnz, df, giant, stride);
     }
     PFZ_HIP(hipGetLastError());
+    if (sb && !short_done) return run_rows(ctx, v, sb, df, true);      // (the second list's long rows)
     return PFZ_OK;
 }
 
@@ -1339,8 +1415,9 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         if (world > 1) PFZ_TRY(merge_sorted_vocab(ctx, comm, v));      // vocabulary = union of the ranks' distinct codes
     } else {
         PFZ_TRY(alloc_vocab_space(ctx, v));
-        for (pfz_strings *s : lists)
-            if (s) PFZ_TRY(run_extract(ctx, v, s, true));
+        bool b_done = false;
+        if (lists[0]) PFZ_TRY(run_extract(ctx, v, lists[0], true, nullptr, world == 1 ? lists[1] : nullptr, &b_done));
+        if (lists[1] && !b_done) PFZ_TRY(run_extract(ctx, v, lists[1], true));
     }
     if (world > 1 && !sorted_vocab) {   // vocabulary = union of the ranks' n-gram sets
         const int64_t n_words = v->n_groups * 8;
@@ -1365,8 +1442,13 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         const bool small = vocab_bound(a_syms, params->ngram_lo, params->ngram_hi) <= 2 * (int64_t)kHistWords && !getenv("PFZ_NO_LDS_HIST");
         int rc = PFZ_OK;
         if (small && world == 1) {
-            for (pfz_strings *s : lists)
-                if (s && rc == PFZ_OK) rc = run_rows(ctx, v, s, DfSink{nullptr, 0});
+            const char *two_knob = getenv("PFZ_K1_TWO_LISTS");
+            if (lists[0] && lists[1] && !(two_knob && atoi(two_knob) == 0)) {
+                rc = run_rows(ctx, v, lists[0], DfSink{nullptr, 0}, false, lists[1]);
+            } else {
+                for (pfz_strings *s : lists)
+                    if (s && rc == PFZ_OK) rc = run_rows(ctx, v, s, DfSink{nullptr, 0});
+            }
             rows_done = true;
         }
         int32_t total = 0;
@@ -1403,6 +1485,23 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
     v->n_docs = 0;
     int64_t local_docs = 0, chunk0 = 0;
     const int R = v->params.ngram_hi - v->params.ngram_lo + 1;
+    // (both lists' histograms in one launch where both count and the rows are done: the second list's chunks follow the first's)
+    const char *two_knob = getenv("PFZ_K1_TWO_LISTS");
+    const bool hist_both = world == 1 && rows_done && lds_hist && lists[0] && lists[1] && lists[0]->n > 0 && lists[1]->n > 0 &&
+                           !(two_knob && atoi(two_knob) == 0);
+    if (hist_both) {
+        pfz_strings *a = lists[0], *b = lists[1];
+        const int64_t nch_a = (a->n + kHistRows - 1) / kHistRows, nch_b = (b->n + kHistRows - 1) / kHistRows;
+        ListB B;
+        B.off = b->offsets;
+        B.n = b->n;
+        B.slots = b->slots;
+        B.row_cnt = b->row_cnt;
+        B.grid0 = (unsigned)nch_a;
+        ProfScope ps(ctx, "k2_df_hist");
+        hipLaunchKernelGGL(k_df_hist, dim3((unsigned)(nch_a + nch_b)), dim3(1024), 0, ctx->stream, a->offsets, a->n, R, a->slots,
+                           a->row_cnt + (a->n + 1), words, (uint32_t *)df_sh, B);
+    }
     for (int li = 0; li < 2; ++li) {
         pfz_strings *s = lists[li];
         if (!s) continue;
@@ -1411,7 +1510,7 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         if (!rows_done) PFZ_TRY(run_rows(ctx, v, s, DfSink{counts && !lds_hist ? df_sh : nullptr, df_shift}));
         s->cache_gen = v->gen;
         if (counts) local_docs += s->n;
-        if (counts && lds_hist && s->n > 0) {
+        if (counts && lds_hist && s->n > 0 && !hist_both) {
             const int64_t nch = (s->n + kHistRows - 1) / kHistRows;
             ProfScope ps(ctx, "k2_df_hist");
             hipLaunchKernelGGL(k_df_hist, dim3((unsigned)nch), dim3(1024), 0, ctx->stream, s->offsets, s->n, R, s->slots,

@@ -241,3 +241,45 @@ def test_fused_launches_of_a_transform(ctx, oracle_mod, monkeypatch, n):
     if n <= 4097:
         o = oracle_mod.TfidfOracle().fit(names[:30000])
         _check_csr(got["11"][1], o.transform(docs), len(o.vocabulary))
+
+
+def test_two_list_fit_in_shared_launches_equals_one_launch_per_list(ctx, oracle_mod, monkeypatch):
+    """a fit over to + from extracts both lists, sorts both lists' short rows and counts both lists' document frequencies in ONE
+    launch each (PFZ_K1_TWO_LISTS=0: a launch per list): same vocabulary, document frequencies, idf and matrices bit for bit --
+    lists of changing sizes (1 .. 12 000), with strings of more than 128 n-grams in either list (k_rows_long's), a to-list too
+    long for the wave kernel (40 000 strings: the lists fall back to their own launches), a from-list of wide characters (another
+    kernel instance: no sharing); the oracle on two of them."""
+    from polyfuzz_amd import _lib, datasets
+    names = datasets.load_company_names()
+    long_a, long_b = " ".join(names[:25]), " ".join(names[100:140])
+    rng = np.random.default_rng(5)
+    cases = []
+    for trial in range(6):
+        n_to, n_from = int(rng.integers(1, 12000)), int(rng.integers(1, 12000))
+        lo = int(rng.integers(0, 40000))
+        to, frm = list(names[lo:lo + n_to]), list(names[lo + 20000:lo + 20000 + n_from])
+        if trial % 3 == 1:
+            to.insert(len(to) // 2, long_a)
+        if trial % 3 == 2:
+            frm.append(long_b)
+            frm.insert(0, "")
+        cases.append((to, frm, True))
+    cases.append((names[:40000], names[50000:53000], True))
+    cases.append((names[:3000], [s + " ŝĝ" for s in names[4000:6000]], False))
+    for ci, (to, frm, clean) in enumerate(cases):
+        params = _lib.TfidfParams(3, 3, int(clean), 1)
+        got = {}
+        for knob in ("1", "0"):
+            monkeypatch.setenv("PFZ_K1_TWO_LISTS", knob)
+            t, f = _lib.DeviceStrings.upload(ctx, to), _lib.DeviceStrings.upload(ctx, frm)
+            vec = _lib.DeviceTfidf.fit(ctx, params, t, f)
+            got[knob] = (vec.export(), vec.transform(f).download(), vec.transform(t).download())
+        for x, y in zip(got["1"][0], got["0"][0]):
+            np.testing.assert_array_equal(x, y, err_msg=f"case {ci}")
+        for m in (1, 2):
+            for x, y in zip(got["1"][m], got["0"][m]):
+                np.testing.assert_array_equal(x, y, err_msg=f"case {ci}")
+        if ci in (1, 2):
+            o = oracle_mod.TfidfOracle().fit(list(to) + list(frm))
+            _check_csr(got["1"][1], o.transform(frm), len(o.vocabulary))
+            _check_csr(got["1"][2], o.transform(to), len(o.vocabulary))
