@@ -528,6 +528,37 @@ __global__ __launch_bounds__(256) void k_group_popc(const uint32_t *__restrict__
                 __popc(b.w);
 }
 
+// ... and, for bitmaps of up to 1024 groups (cleaned 3-grams: 2^18 codes, exactly 1024), the exclusive scan of the counts in the
+// same launch -- one workgroup, a group per thread: prefix[g] = n-grams before group g, prefix[n_groups] = the vocabulary's size,
+// which also goes to the host's pinned word (LazyI32) as the scan kernel's total does
+__global__ __launch_bounds__(1024) void k_group_popc_scan(const uint32_t *__restrict__ bitmap, int32_t n_groups,
+                                                           int32_t *__restrict__ prefix, int32_t *__restrict__ host_total)
+{
+    __shared__ int32_t wsum[16];
+    const int g = threadIdx.x, lane = g & 63, wave = g >> 6;
+    int c = 0;
+    if (g < n_groups) {
+        const uint4 *w4 = (const uint4 *)(bitmap + (int64_t)g * 8);
+        const uint4 a = w4[0], b = w4[1];
+        c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+    }
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (g < n_groups) prefix[g] = base + inc - c;
+    if (g == n_groups - 1) {
+        prefix[n_groups] = base + inc;
+        if (host_total) __hip_atomic_store(host_total, base + inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_set_bits(const uint64_t *__restrict__ codes, int64_t n,
                                                    uint32_t *__restrict__ bitmap)
 {
@@ -666,8 +697,11 @@ __global__ __launch_bounds__(1024) void k_df_hist(const int64_t *__restrict__ of
     for (int t = threadIdx.x; t < words; t += 1024) dst[t] = h[t];
 }
 
+// (idf != NULL -- one GPU: the number of documents is known -- the idf of the two n-grams is written here too: k_idf's
+// formula, one launch less on a path whose short lists pay per launch)
 __global__ __launch_bounds__(256) void k_df_hist_reduce(const uint32_t *__restrict__ partial, int32_t words,
-                                                         int32_t chunks, int64_t vocab, int32_t *__restrict__ df)
+                                                         int32_t chunks, int64_t vocab, int32_t *__restrict__ df,
+                                                         double n_docs = 0.0, double *__restrict__ idf = nullptr)
 {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= words) return;
@@ -680,6 +714,10 @@ __global__ __launch_bounds__(256) void k_df_hist_reduce(const uint32_t *__restri
     }
     df[2 * (int64_t)w] = lo;
     if (2 * (int64_t)w + 1 < vocab) df[2 * (int64_t)w + 1] = hi;
+    if (idf) {
+        idf[2 * (int64_t)w] = log((n_docs + 1.0) / ((double)lo + 1.0)) + 1.0;
+        if (2 * (int64_t)w + 1 < vocab) idf[2 * (int64_t)w + 1] = log((n_docs + 1.0) / ((double)hi + 1.0)) + 1.0;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_rows_short(const int64_t *__restrict__ off, int64_t n, int32_t R,
@@ -1071,6 +1109,13 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df,
 // rank prefix of the vocabulary bitmap; the vocabulary's size starts its way to the host (*size: lazy_get it when needed)
 static int build_prefix(pfz_ctx *ctx, pfz_tfidf *v, LazyI32 *size)
 {
+    if (v->n_groups >= 1 && v->n_groups <= 1024 && !getenv("PFZ_K1_NO_POPC_SCAN")) {      // (env: the two-launch path -- tests)
+        if (size) PFZ_TRY(lazy_acquire(ctx, size));
+        hipLaunchKernelGGL(k_group_popc_scan, dim3(1), dim3(1024), 0, ctx->stream, v->bitmap, (int32_t)v->n_groups, v->prefix,
+                           size ? size->slot : nullptr);
+        PFZ_HIP(hipGetLastError());
+        return size ? lazy_mark(ctx, size) : PFZ_OK;
+    }
     hipLaunchKernelGGL(k_group_popc, dim3(grid_for(v->n_groups)), dim3(256), 0, ctx->stream, v->bitmap, v->n_groups,
                        v->prefix);
     return exclusive_scan_i32(ctx, v->prefix, v->n_groups, size);
@@ -1518,10 +1563,11 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
             chunk0 += nch;
         }
     }
+    const bool idf_fused = lds_hist && world == 1;
     if (lds_hist) {
         ProfScope ps(ctx, "k2_df_hist");
         hipLaunchKernelGGL(k_df_hist_reduce, dim3(grid_for(words)), dim3(256), 0, ctx->stream, (const uint32_t *)df_sh, words,
-                           (int32_t)chunks, v->vocab, v->df);
+                           (int32_t)chunks, v->vocab, v->df, (double)local_docs, idf_fused ? v->idf : nullptr);
     } else {
         hipLaunchKernelGGL(k_df_reduce, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, df_sh, v->vocab, df_shift, v->df);
     }
@@ -1541,8 +1587,9 @@ static int fit_impl(pfz_ctx *ctx, pfz_comm *comm, const pfz_tfidf_params *params
         PFZ_HIP(e);
         v->n_docs = total;
     }
-    hipLaunchKernelGGL(k_idf, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, v->df, v->vocab, (double)v->n_docs,
-                       v->idf);
+    if (!idf_fused)
+        hipLaunchKernelGGL(k_idf, dim3(grid_for(v->vocab)), dim3(256), 0, ctx->stream, v->df, v->vocab, (double)v->n_docs,
+                           v->idf);
     PFZ_HIP(hipGetLastError());
     guard.p = nullptr;
     *out = v;

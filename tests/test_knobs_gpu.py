@@ -26,7 +26,7 @@ def _titles(n_from, n_to):
     return fl[:n_from], tl[:n_to]
 
 
-@pytest.mark.parametrize("knob,value", [("PFZ_K1_WAVE_STRINGS", "8"), ("PFZ_K1_WAVE_STRINGS", "64")])
+@pytest.mark.parametrize("knob,value", [("PFZ_K1_WAVE_STRINGS", "8"), ("PFZ_K1_WAVE_STRINGS", "64"), ("PFZ_K1_NO_POPC_SCAN", "1")])
 def test_vectoriser_knobs(ctx, monkeypatch, knob, value):
     from polyfuzz_amd import datasets
     names = datasets.load_company_names()[:3000]
