@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256) void k_extract_wave(const void *__restrict__ c
         slots = B.slots;
         row_cnt = B.row_cnt;
     }
-    constexpr int kStageBytes = 24 * 1024;
+    // (8 KB of staged characters: 32 strings of 256.  It was 24 KB -- with the 32 KB bitmap copy of a fit 60 KB per workgroup, two
+    // per CU: the 626 workgroups of config 2's two lists in one launch took two rounds, 66 us; at 44 KB three fit and they take one)
+    constexpr int kStageBytes = 8 * 1024;
     __shared__ uint32_t stage[kStageBytes / 4];
     __shared__ uint32_t lbm[LB ? kLdsBitmapWords : 1];
     __shared__ uint32_t s_sym[4][kWaveMaxLen];          // cleaned symbols; bit 31 = breaks every window it is in
