@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void k_index_pieces(int32_t *__restrict__ cnt,
             c = cnt[i];
         }
         tab[i] = (c + kPiece - 1) / kPiece;
+    } else if (i < slots + 2) {
+        tab[i] = 0;                        // (the table's tail: no memset in front of this kernel -- the grid covers slots + kPiece threads)
     }
     // one device-scope atomic per wave that has heavy lists (one per list made this kernel 5.5 -> 15.5 us at 650k slots)
     const bool h = heavy && i < slots && c >= bank_min;
@@ -583,7 +585,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     PFZ_TRY(pool_alloc(ctx, &ix->tab_base, (size_t)(slots + 3) * sizeof(int32_t)));
     ix->tab = ix->tab_base + 1;
     PFZ_TRY(pool_alloc(ctx, &cnt.p, (size_t)(slots + 2) * sizeof(int32_t)));
-    PFZ_HIP(hipMemsetAsync(ix->tab_base, 0, (size_t)(slots + 3) * sizeof(int32_t), ctx->stream));
+    // (no memset of the table: k_index_pieces writes every entry, the dummy's and the two of the tail included)
     if (lds_hist && any) {      // counts per (list, sub-block); cnt itself is written by k_index_pieces
         PFZ_TRY(pool_alloc(ctx, &sub.p, (size_t)(slots + 1) * kSub * sizeof(int32_t)));
         PFZ_HIP(hipMemsetAsync(sub.p, 0, (size_t)slots * kSub * sizeof(int32_t), ctx->stream));
