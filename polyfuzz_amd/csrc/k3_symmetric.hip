@@ -374,6 +374,13 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         const int hi = n_ovf < a.ovf_base + a.ovf_max ? n_ovf : a.ovf_base + a.ovf_max;
         n_items = hi > a.ovf_base ? (hi - a.ovf_base) * n_sl : 0;
     }
+    // pass 0, persistent workgroups: a row's dependent loads -- row bounds -> its entries -> their offset-table entries -- are a
+    // third of the pass (65 of 200 us with nothing else in it: ~3 us of a wave per row).  The NEXT row's chain is fetched while
+    // this row's scatter, sweep and compaction run: the bounds at the top, the entries behind the scatter, the table entries
+    // behind the sweep -- each level has arrived when the next one is issued.
+    bool pf_ready = false;
+    int pf_p0 = 0, pf_p1 = 0, pf_k = 0, pf_cur = 0, pf_nxt = 0;
+    float pf_v = 0.f;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         int row = mode == 2 ? a.ovf[1 + a.ovf_base + item / n_sl] : a.row_begin + item * a.n_parts;
         bool magnet = false;      // pass 1: this item is a magnet row x a slice of the blocks BELOW its own
@@ -413,7 +420,21 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             b_lo = own + 1;
             b_first = b_lo;
         }
-        const int p0 = a.a_indptr[row], p1 = a.a_indptr[row + 1];
+        int p0, p1;
+        if (mode == 0 && pf_ready) {
+            p0 = pf_p0;
+            p1 = pf_p1;
+        } else {
+            p0 = a.a_indptr[row];
+            p1 = a.a_indptr[row + 1];
+        }
+        const bool more = mode == 0 && item + (int)gridDim.x < n_items;
+        const int row2 = a.row_begin + (item + (int)gridDim.x) * a.n_parts;      // (pass 0: the row after this one)
+        int q0 = 0, q1 = 0;
+        if (more) {
+            q0 = a.a_indptr[row2];
+            q1 = a.a_indptr[row2 + 1];
+        }
         const int nnz = p1 - p0;
         const int self_col = mode == 1 ? -1 : row;      // above the own block there is no diagonal
         const uint32_t inv_row = ~(uint32_t)row;
@@ -440,12 +461,18 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
         float as0 = 0.f;
         const bool have0 = lane < nnz;
         const int32_t *trow = a.tab;
-        if (have0) {
+        if (have0 && mode == 0 && pf_ready) {
+            as0 = pf_v * a.scale;
+            trow = a.tab + (int64_t)pf_k * nb;
+            cur0 = pf_cur;
+            nxt0 = pf_nxt;
+        } else if (have0) {
             as0 = a.a_val[p0 + lane] * a.scale;
             trow = a.tab + (int64_t)a.a_idx[p0 + lane] * nb;
             cur0 = trow[b_first];
             nxt0 = trow[b_first + 1];
         }
+        const bool have2 = more && lane < q1 - q0;
 
         uint32_t tq_next = 0xffffffffu;      // (0xff: no sum reaches it)
 #if PFZ_K3_SYM_EXP != 1
@@ -467,6 +494,10 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             if (have0 && it + 1 < n_blk) {
                 cur0 = trow[b_next];
                 nxt0 = trow[b_next + 1];
+            }
+            if (mode == 0 && have2) {           // (level 2 of the next row's chain: its bounds are here by now)
+                pf_k = a.a_idx[q0 + lane];
+                pf_v = a.a_val[q0 + lane];
             }
 #if PFZ_K3_SYM_EXP != 1      // (what-if 1: nothing is handed over)
             if (mode == 1 && !magnet && it + 1 < n_blk) tq_next = a.gmin[(int64_t)b_next * 64 + lane];
@@ -506,7 +537,17 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                     sweep_block<N4, kSymCap>(acc4, cand, st, b * C, self_col, ntop, lane, zero);
                 wave_sync();
             }
+            if (mode == 0 && have2) {           // (level 3: behind the sweep, ahead of the compaction and the stores)
+                const int32_t *t2 = a.tab + (int64_t)pf_k * nb + row2 / C;
+                pf_cur = t2[0];
+                pf_nxt = t2[1];
+            }
             b = b_next;
+        }
+        if (mode == 0) {
+            pf_ready = more;
+            pf_p0 = q0;
+            pf_p1 = q1;
         }
 
         if (mode == 1 && fcnt) drain_stage<kSymCap>(cand, st, fbuf, fcnt, ntop, lane, a, inv_row);
@@ -816,7 +857,12 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
         PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
         a.row_begin = 0;
         a.row_end = (int32_t)n;
-        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3((unsigned)n), dim3(64), 0, ctx->stream, a);
+        // (workgroups that loop over a few rows each: the loop is what lets a row's loads be fetched under the row before it.
+        // 128 per CU, ~3 rows each at 100 000 rows: exactly the 18 that are resident -- 22 rows each, every load prefetched --
+        // was SLOWER, K3 1.842 ms against 1.771, the rows' costs differ too much for a fixed deal; 36 / 72 / 144 per CU
+        // 1.780 / 1.758 / 1.757; a workgroup per row, as before, 1.768 - 1.771)
+        const unsigned grid0 = (unsigned)std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * sym_env_int("PFZ_K3_SYM_P0_PER_CU", 128));
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(grid0), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
         const int64_t pairs = sym_repost_pairs(ix);
         hipLaunchKernelGGL(k3_sym_repost, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, a);
@@ -951,7 +997,8 @@ int k3_sym_sharded(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix, const pfz_
     a.row_begin = part;
     a.row_end = (int32_t)n;
     const unsigned mine0 = (unsigned)((n - part + n_parts - 1) / n_parts);
-    if (mine0) hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(mine0), dim3(64), 0, ctx->stream, a);
+    const unsigned grid0 = std::min<unsigned>(mine0, (unsigned)ctx->prop.multiProcessorCount * (unsigned)sym_env_int("PFZ_K3_SYM_P0_PER_CU", 128));
+    if (mine0) hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(grid0), dim3(64), 0, ctx->stream, a);
     PFZ_HIP(hipGetLastError());
     if (n_parts > 1) PFZ_TRY(comm_allgather_bytes(comm, s->thrv + (size_t)part * a.per, s->thrv, (size_t)a.per * sizeof(int32_t)));
     hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
