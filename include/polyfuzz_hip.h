@@ -364,6 +364,13 @@ int pfz_comm_barrier(pfz_comm *c);
 int pfz_comm_cossim_topn_symmetric(pfz_comm *c, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound,
                                    pfz_topn *out);
 int pfz_index_symmetric_ok(const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t n_parts, int32_t *yes);
+/* The same question asked by ALL ranks together (a collective: every rank calls it, it waits): *yes = 1 only if every rank's own
+ * pfz_index_symmetric_ok says yes AND every rank could allocate the session buffers of its index.  What a rank reads from its own
+ * environment or gets from its own allocator must not send it into pfz_comm_cossim_topn_symmetric while a peer goes to
+ * pfz_comm_allgather_topn: ask this once per job (sizes fixed), then every rank takes the same branch of reference
+ * _tfidf.py:113-116 -> _utils.py:82-91's self-match.  A rank that fails INSIDE pfz_comm_cossim_topn_symmetric afterwards aborts
+ * the communicator (its peers' collectives return PFZ_ERR_RCCL instead of waiting for it). */
+int pfz_comm_symmetric_ok(pfz_comm *c, const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t *yes);
 int pfz_comm_info(const pfz_comm *c, int32_t *rank, int32_t *world);
 /* pfz_tfidf_fit over a corpus that is split across the ranks of `comm`:
  * `replicated` (may be NULL) is identical on every rank and counted once --

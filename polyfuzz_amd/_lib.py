@@ -60,6 +60,7 @@ SIGNATURES = {
     "pfz_index_symmetric_census": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
     "pfz_index_symmetric_ok": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_i32)]),
     "pfz_comm_cossim_topn_symmetric": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_vp]),
+    "pfz_comm_symmetric_ok": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, P(c_i32)]),
     "pfz_topn_alloc": (ctypes.c_int, [c_vp, c_i64, c_i32, P(c_vp)]),
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
@@ -756,6 +757,13 @@ class Comm(_Handle):
             out = DeviceTopN.alloc(self.ctx, local.n_rows, local.ntop)
         check(self.ctx.lib.pfz_comm_merge_to_shards(self.h, local.h, int(to_offset), out.h))
         return out
+
+    def symmetric_ok(self, index, csr, ntop):
+        """COLLECTIVE (every rank calls it): do all ranks agree that this self-match takes K3's symmetric form, and has every rank
+        the session buffers for it?  (pfz_comm_symmetric_ok)"""
+        yes = c_i32(0)
+        check(self.ctx.lib.pfz_comm_symmetric_ok(self.h, index.h, csr.h, int(ntop), ctypes.byref(yes)))
+        return bool(yes.value)
 
     def cossim_topn_symmetric(self, index, csr, ntop, lower_bound, out=None):
         """the self-match of the whole (replicated) list, cut over the ranks in K3's symmetric form: the FULL result on every rank"""

@@ -18,6 +18,7 @@ namespace pfz {
 constexpr int kSelectMinTop = 16;  // above this top_n, intermediate compactions select instead of sorting
 constexpr int kWarmMaxTop = 8;    // threshold warm start (one wave-max round per rank) up to this top_n
 constexpr int kPiece = 16;        // postings per piece (one 128-byte line, one 16-lane DPP row)
+constexpr long long kPieceBoundMax = 1 << 20;   // pfz_index_build sizes the postings by a bound up to this many pieces (128 MB), by the exact count beyond
 
 // ---------------------------------------------------------------------------
 // wave helpers

@@ -621,14 +621,17 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     }
     PFZ_TRY(exclusive_scan_i32(ctx, ix->tab_base, slots + 1, &ix->pieces_lazy));   // tab[i] = first piece of list i, tab[slots] = pieces + the dummy
     // The postings are allocated by a BOUND of the number of pieces (a list of c postings has ceil(c / 16) pieces: at most nnz / 16
-    // + one per non-empty list), not by the count itself: waiting for it here idles the device until the host has enqueued the fill
-    // (50 us of a 0.37-ms step at 10k x 10k).  Only where the bound leaves the 4 GiB the kernels address with 32-bit byte offsets
-    // is the count waited for and checked.
+    // + one per non-empty list), not by the count itself, WHILE THE BOUND IS SMALL (<= 2^20 pieces = 128 MB: every job whose K3 is
+    // short enough to notice): waiting for the count idles the device until the host has enqueued the fill (50 us of a 0.37-ms
+    // step at 10k x 10k).  A larger bound is several times the real index (1M to-rows: 1 GB against 267 MB, twice that with the
+    // symmetric copy) and its K3 takes milliseconds: there the count is waited for, checked against the 4 GiB the kernels address
+    // with 32-bit byte offsets, and the postings get their exact size.
     const int64_t nnz_bound = B->nnz_lazy.pending ? B->nnz_cap : B->nnz;
     int64_t piece_cap = nnz_bound / kPiece + std::min<int64_t>(slots, nnz_bound) + 1;
-    if (piece_cap >= (1 << 25) - 1) {
+    if (piece_cap > kPieceBoundMax) {
         int32_t total = 0;
         PFZ_TRY(lazy_get(ctx, &ix->pieces_lazy, &total));
+        ix->n_pieces = total - 1;       // (lazy_get cleared `pending`: index_ready() will not assign it any more)
         if (total - 1 >= (1 << 25) - 1) {
             set_error("pfz_index_build: %d index pieces (%lld postings padded to 16 per list and block) exceed the 4 GiB "
                       "the kernel addresses with 32-bit byte offsets", total - 1, (long long)csr_nnz(B));

@@ -963,7 +963,22 @@ bool k3_sym_sharded_ok(const pfz_index *ix, const pfz_csr *A, int32_t ntop, int3
     return ix->n_rows >= sym_env_int("PFZ_K3_SYM_MIN", 20480) && ix->n_rows <= 250000;
 }
 
+// Every allocation of the job happens BEFORE its first collective, and a rank that fails there (or in any launch behind) tears the
+// communicator down (comm_abort): its peers' collectives end in an RCCL error instead of waiting for a rank that has left.  That
+// the ranks agree on taking this form at all -- environment, sizes, whether the session buffers exist -- is settled by
+// pfz_comm_symmetric_ok, once per job and before the first call.
+static int k3_sym_sharded_body(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound,
+                               pfz_topn *out);
+
 int k3_sym_sharded(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound, pfz_topn *out)
+{
+    const int rc = k3_sym_sharded_body(ctx, comm, ix, A, ntop, lower_bound, out);
+    if (rc != PFZ_OK && comm_world(comm) > 1) comm_abort(comm);
+    return rc;
+}
+
+static int k3_sym_sharded_body(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound,
+                               pfz_topn *out)
 {
     const int64_t n = ix->n_rows;
     const int nb = ix->n_blocks;
@@ -1079,6 +1094,22 @@ extern "C" int pfz_comm_cossim_topn_symmetric(pfz_comm *c, const pfz_index *ix, 
     PFZ_HIP(hipSetDevice(ctx->device));
     pfz::ProfScope ps(ctx, "k3_cossim_topn");
     return pfz::k3_sym_sharded(ctx, c, ix, A, ntop, lower_bound, out);
+}
+
+extern "C" int pfz_comm_symmetric_ok(pfz_comm *c, const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t *yes)
+{
+    PFZ_REQUIRE(c && ix && A && yes, "pfz_comm_symmetric_ok: NULL argument");
+    pfz_ctx *ctx = ix->ctx;
+    PFZ_HIP(hipSetDevice(ctx->device));
+    // this rank's own answer: the rule of pfz_index_symmetric_ok AND the session buffers of the index (allocated here, so that the
+    // job itself has nothing left to fail on that its peers would not see) ...
+    bool mine = pfz::k3_sym_sharded_ok(ix, A, ntop, pfz::comm_world(c));
+    if (mine) mine = pfz::sym_state_of(ctx, ix) != nullptr;
+    // ... and everybody's
+    bool all = false;
+    PFZ_TRY(pfz::comm_agree(c, mine, &all));
+    *yes = all ? 1 : 0;
+    return PFZ_OK;
 }
 
 extern "C" int pfz_index_symmetric_ok(const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t n_parts, int32_t *yes)

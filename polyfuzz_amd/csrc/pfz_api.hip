@@ -30,8 +30,13 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     return PFZ_ERR_HIP;
 }
 
+// The slot / event pool of a context is touched by whoever frees a matrix or an index -- a Python finalizer on another thread while
+// a ctypes call (GIL released) acquires a slot on the same context: one lock for it, as pool_free has for the device blocks.
+static std::mutex g_lazy_mu;
+
 int lazy_acquire(pfz_ctx *ctx, LazyI32 *z)
 {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
     if (ctx->lazy_slots.empty()) {
         int32_t *chunk = nullptr;
         PFZ_HIP(hipHostMalloc((void **)&chunk, 64 * sizeof(int32_t), hipHostMallocDefault));      // (pinned, mapped: kernels may write it)
@@ -78,6 +83,7 @@ int lazy_get(pfz_ctx *ctx, LazyI32 *z, int32_t *out)
 
 void lazy_release(pfz_ctx *ctx, LazyI32 *z)
 {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
     if (z->slot) ctx->lazy_slots.push_back(z->slot);
     if (z->ev) ctx->lazy_events.push_back(z->ev);
     z->slot = nullptr;

@@ -33,6 +33,7 @@ struct pfz_comm_group {
     int attached = 0;
     std::vector<const void *> send;      // per rank: the buffer it contributes to the running collective
     std::vector<hipEvent_t> ready, done; // per rank: "send buffer final" / "my copies out of the peers are enqueued and run"
+    std::vector<int> vote;               // per rank: comm_agree
     void barrier()
     {
         std::unique_lock<std::mutex> lk(mu);
@@ -183,6 +184,43 @@ int comm_allreduce_sum_i64(pfz_comm *c, int64_t *buf, size_t n)
     return PFZ_OK;
 }
 
+// Do ALL ranks say yes?  A host-side agreement (it waits): what a rank decides from its own environment or its own allocations --
+// "this job takes the symmetric form" -- must be the same everywhere before any rank enters a collective the others would not.
+int comm_agree(pfz_comm *c, bool mine, bool *all)
+{
+    *all = mine;
+    if (!c || c->world == 1) return PFZ_OK;
+    if (c->group) {
+        pfz_comm_group *g = c->group;
+        g->vote[(size_t)c->rank] = mine ? 1 : 0;
+        g->barrier();
+        bool yes = true;
+        for (int v : g->vote) yes = yes && v != 0;
+        g->barrier();                   // (nobody votes again before everybody has read)
+        *all = yes;
+        return PFZ_OK;
+    }
+    int32_t no = mine ? 0 : 1;
+    PFZ_HIP(hipMemcpyAsync(c->flag, &no, sizeof(no), hipMemcpyHostToDevice, c->ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(c->ctx->stream));      // (`no` is a stack word)
+    PFZ_RCCL(ncclAllReduce(c->flag, c->flag, 1, ncclInt32, ncclSum, c->comm, c->ctx->stream));
+    PFZ_HIP(hipMemcpyAsync(&no, c->flag, sizeof(no), hipMemcpyDeviceToHost, c->ctx->stream));
+    PFZ_HIP(hipStreamSynchronize(c->ctx->stream));
+    PFZ_HIP(hipMemsetAsync(c->flag, 0, sizeof(int32_t), c->ctx->stream));      // (pfz_comm_barrier's payload again)
+    *all = no == 0;
+    return PFZ_OK;
+}
+
+// A rank that fails BEHIND an agreement cannot leave its peers inside a collective: the communicator is torn down, the peers'
+// pending RCCL calls end in an error instead of a wait that never ends.
+void comm_abort(pfz_comm *c)
+{
+    if (c && c->comm) {
+        (void)ncclCommAbort(c->comm);
+        c->comm = nullptr;
+    }
+}
+
 }  // namespace pfz
 
 using namespace pfz;
@@ -230,6 +268,7 @@ int pfz_comm_group_create(int32_t world, pfz_comm_group **out)
     g->send.assign((size_t)world, nullptr);
     g->ready.assign((size_t)world, nullptr);
     g->done.assign((size_t)world, nullptr);
+    g->vote.assign((size_t)world, 0);
     *out = g;
     return PFZ_OK;
 }

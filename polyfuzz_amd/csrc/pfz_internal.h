@@ -279,6 +279,8 @@ int comm_world(const pfz_comm *c);
 int comm_allgather_bytes(pfz_comm *c, const void *send, void *recv, size_t bytes_per_rank);
 int comm_allreduce_sum_i32(pfz_comm *c, int32_t *buf, size_t n);
 int comm_allreduce_sum_i64(pfz_comm *c, int64_t *buf, size_t n);
+int comm_agree(pfz_comm *c, bool mine, bool *all);      // host-side AND over the ranks (waits)
+void comm_abort(pfz_comm *c);                           // a rank failed behind an agreement: the peers must not wait for it
 
 // exclusive scan of n int32 counters in place, total written to in[n]
 // (array must have n+1 slots).  Enqueues on ctx->stream.

@@ -158,11 +158,13 @@ static PyObject *pack_one_walk(PyObject **items, Py_ssize_t n, PyObject **objs)
             cap = (cap + len) * 2;
             if (_PyBytes_Resize(&chars, (Py_ssize_t)cap) < 0) {      /* (chars is NULL now, MemoryError set) */
                 Py_DECREF(offs);
-                if (objs)
+                if (objs) {
                     for (Py_ssize_t k = 0; k < i; ++k) {
                         Py_DECREF(objs[k]);
                         objs[k] = NULL;
                     }
+                    release_overwritten_none(nones);      /* (the slots are NULL now, not None: their references go back) */
+                }
                 return NULL;
             }
             buf = PyBytes_AS_STRING(chars);
@@ -177,11 +179,13 @@ static PyObject *pack_one_walk(PyObject **items, Py_ssize_t n, PyObject **objs)
         }
     }
     if (i < n) {                 /* not that kind of list: undo */
-        if (objs)
+        if (objs) {
             for (Py_ssize_t k = 0; k < i; ++k) {
                 Py_DECREF(objs[k]);
                 objs[k] = NULL;
             }
+            release_overwritten_none(nones);              /* (as above: NULL slots hold no reference to None) */
+        }
         Py_DECREF(chars);
         Py_DECREF(offs);
         return NULL;

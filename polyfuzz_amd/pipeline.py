@@ -85,8 +85,10 @@ class HipEngine:
     def allgather_topn(self, comm, local, out):
         return comm.allgather_topn(local, out)
 
-    def symmetric_ok(self, index, csr, ntop, world):
-        return index.symmetric_ok(csr, ntop, world)
+    def symmetric_ok(self, comm, index, csr, ntop):
+        """COLLECTIVE: every rank's own rule (sizes, environment) and allocations, AND-ed over the ranks (pfz_comm_symmetric_ok) --
+        a rank alone must not decide which collectives the job issues"""
+        return comm.symmetric_ok(index, csr, ntop)
 
     def cossim_topn_symmetric(self, comm, index, csr, ntop, lower_bound, out):
         return comm.cossim_topn_symmetric(index, csr, ntop, lower_bound, out)
@@ -135,6 +137,7 @@ class TfidfMatchJob:
         # a self-match cut over several GPUs in K3's symmetric form leaves the FULL result (n_to x top_n) on every rank
         self.full = None
         self.result_is_full = False
+        self._symmetric = None                 # the ranks' common answer to "symmetric form?", asked by the first step
 
     def step(self):
         eng = self.eng
@@ -149,8 +152,11 @@ class TfidfMatchJob:
             self.vec = eng.fit(self.params, self.to_dev, self.from_dev)
         self.to_csr = eng.transform(self.vec, self.to_dev)
         self.index = eng.build_index(self.to_csr)
-        if self.self_match and sharded and self.to_dev is not self.from_dev and eng.symmetric_ok(self.index, self.to_csr, self.top_n,
-                                                                                                  self.comm.world):
+        if self.self_match and sharded and self.to_dev is not self.from_dev and self._symmetric is None:
+            # asked once per job (its sizes are fixed), by all ranks together: ADVICE r5 -- ranks that read different environments
+            # or whose allocations fail differently would otherwise issue different collectives and wait for each other for ever
+            self._symmetric = bool(eng.symmetric_ok(self.comm, self.index, self.to_csr, self.top_n))
+        if self._symmetric:
             # One list against itself, cut over the ranks (bench --scaling strong): the symmetric form of K3 scores every
             # unordered pair of rows ONCE over all ranks -- rank r works on the rows r, r + world, ... of the replicated list,
             # whatever contiguous shard it was handed (the sorted list's cost is spread evenly that way) -- and the ranks'

@@ -125,8 +125,15 @@ class OracleEngine:
     # ---- the self-match cut over the ranks in K3's symmetric form (polyfuzz_amd/csrc/k3_symmetric.hip, k3_sym_sharded) ----
     SYM_BLOCK = 16         # to-rows per block of the emulation (the kernel: 2048)
 
-    def symmetric_ok(self, index, csr, ntop, world):
-        return len(csr.triple[0]) - 1 > 2 * self.SYM_BLOCK
+    force_row_shards_on_rank = None        # tests: this rank alone says no (different environment / failed allocation)
+
+    def symmetric_ok(self, comm, index, csr, ntop):
+        """the collective question (pfz_comm_symmetric_ok): every rank's own answer, AND-ed over the ranks"""
+        mine = len(csr.triple[0]) - 1 > 2 * self.SYM_BLOCK and comm.rank != self.force_row_shards_on_rank
+        torch = self.torch
+        t = torch.tensor([int(mine)], dtype=torch.int32)
+        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MIN)
+        return bool(t.item())
 
     def cossim_topn_symmetric(self, comm, index, csr, ntop, lower_bound, out):
         """The partition rule of the device job, on oracle scores: rank r works on the rows r, r + world, ...; a pair inside one

@@ -73,3 +73,48 @@ def assert_topn_parity(idx, val, exp_idx, exp_val, oracle, a3, b3, n_col, exclud
             assert abs(s_got - exp_val[i, r]) < NEAR_TIE, \
                 f"row {i} rank {r}: got col {got[r]} (oracle score {s_got!r}), expected col " \
                 f"{exp_idx[i, r]} (score {exp_val[i, r]!r})"
+
+
+# ---- the headline held to the REFERENCE's own run (tests/golden/headline_knn_golden.npz, make_golden_headline.py) -----------
+
+def load_headline_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "headline_knn_golden.npz"))
+    return {k: g[k] for k in ("idx", "sim", "sim3", "to_none")}
+
+
+def assert_topn_equals_reference_knn(idx, val, golden, true_score, rows=None, score_tol=SCORE_TOL):
+    """idx / val: an engine's (or the oracle's) self-match top-5 of the 100 000 company names, rows `rows` (default: all), canonical
+    order; golden: what `polyfuzz.models.TFIDF(min_similarity=0, top_n=5, cosine_method="knn").match(names)` -- the REFERENCE, run in the
+    build container -- returned for them.  true_score(r, j) -> float64 cosine of the pairs (r[i], j[i]) from the oracle-built matrix.
+
+    The rule (SURVEY section 7 "Ties"): the scores agree rank by rank within the north-star's 1e-5 on EVERY cell; wherever the index
+    at a rank differs, the reference's choice must score the same as ours at that rank (NEAR_TIE: an exact tie, resolved by
+    sklearn's unspecified argpartition order there and by ascending index here) -- or be the row itself, `_utils.py:61-65`'s quirk:
+    neighbour column 0 is dropped as "self", which keeps the row's own index wherever an exact duplicate took column 0; such a
+    row must have a perfect match here.  Empty cells (score 0 / index -1 here) must be the frame's None cells."""
+    idx, val = np.asarray(idx), np.asarray(val, np.float64)
+    if rows is None:
+        rows = np.arange(len(idx))
+    rows = np.asarray(rows)
+    r_idx, r_sim, r_none = golden["idx"][rows], golden["sim"][rows].astype(np.float64), golden["to_none"][rows]
+    assert idx.shape == r_idx.shape
+    err = np.abs(val - r_sim)
+    assert err.max() <= score_tol, f"max |score - reference| = {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+    empty = idx < 0
+    assert np.array_equal(empty, val == 0)
+    # the reference's None cells are its cells below 0.001 after rounding: ours that round the same way
+    mine_none = np.round(val, 3) < 0.001
+    edge = np.abs(r_sim - 0.0005) < 2 * score_tol
+    assert np.array_equal(mine_none | edge, r_none | edge)
+    rr, kk = np.nonzero((idx != r_idx) & ~r_none & ~empty)
+    jj = r_idx[rr, kk]
+    is_self = jj == rows[rr]
+    ts = true_score(rows[rr[~is_self]], jj[~is_self])
+    not_tie = np.abs(ts - val[rr[~is_self], kk[~is_self]]) > NEAR_TIE
+    assert not not_tie.any(), (f"{int(not_tie.sum())} cells where the reference chose a column that is no tie of ours; first: row "
+                               f"{rows[rr[~is_self]][not_tie][:3]}, reference column {jj[~is_self][not_tie][:3]}")
+    assert (val[rr[is_self], 0] >= 1.0 - NEAR_TIE).all() and (val[rr[is_self], kk[is_self]] >= 1.0 - NEAR_TIE).all()
+    # an empty cell of ours facing a real cell of the reference (or the other way round) was caught by the None test above
+    return {"cells": int(idx.size), "cells_index_differs": int(len(rr)), "of_them_reference_kept_self": int(is_self.sum()),
+            "max_abs_score_err": float(err.max())}

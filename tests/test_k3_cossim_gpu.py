@@ -494,3 +494,9 @@ def test_symmetric_switch_over_large(ctx, monkeypatch, n, expect_sym):
     assert ix.symmetric_launches()[0] == expect_sym
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
+    # at this size the BOUND of the index' pieces (characters / 16 + one per list: ~2.0 M) is beyond the 2^20 up to
+    # which the build sizes the postings by the bound, so it waits for the exact count -- which must reach `n_pieces` (it stayed 0:
+    # the symmetric form re-dealt the dummy piece only and read garbage postings) and size the postings exactly
+    info = ix.info()
+    assert info["n_pieces"] * info["piece_postings"] >= info["nnz"] > 0
+    assert info["n_pieces"] <= info["nnz"] // info["piece_postings"] + info["n_cols"] * info["n_blocks"]

@@ -53,8 +53,10 @@ def _worker(rank, port, out_dir):
     s_idx, s_val = sjob.step().download()
     assert sjob.result_is_full          # (the self-match is cut over the ranks in the symmetric form: full result on every rank)
     s_idx, s_val = sjob.whole_result(s_idx, s_val, sizes)
-    # ... and the row-sharded form of the same self-match (what runs where the symmetric form does not apply)
-    eng.symmetric_ok = lambda *a: False
+    # ... and the row-sharded form of the same self-match (what runs where the symmetric form does not apply).  ONE rank alone
+    # says no -- a different environment, a failed allocation --: the question is a collective, so BOTH ranks take the
+    # row-sharded form instead of issuing different exchanges and waiting for each other
+    eng.force_row_shards_on_rank = 1
     rjob = TfidfMatchJob(None, from_list[b:e], from_list, top_n=TOP_N, comm=comm, rows_per_rank=max(sizes), engine=eng,
                          self_match=True, shard_offset=b)
     r_idx, r_val = rjob.step().download()
