@@ -84,6 +84,10 @@ def parse(argv=None):
     ap.add_argument("--small", action="store_true",
                     help="rehearsal sizes (tests of the launch / rank logic): 2 000 x 2 000 titles, 4 000 x 20 000 x 256 vectors; "
                          "the line says so in config.rehearsal")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="tests only (tests/test_bench_launch_cpu.py): the launch / rendezvous / rank logic of --gpus N on a box "
+                         "WITHOUT a GPU -- TfidfMatchJob driven through tests/cpu_engine.py (oracle arithmetic, gloo exchanges) on a "
+                         "400-name list; prints a rehearsal record, never a bench line")
     ap.add_argument("--config", choices=("tfidf", "c2", "editdistance", "rapidfuzz", "dense", "tfidf_1m"), default="tfidf",
                     help="tfidf: the headline (+ every other config as a sub-record at N = 1); the others: that "
                          "configuration alone as the line")
@@ -107,37 +111,57 @@ class World:
 
 
 class TorchWorld(World):
+    """One process per GPU.  torch.distributed is the RENDEZVOUS only, over gloo (host TCP): the id of the library's communicator is
+    broadcast through it, the bench's own barrier and max-over-ranks run on it.  Round 6: not over torch's
+    "nccl" backend -- that made torch a second RCCL user in the process beside the library's communicator -- and the library is
+    loaded BEFORE torch, so that the librccl it was linked against (/opt/rocm) is the one it runs on, not the copy inside the torch
+    wheel; `config.rccl` in the line says which one the process resolved."""
     kind = "rccl"
 
-    def __init__(self):
+    def __init__(self, need_devices=True):
+        from polyfuzz_amd import _lib
+        _lib.load()                       # (first: the library's own librccl.so.1, see above)
+        self.rccl = _lib.rccl_versions()
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.rank, self.size = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(self.local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        dist.init_process_group("gloo")
+        # every rank needs a device of its own: agree on that before anybody creates a context
+        n_dev = _lib.device_count()
+        t = torch.tensor([n_dev], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        print(f"[bench rank {self.rank}] rendezvous ok (gloo, world {self.size}); {n_dev} device(s) visible; librccl "
+              f"{self.rccl['runtime']} at {self.rccl['path']} (library compiled against rccl.h {self.rccl['header']})",
+              file=sys.stderr, flush=True)
+        if need_devices and int(t.item()) < self.size:
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(f"[bench rank {self.rank}] --gpus {self.size}: {self.size} devices needed, {int(t.item())} visible")
+        if self.rccl["header"] // 10000 != self.rccl["runtime"] // 10000:
+            raise SystemExit(f"[bench rank {self.rank}] librccl {self.rccl['runtime']} at {self.rccl['path']} does not match the rccl.h "
+                             f"{self.rccl['header']} the library was compiled against (major versions differ)")
 
     def barrier(self, ctx):
         ctx.sync()
         self.dist.barrier()
-        self.torch.cuda.synchronize()
         ctx.sync()
 
     def max(self, x):
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def comm(self, ctx):
-        """the library's own RCCL communicator (bootstrap: broadcast of the 128-byte id through torch)"""
+        """the library's own RCCL communicator (bootstrap: broadcast of the 128-byte id through the gloo group)"""
         from polyfuzz_amd import _lib
         err, comm = "", None
         try:
             comm = _lib.Comm.from_torch_distributed(ctx, self.dist)
         except Exception as e:       # keep every rank in step: agree on the outcome before going on
             err = f"{type(e).__name__}: {e}"
-        ok = self.torch.tensor([0 if err else 1], dtype=self.torch.int32, device="cuda")
+        ok = self.torch.tensor([0 if err else 1], dtype=self.torch.int32)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
             return comm, "RCCL all-gather of the per-shard result blocks"
@@ -147,6 +171,53 @@ class TorchWorld(World):
 
     def close(self):
         self.dist.destroy_process_group()
+
+
+class _NoDevice:
+    """the context of --rehearse-cpu: nothing to synchronise, nothing to time"""
+    def sync(self): pass
+    def prof_enable(self, level): pass
+    def prof_reset(self): pass
+    def event_record(self, i): pass
+
+
+def rehearse_cpu(world, args):
+    """NOT a measurement and not a bench line (no metric / value keys): the rank logic of `--gpus N` -- launcher, gloo rendezvous,
+    barrier + max-over-ranks around the timed steps, the sharded self-match job of polyfuzz_amd/pipeline.py with its collective
+    `symmetric_ok` question and its exchanges -- on a box without a GPU, the device replaced by tests/cpu_engine.py."""
+    import zlib
+    from polyfuzz_amd import pipeline, synth
+    from tests.cpu_engine import GlooComm, OracleEngine
+    names = synth.company_names(400, seed=3)
+    bounds = pipeline.balanced_bounds(names, world.size)
+    b, e = bounds[world.rank]
+    job = pipeline.TfidfMatchJob(None, names[b:e], names, top_n=3, comm=GlooComm(world.dist), self_match=True, shard_offset=b,
+                                 rows_per_rank=max(y - x for x, y in bounds), engine=OracleEngine(world.torch))
+    wall, result = timed_steps(world, _NoDevice(), job.step, args.steps, args.warmup)
+    idx, val = result.download()
+    idx, val = job.whole_result(idx, val, [y - x for x, y in bounds])
+    if world.rank != 0:
+        return None
+    return {"rehearsal": "--rehearse-cpu: tests/cpu_engine.py in place of the device -- NOT a measurement", "world": world.size,
+            "steps": args.steps, "rows": len(names), "result_is_full": bool(job.result_is_full),
+            "idx_crc32": zlib.crc32(np.ascontiguousarray(idx, np.int32).tobytes()),
+            "val_crc32": zlib.crc32(np.ascontiguousarray(val, np.float64).tobytes())}
+
+
+def self_launch(gpus):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (how the driver calls the bench): become the
+    launcher -- the contract's own command line, one rank per GPU --, pass rank 0's JSON line through, return the job's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {gpus} without WORLD_SIZE: launching {' '.join(cmd[1:8])} ... ({gpus} ranks)", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 class LocalWorld(World):
@@ -992,15 +1063,24 @@ def main():
         out["config"]["devices_visible"] = n_dev
     else:
         if env_world != args.gpus:
-            if env_world == 1 and args.gpus > 1:
-                raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU), "
-                                 "or with --transport local")
+            if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+                raise SystemExit(self_launch(args.gpus))
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}")
+        if args.rehearse_cpu:
+            world = TorchWorld(need_devices=False)
+            out = rehearse_cpu(world, args)
+            world.close()
+            if out is not None:
+                print(json.dumps(out))
+            return
         world = TorchWorld() if env_world > 1 else World()
         # one process, one GPU: the matchers' own default context, so that the library's kernel timers see their launches too
         ctx = polyfuzz_amd.Context(world.local_rank) if env_world > 1 else polyfuzz_amd.Context.default()
         out = run_rank(world, ctx, args)
         if env_world > 1:
+            if out is not None:
+                out["config"]["rccl"] = world.rccl
+                out["config"]["rendezvous"] = "torch.distributed over gloo (host): id broadcast, barrier, max over ranks; RCCL is the library's alone"
             world.close()
     if out is not None:
         if args.small:

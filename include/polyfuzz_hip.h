@@ -335,6 +335,10 @@ int pfz_linkage_top1(pfz_ctx *ctx, const pfz_topn *result, double min_similarity
  * (torch.distributed / MPI / a file), every rank calls pfz_comm_init. */
 int pfz_comm_unique_id(uint8_t id128[128]);
 int pfz_comm_init(pfz_ctx *ctx, const uint8_t id128[128], int32_t rank, int32_t world, pfz_comm **out);
+/* NCCL_VERSION_CODE of the rccl.h this library was compiled against, and ncclGetVersion() of the librccl the process resolved (a
+ * torch wheel brings its own; the reference has no collective library at all -- joblib only, _distance.py:77).  pfz_comm_init
+ * refuses (PFZ_ERR_RCCL) when the majors differ; bench.py prints both in its line. */
+int pfz_rccl_versions(int32_t *header, int32_t *runtime);
 void pfz_comm_destroy(pfz_comm *c);
 /* The same communicator interface inside ONE process: `world` contexts -- on different GPUs or on the
  * same one -- each driven by its own host thread.  A collective is a host rendezvous of the ranks plus

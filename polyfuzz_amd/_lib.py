@@ -61,6 +61,7 @@ SIGNATURES = {
     "pfz_index_symmetric_ok": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, P(c_i32)]),
     "pfz_comm_cossim_topn_symmetric": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_vp]),
     "pfz_comm_symmetric_ok": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, P(c_i32)]),
+    "pfz_rccl_versions": (ctypes.c_int, [P(c_i32), P(c_i32)]),
     "pfz_topn_alloc": (ctypes.c_int, [c_vp, c_i64, c_i32, P(c_vp)]),
     "pfz_topn_free": (None, [c_vp]),
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
@@ -777,6 +778,24 @@ class Comm(_Handle):
             out = DeviceTopN.alloc(self.ctx, local.n_rows * self.world, local.ntop)
         check(self.ctx.lib.pfz_comm_allgather_topn(self.h, local.h, out.h))
         return out
+
+
+def rccl_versions():
+    """{'header': NCCL_VERSION_CODE the library was compiled against, 'runtime': ncclGetVersion() of the librccl this process
+    resolved, 'path': that library's file (from /proc/self/maps)}"""
+    lib = load()
+    h, r = c_i32(0), c_i32(0)
+    check(lib.pfz_rccl_versions(ctypes.byref(h), ctypes.byref(r)))
+    path = None
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    path = line.split()[-1]
+                    break
+    except OSError:
+        pass
+    return {"header": h.value, "runtime": r.value, "path": path}
 
 
 def tfidf_fit_sharded(ctx, comm, params, replicated, local_shard):

@@ -237,10 +237,29 @@ int pfz_comm_unique_id(uint8_t id128[128])
     return PFZ_OK;
 }
 
+int pfz_rccl_versions(int32_t *header, int32_t *runtime)
+{
+    int v = 0;
+    PFZ_RCCL(ncclGetVersion(&v));
+    if (header) *header = NCCL_VERSION_CODE;
+    if (runtime) *runtime = v;
+    return PFZ_OK;
+}
+
 int pfz_comm_init(pfz_ctx *ctx, const uint8_t id128[128], int32_t rank, int32_t world, pfz_comm **out)
 {
     PFZ_REQUIRE(ctx && id128 && out, "pfz_comm_init: NULL argument");
     PFZ_REQUIRE(world >= 1 && rank >= 0 && rank < world, "pfz_comm_init: rank %d of %d", rank, world);
+    {   // the library was compiled against one rccl.h and runs on whatever librccl the process resolved (a torch wheel ships its
+        // own): structures and enums are stable inside a major version only -- refuse loudly across one
+        int v = 0;
+        PFZ_RCCL(ncclGetVersion(&v));
+        if (v / 10000 != NCCL_VERSION_CODE / 10000) {
+            set_error("pfz_comm_init: compiled against rccl.h %d but the process resolved librccl %d: major versions differ",
+                      (int)NCCL_VERSION_CODE, v);
+            return PFZ_ERR_RCCL;
+        }
+    }
     PFZ_HIP(hipSetDevice(ctx->device));
     ncclUniqueId uid;
     memcpy(&uid, id128, sizeof(uid));
