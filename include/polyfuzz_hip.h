@@ -63,6 +63,9 @@ int pfz_ctx_info(pfz_ctx *ctx, char *name256, int32_t *n_cu, int64_t *hbm_bytes)
 int pfz_event_record(pfz_ctx *ctx, int32_t slot);
 /* blocks until both events completed */
 int pfz_event_elapsed_ms(pfz_ctx *ctx, int32_t slot_begin, int32_t slot_end, float *ms);
+/* block until event slot `slot` has fired (recorded by pfz_event_record, or by pfz_cossim_topn_ranges for its row ranges -- those
+ * are also announced through a word in pinned host memory, which this call polls instead of sleeping on the runtime's event) */
+int pfz_event_wait(pfz_ctx *ctx, int32_t slot);
 /* per-kernel profile: when enabled, every launch of the named hot kernels is
  * bracketed by its own event pair (adds a little launch overhead: ~2 % of a 100k x 100k step).
  * on = 1: every profiled kernel; on = 2: only the dominant ones (k3_cossim_topn, k4_indel, k5_gemm_panel). */
@@ -120,6 +123,12 @@ int pfz_topn_download(pfz_ctx *ctx, const pfz_topn *t, int32_t *out_idx, float *
  * copy goes through a side stream, so work enqueued on the context stream after the event is not waited for.  Blocks. */
 int pfz_topn_download_rows_after(pfz_ctx *ctx, const pfz_topn *t, int64_t row_begin, int64_t row_end,
                                  int32_t event_slot, int32_t *out_idx, float *out_val);
+/* The same in two halves, without the copy into caller buffers: _begin enqueues the side stream's wait for the event and the two
+ * device-to-host copies into pinned staging half `half` (0 / 1) and returns; _finish waits for them and hands out the pinned
+ * pointers (valid until the next _begin on that half).  A caller that consumes range i while range i + 1 is already on its way
+ * (the frame's column fills of reference _utils.py:104-125) alternates the halves. */
+int pfz_topn_rows_begin(pfz_ctx *ctx, const pfz_topn *t, int64_t row_begin, int64_t row_end, int32_t event_slot, int32_t half);
+int pfz_topn_rows_finish(pfz_ctx *ctx, int32_t half, const int32_t **idx, const float **val);
 /* fill a result buffer from host arrays [n_rows * ntop] (results computed elsewhere, e.g. another rank's block) */
 int pfz_topn_upload(pfz_ctx *ctx, pfz_topn *t, const int32_t *idx, const float *val);
 /* raw device pointers (for an RCCL all-gather issued by the caller) */
@@ -153,6 +162,20 @@ int pfz_cossim_topn(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from
 int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix,
                          int64_t row_begin, int64_t row_end, int32_t ntop, float lower_bound,
                          int32_t exclude_diag, int64_t diag_offset, pfz_topn *out);
+
+/* The whole match, its results handed on in n_ranges ascending row ranges: range i = from-rows [range_ends[i-1], range_ends[i])
+ * (the last one ends at the matrix' last row); event slot first_event + i fires when the rows of range i are final in `out`
+ * (consume them with pfz_topn_rows_begin / _finish or pfz_topn_download_rows_after while the device works on).  What
+ * `TFIDF.match` (reference _tfidf.py:68-100 -> _utils.py:82-125) enqueues for a big list, so that the frame's columns are built
+ * under the device's work.  A list against itself in the symmetric form with range ends on multiples of 2048 rows runs ONE
+ * pass-1 launch whose ranges are merged on a side stream as their blocks complete; anything else is a launch per range.
+ * host_idx / host_val (may be NULL): where that streamed form runs, *host_idx / *host_val come back as int32 [n_rows][ntop] /
+ * fp32 [n_rows][ntop] in PINNED HOST memory of the context that the device fills beside `out` -- rows of range i are there once
+ * pfz_event_wait(first_event + i) has returned; valid until the next call with a mirror on this context --, NULL otherwise (then:
+ * pfz_topn_rows_begin / _finish).  diag_offset is 0.  Enqueues. */
+int pfz_cossim_topn_ranges(pfz_ctx *ctx, const pfz_index *to_index, const pfz_csr *from_matrix, int32_t ntop, float lower_bound,
+                           int32_t exclude_diag, int32_t n_ranges, const int64_t *range_ends, int32_t first_event, pfz_topn *out,
+                           const int32_t **host_idx, const float **host_val);
 
 /* One-shot host convenience: upload both CSR matrices, build the index, run
  * pfz_cossim_topn, download.  Blocks. */

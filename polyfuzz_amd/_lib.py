@@ -67,6 +67,10 @@ SIGNATURES = {
     "pfz_topn_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pfz_topn_clear": (ctypes.c_int, [c_vp, c_vp]),
     "pfz_topn_download_rows_after": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    "pfz_topn_rows_begin": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32]),
+    "pfz_topn_rows_finish": (ctypes.c_int, [c_vp, c_i32, P(c_vp), P(c_vp)]),
+    "pfz_cossim_topn_ranges": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32, P(c_i64), c_i32, c_vp, P(c_vp), P(c_vp)]),
+    "pfz_event_wait": (ctypes.c_int, [c_vp, c_i32]),
     "pfz_topn_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pfz_topn_device_ptrs": (ctypes.c_int, [c_vp, P(c_vp), P(c_vp), P(c_i64), P(c_i32)]),
     "pfz_cossim_topn": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_f32, c_i32, c_i64, c_vp]),
@@ -204,6 +208,10 @@ class Context:
     # timers ---------------------------------------------------------------
     def event_record(self, slot):
         check(self.lib.pfz_event_record(self.h, slot))
+
+    def event_wait(self, slot):
+        """block until event slot `slot` has fired (pfz_event_wait)"""
+        check(self.lib.pfz_event_wait(self.h, slot))
 
     def event_elapsed_ms(self, a, b):
         ms = c_f32()
@@ -351,6 +359,17 @@ class DeviceTopN(_Handle):
                                                         _ptr(val)))
         return idx, val
 
+    def rows_begin(self, begin, end, event_slot, half):
+        """enqueue the download of rows [begin, end) behind the context's event `event_slot` into pinned staging half 0 / 1"""
+        check(self.ctx.lib.pfz_topn_rows_begin(self.ctx.h, self.h, int(begin), int(end), int(event_slot), int(half)))
+
+    def rows_finish(self, half):
+        """wait for the download begun on `half`: (address of int32 idx[rows][ntop], address of fp32 val[rows][ntop]) in PINNED
+        memory of the context, valid until the next rows_begin on that half"""
+        a, b = c_vp(), c_vp()
+        check(self.ctx.lib.pfz_topn_rows_finish(self.ctx.h, int(half), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     @classmethod
     def from_host(cls, ctx, idx, val):
         idx = np.ascontiguousarray(idx, np.int32)
@@ -384,6 +403,22 @@ def cossim_topn(ctx, index, from_csr, ntop, lower_bound, exclude_diag=False, dia
         check(ctx.lib.pfz_cossim_topn_rows(ctx.h, index.h, from_csr.h, int(rows[0]), int(rows[1]), int(ntop),
                                            float(lower_bound), int(bool(exclude_diag)), int(diag_offset), out.h))
     return out
+
+
+def cossim_topn_ranges(ctx, index, from_csr, ntop, lower_bound, exclude_diag, range_ends, first_event, out=None, mirror=False):
+    """Enqueue the whole match with its results handed on in ascending row ranges (pfz_cossim_topn_ranges): range i ends at
+    range_ends[i], the context's event first_event + i fires when its rows are final.  Returns the DeviceTopN -- with mirror=True:
+    (DeviceTopN, idx address, val address), the addresses of int32 idx[n][ntop] / fp32 val[n][ntop] in pinned HOST memory that
+    the device fills beside the result (rows of range i valid after ctx.event_wait(first_event + i)), or (DeviceTopN, None,
+    None) where the job does not run in the form that writes one."""
+    if out is None:
+        out = DeviceTopN.alloc(ctx, from_csr.n_rows, ntop)
+    ends = (c_i64 * len(range_ends))(*[int(e) for e in range_ends])
+    hi, hv = c_vp(), c_vp()
+    check(ctx.lib.pfz_cossim_topn_ranges(ctx.h, index.h, from_csr.h, int(ntop), float(lower_bound), int(bool(exclude_diag)),
+                                         len(range_ends), ends, int(first_event), out.h,
+                                         ctypes.byref(hi) if mirror else None, ctypes.byref(hv) if mirror else None))
+    return (out, hi.value, hv.value) if mirror else out
 
 
 def cossim_topn_host(ctx, from_csr3, to_csr3, n_cols, ntop, lower_bound, exclude_diag=False):

@@ -439,6 +439,9 @@ int k3_sym_wanted(const pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int
                   int32_t thr0, float scale, int32_t exclude_diag, int64_t diag_offset, const pfz_topn *out);
 int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t row_begin, int64_t row_end, int32_t ntop,
                   int32_t thr0, float scale, float inv_scale, pfz_topn *out, bool start, bool *declined);
+int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t thr0, float scale, float inv_scale,
+                           pfz_topn *out, int32_t n_ranges, const int64_t *ends, int32_t first_event, int32_t *host_idx, float *host_val,
+                           bool *declined);
 void k3_sym_free(pfz_index *ix);
 
 }  // namespace pfz

@@ -853,6 +853,75 @@ int pfz_cossim_topn_rows(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, in
     return PFZ_OK;
 }
 
+int pfz_cossim_topn_ranges(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t ntop, float lower_bound, int32_t exclude_diag,
+                           int32_t n_ranges, const int64_t *range_ends, int32_t first_event, pfz_topn *out, const int32_t **host_idx,
+                           const float **host_val)
+{
+    if (host_idx) *host_idx = nullptr;
+    if (host_val) *host_val = nullptr;
+    PFZ_REQUIRE(ctx && ix && A && out && range_ends, "pfz_cossim_topn_ranges: NULL argument");
+    PFZ_REQUIRE(n_ranges >= 1 && first_event >= 0 && first_event + n_ranges <= kEventSlots,
+                "pfz_cossim_topn_ranges: %d ranges from event slot %d do not fit the %d slots", n_ranges, first_event, kEventSlots);
+    int64_t prev = 0;
+    bool on_blocks = true;
+    for (int32_t i = 0; i < n_ranges; ++i) {
+        PFZ_REQUIRE(range_ends[i] > prev && range_ends[i] <= A->n_rows, "pfz_cossim_topn_ranges: range ends must ascend inside (0, %lld]",
+                    (long long)A->n_rows);
+        on_blocks = on_blocks && (i == n_ranges - 1 || range_ends[i] % 2048 == 0);
+        prev = range_ends[i];
+    }
+    PFZ_REQUIRE(prev == A->n_rows, "pfz_cossim_topn_ranges: the last range must end at the matrix' last row");
+    PFZ_REQUIRE(ntop >= 1 && lower_bound == lower_bound && A->n_cols == ix->n_cols && out->n_rows >= A->n_rows && out->ntop == ntop,
+                "pfz_cossim_topn_ranges: arguments as for pfz_cossim_topn");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    // a list against itself in the symmetric form: ONE pass-1 launch, the ranges handed on as they finish (k3_symmetric.hip)
+    if (on_blocks && ntop <= kMaxTop && !getenv("PFZ_K3_NO_STREAMED")) {
+        float scale, inv_scale;
+        int32_t thr0;
+        k3_fixed_point(A, ix, lower_bound, &scale, &inv_scale, &thr0);
+        if (k3_sym_wanted(ctx, ix, A, 0, A->n_rows, ntop, thr0, scale, exclude_diag, 0, out) == 1) {
+            // the mirror of the result in pinned host memory, if the caller wants one (kept with the context, grown on demand)
+            int32_t *h_idx = nullptr;
+            float *h_val = nullptr;
+            if (host_idx && host_val) {
+                const size_t cells = (size_t)A->n_rows * (size_t)ntop;
+                const size_t bytes = cells * (sizeof(int32_t) + sizeof(float));
+                if (bytes > ctx->mirror_bytes) {
+                    PFZ_HIP(hipStreamSynchronize(ctx->stream));
+                    if (ctx->stream3) PFZ_HIP(hipStreamSynchronize(ctx->stream3));
+                    if (ctx->mirror) PFZ_HIP(hipHostFree(ctx->mirror));
+                    ctx->mirror = nullptr;
+                    ctx->mirror_bytes = 0;
+                    PFZ_HIP(hipHostMalloc((void **)&ctx->mirror, bytes + bytes / 8, hipHostMallocDefault));
+                    ctx->mirror_bytes = bytes + bytes / 8;
+                }
+                h_idx = (int32_t *)ctx->mirror;
+                h_val = (float *)(ctx->mirror + cells * sizeof(int32_t));
+            }
+            ProfScope ps(ctx, "k3_cossim_topn");
+            bool declined = false;
+            const int rc = k3_sym_launch_streamed(ctx, ix, A, ntop, thr0, scale, inv_scale, out, n_ranges, range_ends, first_event, h_idx, h_val,
+                                                  &declined);
+            if (!declined) {
+                if (rc == PFZ_OK && h_idx) {
+                    *host_idx = h_idx;
+                    *host_val = h_val;
+                }
+                return rc;
+            }
+        }
+    }
+    // everything else: a launch per range, its event on the context's stream
+    prev = 0;
+    for (int32_t i = 0; i < n_ranges; ++i) {
+        PFZ_TRY(pfz_cossim_topn_rows(ctx, ix, A, prev, range_ends[i], ntop, lower_bound, exclude_diag, 0, out));
+        PFZ_HIP(hipEventRecord(ctx->events[first_event + i], ctx->stream));
+        ctx->evt_want[first_event + i] = 0;
+        prev = range_ends[i];
+    }
+    return PFZ_OK;
+}
+
 int pfz_cossim_topn_host(pfz_ctx *ctx, int64_t n_from, int64_t n_to, int64_t n_cols, const int64_t *from_indptr,
                          const int32_t *from_indices, const float *from_data, const int64_t *to_indptr,
                          const int32_t *to_indices, const float *to_data, int32_t ntop, float lower_bound,

@@ -74,6 +74,7 @@ constexpr int kSymSlicedRows = 4096;   // ... for the first so many rows of the 
 #endif
 constexpr int kSymMag = 1;          // "magnet" rows per LDS bank class and block: the rows of the lowest thresholds are taken out of the hand-over
 constexpr int kSymMagBlocks = 8;   // ... and walk the blocks below their own themselves, in items of so many to-blocks
+constexpr int kSymDoneStride = 32;  // a block's item counter (streamed sessions) has a 128-byte line of its own: 2 000 atomics each, from every XCD
 constexpr int kNoThr = 0x7fffffff;     // threshold of a slot without a row (the last block's tail): no sum reaches it
 
 struct K3SymArgs {
@@ -107,6 +108,10 @@ struct K3SymArgs {
     int32_t ovf_base, ovf_max, n_sl;   // pass 2: listed rows [ovf_base, ovf_base + ovf_max), each cut into n_sl slices (1: whole rows -> result)
     int32_t *out_idx;
     float *out_val;
+    int32_t *host_idx;        // streamed session: a mirror of the result in pinned HOST memory (the frame builder reads it there: no
+    float *host_val;          //   device-to-host copy, no stream for the host to wait on), or NULL
+    uint32_t *done;           // [nb] streamed session (k3_sym_launch_streamed): pass-1 items finished per block of their row, or NULL
+    int32_t blk_lo, blk_hi;   // k3_sym_wait: the blocks whose items must have finished
 };
 
 // Where a row's pass-0 threshold sits in thrv: by row -- or, when the job is cut over n_parts GPUs, part by part (part p's
@@ -205,6 +210,65 @@ __global__ __launch_bounds__(256) void k3_sym_repost(const K3SymArgs a)
 constexpr uint32_t kStageOwn = 1u << 30;     // the sum beat the from-row's own threshold: a candidate of the from-row
 constexpr uint32_t kStageFgn = 1u << 31;     // the sum beat the minimum threshold of its lane's eight slots: maybe a candidate of the cell's row
 
+// ---- a session in ONE pass-1 launch whose row ranges are handed on as they finish (k3_sym_launch_streamed) --------------------
+// Whatever pass 1 leaves for the merge -- a row's keys, the candidates pushed to other rows -- is stored WRITE-THROUGH at agent
+// scope (sc1: no dirty line stays behind in this XCD's L2), and an item counts itself on `done[block of its row]` only after
+// those stores are acknowledged (s_waitcnt vmcnt(0); k3_lockstep.hip's chunk flags work the same way).  The merge of a row range
+// is a kernel of its own on a side stream, behind k3_sym_wait: its start invalidates what its XCD's L2 may hold of these rows,
+// and every row of the range -- and every row that pushes to one, all of them in lower or the same blocks -- has counted.
+#ifndef PFZ_K3_SYM_PLAIN_STORES
+#define PFZ_K3_SYM_PLAIN_STORES 0      // 1: A/B builds only (tools/build_variant.sh): plain stores -- a streamed session is then NOT coherent
+#endif
+__device__ inline void store_coherent(uint64_t *p, uint64_t v)
+{
+#if PFZ_K3_SYM_PLAIN_STORES
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+__device__ inline void sym_item_done(const K3SymArgs &a, int blk, int lane)
+{
+    if (!a.done) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&a.done[blk * kSymDoneStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// items of pass 1 that belong to block b of a whole job in one launch: its rows (the last block's have nothing above) + the magnet
+// items of its 32 * kSymMag magnet slots (items of empty slots and of slices that lie at or above the block count too)
+__device__ inline uint32_t sym_items_of_block(const K3SymArgs &a, int b)
+{
+    const int rows = b < a.nb - 1 ? (a.n - b * kSymC < kSymC ? a.n - b * kSymC : kSymC) : 0;
+    return (uint32_t)(rows + 32 * kSymMag * ((a.nb - 1 + kSymMagBlocks - 1) / kSymMagBlocks));
+}
+
+// one wave on the side stream: returns when every pass-1 item of the blocks [blk_lo, blk_hi) has counted itself.  A count that
+// does not arrive within ~10 s is a bug of this file: trap (a loud HIP error) rather than a stream that never ends.
+// (It also does the two chores that would otherwise be launches of their own, each ~20 us of host time on the side stream: it
+// announces the range BEFORE -- whose kernels have finished, the stream is in order -- through its word in pinned host memory, and it
+// clears the list of rows to recompute for the merge that follows.  flag == NULL / blk_lo == blk_hi: nothing to announce / to wait for.)
+__global__ __launch_bounds__(64) void k3_sym_wait(const K3SymArgs a, int32_t *flag, int32_t flag_value)
+{
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        if (flag) __hip_atomic_store(flag, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.ovf[0] = 0;
+    }
+    const uint64_t t0 = wall_clock64();
+    for (int b0 = a.blk_lo; b0 < a.blk_hi; b0 += 64) {
+        const int b = b0 + lane;
+        const bool on = b < a.blk_hi;
+        const uint32_t want = on ? sym_items_of_block(a, b) : 0u;
+        for (;;) {
+            const uint32_t got = on ? __hip_atomic_load(&a.done[b * kSymDoneStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (!__ballot(got < want)) break;
+            if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();      // (100 MHz)
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+
 template <int kCap>
 __device__ inline void drain_stage(uint64_t *cand, TopState &st, uint64_t *fbuf, int &fcnt, int ntop, int lane,
                                    const K3SymArgs &a, uint32_t inv_row)
@@ -228,7 +292,7 @@ __device__ inline void drain_stage(uint64_t *cand, TopState &st, uint64_t *fbuf,
         if ((lo & kStageFgn) && x > thr) {         // one returning atomic, one store
 #endif
             const int pos = atomicAdd(&a.push_cnt[row], 1);
-            if (pos < kSymPush) a.push_buf[(int64_t)row * kSymPush + pos] = (en & 0xffffffff00000000ull) | inv_row;
+            if (pos < kSymPush) store_coherent(&a.push_buf[(int64_t)row * kSymPush + pos], (en & 0xffffffff00000000ull) | inv_row);
         }
         const bool own = (lo & kStageOwn) && x > st.thr;      // (the threshold may have risen since the sum was staged)
         const uint64_t mo = __ballot(own);
@@ -329,8 +393,14 @@ __device__ inline void store_result(const K3SymArgs &a, int row, int r, uint64_t
     if (a.keys_out) {
         a.keys_out[(int64_t)row * a.ntop + r] = key;
     } else {
-        a.out_idx[(int64_t)row * a.ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
-        a.out_val[(int64_t)row * a.ntop + r] = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
+        const int32_t j = key ? (int32_t)(~(uint32_t)key) : -1;
+        const float v = key ? (float)(int32_t)(uint32_t)(key >> 32) * a.inv_scale : 0.f;
+        a.out_idx[(int64_t)row * a.ntop + r] = j;
+        a.out_val[(int64_t)row * a.ntop + r] = v;
+        if (a.host_idx) {          // (visible to the host when the kernel has ended: the word that announces the range is written by a LATER kernel of the stream)
+            a.host_idx[(int64_t)row * a.ntop + r] = j;
+            a.host_val[(int64_t)row * a.ntop + r] = v;
+        }
     }
 }
 
@@ -390,12 +460,16 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
                 const int ns = (nb - 1 + kSymMagBlocks - 1) / kSymMagBlocks;
                 const int mm = item / ns;
                 m_lo = (item - mm * ns) * kSymMagBlocks;
-                row = __builtin_amdgcn_readfirstlane(a.mag[(int64_t)(a.mag_b0 + mm / (32 * kSymMag)) * (32 * kSymMag) + mm % (32 * kSymMag)]);
-                if (row < a.row_begin || row >= a.mag_row_end || m_lo >= row / C || !row_is_mine(a, row)) continue;     // (-1: no magnet)
+                const int mblk = a.mag_b0 + mm / (32 * kSymMag);
+                row = __builtin_amdgcn_readfirstlane(a.mag[(int64_t)mblk * (32 * kSymMag) + mm % (32 * kSymMag)]);
+                if (row < a.row_begin || row >= a.mag_row_end || m_lo >= row / C || !row_is_mine(a, row)) {     // (-1: no magnet)
+                    sym_item_done(a, mblk, lane);
+                    continue;
+                }
                 magnet = true;
             } else {
                 row -= a.n_mag_items * a.n_parts;
-                if (row >= (nb - 1) * C) continue;      // (the last block's rows have nothing above)
+                if (row >= (nb - 1) * C) continue;      // (the last block's rows have nothing above: not launched by a streamed session)
             }
         }
         const int own = row / C;
@@ -559,26 +633,35 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
             // what the row found below its own block, to its own push slots (the merge joins them with the row's keys)
             if (lane < st.cnt) {
                 const int pos = atomicAdd(&a.push_cnt[row], 1);
-                if (pos < kSymPush) a.push_buf[(int64_t)row * kSymPush + pos] = cand[lane];
+                if (pos < kSymPush) store_coherent(&a.push_buf[(int64_t)row * kSymPush + pos], cand[lane]);
             }
         } else if (mode == 2 && n_sl > 1) {
             if (lane < ntop) a.part[(int64_t)item * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
         } else if (mode == 2) {
             for (int r = lane; r < ntop; r += 64) store_result(a, row, r, r < st.cnt ? cand[r] : 0ull);
         } else {
-            if (lane < ntop) a.keys[(int64_t)row * ntop + lane] = lane < st.cnt ? cand[lane] : 0ull;
+            if (lane < ntop) {
+                const uint64_t k = lane < st.cnt ? cand[lane] : 0ull;
+                if (mode == 1) store_coherent(&a.keys[(int64_t)row * ntop + lane], k);
+                else a.keys[(int64_t)row * ntop + lane] = k;
+            }
             if (mode == 0 && lane == 0) a.thrv[thr_pos(a, row)] = st.thr;
         }
+        if (mode == 1) sym_item_done(a, own, lane);
         wave_sync();    // cand is reused by the next item
     }
 }
 
 // own keys + pushed keys -> the row's sorted top-n (one wave per row); rows that were sent more than kSymPush are listed
-__global__ __launch_bounds__(256) void k3_sym_merge(const K3SymArgs a)
+// (kWaves rows per workgroup.  4 as a rule; 1 for a streamed session, whose merges run BESIDE pass 1: a CU's LDS is full of pass-1
+// workgroups of ~10 KB each, and only a workgroup that fits the hole ONE of them leaves -- 4.6 KB here, not 18 -- gets in before
+// pass 1 has finished.  Measured: the four-row merge of the first range sat in its queue for 1.2 ms, stream priority or not.)
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void k3_sym_merge(const K3SymArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][kSymMergeCap];
+    __shared__ __attribute__((aligned(16))) uint64_t cand_all[kWaves][kSymMergeCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = a.row_begin + blockIdx.x * 4 + wave;
+    const int row = a.row_begin + blockIdx.x * kWaves + wave;
     if (row >= a.row_end) return;
     uint64_t *cand = cand_all[wave];
     const int ntop = a.ntop;
@@ -662,6 +745,7 @@ struct K3SymState {
     uint64_t *push_buf = nullptr;
     int32_t *ovf = nullptr;
     uint64_t *part = nullptr;
+    uint32_t *done = nullptr;            // [nb] streamed sessions: pass-1 items finished per block
     // the running session: the next range must start where the last one ended, with the same job
     int64_t next_row = -1;
     uint64_t a_serial = 0;
@@ -675,7 +759,7 @@ void k3_sym_free(pfz_index *ix)
 {
     K3SymState *s = ix->sym;
     if (!s) return;
-    void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
+    void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part, s->done};
     for (void *p : bufs)
         if (p) pool_free(p);
     delete s;
@@ -729,6 +813,7 @@ static int sym_state_alloc(pfz_ctx *ctx, const pfz_index *ix, K3SymState *s)
     PFZ_TRY(pool_alloc(ctx, &s->push_buf, (size_t)n * kSymPush * sizeof(uint64_t)));
     PFZ_TRY(pool_alloc(ctx, &s->ovf, (size_t)(n + 1) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->part, (size_t)kSymSlicedRows * kSymSlices * kSymKeep * sizeof(uint64_t)));
+    PFZ_TRY(pool_alloc(ctx, &s->done, (size_t)(ix->n_blocks + 64) * kSymDoneStride * sizeof(uint32_t)));
     return PFZ_OK;
 }
 
@@ -743,7 +828,7 @@ static K3SymState *sym_state_of(pfz_ctx *ctx, const pfz_index *ix)
     s->n = ix->n_rows;
     ix->sym = s;      // (freed with the index, whatever happens below)
     if (getenv("PFZ_K3_SYM_FAIL_ALLOC") || sym_state_alloc(ctx, ix, s) != PFZ_OK) {      // (the knob: tests of this fallback)
-        void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part};
+        void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part, s->done};
         for (void *p : bufs)
             if (p) pool_free(p);
         *s = K3SymState();
@@ -808,13 +893,18 @@ static void sym_fill_args(K3SymArgs &a, const pfz_index *ix, const pfz_csr *A, K
     a.n_sl = 1;
     a.out_idx = nullptr;
     a.out_val = nullptr;
+    a.done = nullptr;
+    a.blk_lo = a.blk_hi = 0;
+    a.host_idx = nullptr;
+    a.host_val = nullptr;
 }
 
 // pass 2 of the rows the merge listed (sent more than their push slots hold): the first kSymSlicedRows in slices of the to-blocks
 // (a whole row is ~100 us of one wave: a handful of rows would cost that much wall time), their partial lists merged; whatever is
 // listed beyond, as whole rows
-static void sym_launch_pass2(pfz_ctx *ctx, K3SymArgs a)
+static void sym_launch_pass2(pfz_ctx *ctx, K3SymArgs a, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = ctx->stream;
     const int nb = a.nb;
     const unsigned grid2 = (unsigned)ctx->prop.multiProcessorCount * 16;
     const int per = (nb + kSymSlices - 1) / kSymSlices;
@@ -824,13 +914,13 @@ static void sym_launch_pass2(pfz_ctx *ctx, K3SymArgs a)
     a.ovf_base = 0;
     a.ovf_max = kSymSlicedRows;
     if (a.n_sl > 1) {
-        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
-        hipLaunchKernelGGL(k3_sym_merge_slices, dim3(256), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(k3_sym_merge_slices, dim3(256), dim3(256), 0, stream, a);
         a.ovf_base = kSymSlicedRows;
     }
     a.n_sl = 1;
     a.ovf_max = a.n;
-    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 2>), dim3(grid2), dim3(64), 0, stream, a);
 }
 
 // *declined: the buffers of the session could not be allocated -- nothing was enqueued, the caller runs the row-major kernel
@@ -901,12 +991,102 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     // merge, then the rows that were sent too much
     a.row_begin = (int32_t)row_begin;
     a.row_end = (int32_t)row_end;
-    hipLaunchKernelGGL(k3_sym_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k3_sym_merge<4>, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, ctx->stream, a);
     sym_launch_pass2(ctx, a);
     PFZ_HIP(hipGetLastError());
     s->next_row = row_end;
     s->launches += 1;
     s->rows += row_end - row_begin;
+    s->a_serial = A->serial;
+    s->out = out;
+    s->ntop = ntop;
+    s->thr0 = thr0;
+    s->scale = scale;
+    return PFZ_OK;
+}
+
+// ---- the whole job in ONE pass-1 launch, its row ranges handed on as they finish --------------------------------------------------
+// What TFIDF.match wants from a big self-match is its rows in ascending ranges, each as soon as it is final, so that the frame's
+// columns are built while the device works on.  Round 5 enqueued one session launch per range: every range paid its own pass-1
+// tail (a launch ends on its slowest rows), merge and overflow pass -- 2.2 ms of K3 in four ranges where one launch takes 1.8.
+// Here pass 1 is ONE launch over all rows (and all magnet items) on the context's stream; every item counts itself on `done[block
+// of its row]`; on a side stream, per range: k3_sym_wait (one wave) until the blocks up to the range's end are complete -- whoever
+// pushes to a row sits in a lower or the same block --, the range's merge, its overflow pass, and the event the host's download
+// waits for.  ends[i]: multiples of 2048 except the last (= n).  Results: the session's, bit for bit.
+int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int32_t ntop, int32_t thr0, float scale, float inv_scale,
+                           pfz_topn *out, int32_t n_ranges, const int64_t *ends, int32_t first_event, int32_t *host_idx, float *host_val,
+                           bool *declined)
+{
+    const int64_t n = ix->n_rows;
+    const int nb = ix->n_blocks;
+    *declined = false;
+    K3SymState *s = sym_state_of(ctx, ix);
+    if (!s) {
+        *declined = true;
+        return PFZ_OK;
+    }
+    if (!ctx->stream3) {
+        // HIGH priority: the merges are a few microseconds of work that must get wave slots while pass 1 still has tens of thousands of
+        // workgroups to dispatch (at equal priority the side stream's kernels were served when pass 1 had finished: measured)
+        int pr_lo = 0, pr_hi = 0;
+        PFZ_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        PFZ_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, pr_hi));
+        PFZ_HIP(hipEventCreateWithFlags(&ctx->ev3, hipEventDisableTiming));
+    }
+    s->next_row = -1;
+    K3SymArgs a;
+    sym_fill_args(a, ix, A, s, ntop, thr0, scale, inv_scale);
+    a.out_idx = out->idx;
+    a.out_val = out->val;
+    a.host_idx = host_idx;
+    a.host_val = host_val;
+    PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
+    PFZ_HIP(hipMemsetAsync(s->done, 0, (size_t)nb * kSymDoneStride * sizeof(uint32_t), ctx->stream));
+    const unsigned grid0 = (unsigned)std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * sym_env_int("PFZ_K3_SYM_P0_PER_CU", 128));
+    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(grid0), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
+    const int64_t pairs = sym_repost_pairs(ix);
+    hipLaunchKernelGGL(k3_sym_repost, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    PFZ_HIP(hipEventRecord(ctx->ev3, ctx->stream));            // (the counters are zero, the slots re-dealt)
+    // pass 1: every row that has blocks above + the magnet items of every block, one launch
+    const int64_t last_block_row = (int64_t)(nb - 1) * kSymC;
+    a.row_begin = 0;
+    a.row_end = (int32_t)last_block_row;
+    a.mag_b0 = 0;
+    a.mag_row_end = (int32_t)n;
+    a.n_mag_items = (int32_t)((int64_t)nb * 32 * kSymMag * ((nb - 1 + kSymMagBlocks - 1) / kSymMagBlocks));
+    a.done = s->done;
+    hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(a.row_end + a.n_mag_items)), dim3(64), 0, ctx->stream, a);
+    PFZ_HIP(hipGetLastError());
+    a.n_mag_items = 0;
+    // the ranges, on the side stream
+    hipStream_t side = ctx->stream3;
+    PFZ_HIP(hipStreamWaitEvent(side, ctx->ev3, 0));
+    int64_t row0 = 0;
+    int32_t *flag = nullptr;
+    int32_t flag_value = 0;
+    for (int32_t i = 0; i < n_ranges; ++i) {
+        const int64_t row1 = ends[i];
+        a.blk_lo = (int32_t)(row0 / kSymC);
+        a.blk_hi = (int32_t)((row1 + kSymC - 1) / kSymC);
+        hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, side, a, flag, flag_value);
+        a.row_begin = (int32_t)row0;
+        a.row_end = (int32_t)row1;
+        hipLaunchKernelGGL(k3_sym_merge<1>, dim3((unsigned)(row1 - row0)), dim3(64), 0, side, a);
+        sym_launch_pass2(ctx, a, side);
+        PFZ_HIP(hipGetLastError());
+        PFZ_HIP(hipEventRecord(ctx->events[first_event + i], side));
+        PFZ_TRY(event_flag_next(ctx, first_event + i, &flag, &flag_value));       // (... and as a word in pinned memory: pfz_topn_rows_begin / _finish)
+        row0 = row1;
+    }
+    a.blk_lo = a.blk_hi = 0;
+    hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, side, a, flag, flag_value);      // (the last range's word)
+    PFZ_HIP(hipGetLastError());
+    // whatever follows on the context's stream (and its timers) comes after the last range
+    PFZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->events[first_event + n_ranges - 1], 0));      // (the last announcement follows it: nobody on this stream needs it)
+    s->next_row = n;
+    s->launches += 1;
+    s->rows += n;
     s->a_serial = A->serial;
     s->out = out;
     s->ntop = ntop;
@@ -1032,7 +1212,7 @@ static int k3_sym_sharded_body(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix
     // this part's list of every row; the rows it was sent too much for, in full
     a.row_begin = 0;
     a.row_end = (int32_t)n;
-    hipLaunchKernelGGL(k3_sym_merge, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k3_sym_merge<4>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, a);
     sym_launch_pass2(ctx, a);
     PFZ_HIP(hipGetLastError());
     // the parts' lists -> the result, on every GPU

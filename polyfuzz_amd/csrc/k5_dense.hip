@@ -539,10 +539,7 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
     panel = std::max<int64_t>(kTile, std::min<int64_t>(panel / kTile * kTile, ((n_from + kTile - 1) / kTile) * kTile));
     const int64_t n_panels = (n_from + panel - 1) / panel;
     const bool two = n_panels > 1 && !getenv("PFZ_K5_NO_OVERLAP");       // env: A/B timing
-    if (two && !ctx->stream2) {
-        PFZ_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        for (hipEvent_t &ev : ctx->side_events) PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
+    if (two) PFZ_TRY(ensure_side_stream(ctx));
     if (ld > 0) {
         PFZ_TRY(pool_alloc(ctx, &dS[0].p, (size_t)panel * (size_t)ld * sizeof(float)));
         if (two) PFZ_TRY(pool_alloc(ctx, &dS[1].p, (size_t)panel * (size_t)ld * sizeof(float)));

@@ -140,9 +140,27 @@ static int stage_take(pfz_ctx *ctx, size_t bytes, char **out)
 int ensure_side_stream(pfz_ctx *ctx)
 {
     if (!ctx->stream2) {
-        PFZ_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        // HIGH priority: what runs here are short pieces beside a long kernel of the context's stream -- the download of a finished
+        // row range while K3's pass 1 fills every CU (at equal priority the copy was served when pass 1 had ended: measured), the row
+        // top-n of one score panel beside the GEMM of the next (K5)
+        int pr_lo = 0, pr_hi = 0;
+        PFZ_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        PFZ_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, pr_hi));
         for (hipEvent_t &ev : ctx->side_events) PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
+    return PFZ_OK;
+}
+
+int event_flag_next(pfz_ctx *ctx, int32_t slot, int32_t **flag, int32_t *value)
+{
+    if (!ctx->evt_flag) {
+        PFZ_HIP(hipHostMalloc((void **)&ctx->evt_flag, kEventSlots * sizeof(int32_t), hipHostMallocDefault));
+        memset(ctx->evt_flag, 0, kEventSlots * sizeof(int32_t));
+    }
+    ctx->evt_serial = ctx->evt_serial == 0x7fffffff ? 1 : ctx->evt_serial + 1;
+    ctx->evt_want[slot] = ctx->evt_serial;
+    *flag = ctx->evt_flag + slot;
+    *value = ctx->evt_serial;
     return PFZ_OK;
 }
 
@@ -571,12 +589,23 @@ void pfz_ctx_destroy(pfz_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->stage2) (void)hipHostFree(ctx->stage2);
+    if (ctx->evt_flag) (void)hipHostFree(ctx->evt_flag);
+    if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+    for (char *p : ctx->rows_stage)
+        if (p) (void)hipHostFree(p);
+    for (hipEvent_t ev : ctx->rows_ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->side_events)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);
     }
+    if (ctx->stream3) {
+        (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamDestroy(ctx->stream3);
+    }
+    if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
     (void)pool_release(ctx);
     {   // blocks still owned by live handles of this context: free them, the handles become inert
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -613,6 +642,35 @@ int pfz_event_record(pfz_ctx *ctx, int32_t slot)
 {
     PFZ_REQUIRE(ctx && slot >= 0 && slot < kEventSlots, "pfz_event_record: bad slot %d", slot);
     PFZ_HIP(hipEventRecord(ctx->events[slot], ctx->stream));
+    ctx->evt_want[slot] = 0;      // (an event of the context's own stream: no word in pinned memory)
+    return PFZ_OK;
+}
+
+// spin on the pinned word of an event slot (event_flag_next); the side stream running dry without the word is an error, not a hang
+static int event_flag_spin(pfz_ctx *ctx, int32_t slot, const char *who)
+{
+    const int32_t want = ctx->evt_want[slot];
+    const volatile int32_t *flag = ctx->evt_flag + slot;
+    for (uint64_t spins = 0; *flag != want; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xffff) == 0xffff && ctx->stream3 && hipStreamQuery(ctx->stream3) == hipSuccess && *flag != want) {
+            PFZ_HIP(hipStreamSynchronize(ctx->stream3));
+            if (*flag != want) {
+                set_error("%s: event slot %d was never announced", who, slot);
+                return PFZ_ERR_HIP;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return PFZ_OK;
+}
+
+int pfz_event_wait(pfz_ctx *ctx, int32_t slot)
+{
+    PFZ_REQUIRE(ctx && slot >= 0 && slot < kEventSlots, "pfz_event_wait: bad slot %d", slot);
+    if (ctx->evt_want[slot] != 0 && ctx->evt_flag) return event_flag_spin(ctx, slot, "pfz_event_wait");
+    PFZ_HIP(hipSetDevice(ctx->device));
+    PFZ_HIP(hipEventSynchronize(ctx->events[slot]));
     return PFZ_OK;
 }
 
@@ -840,10 +898,7 @@ int pfz_topn_download_rows_after(pfz_ctx *ctx, const pfz_topn *t, int64_t row_be
     PFZ_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)(row_end - row_begin) * (size_t)t->ntop;
     if (n == 0) return PFZ_OK;
-    if (!ctx->stream2) {
-        PFZ_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        for (hipEvent_t &ev : ctx->side_events) PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
+    PFZ_TRY(ensure_side_stream(ctx));
     const size_t bytes = n * (sizeof(int32_t) + sizeof(float));
     if (bytes > ctx->stage2_bytes) {
         PFZ_HIP(hipStreamSynchronize(ctx->stream2));
@@ -862,6 +917,78 @@ int pfz_topn_download_rows_after(pfz_ctx *ctx, const pfz_topn *t, int64_t row_be
     PFZ_HIP(hipStreamSynchronize(ctx->stream2));
     memcpy(out_idx, ctx->stage2, n * sizeof(int32_t));
     memcpy(out_val, ctx->stage2 + n * sizeof(int32_t), n * sizeof(float));
+    return PFZ_OK;
+}
+
+// the two copies of a pfz_topn_rows_begin job into its pinned half, and the event pfz_topn_rows_finish waits for
+static int rows_issue(pfz_ctx *ctx, int32_t half)
+{
+    pfz_ctx::RowsJob &job = ctx->rows_job[half];
+    const pfz_topn *t = job.t;
+    const size_t n = ctx->rows_n[half];
+    if (n) {
+        PFZ_HIP(hipMemcpyAsync(ctx->rows_stage[half], t->idx + job.row_begin * t->ntop, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream2));
+        PFZ_HIP(hipMemcpyAsync(ctx->rows_stage[half] + n * sizeof(int32_t), t->val + job.row_begin * t->ntop, n * sizeof(float),
+                               hipMemcpyDeviceToHost, ctx->stream2));
+    }
+    PFZ_HIP(hipEventRecord(ctx->rows_ev[half], ctx->stream2));
+    job.issued = true;
+    return PFZ_OK;
+}
+
+int pfz_topn_rows_begin(pfz_ctx *ctx, const pfz_topn *t, int64_t row_begin, int64_t row_end, int32_t event_slot, int32_t half)
+{
+    PFZ_REQUIRE(ctx && t, "pfz_topn_rows_begin: NULL argument");
+    PFZ_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= t->n_rows, "pfz_topn_rows_begin: bad row range");
+    PFZ_REQUIRE(event_slot >= 0 && event_slot < kEventSlots && (half == 0 || half == 1), "pfz_topn_rows_begin: bad event slot %d / half %d",
+                event_slot, half);
+    PFZ_HIP(hipSetDevice(ctx->device));
+    PFZ_TRY(ensure_side_stream(ctx));
+    if (!ctx->rows_ev[0])
+        for (hipEvent_t &ev : ctx->rows_ev) PFZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const size_t n = (size_t)(row_end - row_begin) * (size_t)t->ntop;
+    const size_t bytes = (n * (sizeof(int32_t) + sizeof(float)) + 255) & ~(size_t)255;
+    if (bytes > ctx->rows_bytes[half]) {
+        if (ctx->rows_stage[half]) {
+            PFZ_HIP(hipStreamSynchronize(ctx->stream2));
+            PFZ_HIP(hipHostFree(ctx->rows_stage[half]));
+        }
+        ctx->rows_stage[half] = nullptr;
+        ctx->rows_bytes[half] = 0;
+        PFZ_HIP(hipHostMalloc((void **)&ctx->rows_stage[half], bytes + bytes / 4, hipHostMallocDefault));
+        ctx->rows_bytes[half] = bytes + bytes / 4;
+    }
+    ctx->rows_n[half] = n;
+    pfz_ctx::RowsJob &job = ctx->rows_job[half];
+    job.t = t;
+    job.row_begin = row_begin;
+    job.row_end = row_end;
+    job.slot = event_slot;
+    job.issued = false;
+    const int32_t want = ctx->evt_want[event_slot];
+    if (want == 0) {                 // an event of the context's stream: the side stream waits for it
+        PFZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->events[event_slot], 0));
+        return rows_issue(ctx, half);
+    }
+    // an event of a side stream with a word in pinned memory: if it has fired, the copies start now (beside whatever the host does
+    // next); if not, pfz_topn_rows_finish polls the word and starts them then
+    if (__atomic_load_n(&ctx->evt_flag[event_slot], __ATOMIC_ACQUIRE) == want) return rows_issue(ctx, half);
+    return PFZ_OK;
+}
+
+int pfz_topn_rows_finish(pfz_ctx *ctx, int32_t half, const int32_t **idx, const float **val)
+{
+    PFZ_REQUIRE(ctx && idx && val && (half == 0 || half == 1) && ctx->rows_ev[0] && ctx->rows_job[half].t,
+                "pfz_topn_rows_finish: no pfz_topn_rows_begin on half %d", half);
+    PFZ_HIP(hipSetDevice(ctx->device));
+    pfz_ctx::RowsJob &job = ctx->rows_job[half];
+    if (!job.issued) {
+        PFZ_TRY(event_flag_spin(ctx, job.slot, "pfz_topn_rows_finish"));
+        PFZ_TRY(rows_issue(ctx, half));
+    }
+    PFZ_HIP(hipEventSynchronize(ctx->rows_ev[half]));
+    *idx = (const int32_t *)ctx->rows_stage[half];
+    *val = (const float *)(ctx->rows_stage[half] + ctx->rows_n[half] * sizeof(int32_t));
     return PFZ_OK;
 }
 

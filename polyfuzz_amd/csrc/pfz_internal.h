@@ -76,6 +76,8 @@ struct pfz_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // side stream (K5: row top-n of one score panel beside the GEMM of the next), created on first use
     hipEvent_t side_events[4] = {};       // K5: panel ready x2, panel consumed x2
+    hipStream_t stream3 = nullptr;        // K3's streamed self-match: the per-range merges beside the one pass-1 launch (k3_sym_launch_streamed)
+    hipEvent_t ev3 = nullptr;             // ... "pass 1 is about to start" on the main stream
     hipDeviceProp_t prop;
     hipEvent_t events[pfz::kEventSlots] = {};
     bool prof = false;
@@ -90,6 +92,18 @@ struct pfz_ctx {
     size_t stage_bytes = 0, stage_off = 0;
     char *stage2 = nullptr;               // pinned staging of the side stream's downloads (pfz_topn_download_rows_after)
     size_t stage2_bytes = 0;
+    // "event slot i has fired" as a word in pinned host memory, for events that fire on a side stream (K3's streamed self-match): the
+    // host polls the word and enqueues its copy WITHOUT a stream dependency -- a copy that waits for another stream's event was
+    // started a millisecond late by the runtime (measured, k3_sym_launch_streamed).  evt_want[i] = 0: slot i has no word, use the event
+    int32_t *evt_flag = nullptr;          // [kEventSlots] pinned, written by the side stream's kernels (k3_sym_wait)
+    int32_t evt_want[pfz::kEventSlots] = {};
+    int32_t evt_serial = 0;
+    struct RowsJob { const pfz_topn *t = nullptr; int64_t row_begin = 0, row_end = 0; int32_t slot = -1; bool issued = false; } rows_job[2];
+    char *mirror = nullptr;               // pinned host mirror of a streamed match's result (pfz_cossim_topn_ranges)
+    size_t mirror_bytes = 0;
+    char *rows_stage[2] = {};             // pinned staging halves of pfz_topn_rows_begin / _finish
+    size_t rows_bytes[2] = {}, rows_n[2] = {};
+    hipEvent_t rows_ev[2] = {};
     // single-pass scan (exclusive_scan_i32): per-tile state words + the tile ticket, zeroed once; every call has its own epoch
     uint64_t *scan_state = nullptr;
     size_t scan_tiles = 0;
@@ -244,6 +258,9 @@ int64_t csr_nnz(const pfz_csr *m);
 int index_ready(const pfz_index *ix);
 // the context's side stream (ctx->stream2) and its four events (ctx->side_events), created on first use
 int ensure_side_stream(pfz_ctx *ctx);
+// event slot `slot` will be announced by a word in pinned host memory too: *flag / *value = the word and what a kernel behind the
+// event's work has to store there (system scope)
+int event_flag_next(pfz_ctx *ctx, int32_t slot, int32_t **flag, int32_t *value);
 // Host <-> device copies of caller-owned (pageable) buffers through the context's pinned staging buffer.
 // Handing a pageable pointer to hipMemcpy makes the runtime register those pages with the GPU driver; when
 // the caller later frees the buffer (a numpy array, a Python bytes object) the unmap evicts and restores the

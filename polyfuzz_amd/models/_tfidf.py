@@ -22,26 +22,41 @@ from .. import _lib
 from ._base import BaseMatcher
 from ._utils import topn_to_frame, object_column, clip_top_n, FrameBuilder, _METHODS
 
-_SPLIT_MIN_ROWS = 20000      # from-rows from which match() pipelines several K3 launches with the frame building
-_SPLIT_EVENT = 56            # context event slots 56 .. : launch i done
-# shares of the from-rows per launch: the last part's columns are built AFTER the device has finished, so it is the small one
-_SPLIT_SHARES = {2: (0.6, 0.4), 5: (0.4, 0.3, 0.2, 0.1)}      # (profiles/experiments/r04_match_split_probe.txt)
-# a list against itself runs K3's symmetric form (csrc/k3_symmetric.hip): a row only walks the to-blocks from its own upwards, so
-# the first rows are the expensive ones and the ranges are cut accordingly (profiles/experiments/r04_match_split_symmetric.txt)
-_SPLIT_SHARES_SELF = (0.3, 0.3, 0.25, 0.15)
+_SPLIT_MIN_ROWS = 20000      # from-rows from which match() has its result handed on in row ranges, the frame built under the device's work
+_SPLIT_EVENT = 48            # context event slots 48 .. 63: range i final
+_SPLIT_BLOCK = 2048          # range ends are multiples of K3's to-block (what lets a self-match run ONE pass-1 launch: pfz_cossim_topn_ranges)
 _SYMMETRIC_ROWS = (20480, 250000)       # the list sizes K3 takes in its symmetric form (pfz_cossim_topn, include/polyfuzz_hip.h)
 
 
-def _split_shares(n, self_match=False):
-    """shares of the from-rows per K3 launch of a big match (PFZ_MATCH_SHARES=0.4,0.3,0.2,0.1 overrides: tuning)"""
+def _split_ends(n, self_match=False):
+    """The ends of the row ranges of a big match (PFZ_MATCH_SHARES=0.4,0.3,0.2,0.1 overrides the shares: tuning).
+    Two lists: the device's time per row is flat and every range is a launch of its own -- few ranges, the last one (whose columns
+    are built after the device has finished) the smallest (profiles/experiments/r04_match_split_probe.txt).
+    A list against itself (K3's symmetric form, csrc/k3_symmetric.hip): a row only walks the to-blocks from its own upwards, so the
+    device's time per row FALLS along the list -- 1 - (1 - x)^2 of pass 1 is spent when a share x of the rows is done -- while the
+    host's time per row (the frame's gathers) is flat: the host cannot start before the first range is final and falls behind in the
+    cheap last third.  Ranges cost little there (one pass-1 launch; a wait, a merge and an overflow pass per range on a side
+    stream), so: twelve ranges of equal ROWS (measured on one box, tools/r6_match_ab.py: the round-5 form in four launches 3.75 ms,
+    five ranges 3.6, ten 3.475, twelve 3.46, sixteen 3.48)."""
     env = os.environ.get("PFZ_MATCH_SHARES")
+    shares = None
     if env:
         sh = tuple(float(x) for x in env.split(","))
-        if len(sh) >= 1 and all(x > 0 for x in sh) and len(sh) <= 8:
-            return tuple(x / sum(sh) for x in sh)
-    if self_match and _SYMMETRIC_ROWS[0] <= n <= _SYMMETRIC_ROWS[1] and n >= 2 * _SPLIT_MIN_ROWS and os.environ.get("PFZ_K3_SYM") != "0":
-        return _SPLIT_SHARES_SELF
-    return _SPLIT_SHARES[5 if n >= 2 * _SPLIT_MIN_ROWS else 2]
+        if 1 <= len(sh) <= 16 and all(x > 0 for x in sh):
+            shares = tuple(x / sum(sh) for x in sh)
+    if shares is None:
+        if self_match and _SYMMETRIC_ROWS[0] <= n <= _SYMMETRIC_ROWS[1] and n >= 2 * _SPLIT_MIN_ROWS and os.environ.get("PFZ_K3_SYM") != "0":
+            shares = (1.0 / 12,) * 12
+        else:
+            shares = (0.4, 0.3, 0.2, 0.1) if n >= 2 * _SPLIT_MIN_ROWS else (0.6, 0.4)
+    ends, acc = [], 0.0
+    for f in shares[:-1]:
+        acc += f
+        e = int(n * acc) // _SPLIT_BLOCK * _SPLIT_BLOCK
+        if e > (ends[-1] if ends else 0) and e < n:
+            ends.append(e)
+    ends.append(n)
+    return ends
 
 
 def _clean_string(string: str) -> str:
@@ -52,6 +67,7 @@ def _clean_string(string: str) -> str:
     return string
 
 
+_TRACE = bool(os.environ.get("PFZ_MATCH_TRACE"))      # host-side stamps of a big match's ranges in .last_trace (tools/r6_match_ab.py)
 _FROM_IN_PACK = os.environ.get("PFZ_FROM_IN_PACK", "1") != "0"      # (A/B knob of tools/match_wall_probe.py; the frames are the same)
 
 
@@ -164,22 +180,17 @@ class TFIDF(BaseMatcher):
         lower = float(self.min_similarity) if self.cosine_method in ("sparse", "hip") else 0.0
         n = len(from_list)
         names = from_list if self_match else to_list
-        # A big match is enqueued as two (four from 40k rows) launches over the from-rows: each part's result is
-        # downloaded on a side stream and turned into frame columns while the device works on the next parts, so only
-        # the last part's columns are built after the device has finished
+        # A big match has its result handed on in ascending row ranges (pfz_cossim_topn_ranges): each range is downloaded on a side
+        # stream as soon as it is final and turned into frame columns while the device works on the later ones
         split = n >= _SPLIT_MIN_ROWS and top_n >= 1 and _lib._pack is not None and isinstance(names, (list, tuple))
         if split:
-            shares = _split_shares(n, self_match)
-            n_parts, cuts, acc = len(shares), [0], 0.0
-            for f in shares[:-1]:
-                acc += f
-                cuts.append(int(n * acc))
-            cuts.append(n)
-            res = None
-            for i in range(n_parts):
-                res = _lib.cossim_topn(ctx, self._dev_index, from_dev, top_n, lower, exclude_diag=self_match, out=res,
-                                       rows=(cuts[i], cuts[i + 1]))
-                ctx.event_record(_SPLIT_EVENT + i)
+            ends = _split_ends(n, self_match)
+            # (mirror: where the device can fill a copy of the result in pinned host memory itself -- a list against itself in K3's
+            # streamed form -- the columns are filled from there; otherwise every range is downloaded on a side stream)
+            res, h_idx, h_val = _lib.cossim_topn_ranges(ctx, self._dev_index, from_dev, top_n, lower, self_match, ends, _SPLIT_EVENT,
+                                                        mirror=True)
+            if not h_idx:
+                res.rows_begin(0, ends[0], _SPLIT_EVENT, 0)
         else:
             res = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=self_match)
         t1 = time.perf_counter()
@@ -189,12 +200,24 @@ class TFIDF(BaseMatcher):
             fb = FrameBuilder(from_list, names, top_n, from_col)
             waited = framed = 0.0
             tp = t2
-            for i in range(n_parts):
-                idx, val = res.download_rows_after(cuts[i], cuts[i + 1], _SPLIT_EVENT + i)
+            row0 = 0
+            trace = [("enqueued", t1 - t0), ("frame wrapped", time.perf_counter() - t0)] if _TRACE else None
+            for i, row1 in enumerate(ends):
+                if h_idx:
+                    ctx.event_wait(_SPLIT_EVENT + i)      # (polls the range's word in pinned memory)
+                    idx_addr, val_addr = h_idx + 4 * top_n * row0, h_val + 4 * top_n * row0
+                else:
+                    idx_addr, val_addr = res.rows_finish(i & 1)
+                    if i + 1 < len(ends):         # the next range's copies are on their way while this one's columns are filled
+                        res.rows_begin(row1, ends[i + 1], _SPLIT_EVENT + i + 1, (i + 1) & 1)
                 ta = time.perf_counter()
-                fb.fill(idx, val, cuts[i])         # ... while the device runs the later launches
+                fb.fill_raw(idx_addr, val_addr, row1 - row0, row0)
                 tb = time.perf_counter()
+                if trace is not None:
+                    trace += [(f"range {i} [{row0}, {row1}) here", ta - t0), (f"range {i} filled", tb - t0)]
                 waited, framed, tp = waited + (ta - tp), framed + (tb - ta), tb
+                row0 = row1
+            self.last_trace = trace
             frame = fb.frame()
             t4 = time.perf_counter()
             framed += t4 - tp

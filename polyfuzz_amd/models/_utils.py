@@ -141,6 +141,15 @@ class FrameBuilder:
                     np.shares_memory(f.iloc[:, -1].values, self.sims[-1]):
                 self._frame = f
 
+    def fill_raw(self, idx_addr, val_addr, m, row0):
+        """fill() from the addresses of int32 idx[m][top_n] / fp32 val[m][top_n] (the context's pinned staging: no copy between
+        the device's result and the columns)"""
+        if not m or not self.top_n:
+            return
+        _lib._pack.fill_columns(self.to_list, idx_addr, val_addr, m, self.top_n,
+                                tuple(a.ctypes.data + 8 * row0 for a in self.names),
+                                tuple(a.ctypes.data + 8 * row0 for a in self.sims), _FILL_THREADS)
+
     def fill(self, idx, val, row0=0):
         m = len(idx)
         if not m or not self.top_n:

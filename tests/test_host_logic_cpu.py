@@ -137,7 +137,8 @@ def test_synthetic_names_are_deterministic_and_name_like():
 def test_frame_helper_equals_numpy_twin(threads, monkeypatch):
     """_pack.fill_columns (C, optionally threaded with atomic reference counts) builds exactly the frame of
     the numpy twin -- np.round(., 3), the < 0.001 rule at the rounding boundary, -1 / out-of-range rows --
-    and leaves every reference count balanced."""
+    and leaves every reference count balanced; a frame filled in row ranges from raw addresses (what TFIDF.match does under the
+    device's work, from the context's pinned memory) is the same frame."""
     import sys
     from polyfuzz_amd import _lib
     from polyfuzz_amd.models import _utils
@@ -161,6 +162,18 @@ def test_frame_helper_equals_numpy_twin(threads, monkeypatch):
                 np.testing.assert_array_equal(a[c].to_numpy(), b[c].to_numpy())
             else:
                 assert a[c].tolist() == b[c].tolist(), c
+
+    # in row ranges, each from raw addresses (the context's pinned staging in TFIDF.match)
+    none0 = sys.getrefcount(None)
+    fb = _utils.FrameBuilder(from_list, to_list, top_n)
+    for lo, hi in ((0, 9000), (9000, 9001), (9001, n)):
+        i2, v2 = np.ascontiguousarray(idx[lo:hi]), np.ascontiguousarray(val[lo:hi])
+        fb.fill_raw(i2.ctypes.data, v2.ctypes.data, hi - lo, lo)
+    c = fb.frame()
+    for col in a.columns:
+        assert (np.array_equal(c[col].to_numpy(), a[col].to_numpy()) if col.startswith("Similarity") else c[col].tolist() == a[col].tolist())
+    del c, fb
+    assert abs(sys.getrefcount(None) - none0) < 50            # (None's count is the interpreter's too: balanced up to its own traffic)
 
     def held(i):          # references a frame holds on to_list[i] while alive / after it is gone
         before = sys.getrefcount(to_list[i])

@@ -8,13 +8,12 @@ from polyfuzz_amd import datasets
 from polyfuzz_amd.models import TFIDF, _tfidf
 names = datasets.load_company_names()
 ctx = polyfuzz_amd.Context.default()
-SHARES = [(1.0,), (0.6, 0.4), (0.5, 0.3, 0.2), (0.4, 0.3, 0.2, 0.1), (0.3, 0.3, 0.25, 0.15), (0.25, 0.25, 0.25, 0.25),
-          (0.22, 0.23, 0.23, 0.32), (0.3, 0.25, 0.2, 0.15, 0.1), (0.35, 0.3, 0.2, 0.1, 0.05)]
+SHARES = [(1.0,), (0.3, 0.3, 0.25, 0.15), (0.1,) + (0.15,) * 6, (0.08,) + (0.115,) * 8, (0.06, 0.1, 0.12, 0.14, 0.14, 0.14, 0.15, 0.15),
+          (0.1, 0.2, 0.2, 0.2, 0.15, 0.15), (0.15, 0.25, 0.25, 0.2, 0.15), (0.05,) + (0.095,) * 10, (0.1, 0.15, 0.15, 0.15, 0.15, 0.1, 0.1, 0.1)]
 if len(sys.argv) > 1:      # python tools/match_split_probe.py 0.4,0.3,0.2,0.1 0.5,0.5 ...
     SHARES = [tuple(float(x) for x in a.split(",")) for a in sys.argv[1:]]
 for shares in SHARES:
-    _tfidf._SPLIT_SHARES[5] = shares
-    _tfidf._SPLIT_SHARES_SELF = shares
+    os.environ["PFZ_MATCH_SHARES"] = ",".join(str(x) for x in shares)      # (read by _tfidf._split_ends on every match)
     m = TFIDF(min_similarity=0, top_n=5)
     for _ in range(3):
         m.match(names)

@@ -15,6 +15,7 @@ ts.sort(key=lambda x: x[0]); print('match median %.3f ms' % ts[4][0], {k: round(
 PY
 PYTHONPATH=$GRAFT_REPO_ROOT python $O/m.py
 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O/t -o m -- env PYTHONPATH=$GRAFT_REPO_ROOT python $O/m.py > $O/log.txt 2>&1; echo rc=$?; grep "match median" $O/log.txt
+python tools/r6_trace_parse.py; exit 0
 python - <<'PY'
 import sqlite3, glob
 db = sqlite3.connect(glob.glob('gpurun_out/r5_match_trace/t/*.db')[0])
