@@ -227,6 +227,26 @@ class TfidfMatchJob:
         return out
 
 
+def sharded_self_match(ctx, comm, names, top_n=1, min_similarity=0.0, n_gram_range=(3, 3), clean_string=True,
+                       remove_space_ngrams=True, engine=None):
+    """`TFIDF(min_similarity, top_n, ...).match(names)` (reference _tfidf.py:68-100, a list against itself) on the GPUs of a
+    communicator: EVERY rank calls it with the same list and gets the same, full frame -- Python list in, DataFrame out, the unit
+    SURVEY section 8d's metric is defined on.  Every rank packs and uploads the list (it is replicated), works on its share of
+    the rows (`TfidfMatchJob`: K3's symmetric form cut over the ranks where it applies, cost-balanced row shards otherwise), the
+    exchange leaves the full result on every rank, and every rank builds the frame from it."""
+    from .models._utils import topn_to_frame
+    names = list(names)
+    bounds = balanced_bounds(names, comm.world)
+    b, e = bounds[comm.rank]
+    sizes = [y - x for x, y in bounds]
+    job = TfidfMatchJob(ctx, names[b:e], names, top_n=top_n, min_similarity=min_similarity, n_gram_range=n_gram_range,
+                        clean_string=clean_string, remove_space_ngrams=remove_space_ngrams, comm=comm, self_match=True,
+                        shard_offset=b, rows_per_rank=max(sizes), engine=engine)
+    idx, val = job.step().download()
+    idx, val = job.whole_result(idx, val, sizes)
+    return topn_to_frame(np.ascontiguousarray(idx, np.int32), np.ascontiguousarray(val, np.float32), names, names, top_n)
+
+
 class ToShardedMatchJob:
     """The other sharding of the TF-IDF match: the TO-list is row-sharded over the ranks, the from-list replicated
     (BASELINE north_star's variant; needed when the to-side index does not fit one GPU).  Every rank fits the exact

@@ -63,6 +63,16 @@ def _worker(rank, port, out_dir):
     assert not rjob.result_is_full
     r_idx, r_val = rjob.whole_result(r_idx, r_val, sizes)
     assert np.array_equal(r_idx, s_idx) and np.array_equal(r_val, s_val)
+    # the user-level call on the communicator: every rank gets the full frame (bench.py's timed step at N > 1)
+    eng.force_row_shards_on_rank = None
+    from polyfuzz_amd import pipeline
+    frame = pipeline.sharded_self_match(None, comm, from_list, top_n=TOP_N, min_similarity=0.0, engine=eng)
+    assert frame["From"].tolist() == from_list and len(frame.columns) == 1 + 2 * TOP_N
+    for r in range(TOP_N):
+        exp3 = np.round(s_val[:, r].astype(np.float32).astype(np.float64), 3)
+        gone = (exp3 < 0.001) | (s_idx[:, r] < 0)
+        assert frame["To" if r == 0 else f"To_{r + 1}"].tolist() == [None if g else from_list[j] for g, j in zip(gone, s_idx[:, r])]
+        np.testing.assert_array_equal(frame["Similarity" if r == 0 else f"Similarity_{r + 1}"].to_numpy(), np.where(gone, 0.0, exp3))
     np.savez(os.path.join(out_dir, f"sharded{rank}.npz"), idx=idx, val=val, idf=job.vec.v.idf,
              vocab=np.array(job.vec.v.vocabulary), s_idx=s_idx, s_val=s_val, s_ndocs=sjob.vec.v.n_docs)
     dist.barrier()
