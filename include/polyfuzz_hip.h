@@ -323,7 +323,8 @@ int pfz_dense_dot_topn_host(pfz_ctx *ctx, const float *from_vec, int64_t n_from,
  * from-side is matched against a replicated to-side on every GPU (BASELINE config 5).  normalize != 0:
  * rows are scaled by 1/||row|| (true cosine), 0: raw dot products.  pfz_dense_topn enqueues on the
  * context stream and leaves (idx, score) in `out` (rows [0, n_from)); exclude_diag drops
- * j == i + diag_offset.  1 <= ntop <= 1024. */
+ * j == i + diag_offset.  ntop >= 1 (beyond 1024 in passes of 1024 over the same score panel, each continuing below the last key of
+ * the one before: the reference clips top_n to the number of distinct to-strings only, _utils.py:54-56). */
 typedef struct pfz_dense pfz_dense;
 int pfz_dense_upload(pfz_ctx *ctx, const float *vec, int64_t n, int64_t dim, int32_t normalize, pfz_dense **out);
 int pfz_dense_shape(const pfz_dense *m, int64_t *n, int64_t *dim);

@@ -288,11 +288,16 @@ __device__ inline uint64_t wave_max_u64_5(uint64_t v)
 }
 
 // One wave per score row: top-n of the scores > thr.  kCap5: candidate keys per wave (>= ntop + 1 + 64).
-template <int kCap5>
+// kDeep (round 6: top_n beyond the 1024 keys one pass keeps -- the reference clips top_n to the number of distinct to-strings
+// only, _utils.py:54-56): a PASS of a deep top-n.  It keeps the `ntop` best keys strictly BELOW ub[row] (keys are distinct:
+// score bits << 32 | ~column), writes them at columns col0 .. of the row's out_ld-wide result and leaves its last key in ub[row]
+// for the pass that follows (0 when the row has run out of candidates: nothing is below 0).  The scheme of K3's deep passes.
+template <int kCap5, bool kDeep = false>
 __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, int64_t ld, int64_t a0, int64_t a1,
                                                     int64_t n_b, int32_t ntop, float lower_bound, int32_t exclude_diag,
                                                     int64_t diag_offset, int32_t *__restrict__ out_idx,
-                                                    float *__restrict__ out_val, const float *__restrict__ M, int64_t ldm)
+                                                    float *__restrict__ out_val, const float *__restrict__ M, int64_t ldm,
+                                                    int32_t out_ld = 0, int32_t col0 = 0, uint64_t *__restrict__ ub = nullptr)
 {
     __shared__ __attribute__((aligned(16))) uint64_t cand_all[4][kCap5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
     int cnt = 0;
     float thr = lower_bound;
     int want = ntop;            // how many keys a compaction keeps
+    const uint64_t ubk = kDeep ? ub[row - a0] : ~0ull;
 
     // sorted == false (intermediate compactions) and a large top_n: select the ntop-th largest key bit by bit
     // (64 ballot steps) instead of one wave-max round per kept key -- the same scheme as K3's compact()
@@ -414,7 +420,8 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t j = c + q;
-            const bool pred = vv[q] > thr && j < n_b && j != self_col;
+            bool pred = vv[q] > thr && j < n_b && j != self_col;
+            if (kDeep) pred = pred && (((uint64_t)__float_as_uint(vv[q]) << 32) | (uint32_t)(~(uint32_t)j)) < ubk;
             const uint64_t mk = __ballot(pred);
             if (mk) {
                 const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
@@ -425,11 +432,13 @@ __global__ __launch_bounds__(256) void k5_row_topn(const float *__restrict__ S, 
         }
     }
     compact(true);
+    const int64_t o_ld = kDeep ? out_ld : ntop;
     for (int r = lane; r < ntop; r += 64) {
         const uint64_t key = r < cnt ? cand[r] : 0ull;
-        out_idx[row * ntop + r] = key ? (int32_t)(~(uint32_t)key) : -1;
-        out_val[row * ntop + r] = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;
+        out_idx[row * o_ld + col0 + r] = key ? (int32_t)(~(uint32_t)key) : -1;
+        out_val[row * o_ld + col0 + r] = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;
     }
+    if (kDeep && lane == 0) ub[row - a0] = cnt >= ntop ? cand[ntop - 1] : 0ull;
 }
 
 }  // namespace pfz
@@ -512,10 +521,7 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
                 (long long)to->dim);
     PFZ_REQUIRE(ntop >= 1, "pfz_dense_topn: ntop must be >= 1");
     PFZ_REQUIRE(lower_bound == lower_bound, "pfz_dense_topn: lower_bound is NaN");
-    if (ntop > 1024) {
-        set_error("pfz_dense_topn: ntop=%d exceeds the kernel's limit of 1024", ntop);
-        return PFZ_ERR_UNSUPPORTED;
-    }
+    constexpr int32_t kDeepPass = 1024;      // keys one pass keeps (k5_row_topn<1152>)
     PFZ_REQUIRE(out->n_rows >= from->n && out->ntop == ntop, "pfz_dense_topn: result buffer is %lldx%d, need %lldx%d",
                 (long long)out->n_rows, out->ntop, (long long)from->n, ntop);
     const int64_t n_from = from->n, n_to = to->n, dim = from->ld;        // the padded width: a multiple of 32
@@ -525,7 +531,7 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
     struct Buf {
         void *p = nullptr;
         ~Buf() { if (p) pool_free(p); }
-    } dS[2], dM[2];
+    } dS[2], dM[2], dU[2];
     const int64_t ld = ((n_to + 255) / 256) * 256;                      // whole float4 x 64-lane steps
     // Two score panels of <= 4 GiB (PFZ_K5_PANEL_BYTES overrides).  At 500 000 to-vectors that is 2048 rows: each B tile
     // serves 16 row tiles per panel.  (16 GiB panels are 1.5 % faster per step -- B is re-read once per panel -- but
@@ -546,6 +552,10 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         // block maxima (one float per row and 64 columns), written by the second-generation GEMM
         PFZ_TRY(pool_alloc(ctx, &dM[0].p, (size_t)panel * (size_t)(ld / 64) * sizeof(float)));
         if (two) PFZ_TRY(pool_alloc(ctx, &dM[1].p, (size_t)panel * (size_t)(ld / 64) * sizeof(float)));
+    }
+    if (ntop > kDeepPass) {      // a deep top-n: every row's last key of the pass before
+        PFZ_TRY(pool_alloc(ctx, &dU[0].p, (size_t)panel * sizeof(uint64_t)));
+        if (two) PFZ_TRY(pool_alloc(ctx, &dU[1].p, (size_t)panel * sizeof(uint64_t)));
     }
     hipEvent_t *ready = ctx->side_events, *consumed = ctx->side_events + 2;
     int64_t pi = 0;
@@ -573,7 +583,16 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         }
         {
             ProfScope ps(ctx, "k5_row_topn", ts);
-            if (ntop <= 128)
+            if (ntop > kDeepPass) {
+                // passes of 1024 over the same score panel, each continuing strictly below the last key of the one before (the
+                // block maxima are of no use below a bound: the passes stream the rows)
+                PFZ_HIP(hipMemsetAsync(dU[buf].p, 0xff, (size_t)(a1 - a0) * sizeof(uint64_t), ts));
+                for (int32_t col0 = 0; col0 < ntop; col0 += kDeepPass)
+                    hipLaunchKernelGGL((k5_row_topn<1152, true>), dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ts, (const float *)S, ld,
+                                       a0, a1, n_to, std::min(kDeepPass, ntop - col0), lower_bound, exclude_diag, diag_offset, out->idx,
+                                       out->val, (const float *)nullptr, ld / 64, ntop, col0, (uint64_t *)dU[buf].p);
+            }
+            else if (ntop <= 128)
                 hipLaunchKernelGGL(k5_row_topn<256>, dim3((unsigned)((a1 - a0 + 3) / 4)), dim3(256), 0, ts, (const float *)S, ld, a0,
                                    a1, n_to, ntop, lower_bound, exclude_diag, diag_offset, out->idx, out->val, M, ld / 64);
             else
