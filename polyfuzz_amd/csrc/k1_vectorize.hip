@@ -1111,7 +1111,7 @@ static int run_rows(pfz_ctx *ctx, const pfz_tfidf *v, pfz_strings *s, DfSink df,
 // rank prefix of the vocabulary bitmap; the vocabulary's size starts its way to the host (*size: lazy_get it when needed)
 static int build_prefix(pfz_ctx *ctx, pfz_tfidf *v, LazyI32 *size)
 {
-    if (v->n_groups >= 1 && v->n_groups <= 1024 && !getenv("PFZ_K1_NO_POPC_SCAN")) {      // (env: the two-launch path -- tests)
+    if (v->n_groups >= 1 && v->n_groups <= 1024) {      // (beyond: the two-launch path -- wider codes reach it, tests/test_vectorize_gpu.py)
         if (size) PFZ_TRY(lazy_acquire(ctx, size));
         hipLaunchKernelGGL(k_group_popc_scan, dim3(1), dim3(1024), 0, ctx->stream, v->bitmap, (int32_t)v->n_groups, v->prefix,
                            size ? size->slot : nullptr);

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) void k3_cossim_topn_kernel(
 // re-dealt: posting i gets the rank j it has among the postings of its bank, and the list is written out by (j, bank) --
 // banks cycle 0, 1, 2 ... 31, 0, 1 ... as long as every bank has postings left, so any 64 consecutive postings hit every
 // bank about twice, wherever a round's piece numbering happens to cut.  One wave per heavy list; results are unchanged.
-constexpr int kBankMin = 64, kBankCap = 1024;     // (kBankMin: tuning knob PFZ_K3_BANK_MIN -- 16 ... 128 give the same K3 time)
+constexpr int kBankMin = 64, kBankCap = 1024;     // (kBankMin: 16 ... 128 gave the same K3 time, round 4)
 __global__ __launch_bounds__(256) void k_index_bank_order(const int32_t *__restrict__ cnt, const int32_t *__restrict__ tab,
                                                            const int32_t *__restrict__ heavy, int32_t heavy_cap,
                                                            int2 *__restrict__ post)
@@ -598,7 +598,7 @@ int pfz_index_build(pfz_ctx *ctx, const pfz_csr *B, pfz_index **out)
     const char *bo_env = getenv("PFZ_K3_BANK_ORDER");
     const bool bank_order = any && lds_hist && !getenv("PFZ_K3_NO_BANK_ORDER") &&
                             ((bo_env && atoi(bo_env) > 0) || (!bo_env && B->n_rows >= 32768));
-    const int32_t bank_min = std::max(2, env_int("PFZ_K3_BANK_MIN", kBankMin));
+    const int32_t bank_min = kBankMin;
     const int32_t heavy_cap = (int32_t)std::min<int64_t>(slots, (int64_t)1 << 22);
     Tmp heavy;
     if (bank_order) {

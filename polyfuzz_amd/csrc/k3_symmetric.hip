@@ -74,6 +74,7 @@ constexpr int kSymSlicedRows = 4096;   // ... for the first so many rows of the 
 #endif
 constexpr int kSymMag = 1;          // "magnet" rows per LDS bank class and block: the rows of the lowest thresholds are taken out of the hand-over
 constexpr int kSymMagBlocks = 8;   // ... and walk the blocks below their own themselves, in items of so many to-blocks
+constexpr int kSymP0PerCu = 128;    // pass 0: persistent workgroups per CU (~3 rows each at 100 000 rows; 18 / 36 / 72 / 144 per CU: 1.842 / 1.780 / 1.758 / 1.757 ms of K3, round 5)
 constexpr int kSymDoneStride = 32;  // a block's item counter (streamed sessions) has a 128-byte line of its own: 2 000 atomics each, from every XCD
 constexpr int kNoThr = 0x7fffffff;     // threshold of a slot without a row (the last block's tail): no sum reaches it
 
@@ -951,7 +952,7 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
         // 128 per CU, ~3 rows each at 100 000 rows: exactly the 18 that are resident -- 22 rows each, every load prefetched --
         // was SLOWER, K3 1.842 ms against 1.771, the rows' costs differ too much for a fixed deal; 36 / 72 / 144 per CU
         // 1.780 / 1.758 / 1.757; a workgroup per row, as before, 1.768 - 1.771)
-        const unsigned grid0 = (unsigned)std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * sym_env_int("PFZ_K3_SYM_P0_PER_CU", 128));
+        const unsigned grid0 = (unsigned)std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * kSymP0PerCu);
         hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(grid0), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
         const int64_t pairs = sym_repost_pairs(ix);
@@ -1042,7 +1043,7 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
     a.host_val = host_val;
     PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
     PFZ_HIP(hipMemsetAsync(s->done, 0, (size_t)nb * kSymDoneStride * sizeof(uint32_t), ctx->stream));
-    const unsigned grid0 = (unsigned)std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * sym_env_int("PFZ_K3_SYM_P0_PER_CU", 128));
+    const unsigned grid0 = (unsigned)std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * kSymP0PerCu);
     hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(grid0), dim3(64), 0, ctx->stream, a);
     hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
     const int64_t pairs = sym_repost_pairs(ix);
@@ -1192,7 +1193,7 @@ static int k3_sym_sharded_body(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix
     a.row_begin = part;
     a.row_end = (int32_t)n;
     const unsigned mine0 = (unsigned)((n - part + n_parts - 1) / n_parts);
-    const unsigned grid0 = std::min<unsigned>(mine0, (unsigned)ctx->prop.multiProcessorCount * (unsigned)sym_env_int("PFZ_K3_SYM_P0_PER_CU", 128));
+    const unsigned grid0 = std::min<unsigned>(mine0, (unsigned)ctx->prop.multiProcessorCount * (unsigned)kSymP0PerCu);
     if (mine0) hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(grid0), dim3(64), 0, ctx->stream, a);
     PFZ_HIP(hipGetLastError());
     if (n_parts > 1) PFZ_TRY(comm_allgather_bytes(comm, s->thrv + (size_t)part * a.per, s->thrv, (size_t)a.per * sizeof(int32_t)));

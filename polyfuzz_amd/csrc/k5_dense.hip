@@ -533,13 +533,12 @@ int pfz_dense_topn(pfz_ctx *ctx, const pfz_dense *from, const pfz_dense *to, int
         ~Buf() { if (p) pool_free(p); }
     } dS[2], dM[2], dU[2];
     const int64_t ld = ((n_to + 255) / 256) * 256;                      // whole float4 x 64-lane steps
-    // Two score panels of <= 4 GiB (PFZ_K5_PANEL_BYTES overrides).  At 500 000 to-vectors that is 2048 rows: each B tile
+    // Two score panels of <= 4 GiB.  At 500 000 to-vectors that is 2048 rows: each B tile
     // serves 16 row tiles per panel.  (16 GiB panels are 1.5 % faster per step -- B is re-read once per panel -- but
     // their first allocation costs a second, which a one-shot host call cannot afford.)  The row top-n of panel p
     // runs on a side stream while the GEMM of panel p + 1 fills the other buffer; with block maxima it is a ~0.2 ms
     // kernel per panel and the overlap no longer matters, without them (d % 32 != 0) it is a full read of the panel.
-    int64_t panel_bytes = (int64_t)4 << 30;
-    if (const char *e = getenv("PFZ_K5_PANEL_BYTES")) panel_bytes = std::max<int64_t>(atoll(e), 1 << 20);
+    const int64_t panel_bytes = (int64_t)4 << 30;
     int64_t panel = ld > 0 ? panel_bytes / (ld * 4) : n_from;
     if (const char *forced = getenv("PFZ_K5_PANEL_ROWS")) panel = atoll(forced);   // tests: several panels on small inputs
     panel = std::max<int64_t>(kTile, std::min<int64_t>(panel / kTile * kTile, ((n_from + kTile - 1) / kTile) * kTile));

@@ -986,12 +986,10 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         // split: 2.3 against 3.2).  From 2 048 rows on a row is one unit.
         if (c == 0 && n >= 2048 && kK7Waves == 1) parts_of[c] = 1;
         if (const char *e = getenv("PFZ_K7_PARTS")) parts_of[c] = std::max(1, atoi(e));
-        if (const char *e = getenv("PFZ_K7_PARTS0")) { if (c == 0) parts_of[c] = std::max(1, atoi(e)); }      // (tuning: class 0 alone)
         max_parts = std::max(max_parts, parts_of[c]);
     }
     int32_t hand_batches = kHandBatches, hand_min_groups = kHandMinGroups, cont_parts = kContParts;
     int32_t short_len = kHandShortLen, short_batches = kHandShortBatches;
-    if (const char *e = getenv("PFZ_K7_HAND")) sscanf(e, "%d,%d,%d,%d,%d", &hand_batches, &hand_min_groups, &cont_parts, &short_len, &short_batches);      // tuning
     if (const char *e = getenv("PFZ_K7_HAND_BATCHES")) hand_batches = atoi(e), hand_min_groups = 0;      // tests: hand over early
     cont_parts = std::max(1, std::min(cont_parts, 64));
     const int32_t n_parts_total = max_parts + 1 + cont_parts;
@@ -1100,13 +1098,6 @@ static int fuzz_run(pfz_ctx *ctx, const pfz_strings *F_c, const pfz_strings *T_c
         L.cont_region = (int32_t *)d_cont_region.p + (size_t)c * cont_cap;
         // persistent one-wave workgroups: the rows, then -- in the same launch -- the remainders of the heavy ones
         const unsigned grid = (unsigned)grid_of(c, hand);
-        if (getenv("PFZ_K7_DEBUG")) {
-            int occ = -1;
-            if (c == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k7_fuzz_kernel<1>, kK7Threads, lds);
-            else if (c == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k7_fuzz_kernel<2>, kK7Threads, lds);
-            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k7_fuzz_kernel<4>, kK7Threads, lds);
-            fprintf(stderr, "k7 class %d: rows %d parts %d grid %u dynamic LDS %zu B, workgroups per CU %d\n", c, A.n_rows, A.parts, grid, lds, occ);
-        }
         // WRatio -- what PolyFuzz("EditDistance") and RapidFuzz() run by default -- has instances of its own: the scorer a
         // compile-time constant (no scalar dispatch inside the sweeps, only that scorer's values live)
         if (scorer == kWRatio) {

@@ -124,7 +124,7 @@ def test_index_build_paths_agree(ctx, oracle_mod, monkeypatch):
 @pytest.mark.parametrize("knobs", [
     {"PFZ_K3_BLOCK": "4096"}, {"PFZ_K3_BLOCK": "1024"}, {"PFZ_K3_BLOCK": "1536"},
     {"PFZ_K3_SLICES": "3"}, {"PFZ_K3_SLICES": "7", "PFZ_K3_BLOCK": "1024"},
-    {"PFZ_K3_BANK_ORDER": "1", "PFZ_K3_BANK_MIN": "4"}, {"PFZ_K3_BANK_ORDER": "1", "PFZ_K3_BLOCK": "4096"}, {"PFZ_K3_NO_BANK_ORDER": "1"},
+    {"PFZ_K3_BANK_ORDER": "1"}, {"PFZ_K3_BANK_ORDER": "1", "PFZ_K3_BLOCK": "4096"}, {"PFZ_K3_NO_BANK_ORDER": "1"},
 ])
 def test_tuning_knobs_do_not_change_results(ctx, oracle_mod, monkeypatch, knobs):
     """Every launch shape the tuning knobs can select (to-block size, to-side slices) gives the default

@@ -26,7 +26,7 @@ def _titles(n_from, n_to):
     return fl[:n_from], tl[:n_to]
 
 
-@pytest.mark.parametrize("knob,value", [("PFZ_K1_WAVE_STRINGS", "8"), ("PFZ_K1_WAVE_STRINGS", "64"), ("PFZ_K1_NO_POPC_SCAN", "1")])
+@pytest.mark.parametrize("knob,value", [("PFZ_K1_WAVE_STRINGS", "8"), ("PFZ_K1_WAVE_STRINGS", "64")])
 def test_vectoriser_knobs(ctx, monkeypatch, knob, value):
     from polyfuzz_amd import datasets
     names = datasets.load_company_names()[:3000]
@@ -74,14 +74,14 @@ def test_dense_panel_bytes_knob(ctx, monkeypatch):
     a = rng.standard_normal((700, 96), dtype=np.float32)
     b = rng.standard_normal((5000, 96), dtype=np.float32)
     ref = _lib.dense_cossim_topn_host(ctx, a, b, 5, 0.0, False, normalize=True)
-    monkeypatch.setenv("PFZ_K5_PANEL_BYTES", str(2 << 20))          # 2 MiB panels: 100 from-rows at a time
+    monkeypatch.setenv("PFZ_K5_PANEL_ROWS", "128")                  # 128-row panels: six of them
     got = _lib.dense_cossim_topn_host(ctx, a, b, 5, 0.0, False, normalize=True)
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
 
 
-@pytest.mark.parametrize("knob,value", [("PFZ_K7_NO_HANDOVER", "1"), ("PFZ_K7_NO_SIDE_STREAM", "1"), ("PFZ_K7_PARTS0", "3"),
-                                        ("PFZ_K7_DEBUG", "1"), ("PFZ_K7_ROW_STATS", "/tmp/pfz_k7_rowstats_test.bin")])
+@pytest.mark.parametrize("knob,value", [("PFZ_K7_NO_HANDOVER", "1"), ("PFZ_K7_NO_SIDE_STREAM", "1"),
+                                        ("PFZ_K7_ROW_STATS", "/tmp/pfz_k7_rowstats_test.bin")])
 def test_fuzz_knobs(ctx, monkeypatch, knob, value):
     """K7's schedule knobs and diagnostics: a list with one very long from-string (the side stream's class) and short heavy ones."""
     from polyfuzz_amd import _lib
