@@ -4,7 +4,7 @@
 OUT=${1:-gpurun_out/pmc_traffic}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p "$OUT"
 for cfg in tfidf c2 tfidf_1m; do
-  extra=""; [ $cfg = tfidf ] && extra="--no-configs"
+  extra=""; [ $cfg = tfidf ] && extra="--no-configs --step device"
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 240 rocprofv3 --pmc $c --kernel-trace -d "$OUT/${cfg}_$c" -o bench -- python bench.py --config $cfg --steps 2 --warmup 1 \
       --no-cpu-baseline --no-match-wall $extra > "$OUT/${cfg}_$c.log" 2>&1

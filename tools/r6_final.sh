@@ -1,12 +1,12 @@
 #!/bin/bash
-# End-of-round evidence of round 5 in ONE gpurun call, from the build this snapshot holds: the whole GPU suite + smoke, the default
+# End-of-round evidence of round 6 in ONE gpurun call, from the build this snapshot holds: the whole GPU suite + smoke, the default
 # bench line, rocprofv3 stats + PMC passes of the same command, K3's fabric traffic on the three TF-IDF workloads, K7's timings.
-# Run it through tools/r5_final_local.sh (build container): that wrapper stamps the commit the sources are at (.git does not
+# Run it through tools/r6_final_local.sh (build container): that wrapper stamps the commit the sources are at (.git does not
 # travel), refuses a dirty tree, and files the results under profiles/ only if HEAD is still that commit when the call returns.
-# usage (GPU box): bash tools/r5_final.sh
+# usage (GPU box): bash tools/r6_final.sh
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-HEAD_ID=$(cat tools/.build_head 2>/dev/null) || { echo "tools/.build_head is missing: run tools/r5_final_local.sh"; exit 2; }
-O=gpurun_out/r05_final; rm -rf $O; mkdir -p $O; echo "$HEAD_ID" > $O/source_commit.txt
+HEAD_ID=$(cat tools/.build_head 2>/dev/null) || { echo "tools/.build_head is missing: run tools/r6_final_local.sh"; exit 2; }
+O=gpurun_out/r06_final; rm -rf $O; mkdir -p $O; echo "$HEAD_ID" > $O/source_commit.txt
 timeout 2400 python -m pytest tests/ -m gpu -q --timeout 900 > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 300 $O/bench.err
@@ -15,11 +15,15 @@ timeout 900 bash tools/pmc_traffic.sh $O/pmc > $O/pmc.log 2>&1
 timeout 600 bash tools/profile_other.sh $O/other > $O/other.log 2>&1
 timeout 300 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio,partial_token_ratio > $O/k7_fuzz.txt 2>&1
 timeout 300 python tools/k7_rowstats.py WRatio >> $O/k7_fuzz.txt 2>&1
-for f in $O/profile/summary.txt $O/profile/summary_headline.txt $O/k7_fuzz.txt; do [ -f $f ] && sed -i "1i (source commit $HEAD_ID; tools/r5_final.sh)" $f; done
+# the user-level call: round 5's form (a session launch per range) against the streamed session, one process, one box
+timeout 300 python tools/r6_match_ab.py "r5form:PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15" "streamed5:PFZ_MATCH_SHARES=1;1;1;1;1" "streamed12 (default):" "streamed16:PFZ_MATCH_SHARES=1;1;1;1;1;1;1;1;1;1;1;1;1;1;1;1" > $O/match_ab.txt 2>&1
+# `python bench.py --gpus 2` as the driver would call it, on a box with one device: launches itself, every rank says what is missing
+timeout 300 python bench.py --gpus 2 --steps 2 > $O/gpus2_selflaunch.txt 2>&1; echo "bench --gpus 2 rc=$? (expected: not 0 on a one-GPU box)" >> $O/gpus2_selflaunch.txt
+for f in $O/profile/summary.txt $O/profile/summary_headline.txt $O/profile/summary_match.txt $O/k7_fuzz.txt $O/match_ab.txt; do [ -f $f ] && sed -i "1i (source commit $HEAD_ID; tools/r6_final.sh)" $f; done
 python - <<PY
 import json
 d=json.load(open("$O/bench.json"))
-print({k: d.get(k) for k in ("value","ms_per_step","match_wall_ms","latency_top1_ms","kernel_ms_per_step")})
+print({k: d.get(k) for k in ("value","ms_per_step","match_wall_ms","latency_top1_ms","kernel_ms_per_step","device_step","k3_ms_per_step_inside_the_call")})
 print({k:d["roofline"].get(k) for k in ("bound","frac","frac_hbm_priced","lds_floor_ms","avg_launch_ms","traffic","symmetric_form")})
 print("parity", (d.get("parity_check") or {}).get("ok"), "pins", d.get("library_pins"))
 for name, c in d.get("configs", {}).items():
