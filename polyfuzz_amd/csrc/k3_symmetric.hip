@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void k3_sym_wait(const K3SymArgs a, int32_t *fl
     const int lane = threadIdx.x;
     if (lane == 0) {
         if (flag) __hip_atomic_store(flag, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        a.ovf[0] = 0;
+        if (a.blk_lo < a.blk_hi) a.ovf[0] = 0;       // (the last launch only announces: the session's buffers are not touched any more)
     }
     const uint64_t t0 = wall_clock64();
     for (int b0 = a.blk_lo; b0 < a.blk_hi; b0 += 64) {
@@ -1083,8 +1083,9 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
     a.blk_lo = a.blk_hi = 0;
     hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, side, a, flag, flag_value);      // (the last range's word)
     PFZ_HIP(hipGetLastError());
+    PFZ_HIP(hipEventRecord(ctx->ev3, side));
     // whatever follows on the context's stream (and its timers) comes after the last range
-    PFZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->events[first_event + n_ranges - 1], 0));      // (the last announcement follows it: nobody on this stream needs it)
+    PFZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev3, 0));      // (ev3: free again once pass 1 had been launched behind it)
     s->next_row = n;
     s->launches += 1;
     s->rows += n;
