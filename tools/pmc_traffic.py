@@ -16,7 +16,7 @@ def avg(db_path, counter):
     dispatch per launch), or -- a list against itself -- the symmetric form, whose launch is four dispatches (k3_sym_kernel
     in its three passes + k3_sym_order / repost / merge / merge_slices: summed, per dispatch of the merge)"""
     db = sqlite3.connect(db_path)
-    sym = db.execute("select count(*) from counters_collection where counter_name = ? and kernel_name like '%k3_sym_merge(%'",
+    sym = db.execute("select count(*) from counters_collection where counter_name = ? and (kernel_name like '%k3_sym_merge<%' or kernel_name like '%k3_sym_merge(%')",
                      (counter,)).fetchone()[0]
     if sym:
         total = db.execute("select sum(value) from counters_collection where counter_name = ? and kernel_name like '%k3_sym_%'",
