@@ -458,6 +458,47 @@ def test_symmetric_kernel_on_real_names(ctx, oracle_mod, monkeypatch):
     np.testing.assert_array_equal(r1[1], r0[1])
 
 
+@pytest.mark.parametrize("n,ntop", [(20480, 5), (30001, 32), (45056, 1)])
+def test_streamed_session_at_other_sizes(ctx, monkeypatch, n, ntop):
+    """Round 6: `pfz_cossim_topn_ranges` (one pass-1 launch, the ranges merged on a side stream and mirrored into pinned host
+    memory) away from the headline's size: the smallest list the symmetric form takes (ten to-blocks), a list whose last block is
+    nearly empty, top_n at the form's limit of 32 and at 1, ranges of one block -- against the row-major kernel bit for bit, through
+    the host mirror and in the device buffer; and `TFIDF.match` (which enqueues it from 40 000 rows on) against the same matcher
+    with the streamed form switched off."""
+    import ctypes
+    from polyfuzz_amd import _lib, synth
+    from polyfuzz_amd.models import TFIDF
+    from polyfuzz_amd.models._tfidf import _SPLIT_EVENT
+    names = synth.company_names(n, seed=n)
+    s = _lib.DeviceStrings.upload(ctx, names)
+    a = _lib.DeviceTfidf.fit(ctx, _lib.TfidfParams(3, 3, 1, 1), s, None).transform(s)
+    monkeypatch.setenv("PFZ_K3_SYM", "0")
+    r_idx, r_val = _lib.cossim_topn(ctx, _lib.DeviceIndex.build(ctx, a), a, ntop, 0.0, exclude_diag=True).download()
+    monkeypatch.delenv("PFZ_K3_SYM", raising=False)
+    for ends in ([n], [2048 * (i + 1) for i in range(min(15, (n - 1) // 2048))] + [n], [4096, 6144, n]):
+        ix = _lib.DeviceIndex.build(ctx, a)
+        res, h_idx, h_val = _lib.cossim_topn_ranges(ctx, ix, a, ntop, 0.0, True, ends, _SPLIT_EVENT, mirror=True)
+        assert h_idx and ix.symmetric_launches() == (1, n)
+        row0 = 0
+        for i, row1 in enumerate(ends):
+            ctx.event_wait(_SPLIT_EVENT + i)
+            m = (row1 - row0) * ntop
+            g_idx = np.ctypeslib.as_array(ctypes.cast(h_idx + 4 * ntop * row0, ctypes.POINTER(ctypes.c_int32)), (m,)).reshape(-1, ntop)
+            g_val = np.ctypeslib.as_array(ctypes.cast(h_val + 4 * ntop * row0, ctypes.POINTER(ctypes.c_float)), (m,)).reshape(-1, ntop)
+            np.testing.assert_array_equal(g_idx, r_idx[row0:row1])
+            np.testing.assert_array_equal(g_val, r_val[row0:row1])
+            row0 = row1
+        d_idx, d_val = res.download()
+        np.testing.assert_array_equal(d_idx, r_idx)
+        np.testing.assert_array_equal(d_val, r_val)
+    if n >= 40000:
+        frames = {}
+        for knob in ("0", "1"):
+            monkeypatch.setenv("PFZ_K3_NO_STREAMED", knob) if knob == "1" else monkeypatch.delenv("PFZ_K3_NO_STREAMED", raising=False)
+            frames[knob] = TFIDF(min_similarity=0, top_n=2).match(names)
+        assert frames["0"].equals(frames["1"])
+
+
 @pytest.mark.parametrize("n,expect_sym", [(20479, 0), (20480, 1)])
 def test_symmetric_switch_over_small(ctx, monkeypatch, n, expect_sym):
     """Either side of the automatic choice's lower end (20 480 rows = ten to-blocks): one row fewer runs the row-major kernel,
