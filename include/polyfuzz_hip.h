@@ -63,6 +63,11 @@ int pfz_ctx_info(pfz_ctx *ctx, char *name256, int32_t *n_cu, int64_t *hbm_bytes)
 int pfz_event_record(pfz_ctx *ctx, int32_t slot);
 /* blocks until both events completed */
 int pfz_event_elapsed_ms(pfz_ctx *ctx, int32_t slot_begin, int32_t slot_end, float *ms);
+/* `bytes` of the context's PINNED staging buffer for the caller to fill (*host; NULL when the request is too large for it): what is
+ * handed to pfz_strings_upload from there is read by the DMA where it lies -- the host's string packer (the lists of reference
+ * _base.py:13-16, `match(from_list, to_list)`) writes offsets and code units straight into it instead of into a buffer that is then
+ * copied into it.  Valid until the next upload or download on this context. */
+int pfz_stage_reserve(pfz_ctx *ctx, int64_t bytes, void **host);
 /* block until event slot `slot` has fired (recorded by pfz_event_record, or by pfz_cossim_topn_ranges for its row ranges -- those
  * are also announced through a word in pinned host memory, which this call polls instead of sleeping on the runtime's event) */
 int pfz_event_wait(pfz_ctx *ctx, int32_t slot);

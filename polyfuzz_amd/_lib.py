@@ -71,6 +71,7 @@ SIGNATURES = {
     "pfz_topn_rows_finish": (ctypes.c_int, [c_vp, c_i32, P(c_vp), P(c_vp)]),
     "pfz_cossim_topn_ranges": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32, P(c_i64), c_i32, c_vp, P(c_vp), P(c_vp)]),
     "pfz_event_wait": (ctypes.c_int, [c_vp, c_i32]),
+    "pfz_stage_reserve": (ctypes.c_int, [c_vp, c_i64, P(c_vp)]),
     "pfz_topn_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pfz_topn_device_ptrs": (ctypes.c_int, [c_vp, P(c_vp), P(c_vp), P(c_i64), P(c_i32)]),
     "pfz_cossim_topn": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_f32, c_i32, c_i64, c_vp]),
@@ -501,7 +502,36 @@ class DeviceStrings(_Handle):
 
     @classmethod
     def upload(cls, ctx, strings):
+        if len(strings) >= 1024:          # (1-byte strings: packed straight into the pinned staging buffer)
+            direct = cls.upload_direct(ctx, strings)
+            if direct is not None:
+                return direct
         return cls.upload_packed(ctx, *pack_strings(strings))
+
+    @classmethod
+    def upload_direct(cls, ctx, strings, objects=None):
+        """A list of 1-byte (Latin-1) str packed STRAIGHT into the context's pinned staging buffer and uploaded from there (no
+        bytes object, no copy into the staging buffer: 3 MB of host copies less in front of the device's first kernel for 100 000
+        names).  objects: see pack_strings.  Returns None -- nothing changed -- when the list is not of that kind (wide or
+        non-str items, too big for the staging buffer, no C helper): the caller takes pack_strings + upload_packed."""
+        if _pack is None or not hasattr(_pack, "pack_into") or not isinstance(strings, (list, tuple)):
+            return None
+        n = len(strings)
+        off_bytes = (8 * (n + 1) + 255) & ~255
+        cap = off_bytes + 48 * n + 65536
+        host = c_vp()
+        check(ctx.lib.pfz_stage_reserve(ctx.h, cap, ctypes.byref(host)))
+        if not host.value:
+            return None
+        n_chars = _pack.pack_into(strings, objects.ctypes.data if objects is not None else 0, host.value, off_bytes, cap)
+        if n_chars is None:
+            return None
+        h = c_vp()
+        check(ctx.lib.pfz_strings_upload(ctx.h, c_vp(host.value + off_bytes), c_vp(host.value), n, 1, ctypes.byref(h)))
+        s = cls(ctx, h)
+        s.n = n
+        s.char_width = 1
+        return s
 
     @classmethod
     def upload_packed(cls, ctx, chars, off, width):

@@ -1304,13 +1304,8 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
     PFZ_REQUIRE(ctx && out && offsets && n >= 0, "pfz_strings_upload: bad arguments");
     PFZ_REQUIRE(char_width == 1 || char_width == 4, "pfz_strings_upload: char_width must be 1 or 4 (got %d)", char_width);
     PFZ_REQUIRE(offsets[0] == 0, "pfz_strings_upload: offsets[0] must be 0");
-    int64_t max_len = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t len = offsets[i + 1] - offsets[i];
-        PFZ_REQUIRE(len >= 0, "pfz_strings_upload: offsets not monotone at %lld", (long long)i);
-        if (len > max_len) max_len = len;
-    }
     const int64_t n_units = offsets[n];
+    PFZ_REQUIRE(n_units >= 0, "pfz_strings_upload: negative total length");
     PFZ_REQUIRE(n_units == 0 || chars, "pfz_strings_upload: chars is NULL");
     if (n >= ((int64_t)1 << 31) - 2 || n_units >= ((int64_t)1 << 40)) {
         set_error("pfz_strings_upload: list too large (%lld strings, %lld code units)", (long long)n, (long long)n_units);
@@ -1322,8 +1317,6 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
     s->n = n;
     s->n_units = n_units;
     s->char_width = char_width;
-    s->max_len = max_len;
-    s->h_off.assign(offsets, offsets + n + 1);
     const size_t char_bytes = (size_t)n_units * (size_t)char_width, off_bytes = (size_t)(n + 1) * sizeof(int64_t);
     if (char_bytes + off_bytes <= (48u << 10)) {
         // a query batch: offsets and code units in ONE block and one host-to-device copy (every copy is ~10 us of a 150-us
@@ -1342,6 +1335,15 @@ int pfz_strings_upload(pfz_ctx *ctx, const void *chars, const int64_t *offsets, 
         if (n_units > 0) PFZ_TRY(copy_h2d(ctx, s->chars, chars, char_bytes));
         PFZ_TRY(copy_h2d(ctx, s->offsets, offsets, off_bytes));
     }
+    // (the host's own look at the offsets BEHIND the copies: the DMA is on its way while 100 000 lengths are checked and kept)
+    int64_t max_len = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        PFZ_REQUIRE(len >= 0, "pfz_strings_upload: offsets not monotone at %lld", (long long)i);
+        if (len > max_len) max_len = len;
+    }
+    s->max_len = max_len;
+    s->h_off.assign(offsets, offsets + n + 1);
     *out = s.release();
     return PFZ_OK;
 }

@@ -167,6 +167,12 @@ int event_flag_next(pfz_ctx *ctx, int32_t slot, int32_t **flag, int32_t *value)
 int copy_h2d(pfz_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return PFZ_OK;
+    if (ctx->stage && (const char *)src_host >= ctx->stage && (const char *)src_host + bytes <= ctx->stage + ctx->stage_bytes) {
+        // the source already lies in the pinned staging buffer (pfz_stage_reserve: the string packer wrote it there): no copy of a
+        // copy -- the DMA reads it where it is; the region is not handed out again before the stream has been waited for (stage_take)
+        PFZ_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return PFZ_OK;
+    }
     if (bytes > kStageDirect) {
         PFZ_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
         PFZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -662,6 +668,18 @@ static int event_flag_spin(pfz_ctx *ctx, int32_t slot, const char *who)
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return PFZ_OK;
+}
+
+int pfz_stage_reserve(pfz_ctx *ctx, int64_t bytes, void **host)
+{
+    PFZ_REQUIRE(ctx && host && bytes >= 0, "pfz_stage_reserve: bad arguments");
+    *host = nullptr;
+    if ((size_t)bytes > kStageBytes / 2) return PFZ_OK;      // (too big for the ring: the caller takes the ordinary path)
+    PFZ_HIP(hipSetDevice(ctx->device));
+    char *p = nullptr;
+    PFZ_TRY(stage_take(ctx, (size_t)bytes, &p));
+    *host = p;
     return PFZ_OK;
 }
 

@@ -198,6 +198,75 @@ static PyObject *pack_one_walk(PyObject **items, Py_ssize_t n, PyObject **objs)
     return Py_BuildValue("(NNi)", chars, offs, 1);
 }
 
+/* pack_into(strings, obj_addr, buf_addr, off_bytes, cap) -> number of characters, or None
+ *
+ * pack_one_walk() into memory the caller owns (the engine's PINNED staging buffer, pfz_stage_reserve): int64 offsets[n + 1] at
+ * buf, the 1-byte characters at buf + off_bytes, cap bytes in all.  None -- and nothing left behind, objs untouched again -- when the
+ * list is not all ready 1-byte str or does not fit: the caller takes pack() and the copying upload. */
+static PyObject *pack_into(PyObject *self, PyObject *args)
+{
+    (void)self;
+    PyObject *arg;
+    unsigned long long obj_addr = 0, buf_addr = 0;
+    Py_ssize_t off_bytes = 0, cap = 0;
+    if (!PyArg_ParseTuple(args, "OKKnn", &arg, &obj_addr, &buf_addr, &off_bytes, &cap)) return NULL;
+    PyObject *seq = PySequence_Fast(arg, "pack_into() expects a sequence of str");
+    if (!seq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    PyObject **items = PySequence_Fast_ITEMS(seq);
+    PyObject **objs = (PyObject **)(uintptr_t)obj_addr;
+    if (!buf_addr || off_bytes < (n + 1) * (Py_ssize_t)sizeof(int64_t) || cap < off_bytes) {
+        Py_DECREF(seq);
+        PyErr_SetString(PyExc_ValueError, "pack_into(): the buffer does not hold the offsets");
+        return NULL;
+    }
+    if (objs)
+        for (Py_ssize_t i = 0; i < n; ++i)
+            if (objs[i] != NULL && objs[i] != Py_None) {
+                Py_DECREF(seq);
+                PyErr_SetString(PyExc_ValueError, "pack_into(): the object array must be a fresh np.empty array");
+                return NULL;
+            }
+    int64_t *op = (int64_t *)(uintptr_t)buf_addr;
+    char *buf = (char *)(uintptr_t)buf_addr + off_bytes;
+    const size_t room = (size_t)(cap - off_bytes);
+    size_t pos = 0;
+    op[0] = 0;
+    Py_ssize_t i = 0, nones = 0;
+    for (; i < n; ++i) {
+        if (i + 16 < n) {
+            __builtin_prefetch(items[i + 16], 1, 1);
+            __builtin_prefetch((const char *)items[i + 16] + 64, 0, 1);
+        }
+        PyObject *s = items[i];
+        if (!PyUnicode_Check(s) || !PyUnicode_IS_READY(s) || PyUnicode_KIND(s) != PyUnicode_1BYTE_KIND) break;
+        const size_t len = (size_t)PyUnicode_GET_LENGTH(s);
+        if (pos + len > room) break;
+        memcpy(buf + pos, PyUnicode_1BYTE_DATA(s), len);
+        pos += len;
+        op[i + 1] = (int64_t)pos;
+        if (objs) {
+            if (objs[i] == Py_None) ++nones;
+            Py_INCREF(s);
+            objs[i] = s;
+        }
+    }
+    if (i < n) {                 /* not that kind of list, or too long: undo */
+        if (objs) {
+            for (Py_ssize_t k = 0; k < i; ++k) {
+                Py_DECREF(objs[k]);
+                objs[k] = NULL;
+            }
+            release_overwritten_none(nones);
+        }
+        Py_DECREF(seq);
+        Py_RETURN_NONE;
+    }
+    release_overwritten_none(nones);
+    Py_DECREF(seq);
+    return PyLong_FromSize_t(pos);
+}
+
 static PyObject *pack(PyObject *self, PyObject *args)
 {
     (void)self;
@@ -605,6 +674,7 @@ static PyMethodDef methods[] = {
     {"linkage", linkage, METH_VARARGS, "linkage(from_ids, to_ids, n_strings) -> (cluster int32[n], order int32[k]) as bytes"},
     {"pack", pack, METH_VARARGS, "pack(list[str] [, n_threads]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)"},
     {"gather_objects", gather_objects, METH_VARARGS, "gather_objects(names, idx_addr, n, obj_addr, keep_addr): obj[i] <- names[idx[i]] or None"},
+    {"pack_into", pack_into, METH_VARARGS, "pack_into(strings, obj_addr, buf_addr, off_bytes, cap): offsets + 1-byte characters into the caller's buffer -> characters, or None"},
     {"fill_objects", fill_objects, METH_VARARGS, "fill_objects(seq, obj_addr, n): a fresh object array <- new references to seq[i]"},
     {"fill_columns", fill_columns, METH_VARARGS,
      "fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads): the (To, Similarity) column pairs"},

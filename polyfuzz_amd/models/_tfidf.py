@@ -68,6 +68,7 @@ def _clean_string(string: str) -> str:
 
 
 _TRACE = bool(os.environ.get("PFZ_MATCH_TRACE"))      # host-side stamps of a big match's ranges in .last_trace (tools/r6_match_ab.py)
+_DIRECT_PACK = os.environ.get("PFZ_DIRECT_PACK", "1") != "0"    # (A/B knob: 0 = pack into a bytes object, copy that into the staging buffer)
 _FROM_IN_PACK = os.environ.get("PFZ_FROM_IN_PACK", "1") != "0"      # (A/B knob of tools/match_wall_probe.py; the frames are the same)
 
 
@@ -252,6 +253,9 @@ class TFIDF(BaseMatcher):
     def _upload(self, strings, objects=None):
         """objects: see _lib.pack_strings (the From column, filled in the packer's walk over the strings)"""
         ctx = _lib.Context.default()
+        direct = _lib.DeviceStrings.upload_direct(ctx, strings, objects) if len(strings) >= 1024 and _DIRECT_PACK else None
+        if direct is not None:          # (1-byte strings packed straight into the pinned staging buffer)
+            return direct
         packed = _lib.pack_strings(strings, objects)
         if self.clean_string and packed[2] != 1:
             # code points > 0xFF: clean on the host (str.lower() can map into ASCII); cleaning is idempotent,

@@ -290,3 +290,37 @@ def test_small_frames_put_together_from_their_blocks_equal_the_constructor_s(n, 
     del fast, slow
     after = sys.getrefcount(to_list[7])          # (outside the assert: pytest's rewriting keeps the operand alive)
     assert after == before
+
+
+def test_pack_into_a_caller_s_buffer_equals_pack():
+    """_pack.pack_into (round 6: the string packer writing straight into the engine's pinned staging buffer): offsets and
+    characters equal to pack()'s, the From column filled in the same walk, reference counts exact; a wide string, a non-str item
+    or a buffer that is too small give None and leave nothing behind."""
+    import sys
+    from polyfuzz_amd import _lib
+    if _lib._pack is None or not hasattr(_lib._pack, "pack_into"):
+        pytest.skip("_pack.so not built")
+    names = [f"name {i} inc é" for i in range(5000)] + ["", "x"]
+    n = len(names)
+    raw, off, width = _lib._pack.pack(names, 1)
+    assert width == 1
+    off_bytes = (8 * (n + 1) + 255) & ~255
+    buf = np.zeros(off_bytes + len(raw) + 64, np.uint8)
+    col = np.empty(n, dtype=object)
+    rc0 = sys.getrefcount(names[3])
+    got = _lib._pack.pack_into(names, col.ctypes.data, buf.ctypes.data, off_bytes, len(buf))
+    assert got == len(raw)
+    assert buf[:8 * (n + 1)].tobytes() == off and buf[off_bytes:off_bytes + len(raw)].tobytes() == raw
+    rc1 = sys.getrefcount(names[3])            # (outside the asserts: pytest's rewriting keeps operands in temporaries)
+    assert all(col[i] is names[i] for i in range(n)) and rc1 == rc0 + 1
+    del col
+    rc2 = sys.getrefcount(names[3])
+    assert rc2 == rc0
+    for bad, cap in ((names[:10] + ["日本"] + names[10:20], len(buf)), (names[:10] + [5], len(buf)), (names, off_bytes + 100)):
+        col = np.empty(len(bad), dtype=object)
+        rc0 = sys.getrefcount(bad[3])
+        assert _lib._pack.pack_into(bad, col.ctypes.data, buf.ctypes.data, off_bytes, cap) is None
+        rc1 = sys.getrefcount(bad[3])
+        assert all(c is None for c in col) and rc1 == rc0
+    with pytest.raises(ValueError):
+        _lib._pack.pack_into(names, 0, buf.ctypes.data, 8, len(buf))

@@ -7,9 +7,9 @@ import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from polyfuzz_amd import datasets
-from polyfuzz_amd.models import TFIDF, _utils
+from polyfuzz_amd.models import TFIDF, _utils, _tfidf
 names = datasets.load_company_names()
-KEYS = ("PFZ_K3_NO_STREAMED", "PFZ_MATCH_SHARES")
+KEYS = ("PFZ_K3_NO_STREAMED", "PFZ_MATCH_SHARES", "PFZ_DIRECT_PACK")
 variants = [("r5form", {"PFZ_K3_NO_STREAMED": "1", "PFZ_MATCH_SHARES": "0.3,0.3,0.25,0.15"}),
             ("streamed5", {"PFZ_MATCH_SHARES": "0.2,0.2,0.2,0.2,0.2"}),
             ("streamed4", {"PFZ_MATCH_SHARES": "0.25,0.3,0.25,0.2"}),
@@ -30,6 +30,7 @@ for rep in range(16):
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(env)
+        _tfidf._DIRECT_PACK = os.environ.get("PFZ_DIRECT_PACK", "1") != "0"      # (read at import: set as the variant says)
         df = None
         t0 = time.perf_counter(); df = m.match(names); dt = (time.perf_counter() - t0) * 1e3
         if rep >= 3:
