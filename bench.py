@@ -98,8 +98,8 @@ def parse(argv=None):
                          "device-resident step alone (list resident in HBM: fit + vectorise + index + K3)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="tests only (tests/test_bench_launch_cpu.py): the launch / rendezvous / rank logic of --gpus N on a box "
-                         "WITHOUT a GPU -- TfidfMatchJob driven through tests/cpu_engine.py (oracle arithmetic, gloo exchanges) on a "
-                         "400-name list; prints a rehearsal record, never a bench line")
+                         "WITHOUT a GPU -- hands the ranks to tests/bench_rehearsal.py (TfidfMatchJob through tests/cpu_engine.py on a "
+                         "400-name list); prints a rehearsal record, never a bench line")
     ap.add_argument("--config", choices=("tfidf", "c2", "editdistance", "rapidfuzz", "dense", "tfidf_1m"), default="tfidf",
                     help="tfidf: the headline (+ every other config as a sub-record at N = 1); the others: that "
                          "configuration alone as the line")
@@ -189,37 +189,6 @@ class TorchWorld(World):
 
     def close(self):
         self.dist.destroy_process_group()
-
-
-class _NoDevice:
-    """the context of --rehearse-cpu: nothing to synchronise, nothing to time"""
-    def sync(self): pass
-    def prof_enable(self, level): pass
-    def prof_reset(self): pass
-    def event_record(self, i): pass
-
-
-def rehearse_cpu(world, args):
-    """NOT a measurement and not a bench line (no metric / value keys): the rank logic of `--gpus N` -- launcher, gloo rendezvous,
-    barrier + max-over-ranks around the timed steps, the sharded self-match job of polyfuzz_amd/pipeline.py with its collective
-    `symmetric_ok` question and its exchanges -- on a box without a GPU, the device replaced by tests/cpu_engine.py."""
-    import zlib
-    from polyfuzz_amd import pipeline, synth
-    from tests.cpu_engine import GlooComm, OracleEngine
-    names = synth.company_names(400, seed=3)
-    bounds = pipeline.balanced_bounds(names, world.size)
-    b, e = bounds[world.rank]
-    job = pipeline.TfidfMatchJob(None, names[b:e], names, top_n=3, comm=GlooComm(world.dist), self_match=True, shard_offset=b,
-                                 rows_per_rank=max(y - x for x, y in bounds), engine=OracleEngine(world.torch))
-    wall, result = timed_steps(world, _NoDevice(), job.step, args.steps, args.warmup)
-    idx, val = result.download()
-    idx, val = job.whole_result(idx, val, [y - x for x, y in bounds])
-    if world.rank != 0:
-        return None
-    return {"rehearsal": "--rehearse-cpu: tests/cpu_engine.py in place of the device -- NOT a measurement", "world": world.size,
-            "steps": args.steps, "rows": len(names), "result_is_full": bool(job.result_is_full),
-            "idx_crc32": zlib.crc32(np.ascontiguousarray(idx, np.int32).tobytes()),
-            "val_crc32": zlib.crc32(np.ascontiguousarray(val, np.float64).tobytes())}
 
 
 def self_launch(gpus):
@@ -1202,8 +1171,11 @@ def main():
                 raise SystemExit(self_launch(args.gpus))
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}")
         if args.rehearse_cpu:
+            # (tests only: the rank logic behind the launcher on a box without a GPU -- the stand-in for the device, and with it
+            # every use of oracle/, lives under tests/: tests/bench_rehearsal.py)
+            import importlib
             world = TorchWorld(need_devices=False)
-            out = rehearse_cpu(world, args)
+            out = importlib.import_module("tests.bench_rehearsal").rehearse_cpu(world, args, timed_steps)
             world.close()
             if out is not None:
                 print(json.dumps(out))

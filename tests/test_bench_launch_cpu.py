@@ -2,9 +2,9 @@
 (that call used to end in a SystemExit telling the caller to use the launcher).  bench.py now becomes the
 launcher itself: one rank per GPU, rendezvous over gloo (torch.distributed is never an RCCL user), and
 * on a box without enough devices every rank says so -- "N devices needed, M visible" -- and the job's exit code is not 0;
-* `--rehearse-cpu` (tests only) drives the rank logic behind the launcher -- barrier / max-over-ranks around the timed steps,
-  `TfidfMatchJob`'s sharded self-match with its collective questions and exchanges -- through tests/cpu_engine.py at world 2, and
-  the result is the single-process oracle's."""
+* `--rehearse-cpu` (tests only: bench.py hands its ranks to tests/bench_rehearsal.py) drives the rank logic behind the launcher --
+  barrier / max-over-ranks around the timed steps, `TfidfMatchJob`'s sharded self-match with its collective questions and
+  exchanges -- through tests/cpu_engine.py at world 2, and the result is the single-process oracle's."""
 import json
 import os
 import subprocess

@@ -16,7 +16,7 @@ timeout 600 bash tools/profile_other.sh $O/other > $O/other.log 2>&1
 timeout 300 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio,partial_token_ratio > $O/k7_fuzz.txt 2>&1
 timeout 300 python tools/k7_rowstats.py WRatio >> $O/k7_fuzz.txt 2>&1
 # the user-level call: round 5's form (a session launch per range) against the streamed session, one process, one box
-timeout 300 python tools/r6_match_ab.py "r5form:PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15" "streamed5:PFZ_MATCH_SHARES=1;1;1;1;1" "streamed12 (default):" "streamed16:PFZ_MATCH_SHARES=1;1;1;1;1;1;1;1;1;1;1;1;1;1;1;1" > $O/match_ab.txt 2>&1
+timeout 300 python tools/r6_match_ab.py "round 5 (launch per range, copying upload):PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15,PFZ_DIRECT_PACK=0" "launch per range, direct pack:PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15" "streamed12, copying upload:PFZ_DIRECT_PACK=0" "streamed5:PFZ_MATCH_SHARES=1;1;1;1;1" "streamed12 (default):" "streamed16:PFZ_MATCH_SHARES=1;1;1;1;1;1;1;1;1;1;1;1;1;1;1;1" > $O/match_ab.txt 2>&1
 # `python bench.py --gpus 2` as the driver would call it, on a box with one device: launches itself, every rank says what is missing
 timeout 300 python bench.py --gpus 2 --steps 2 > $O/gpus2_selflaunch.txt 2>&1; echo "bench --gpus 2 rc=$? (expected: not 0 on a one-GPU box)" >> $O/gpus2_selflaunch.txt
 for f in $O/profile/summary.txt $O/profile/summary_headline.txt $O/profile/summary_match.txt $O/k7_fuzz.txt $O/match_ab.txt; do [ -f $f ] && sed -i "1i (source commit $HEAD_ID; tools/r6_final.sh)" $f; done

@@ -46,4 +46,4 @@ if os.environ.get("PFZ_MATCH_TRACE"):
 for name, _ in variants:
     ts, st = res[name]
     i = int(np.argsort(ts)[len(ts) // 2])
-    print(f"{name:22s}: wall median {ts[i]:.3f} ms (min {min(ts):.3f}); stages " + ", ".join(f"{k} {v:.2f}" for k, v in st[i].items()), flush=True)
+    print(f"{name:44s}: wall median {ts[i]:.3f} ms (min {min(ts):.3f}); stages " + ", ".join(f"{k} {v:.2f}" for k, v in st[i].items()), flush=True)
