@@ -125,6 +125,10 @@ class FrameBuilder:
         self.from_col = object_column(from_list) if from_col is None else from_col
         self.names = [np.empty(self.n, dtype=object) for _ in range(top_n)]
         self.sims = [np.empty(self.n, np.float64) for _ in range(top_n)]
+        # (the columns' data addresses, taken ONCE: `ndarray.ctypes` builds a helper object on every access -- ten of them per
+        # filled row range were 10 - 18 us of a range's 80)
+        self._name_at = [a.ctypes.data for a in self.names]
+        self._sim_at = [a.ctypes.data for a in self.sims]
         # The DataFrame is wrapped around the (still empty) columns NOW -- the caller is waiting for the device anyway, and
         # pandas takes ~0.5 ms to look at eleven 100 000-element columns -- and `fill` writes through the arrays it shares
         # with them.  Only if this pandas really shares them (copy=False is a request): otherwise frame() builds it at the end.
@@ -146,9 +150,9 @@ class FrameBuilder:
         the device's result and the columns)"""
         if not m or not self.top_n:
             return
-        _lib._pack.fill_columns(self.to_list, idx_addr, val_addr, m, self.top_n,
-                                tuple(a.ctypes.data + 8 * row0 for a in self.names),
-                                tuple(a.ctypes.data + 8 * row0 for a in self.sims), _FILL_THREADS)
+        at = 8 * row0
+        _lib._pack.fill_columns(self.to_list, idx_addr, val_addr, m, self.top_n, tuple(b + at for b in self._name_at),
+                                tuple(b + at for b in self._sim_at), _FILL_THREADS)
 
     def fill(self, idx, val, row0=0):
         m = len(idx)
@@ -156,9 +160,7 @@ class FrameBuilder:
             return
         idx = np.ascontiguousarray(idx, np.int32).reshape(m, self.top_n)
         val = np.ascontiguousarray(val, np.float32).reshape(m, self.top_n)
-        _lib._pack.fill_columns(self.to_list, idx.ctypes.data, val.ctypes.data, m, self.top_n,
-                                tuple(a.ctypes.data + 8 * row0 for a in self.names),
-                                tuple(a.ctypes.data + 8 * row0 for a in self.sims), _FILL_THREADS)
+        self.fill_raw(idx.ctypes.data, val.ctypes.data, m, row0)
 
     def _wrap(self):
         if self.top_n and self.n < 8192 and _fast_frame_ok():
