@@ -423,6 +423,15 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
     int *const mark = (int *)(sm.cand + kSymCap) - 64;          // scatter scratch: the tail of the candidate buffer
     if ((uint32_t)(uintptr_t)sm.acc != 0u) __builtin_trap();    // layout assumption of run_steps()
     const int lane = threadIdx.x;
+    if (MODE == 2) {
+        // pass 2 is launched blind (the host does not know how many rows the merge listed -- as a rule a handful, often none):
+        // a workgroup without an item leaves before it clears 8 KB of accumulators.  (A streamed session launches it once per row
+        // range, beside pass 1: twelve times two grids of idle workgroups were 0.5 ms of wave time per match.)
+        int n_ovf = a.ovf[0];
+        n_ovf = n_ovf > a.n ? a.n : n_ovf;
+        const int hi = n_ovf < a.ovf_base + a.ovf_max ? n_ovf : a.ovf_base + a.ovf_max;
+        if ((int)blockIdx.x >= (hi > a.ovf_base ? (hi - a.ovf_base) * a.n_sl : 0)) return;
+    }
     int4 *acc4 = (int4 *)acc;
     constexpr int N4 = C / 4;
     int zero;
@@ -903,11 +912,11 @@ static void sym_fill_args(K3SymArgs &a, const pfz_index *ix, const pfz_csr *A, K
 // pass 2 of the rows the merge listed (sent more than their push slots hold): the first kSymSlicedRows in slices of the to-blocks
 // (a whole row is ~100 us of one wave: a handful of rows would cost that much wall time), their partial lists merged; whatever is
 // listed beyond, as whole rows
-static void sym_launch_pass2(pfz_ctx *ctx, K3SymArgs a, hipStream_t stream = nullptr)
+static void sym_launch_pass2(pfz_ctx *ctx, K3SymArgs a, hipStream_t stream = nullptr, int per_cu = 16)
 {
     if (!stream) stream = ctx->stream;
     const int nb = a.nb;
-    const unsigned grid2 = (unsigned)ctx->prop.multiProcessorCount * 16;
+    const unsigned grid2 = (unsigned)ctx->prop.multiProcessorCount * (unsigned)per_cu;
     const int per = (nb + kSymSlices - 1) / kSymSlices;
     a.n_mag_items = 0;
     a.n_parts = 1;         // (the listed rows are recomputed in full, whoever they belong to)
@@ -1074,7 +1083,7 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
         a.row_begin = (int32_t)row0;
         a.row_end = (int32_t)row1;
         hipLaunchKernelGGL(k3_sym_merge<1>, dim3((unsigned)(row1 - row0)), dim3(64), 0, side, a);
-        sym_launch_pass2(ctx, a, side);
+        sym_launch_pass2(ctx, a, side, 2);       // (a range's overflow rows are few: two workgroups per CU loop over them)
         PFZ_HIP(hipGetLastError());
         PFZ_HIP(hipEventRecord(ctx->events[first_event + i], side));
         PFZ_TRY(event_flag_next(ctx, first_event + i, &flag, &flag_value));       // (... and as a word in pinned memory: pfz_topn_rows_begin / _finish)
