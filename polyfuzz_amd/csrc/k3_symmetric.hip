@@ -666,6 +666,9 @@ __global__ __launch_bounds__(64) void k3_sym_kernel(const K3SymArgs a)
 // (kWaves rows per workgroup.  4 as a rule; 1 for a streamed session, whose merges run BESIDE pass 1: a CU's LDS is full of pass-1
 // workgroups of ~10 KB each, and only a workgroup that fits the hole ONE of them leaves -- 4.6 KB here, not 18 -- gets in before
 // pass 1 has finished.  Measured: the four-row merge of the first range sat in its queue for 1.2 ms, stream priority or not.)
+#ifndef PFZ_K3_SYM_MERGE_W
+#define PFZ_K3_SYM_MERGE_W 1       // rows per workgroup of a streamed range's merge (tuning builds: 2 still fits the hole, 9.2 KB)
+#endif
 template <int kWaves>
 __global__ __launch_bounds__(64 * kWaves) void k3_sym_merge(const K3SymArgs a)
 {
@@ -1082,7 +1085,8 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
         hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, side, a, flag, flag_value);
         a.row_begin = (int32_t)row0;
         a.row_end = (int32_t)row1;
-        hipLaunchKernelGGL(k3_sym_merge<1>, dim3((unsigned)(row1 - row0)), dim3(64), 0, side, a);
+        hipLaunchKernelGGL(k3_sym_merge<PFZ_K3_SYM_MERGE_W>, dim3((unsigned)((row1 - row0 + PFZ_K3_SYM_MERGE_W - 1) / PFZ_K3_SYM_MERGE_W)),
+                           dim3(64 * PFZ_K3_SYM_MERGE_W), 0, side, a);
         sym_launch_pass2(ctx, a, side, 2);       // (a range's overflow rows are few: two workgroups per CU loop over them)
         PFZ_HIP(hipGetLastError());
         PFZ_HIP(hipEventRecord(ctx->events[first_event + i], side));
