@@ -257,7 +257,18 @@ def recorded_traffic(key):
 
 
 def n_cores():
-    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """host threads the all-cores CPU arms use: the affinity mask, capped by the cgroup's CPU quota where there is one -- the GPU
+    box shows 256 CPUs in its mask and grants 16 CPUs' worth of time (cpu.max 1600000 / 100000, tools/r6_topo_probe.sh): 256 threads
+    there are 16 cores thrashing, and "cores: 256" in a CPU arm's record said more than the box gave"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def median(xs):
