@@ -6,12 +6,17 @@
  * (no intermediate joined str, no per-string Python call).  Replaces nothing in the reference: its
  * matchers hand Python lists straight to sklearn / rapidfuzz (reference models/_base.py:13-16).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE          /* sched_getcpu, pthread_attr_setaffinity_np */
+#endif
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <stdio.h>
+#include <time.h>
 
 /* pack(list[str] [, n_threads [, obj_addr]]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)
  * obj_addr != 0: the data address of a FRESH np.empty(n, object) array that becomes the From column of the result frame
@@ -45,6 +50,179 @@ static void release_overwritten_none(Py_ssize_t k)
 #else
     (void)k;                                   /* immortal None: np.empty's Py_INCREF(None) was a no-op too */
 #endif
+}
+
+/* Where the helper threads of fill_ranges / pack_into run: on the cores that share the calling thread's L3 (its CCD on an EPYC
+ * host), each on a core of its own -- never on the caller's core or its SMT sibling.  The strings' headers lie in the caller's
+ * caches (it has just walked them); from another CCD, let alone the other socket, every one of them is a remote miss (measured on
+ * the MI355X host, 2 x EPYC 9575F: four unpinned helpers made the frame fill 4 x SLOWER).  Read from sysfs once per CPU the caller
+ * is found on; any failure = no pinning.  PFZ_HOST_PIN=0 turns it off. */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <sched.h>
+
+static int parse_cpu_list(const char *path, cpu_set_t *set)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    char line[4096];
+    if (!fgets(line, sizeof line, f)) {
+        fclose(f);
+        return -1;
+    }
+    fclose(f);
+    CPU_ZERO(set);
+    for (char *p = line; *p && *p != '\n';) {
+        char *end;
+        long a = strtol(p, &end, 10), b = a;
+        if (end == p) return -1;
+        if (*end == '-') {
+            p = end + 1;
+            b = strtol(p, &end, 10);
+            if (end == p) return -1;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, set);
+        p = *end == ',' ? end + 1 : end;
+    }
+    return 0;
+}
+
+/* the caller's L3 domain without the caller's own core, as an affinity mask (what l3_local_cpus counted the cores of) */
+static cpu_set_t g_l3_mask;
+static int g_l3_mask_for = -1;
+
+static int pin_is_off(void)
+{
+    const char *e = getenv("PFZ_HOST_PIN");
+    return e && e[0] == '0';
+}
+
+/* cpus[0..k): one CPU per physical core of the caller's L3 domain, the caller's own core left out; returns k (0: do not pin) */
+static int l3_local_cpus(int *cpus, int max)
+{
+    static int cached_for = -1, cached_n = 0, cached[64];
+    if (pin_is_off()) return 0;
+    const int me = sched_getcpu();
+    if (me < 0) return 0;
+    if (me != cached_for) {
+        cached_for = me;
+        cached_n = 0;
+        char path[160];
+        cpu_set_t l3, allowed, sib;
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", me);
+        if (parse_cpu_list(path, &l3) != 0 || sched_getaffinity(0, sizeof allowed, &allowed) != 0) return 0;
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", me);
+        if (parse_cpu_list(path, &sib) != 0) CPU_ZERO(&sib);
+        CPU_SET(me, &sib);
+        CPU_ZERO(&g_l3_mask);
+        g_l3_mask_for = -1;
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &l3) && CPU_ISSET(c, &allowed) && !CPU_ISSET(c, &sib)) {
+                CPU_SET(c, &g_l3_mask);
+                g_l3_mask_for = me;
+            }
+        for (int c = 0; c < CPU_SETSIZE && cached_n < 64; ++c) {
+            if (!CPU_ISSET(c, &l3) || !CPU_ISSET(c, &allowed) || CPU_ISSET(c, &sib)) continue;
+            cpu_set_t its;
+            snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+            if (parse_cpu_list(path, &its) == 0) {
+                int first = c;
+                for (int d = 0; d < c; ++d)
+                    if (CPU_ISSET(d, &its)) {
+                        first = d;
+                        break;
+                    }
+                if (first != c && CPU_ISSET(first, &l3) && CPU_ISSET(first, &allowed)) continue;      /* (its core is taken by a lower sibling) */
+            }
+            cached[cached_n++] = c;
+        }
+    }
+    int k = 0;
+    for (; k < cached_n && k < max; ++k) cpus[k] = cached[k];
+    return k;
+}
+
+/* A crew: the helper threads of ONE call (pack_into on threads, fill_ranges).
+ * - Confined to the caller's L3 domain minus the caller's own core -- to the whole domain, not to a core each: the scheduler picks
+ *   idle cores among them (a helper nailed to one core waits whenever a neighbour on the host has that core).
+ * - Started as a chain: the caller starts one helper, every helper starts the next before it takes work -- one pthread_create
+ *   (20 - 30 us with the affinity attribute) on the caller's path instead of three.
+ * - Detached, and NOBODY waits for a helper as such: the work is drawn from counters and the phases end when the work of the phase
+ *   is done, whoever did it.  A helper the scheduler has not run yet (placed behind a spinning thread, on a core that sleeps) does not
+ *   hold the call up -- with a barrier over the threads one call in ten took 6 - 13 ms instead of 3 on a freshly started box; it
+ *   finds nothing left when it gets there and leaves.  The job lives on the heap behind the crew's header and is freed by whoever
+ *   lets go of it last. */
+struct crew;
+typedef struct {
+    struct crew *c;
+    int tid;
+} crew_slot;
+
+typedef struct crew {
+    int refs;                               /* atomic: the caller + every helper planned */
+    int planned;
+    int confine;                            /* helpers get the L3 mask */
+    cpu_set_t mask;
+    void (*run)(void *job, int tid);        /* tid 1 .. planned (the caller is 0 and calls run itself) */
+    crew_slot slot[16];
+    _Alignas(64) char job[];
+} crew;
+
+static crew *crew_new(size_t job_bytes, int helpers, void (*run)(void *, int))
+{
+    crew *c = (crew *)calloc(1, sizeof(crew) + job_bytes);
+    if (!c) return NULL;
+    if (helpers > 15) helpers = 15;
+    if (helpers < 0) helpers = 0;
+    c->planned = helpers;
+    c->refs = 1 + helpers;
+    c->run = run;
+    c->confine = g_l3_mask_for >= 0 && !pin_is_off();
+    if (c->confine) c->mask = g_l3_mask;
+    return c;
+}
+
+static void crew_release(crew *c, int n)
+{
+    if (n > 0 && __atomic_sub_fetch(&c->refs, n, __ATOMIC_ACQ_REL) == 0) free(c);
+}
+
+static void *crew_helper(void *arg);
+
+/* start helper `tid` (and with it the chain behind it); a start that fails lets go of the references of every helper not started */
+static void crew_spawn(crew *c, int tid)
+{
+    if (tid > c->planned) return;
+    c->slot[tid].c = c;
+    c->slot[tid].tid = tid;
+    pthread_attr_t attr;
+    pthread_t th;
+    int rc = -1;
+    if (pthread_attr_init(&attr) == 0) {
+        pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);
+        if (c->confine) pthread_attr_setaffinity_np(&attr, sizeof c->mask, &c->mask);
+        rc = pthread_create(&th, &attr, crew_helper, &c->slot[tid]);
+        if (rc != 0 && c->confine) {            /* (an affinity the kernel refuses: anywhere, then) */
+            pthread_attr_destroy(&attr);
+            if (pthread_attr_init(&attr) == 0) {
+                pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);
+                rc = pthread_create(&th, &attr, crew_helper, &c->slot[tid]);
+            }
+        }
+        pthread_attr_destroy(&attr);
+    }
+    if (rc != 0) crew_release(c, c->planned - tid + 1);
+}
+
+static void *crew_helper(void *arg)
+{
+    crew *c = ((crew_slot *)arg)->c;
+    const int tid = ((crew_slot *)arg)->tid;
+    crew_spawn(c, tid + 1);
+    c->run(c->job, tid);
+    crew_release(c, 1);
+    return NULL;
 }
 
 typedef struct {
@@ -198,7 +376,121 @@ static PyObject *pack_one_walk(PyObject **items, Py_ssize_t n, PyObject **objs)
     return Py_BuildValue("(NNi)", chars, offs, 1);
 }
 
-/* pack_into(strings, obj_addr, buf_addr, off_bytes, cap) -> number of characters, or None
+/* pack_into on threads (n_threads > 1, no From column, >= 16 384 strings).  The list is cut into chunks of 2 048 strings that the
+ * caller and its crew DRAW (an atomic counter) --
+ * walk 1: kind checks + lengths (off[i + 1] = len) and the chunk's total; when every chunk of walk 1 is DONE (a count of chunks,
+ * not of threads) everybody adds up the totals in front of the chunks it draws in walk 2: the characters to their place,
+ * off[i + 1] = the end.  The threads only READ the strings (the calling thread keeps the GIL and is one of them); no reference
+ * count is touched -- the frame's From column is the range fill's business then (fill_ranges). */
+enum { PINTO_CHUNK = 2048 };
+
+typedef struct {
+    PyObject **items;
+    Py_ssize_t n;
+    int64_t *off;
+    char *buf;
+    size_t room;
+    int n_chunks;
+    int bad;                           /* atomic */
+    int next1, done1, next2, done2;    /* atomic: the chunk draws of the two walks and the chunks finished */
+    size_t total[];                    /* per chunk */
+} pinto_job;
+
+static void pinto_run(void *arg, int tid)
+{
+    (void)tid;
+    pinto_job *job = (pinto_job *)arg;
+    PyObject **items = job->items;
+    int64_t *op = job->off;
+    const int n_chunks = job->n_chunks;
+    for (;;) {
+        const int c = __atomic_fetch_add(&job->next1, 1, __ATOMIC_RELAXED);
+        if (c >= n_chunks) break;
+        const Py_ssize_t lo = (Py_ssize_t)c * PINTO_CHUNK, hi = lo + PINTO_CHUNK < job->n ? lo + PINTO_CHUNK : job->n;
+        size_t sum = 0;
+        for (Py_ssize_t i = lo; i < hi; ++i) {
+            if (i + 16 < hi) __builtin_prefetch(items[i + 16], 0, 1);
+            PyObject *s = items[i];
+            if (!PyUnicode_Check(s) || !PyUnicode_IS_READY(s) || PyUnicode_KIND(s) != PyUnicode_1BYTE_KIND) {
+                __atomic_store_n(&job->bad, 1, __ATOMIC_RELAXED);
+                break;
+            }
+            const size_t len = (size_t)PyUnicode_GET_LENGTH(s);
+            op[i + 1] = (int64_t)len;
+            sum += len;
+        }
+        job->total[c] = sum;
+        __atomic_add_fetch(&job->done1, 1, __ATOMIC_RELEASE);
+    }
+    if (__atomic_load_n(&job->next2, __ATOMIC_RELAXED) >= n_chunks) return;        /* (a late-comer: nothing left to draw) */
+    while (__atomic_load_n(&job->done1, __ATOMIC_ACQUIRE) < n_chunks) __builtin_ia32_pause();
+    if (__atomic_load_n(&job->bad, __ATOMIC_RELAXED)) return;
+    size_t all = 0;
+    for (int c = 0; c < n_chunks; ++c) all += job->total[c];
+    if (all > job->room) return;          /* (everybody computes the same sum and leaves; the caller reports it) */
+    char *buf = job->buf;
+    int summed = 0;                        /* chunks [0, summed) are added up in pos */
+    size_t pos = 0;
+    for (;;) {
+        const int c = __atomic_fetch_add(&job->next2, 1, __ATOMIC_RELAXED);
+        if (c >= n_chunks) break;
+        for (; summed < c; ++summed) pos += job->total[summed];
+        const Py_ssize_t lo = (Py_ssize_t)c * PINTO_CHUNK, hi = lo + PINTO_CHUNK < job->n ? lo + PINTO_CHUNK : job->n;
+        size_t at = pos;
+        for (Py_ssize_t i = lo; i < hi; ++i) {
+            if (i + 16 < hi) {
+                __builtin_prefetch(items[i + 16], 0, 1);
+                __builtin_prefetch((const char *)items[i + 16] + 64, 0, 1);
+            }
+            const size_t len = (size_t)op[i + 1];
+            memcpy(buf + at, PyUnicode_1BYTE_DATA(items[i]), len);
+            at += len;
+            op[i + 1] = (int64_t)at;
+        }
+        __atomic_add_fetch(&job->done2, 1, __ATOMIC_RELEASE);
+    }
+}
+
+/* -> characters packed; -1: not that kind of list / does not fit (nothing left behind that matters: the caller's buffer only);
+ * -2: no helper could be placed on the caller's L3 (or no memory for the job) -- the caller takes the single walk */
+static Py_ssize_t pack_into_threads(PyObject **items, Py_ssize_t n, int64_t *op, char *buf, size_t room, int n_threads)
+{
+    int local[16];
+    const int n_local = l3_local_cpus(local, 16);
+    if (n_threads > 16) n_threads = 16;
+    if (!pin_is_off()) {
+        if (n_local == 0) return -2;
+        if (n_threads > 1 + n_local) n_threads = 1 + n_local;
+    }
+    const int n_chunks = (int)((n + PINTO_CHUNK - 1) / PINTO_CHUNK);
+    crew *c = crew_new(sizeof(pinto_job) + (size_t)n_chunks * sizeof(size_t), n_threads - 1, pinto_run);
+    if (!c) return -2;
+    pinto_job *job = (pinto_job *)c->job;
+    job->items = items;
+    job->n = n;
+    job->off = op;
+    job->buf = buf;
+    job->room = room;
+    job->n_chunks = n_chunks;
+    op[0] = 0;
+    crew_spawn(c, 1);
+    pinto_run(job, 0);
+    /* the call is over when the WORK is: every chunk of walk 2 done -- or walk 1 done and found wanting */
+    Py_ssize_t got = -1;
+    while (__atomic_load_n(&job->done1, __ATOMIC_ACQUIRE) < n_chunks) __builtin_ia32_pause();
+    if (!__atomic_load_n(&job->bad, __ATOMIC_RELAXED)) {
+        size_t all = 0;
+        for (int k = 0; k < n_chunks; ++k) all += job->total[k];
+        if (all <= room) {
+            while (__atomic_load_n(&job->done2, __ATOMIC_ACQUIRE) < n_chunks) __builtin_ia32_pause();
+            got = (Py_ssize_t)all;
+        }
+    }
+    crew_release(c, 1);
+    return got;
+}
+
+/* pack_into(strings, obj_addr, buf_addr, off_bytes, cap [, n_threads]) -> number of characters, or None
  *
  * pack_one_walk() into memory the caller owns (the engine's PINNED staging buffer, pfz_stage_reserve): int64 offsets[n + 1] at
  * buf, the 1-byte characters at buf + off_bytes, cap bytes in all.  None -- and nothing left behind, objs untouched again -- when the
@@ -209,7 +501,8 @@ static PyObject *pack_into(PyObject *self, PyObject *args)
     PyObject *arg;
     unsigned long long obj_addr = 0, buf_addr = 0;
     Py_ssize_t off_bytes = 0, cap = 0;
-    if (!PyArg_ParseTuple(args, "OKKnn", &arg, &obj_addr, &buf_addr, &off_bytes, &cap)) return NULL;
+    int n_threads = 1;
+    if (!PyArg_ParseTuple(args, "OKKnn|i", &arg, &obj_addr, &buf_addr, &off_bytes, &cap, &n_threads)) return NULL;
     PyObject *seq = PySequence_Fast(arg, "pack_into() expects a sequence of str");
     if (!seq) return NULL;
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
@@ -230,6 +523,14 @@ static PyObject *pack_into(PyObject *self, PyObject *args)
     int64_t *op = (int64_t *)(uintptr_t)buf_addr;
     char *buf = (char *)(uintptr_t)buf_addr + off_bytes;
     const size_t room = (size_t)(cap - off_bytes);
+    if (!objs && n_threads > 1 && n >= 16384) {
+        const Py_ssize_t got = pack_into_threads(items, n, op, buf, room, n_threads);
+        if (got != -2) {
+            Py_DECREF(seq);
+            if (got < 0) Py_RETURN_NONE;
+            return PyLong_FromSsize_t(got);
+        }
+    }
     size_t pos = 0;
     op[0] = 0;
     Py_ssize_t i = 0, nones = 0;
@@ -528,6 +829,345 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
     Py_RETURN_NONE;
 }
 
+/* fill_ranges(names, idx_addr, val_addr, top_n, obj_addrs, sim_addrs, ends, wait_addr, ctx_addr, first_slot, n_threads
+ *             [, stamps_addr [, from_obj_addr]])
+ *
+ * The (To_r, Similarity_r) column pairs of a BIG match whose result arrives in ascending row ranges (pfz_cossim_topn_ranges with a
+ * mirror: idx / val are the whole result in pinned host memory, range i = rows [ends[i-1], ends[i]) valid once
+ * wait(ctx, first_slot + i) -- pfz_event_wait, a spin on a word in pinned memory -- has returned 0).  Same cells as fill_columns.
+ * from_obj_addr != 0: the match is a list against itself (n rows = len(names)) and the From column -- a fresh object array, slot
+ * i <- a new reference to names[i] -- is filled in the same closing walk.
+ *
+ * Round 6: the frame's gathers were the user-level call's tail -- from the seventh of twelve ranges on the host found the ranges
+ * waiting, and the call ended 0.4 - 0.8 ms behind the device.  What was measured on the way here (the MI355X host, 2 x EPYC 9575F;
+ * tools/ubench/frame_fill_mt.c is the model, tools/r6_match_ab.py the call):
+ *   - threads with atomic reference counts in the gathers lose (3.9 ms on four against 3.0 on one);
+ *   - helper threads the scheduler places lose whatever they do: 0.44 -> 0.95 ms for the bare STORES on two threads -- the names and
+ *     the columns lie in the caller's caches, from another CCD or the other socket every line is a remote miss; pinned to the cores
+ *     that share the caller's L3 the same stores take 0.27 / 0.16 / 0.13 ms on 2 / 4 / 8 threads (the crew above, l3_local_cpus);
+ *   - every object owned by one thread by its address, each thread scanning all cells for its own: 4 x slower than one thread.
+ * So: NO thread touches a reference count while the gathers run.  A thread stores the pointers and counts, per list position,
+ * how many it stored, in an array of its own; when every task is done, the positions are cut into chunks that the threads draw, and
+ * whoever draws a chunk adds its counts to the objects' reference counts -- with ATOMIC adds, one per name: one object may sit at
+ * several positions of a list, in two chunks.  The calling thread holds the GIL from the first store to the last add.
+ * A task = (range, 1024 rows, every column); a thread that draws a task of a range nobody has seen final yet waits for it itself.
+ * The slots' old contents (np.empty's None or NULL) are checked and counted by whoever overwrites them.
+ * A wait that fails stops the draw; what was stored by then is counted like the rest (the columns stay consistent), then it raises.
+ * Where reference counts cannot be edited directly (CPython >= 3.12: immortal objects) the closing walk is the calling thread's.
+ */
+typedef int (*pfz_wait_fn)(void *ctx, int32_t slot);
+
+enum { RFILL_ROWS = 1024, RFILL_WALK = 2048 };
+
+typedef struct {
+    PyObject **items;
+    Py_ssize_t n_names, top_n;
+    const int32_t *idx;
+    const float *val;
+    pfz_wait_fn wait;
+    void *ctx;
+    int first_slot;
+    int n_threads;           /* the caller + the helpers planned: the count arrays */
+    int n_ranges;
+    long n_tasks;
+    long n_walk;             /* chunks of the closing walk */
+    long next_task, tasks_done;      /* atomic */
+    long next_walk, walk_done;       /* atomic */
+    int error;               /* atomic: 1 = a wait failed, 2 = a slot was not fresh */
+    int32_t *cnt;            /* n_threads x n_names */
+    PyObject **from_obj;     /* the From column of a self-match, or NULL */
+    double *stamps;          /* 2 x n_ranges (seconds, CLOCK_MONOTONIC): range seen final / its last task done; or NULL */
+    long none_new[16], none_old[16];
+    int64_t ends[64];
+    long task_end[64];       /* task_end[i] = number of tasks of ranges 0..i */
+    long left[64];           /* tasks of range i not finished yet (atomic): stamps */
+    int ready[64];           /* range i has been seen final (atomic) */
+    PyObject **obj[1024];
+    double *sim[1024];
+} rfill_job;
+
+static double mono_now(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static void rfill_task(rfill_job *job, int tid, Py_ssize_t lo, Py_ssize_t hi)
+{
+    const Py_ssize_t top_n = job->top_n, n_names = job->n_names;
+    PyObject *dummy = Py_None;
+    PyObject **items = n_names ? job->items : &dummy;
+    int32_t *cnt = job->cnt + (size_t)tid * (size_t)(n_names ? n_names : 1);
+    long none_new = 0, none_old = 0;
+    int stale = 0;
+    for (Py_ssize_t r = 0; r < top_n; ++r) {
+        const int32_t *idx = job->idx + r;
+        const float *val = job->val + r;
+        PyObject **obj = job->obj[r];
+        double *sim = job->sim[r];
+        for (Py_ssize_t i = lo; i < hi; ++i) {
+            const int32_t j = idx[i * top_n];
+            const double t = rint((double)val[i * top_n] * 1000.0);       /* numpy's round(x, 3) = rint(x * 1000) / 1000 */
+            const int keep = !(t < 1.0) & (j >= 0) & (j < n_names);       /* (rint(.) / 1000 < 0.001 exactly when rint(.) < 1) */
+            const Py_ssize_t jj = keep ? j : 0;
+            PyObject *o = items[jj];
+            o = keep ? o : Py_None;
+            cnt[jj] += keep;
+            none_new += !keep;
+            PyObject *old = obj[i];
+            none_old += old == Py_None;
+            stale |= (old != NULL) & (old != Py_None);
+            sim[i] = keep ? t / 1000.0 : 0.0;
+            obj[i] = o;
+        }
+    }
+    job->none_new[tid] += none_new;
+    job->none_old[tid] += none_old;
+    if (stale) __atomic_store_n(&job->error, 2, __ATOMIC_RELAXED);
+}
+
+/* the closing walk over list positions [lo, hi): the counts of every thread to the objects, the From column of a self-match */
+static void rfill_count(rfill_job *job, int tid, Py_ssize_t lo, Py_ssize_t hi, int atomic)
+{
+    const Py_ssize_t n = job->n_names;
+    PyObject **items = job->items, **from = job->from_obj;
+    long none_old = 0;
+    int stale = 0;
+    for (Py_ssize_t j = lo; j < hi; ++j) {
+        if (j + 8 < hi) __builtin_prefetch(items[j + 8], 1, 1);
+        long c = from != NULL;
+        for (int u = 0; u < job->n_threads; ++u) {
+            int32_t *p = job->cnt + (size_t)u * (size_t)n + j;
+            c += *p;
+            *p = 0;               /* (the arrays are kept between calls: left zeroed) */
+        }
+        PyObject *o = items[j];
+        if (from) {
+            PyObject *old = from[j];
+            none_old += old == Py_None;
+            stale |= (old != NULL) & (old != Py_None);
+            from[j] = o;
+        }
+        if (!c) continue;
+#if PFZ_DIRECT_REFCNT
+        if (atomic) __atomic_fetch_add(&o->ob_refcnt, (Py_ssize_t)c, __ATOMIC_RELAXED);
+        else o->ob_refcnt += c;
+#else
+        (void)atomic;
+        for (; c > 0; --c) Py_INCREF(o);
+#endif
+    }
+    job->none_old[tid] += none_old;
+    if (stale) __atomic_store_n(&job->error, 2, __ATOMIC_RELAXED);
+}
+
+static void rfill_run(void *arg, int tid)
+{
+    rfill_job *job = (rfill_job *)arg;
+    const long n_tasks = job->n_tasks;
+    int range = 0;
+    for (;;) {
+        const long t = __atomic_fetch_add(&job->next_task, 1, __ATOMIC_RELAXED);
+        if (t >= n_tasks) break;
+        /* (after a wait has failed the tasks left are drawn and counted without being done: the gathers' end is a count of tasks) */
+        if (__atomic_load_n(&job->error, __ATOMIC_RELAXED) != 1) {
+            while (t >= job->task_end[range]) ++range;
+            int ok = 1;
+            if (!__atomic_load_n(&job->ready[range], __ATOMIC_ACQUIRE)) {
+                if (job->wait(job->ctx, job->first_slot + range) != 0) {
+                    __atomic_store_n(&job->error, 1, __ATOMIC_RELAXED);
+                    ok = 0;
+                } else if (!__atomic_exchange_n(&job->ready[range], 1, __ATOMIC_ACQ_REL) && job->stamps) {
+                    job->stamps[2 * range] = mono_now();
+                }
+            }
+            if (ok) {
+                const Py_ssize_t row0 = range ? (Py_ssize_t)job->ends[range - 1] : 0, row1 = (Py_ssize_t)job->ends[range];
+                const long k = t - (range ? job->task_end[range - 1] : 0);
+                const Py_ssize_t lo = row0 + k * RFILL_ROWS, hi = lo + RFILL_ROWS < row1 ? lo + RFILL_ROWS : row1;
+                rfill_task(job, tid, lo, hi);
+                if (__atomic_sub_fetch(&job->left[range], 1, __ATOMIC_ACQ_REL) == 0 && job->stamps) job->stamps[2 * range + 1] = mono_now();
+            }
+        }
+        __atomic_add_fetch(&job->tasks_done, 1, __ATOMIC_RELEASE);
+    }
+    if (__atomic_load_n(&job->next_walk, __ATOMIC_RELAXED) >= job->n_walk) return;        /* (a late-comer: nothing left to draw) */
+    /* every task done -- by whomever -- before anybody counts: the counts of a position come from all the threads */
+    while (__atomic_load_n(&job->tasks_done, __ATOMIC_ACQUIRE) < n_tasks) __builtin_ia32_pause();
+#if !PFZ_DIRECT_REFCNT
+    if (tid != 0) return;          /* (no atomic adds beside immortal objects: the closing walk is the caller's alone) */
+#endif
+    for (;;) {
+        const long w = __atomic_fetch_add(&job->next_walk, 1, __ATOMIC_RELAXED);
+        if (w >= job->n_walk) break;
+        const Py_ssize_t lo = (Py_ssize_t)w * RFILL_WALK, hi = lo + RFILL_WALK < job->n_names ? lo + RFILL_WALK : job->n_names;
+        rfill_count(job, tid, lo, hi, PFZ_DIRECT_REFCNT && job->n_threads > 1);
+        __atomic_add_fetch(&job->walk_done, 1, __ATOMIC_RELEASE);
+    }
+}
+
+static int32_t *g_rfill_cnt = NULL;        /* the threads' count arrays, kept (and kept zeroed) between calls; GIL-protected */
+static size_t g_rfill_cap = 0;
+
+static PyObject *fill_ranges(PyObject *self, PyObject *args)
+{
+    (void)self;
+    PyObject *names, *obj_addrs, *sim_addrs, *ends_t;
+    unsigned long long idx_addr, val_addr, wait_addr, ctx_addr, stamps_addr = 0, from_obj_addr = 0;
+    Py_ssize_t top_n;
+    int first_slot, n_threads;
+    if (!PyArg_ParseTuple(args, "OKKnO!O!O!KKii|KK", &names, &idx_addr, &val_addr, &top_n, &PyTuple_Type, &obj_addrs, &PyTuple_Type,
+                          &sim_addrs, &PyTuple_Type, &ends_t, &wait_addr, &ctx_addr, &first_slot, &n_threads, &stamps_addr, &from_obj_addr))
+        return NULL;
+    const Py_ssize_t n_ranges = PyTuple_GET_SIZE(ends_t);
+    if (top_n < 1 || top_n > 1024 || PyTuple_GET_SIZE(obj_addrs) != top_n || PyTuple_GET_SIZE(sim_addrs) != top_n || n_ranges < 1 ||
+        n_ranges > 64 || !wait_addr || !idx_addr || !val_addr) {
+        PyErr_SetString(PyExc_ValueError, "fill_ranges(): need 1..1024 column pairs, 1..64 range ends, the result's addresses and a wait function");
+        return NULL;
+    }
+    PyObject *seq = PySequence_Fast(names, "fill_ranges() expects a sequence of names");
+    if (!seq) return NULL;
+    /* helpers only where they can sit on the caller's L3 (anywhere else they cost more than they do: see above) */
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    int local[16];
+    const int n_local = n_threads > 1 ? l3_local_cpus(local, 16) : 0;
+    if (n_threads > 1 + n_local && !pin_is_off()) n_threads = 1 + n_local;
+    crew *c = crew_new(sizeof(rfill_job), n_threads - 1, rfill_run);
+    if (!c) {
+        Py_DECREF(seq);
+        return PyErr_NoMemory();
+    }
+    rfill_job *job = (rfill_job *)c->job;
+    for (Py_ssize_t r = 0; r < top_n; ++r) {
+        job->obj[r] = (PyObject **)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(obj_addrs, r));
+        job->sim[r] = (double *)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(sim_addrs, r));
+    }
+    int64_t prev = 0;
+    long tasks = 0;
+    for (Py_ssize_t i = 0; i < n_ranges && !PyErr_Occurred(); ++i) {
+        job->ends[i] = (int64_t)PyLong_AsLongLong(PyTuple_GET_ITEM(ends_t, i));
+        if (!PyErr_Occurred() && job->ends[i] <= prev) PyErr_SetString(PyExc_ValueError, "fill_ranges(): range ends must ascend from above 0");
+        job->left[i] = (long)((job->ends[i] - prev + RFILL_ROWS - 1) / RFILL_ROWS);
+        tasks += job->left[i];
+        job->task_end[i] = tasks;
+        prev = job->ends[i];
+    }
+    if (!PyErr_Occurred() && from_obj_addr && PySequence_Fast_GET_SIZE(seq) != (Py_ssize_t)prev)
+        PyErr_SetString(PyExc_ValueError, "fill_ranges(): a From column needs a list against itself (as many rows as names)");
+    job->items = PySequence_Fast_ITEMS(seq);
+    job->n_names = PySequence_Fast_GET_SIZE(seq);
+    const size_t need = (size_t)n_threads * (size_t)(job->n_names ? job->n_names : 1);
+    if (!PyErr_Occurred() && need > g_rfill_cap) {
+        free(g_rfill_cnt);
+        g_rfill_cnt = (int32_t *)calloc(need, sizeof(int32_t));
+        g_rfill_cap = g_rfill_cnt ? need : 0;
+        if (!g_rfill_cnt) PyErr_NoMemory();
+    }
+    if (PyErr_Occurred()) {
+        crew_release(c, c->refs);           /* (nobody was started) */
+        Py_DECREF(seq);
+        return NULL;
+    }
+    job->top_n = top_n;
+    job->idx = (const int32_t *)(uintptr_t)idx_addr;
+    job->val = (const float *)(uintptr_t)val_addr;
+    job->n_ranges = (int)n_ranges;
+    job->n_tasks = tasks;
+    job->n_walk = (long)((job->n_names + RFILL_WALK - 1) / RFILL_WALK);
+    job->wait = (pfz_wait_fn)(uintptr_t)wait_addr;
+    job->ctx = (void *)(uintptr_t)ctx_addr;
+    job->first_slot = first_slot;
+    job->n_threads = n_threads;
+    job->stamps = (double *)(uintptr_t)stamps_addr;
+    job->from_obj = (PyObject **)(uintptr_t)from_obj_addr;
+    job->cnt = g_rfill_cnt;
+    crew_spawn(c, 1);
+    rfill_run(job, 0);
+    /* the call is over when the WORK is: every chunk of the closing walk done, whoever did it */
+    while (__atomic_load_n(&job->walk_done, __ATOMIC_ACQUIRE) < job->n_walk) __builtin_ia32_pause();
+    long none_new = 0, none_old = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        none_new += job->none_new[t];
+        none_old += job->none_old[t];
+    }
+    const int error = job->error;
+    crew_release(c, 1);
+#if PFZ_DIRECT_REFCNT
+    Py_None->ob_refcnt += none_new;
+#endif
+    release_overwritten_none(none_old);
+    Py_DECREF(seq);
+    if (error == 1) {
+        PyErr_SetString(PyExc_RuntimeError, "fill_ranges(): waiting for a row range of the result failed");
+        return NULL;
+    }
+    if (error == 2) {
+        PyErr_SetString(PyExc_ValueError, "fill_ranges(): the object columns must be fresh np.empty arrays");
+        return NULL;
+    }
+    Py_RETURN_NONE;
+}
+
+/* Test seams of fill_ranges (tests/test_frame_ranges_cpu.py: no device there).  A Python callback cannot stand in for
+ * pfz_event_wait -- the workers are not Python threads and the caller holds the GIL --, so the stand-in lives here:
+ * test_wait(ctx = int32 flags[], slot) spins until flags[slot] != 0 and fails when it is negative; test_wait_addr() returns its
+ * address; test_set_flags(addr, n, usec, value) sets flags[0..n) to value one by one, usec apart, from a detached thread. */
+static int test_wait(void *ctx, int32_t slot)
+{
+    volatile int32_t *flag = (volatile int32_t *)ctx + slot;
+    while (*flag == 0) __builtin_ia32_pause();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return *flag < 0 ? -1 : 0;
+}
+
+static PyObject *test_wait_addr(PyObject *self, PyObject *args)
+{
+    (void)self;
+    (void)args;
+    return PyLong_FromUnsignedLongLong((unsigned long long)(uintptr_t)&test_wait);
+}
+
+typedef struct {
+    int32_t *flags;
+    int n, usec, value;
+} flag_setter;
+
+static void *flag_setter_run(void *arg)
+{
+    flag_setter *f = (flag_setter *)arg;
+    for (int i = 0; i < f->n; ++i) {
+        struct timespec t = {0, (long)f->usec * 1000L};
+        nanosleep(&t, NULL);
+        __atomic_store_n(&f->flags[i], f->value, __ATOMIC_RELEASE);
+    }
+    free(f);
+    return NULL;
+}
+
+static PyObject *test_set_flags(PyObject *self, PyObject *args)
+{
+    (void)self;
+    unsigned long long addr;
+    int n, usec, value;
+    if (!PyArg_ParseTuple(args, "Kiii", &addr, &n, &usec, &value)) return NULL;
+    flag_setter *f = (flag_setter *)malloc(sizeof *f);
+    if (!f) return PyErr_NoMemory();
+    f->flags = (int32_t *)(uintptr_t)addr;
+    f->n = n;
+    f->usec = usec;
+    f->value = value;
+    pthread_t th;
+    if (pthread_create(&th, NULL, flag_setter_run, f) != 0) {
+        free(f);
+        PyErr_SetString(PyExc_RuntimeError, "test_set_flags(): no thread");
+        return NULL;
+    }
+    pthread_detach(th);
+    Py_RETURN_NONE;
+}
+
 /* fill_objects(seq, obj_addr, n): the From column -- slot i of a fresh np.empty(n, object) array gets a new
  * reference to seq[i].  (numpy's `arr[:] = list` walks the list through the generic sequence protocol: 1.5 - 3 ms
  * for 100 000 strings, most of a match's host time that the device cannot hide.) */
@@ -675,6 +1315,11 @@ static PyMethodDef methods[] = {
     {"pack", pack, METH_VARARGS, "pack(list[str] [, n_threads]) -> (code units: bytes, offsets int64[n+1]: bytes, bytes per code unit)"},
     {"gather_objects", gather_objects, METH_VARARGS, "gather_objects(names, idx_addr, n, obj_addr, keep_addr): obj[i] <- names[idx[i]] or None"},
     {"pack_into", pack_into, METH_VARARGS, "pack_into(strings, obj_addr, buf_addr, off_bytes, cap): offsets + 1-byte characters into the caller's buffer -> characters, or None"},
+    {"fill_ranges", fill_ranges, METH_VARARGS,
+     "fill_ranges(names, idx_addr, val_addr, top_n, obj_addrs, sim_addrs, ends, wait_addr, ctx_addr, first_slot, n_threads[, stamps_addr[, from_obj_addr]]): "
+     "the column pairs of a match that arrives in row ranges, on n_threads threads"},
+    {"test_wait_addr", test_wait_addr, METH_NOARGS, "address of the flag-array stand-in for pfz_event_wait (tests)"},
+    {"test_set_flags", test_set_flags, METH_VARARGS, "test_set_flags(addr, n, usec, value): set int32 flags one by one from a thread (tests)"},
     {"fill_objects", fill_objects, METH_VARARGS, "fill_objects(seq, obj_addr, n): a fresh object array <- new references to seq[i]"},
     {"fill_columns", fill_columns, METH_VARARGS,
      "fill_columns(names, idx_addr, val_addr, n, top_n, obj_addrs, sim_addrs, n_threads): the (To, Similarity) column pairs"},

@@ -69,6 +69,8 @@ def _clean_string(string: str) -> str:
 
 _TRACE = bool(os.environ.get("PFZ_MATCH_TRACE"))      # host-side stamps of a big match's ranges in .last_trace (tools/r6_match_ab.py)
 _DIRECT_PACK = os.environ.get("PFZ_DIRECT_PACK", "1") != "0"    # (A/B knob: 0 = pack into a bytes object, copy that into the staging buffer)
+_RANGE_FILL = os.environ.get("PFZ_RANGE_FILL", "1") != "0"      # (A/B knob: 0 = the ranges waited for and filled one by one from Python, round 6's first form)
+_FROM_IN_FILL = os.environ.get("PFZ_FROM_IN_FILL")      # (A/B knob: 1 / 0 = the From column of a big self-match in the range fill's closing walk / in the packer's walk; unset: in the fill exactly when the packer runs on threads, which touch no reference count)
 _FROM_IN_PACK = os.environ.get("PFZ_FROM_IN_PACK", "1") != "0"      # (A/B knob of tools/match_wall_probe.py; the frames are the same)
 
 
@@ -174,7 +176,11 @@ class TFIDF(BaseMatcher):
         ctx = _lib.Context.default()
         t0 = time.perf_counter()
         # the From column of the frame is filled by the string packer's own walk over from_list (a list): no second pass
-        col = [np.empty(len(from_list), dtype=object)] if isinstance(from_list, list) and len(from_list) >= 1024 and _FROM_IN_PACK else None
+        # (a big match of a list: the threads of the frame's range fill take the From column too, _pack.fill_ranges -- PFZ_FROM_IN_FILL)
+        in_fill = _lib._PACK_INTO_THREADS > 1 if _FROM_IN_FILL is None else _FROM_IN_FILL != "0"
+        ranged = _RANGE_FILL and in_fill and to_list is None and isinstance(from_list, list) and len(from_list) >= _SPLIT_MIN_ROWS and \
+            _lib._pack is not None and hasattr(_lib._pack, "fill_ranges")
+        col = [np.empty(len(from_list), dtype=object)] if isinstance(from_list, list) and len(from_list) >= 1024 and _FROM_IN_PACK and not ranged else None
         from_dev, to_dev = self._extract_tf_idf(from_list, to_list, re_train, col)
         top_n = clip_top_n(self.top_n, to_list)                   # _utils.py:54-56
         self_match = to_list is None
@@ -195,14 +201,29 @@ class TFIDF(BaseMatcher):
         else:
             res = _lib.cossim_topn(ctx, self._dev_index, from_dev, max(top_n, 1), lower, exclude_diag=self_match)
         t1 = time.perf_counter()
-        from_col = col[0] if col and col[0] is not None else object_column(from_list)        # (host work while the device runs K3)
+        pending = ranged and split and bool(h_idx)
+        from_col = col[0] if col and col[0] is not None else None if pending else object_column(from_list)        # (host work while the device runs K3)
         t2 = time.perf_counter()
         if split:
-            fb = FrameBuilder(from_list, names, top_n, from_col)
+            fb = FrameBuilder(from_list, names, top_n, from_col, from_pending=pending)
             waited = framed = 0.0
             tp = t2
             row0 = 0
             trace = [("enqueued", t1 - t0), ("frame wrapped", time.perf_counter() - t0)] if _TRACE else None
+            if h_idx and _RANGE_FILL and hasattr(_lib._pack, "fill_ranges"):
+                # the whole result arrives in the pinned mirror: the frame's threads wait for the ranges themselves and gather each
+                # as soon as it is final (_pack.fill_ranges) -- no Python between a range's announcement and its columns
+                wait_addr, ctx_addr = ctx.event_wait_fn()
+                stamps = np.zeros(2 * len(ends)) if _TRACE else None
+                fb.fill_ranges(h_idx, h_val, ends, wait_addr, ctx_addr, _SPLIT_EVENT, stamps)
+                tb = time.perf_counter()
+                if trace is not None:
+                    off = time.perf_counter() - time.monotonic()       # (the same clock on Linux; the difference is the call's cost)
+                    for i in range(len(ends)):
+                        trace += [(f"range {i} [{ends[i - 1] if i else 0}, {ends[i]}) here", stamps[2 * i] + off - t0),
+                                  (f"range {i} filled", stamps[2 * i + 1] + off - t0)]
+                framed, tp = framed + (tb - tp), tb
+                ends = ()
             for i, row1 in enumerate(ends):
                 if h_idx:
                     ctx.event_wait(_SPLIT_EVENT + i)      # (polls the range's word in pinned memory)

@@ -29,6 +29,18 @@ def _fill_threads():
 _FILL_THREADS = _fill_threads()
 
 
+# host threads of a BIG match's frame (_pack.fill_ranges: the result arrives in row ranges, the threads gather a range's columns as
+# soon as it is final; no reference count is touched while they run -- every thread counts what it stored, the counts are added at
+# the end; helpers run on the cores that share the caller's L3, nowhere else).  PFZ_RANGE_THREADS overrides (1 = the calling thread
+# alone); by default four where the process may use twice that many CPUs.
+def _range_threads():
+    env = os.environ.get("PFZ_RANGE_THREADS")
+    return max(1, min(16, int(env))) if env else max(1, min(4, _lib.usable_cpus() // 2))
+
+
+_RANGE_THREADS = _range_threads()
+
+
 def object_column(strings) -> np.ndarray:
     """list[str] -> 1-D object ndarray (the From column; built while the GPU is still busy)."""
     arr = np.empty(len(strings), dtype=object)
@@ -120,9 +132,12 @@ class FrameBuilder:
     Similarity columns of rows [row0, row0 + len(idx)) -- so the first part of a split match can be turned into
     columns while the device still works on the rest -- and `frame()` wraps the columns."""
 
-    def __init__(self, from_list, to_list, top_n, from_col=None):
+    def __init__(self, from_list, to_list, top_n, from_col=None, from_pending=False):
+        """from_pending: the From column is left empty here -- fill_ranges' threads fill it from from_list before the first range"""
         self.n, self.top_n, self.to_list = len(from_list), top_n, to_list
-        self.from_col = object_column(from_list) if from_col is None else from_col
+        self.from_list = from_list
+        self.from_pending = bool(from_pending and from_col is None)
+        self.from_col = np.empty(self.n, dtype=object) if self.from_pending else object_column(from_list) if from_col is None else from_col
         self.names = [np.empty(self.n, dtype=object) for _ in range(top_n)]
         self.sims = [np.empty(self.n, np.float64) for _ in range(top_n)]
         # (the columns' data addresses, taken ONCE: `ndarray.ctypes` builds a helper object on every access -- ten of them per
@@ -136,10 +151,11 @@ class FrameBuilder:
         if self.n >= 8192 and top_n and os.environ.get("PFZ_EARLY_FRAME", "1") != "0":     # (a small frame is made in no time, and the sharing checks below would be most of a single query's host time)
             # (pandas scans an object column for date-likes until it meets a non-null: an all-None column is scanned to its end.
             # The first slot holds a string while the frame is made, and None again before anything is filled in)
-            for a in self.names:
+            empty = self.names + ([self.from_col] if self.from_pending else [])
+            for a in empty:
                 a[0] = ""
             f = self._wrap()
-            for a in self.names:
+            for a in empty:
                 a[0] = None
             if np.shares_memory(f["To"].values, self.names[0]) and np.shares_memory(f["Similarity"].values, self.sims[0]) and \
                     np.shares_memory(f.iloc[:, -1].values, self.sims[-1]):
@@ -153,6 +169,19 @@ class FrameBuilder:
         at = 8 * row0
         _lib._pack.fill_columns(self.to_list, idx_addr, val_addr, m, self.top_n, tuple(b + at for b in self._name_at),
                                 tuple(b + at for b in self._sim_at), _FILL_THREADS)
+
+    def fill_ranges(self, idx_addr, val_addr, ends, wait_addr, ctx_addr, first_slot, stamps=None):
+        """every row range of a result that arrives in ascending ranges [0, ends[0]), [ends[0], ends[1]) ... at idx_addr / val_addr
+        (the whole result, pinned host memory): range i is filled once wait(ctx, first_slot + i) has returned -- on _RANGE_THREADS
+        threads that wait for the ranges themselves (_pack.fill_ranges).  stamps: float64[2 * len(ends)] or None (seconds on
+        time.monotonic's clock: range seen final / filled)"""
+        if not self.top_n or not len(ends):
+            return
+        pending = self.from_pending and self.from_list is self.to_list        # (the closing walk fills the From column of a list against itself)
+        self.from_pending = self.from_pending and not pending
+        _lib._pack.fill_ranges(self.to_list, idx_addr, val_addr, self.top_n, tuple(self._name_at), tuple(self._sim_at),
+                               tuple(int(e) for e in ends), wait_addr, ctx_addr, first_slot, _RANGE_THREADS,
+                               stamps.ctypes.data if stamps is not None else 0, self.from_col.ctypes.data if pending else 0)
 
     def fill(self, idx, val, row0=0):
         m = len(idx)
@@ -172,6 +201,9 @@ class FrameBuilder:
         return pd.DataFrame(data, copy=False)
 
     def frame(self):
+        if self.from_pending:           # (nobody filled the From column: a path without fill_ranges)
+            self.from_col[:] = object_column(self.from_list)
+            self.from_pending = False
         return self._frame if self._frame is not None else self._wrap()
 
 

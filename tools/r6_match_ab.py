@@ -6,10 +6,10 @@ usage: python tools/r6_match_ab.py [name:ENV=v,ENV=v ...]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from polyfuzz_amd import datasets
+from polyfuzz_amd import datasets, _lib
 from polyfuzz_amd.models import TFIDF, _utils, _tfidf
 names = datasets.load_company_names()
-KEYS = ("PFZ_K3_NO_STREAMED", "PFZ_MATCH_SHARES", "PFZ_DIRECT_PACK")
+KEYS = ("PFZ_K3_NO_STREAMED", "PFZ_MATCH_SHARES", "PFZ_DIRECT_PACK", "PFZ_RANGE_FILL", "PFZ_RANGE_THREADS", "PFZ_PACK_INTO_THREADS", "PFZ_FROM_IN_FILL", "PFZ_HOST_PIN")
 variants = [("r5form", {"PFZ_K3_NO_STREAMED": "1", "PFZ_MATCH_SHARES": "0.3,0.3,0.25,0.15"}),
             ("streamed5", {"PFZ_MATCH_SHARES": "0.2,0.2,0.2,0.2,0.2"}),
             ("streamed4", {"PFZ_MATCH_SHARES": "0.25,0.3,0.25,0.2"}),
@@ -22,6 +22,17 @@ if len(sys.argv) > 1:
     for a in sys.argv[1:]:
         name, _, envs = a.partition(":")
         variants.append((name, {kv.split("=")[0]: kv.split("=")[1].replace(";", ",") for kv in envs.split(",") if kv}))
+def apply_env():
+    # (knobs read at import: set as the variant says)
+    _tfidf._DIRECT_PACK = os.environ.get("PFZ_DIRECT_PACK", "1") != "0"
+    _tfidf._RANGE_FILL = os.environ.get("PFZ_RANGE_FILL", "1") != "0"
+    _tfidf._FROM_IN_FILL = os.environ.get("PFZ_FROM_IN_FILL")
+    _utils._RANGE_THREADS = _utils._range_threads()
+    if hasattr(_lib, "_pack_into_threads"):
+        _lib._PACK_INTO_THREADS = _lib._pack_into_threads()
+
+
+first_sig = None
 m = TFIDF(min_similarity=0, top_n=5)
 res = {k: ([], []) for k, _ in variants}
 df = None
@@ -30,9 +41,15 @@ for rep in range(16):
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(env)
-        _tfidf._DIRECT_PACK = os.environ.get("PFZ_DIRECT_PACK", "1") != "0"      # (read at import: set as the variant says)
+        apply_env()
         df = None
         t0 = time.perf_counter(); df = m.match(names); dt = (time.perf_counter() - t0) * 1e3
+        if rep == 0:         # (every variant returns the same frame)
+            sig = (df["To"].tolist(), df["To_5"].tolist(), df["Similarity_3"].to_numpy().copy())
+            if first_sig is None:
+                first_sig = sig
+            assert sig[0] == first_sig[0] and sig[1] == first_sig[1] and np.array_equal(sig[2], first_sig[2]), name
+            del sig
         if rep >= 3:
             res[name][0].append(dt); res[name][1].append(m.last_timings)
 if os.environ.get("PFZ_MATCH_TRACE"):
@@ -40,6 +57,7 @@ if os.environ.get("PFZ_MATCH_TRACE"):
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(env)
+        apply_env()
         df = None
         t0 = time.perf_counter(); df = m.match(names); dt = (time.perf_counter() - t0) * 1e3
         print(name, f"{dt:.3f} ms:", "; ".join(f"{k} {v * 1e3:.2f}" for k, v in (m.last_trace or [])))
