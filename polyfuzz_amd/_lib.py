@@ -454,16 +454,32 @@ except ImportError:  # pragma: no cover - not built
     _pack = None
 
 
-def _pack_threads():
-    """host threads of the string packer (PFZ_PACK_THREADS overrides; small hosts stay serial)"""
-    env = os.environ.get("PFZ_PACK_THREADS")
-    if env:
-        return max(1, int(env))
-    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return 4 if cpus >= 16 else 1
+def usable_cpus():
+    """CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota where there is one (the MI355X boxes
+    show 256 CPUs and grant 16 CPUs' worth of time)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
-_PACK_THREADS = _pack_threads()
+def host_threads():
+    """Host threads of the two big host-side walks of a match -- the string packer (pack_into / pack) and the frame's gathers
+    (_pack.fill_ranges) -- the calling thread included.  PFZ_HOST_THREADS overrides (1 = everything on the calling thread); by
+    default four where the process may use at least twice that many CPUs.  The helpers run on the cores that share the calling
+    thread's L3 and nowhere else (_pack.c: the crew; PFZ_HOST_PIN=0 lets the scheduler place them -- measured 4 x slower on the
+    two-socket MI355X host); a host that does not tell its cache topology gets none.
+    Measured there (tools/r6_match_ab.py): TFIDF(top_n=5).match(100 000 names) 3.2 - 3.3 -> 2.9 ms."""
+    env = os.environ.get("PFZ_HOST_THREADS")
+    return max(1, min(16, int(env))) if env else max(1, min(4, usable_cpus() // 2))
+
+
+_PACK_THREADS = _PACK_INTO_THREADS = host_threads()       # (the general packer's walks / pack_into's: separate names for the A/B tools)
 
 
 def pack_strings(strings, objects=None):
@@ -500,32 +516,6 @@ def _pack_strings_py(strings):
     if len(chars) != off[-1]:
         raise ValueError("string packing length mismatch")
     return chars, off, width
-
-
-def usable_cpus():
-    """CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota where there is one (the MI355X boxes
-    show 256 CPUs and grant 16 CPUs' worth of time)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            n = min(n, int(quota) // int(period))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
-
-
-# host threads of pack_into for a big list (>= 16 384 strings) when no From column rides on its walk (the frame of a big self-match is
-# filled by _pack.fill_ranges, From column included): the threads only read the strings, and run on the cores that share the
-# calling thread's L3 (none there: the single walk).  PFZ_PACK_INTO_THREADS overrides; 1 = the calling thread's single walk.
-# Measured on the MI355X host (tools/r6_match_ab.py): TFIDF.match(100 000 names) 3.31 -> 2.97 ms with four.
-def _pack_into_threads():
-    env = os.environ.get("PFZ_PACK_INTO_THREADS")
-    return max(1, min(16, int(env))) if env else max(1, min(4, usable_cpus() // 2))
-
-
-_PACK_INTO_THREADS = _pack_into_threads()
 
 
 class DeviceStrings(_Handle):

@@ -681,10 +681,9 @@ static PyObject *pack(PyObject *self, PyObject *args)
  * obj_addrs / sim_addrs: tuples of the data addresses of top_n FRESH numpy object arrays (every slot NULL
  * or None, as np.empty(n, object) leaves them) and top_n float64 arrays, n elements each.
  *
- * The gathers are random reads of PyObject headers -- one cache miss per name -- so the loop prefetches a
- * few rows ahead, and above ~64k entries the (column, row-chunk) tasks are spread over n_threads pthreads.
- * The workers make no Python API call: they bump reference counts with atomic adds and store into disjoint
- * slots, while the calling thread keeps the GIL and waits, so no other reference-count update can race.
+ * The gathers are random reads of PyObject headers -- one cache miss per name -- so the loop prefetches a few rows ahead.  On the
+ * calling thread (n_threads is accepted and ignored: workers with atomic reference counts, rounds 2-5's opt-in, were slower than
+ * one thread -- a big fill goes to fill_ranges' crew instead, which touches no count while it gathers).
  */
 typedef struct {
     PyObject **items;
@@ -693,11 +692,9 @@ typedef struct {
     const float *val;
     PyObject ***obj;
     double **sim;
-    Py_ssize_t chunk, n_chunks;
-    long next_task;   /* atomic */
 } fill_job;
 
-static void fill_range(const fill_job *job, Py_ssize_t r, Py_ssize_t lo, Py_ssize_t hi, int atomic)
+static void fill_range(const fill_job *job, Py_ssize_t r, Py_ssize_t lo, Py_ssize_t hi)
 {
     enum { AHEAD = 12 };
     const Py_ssize_t stride = job->top_n;
@@ -718,29 +715,9 @@ static void fill_range(const fill_job *job, Py_ssize_t r, Py_ssize_t lo, Py_ssiz
         if (s < 0.001 || j < 0 || j >= n_names) s = 0.0;
         else o = items[j];
         sim[i] = s;
-#if PFZ_DIRECT_REFCNT
-        if (atomic) __atomic_fetch_add(&o->ob_refcnt, 1, __ATOMIC_RELAXED);
-        else Py_INCREF(o);
-#else
-        (void)atomic;
         Py_INCREF(o);
-#endif
         obj[i] = o;
     }
-}
-
-static void *fill_worker(void *arg)
-{
-    fill_job *job = (fill_job *)arg;
-    const long n_tasks = (long)(job->n_chunks * job->top_n);
-    for (;;) {
-        const long t = __atomic_fetch_add(&job->next_task, 1, __ATOMIC_RELAXED);
-        if (t >= n_tasks) break;
-        const Py_ssize_t r = t / job->n_chunks, c = t % job->n_chunks;
-        const Py_ssize_t lo = c * job->chunk, hi = lo + job->chunk < job->n ? lo + job->chunk : job->n;
-        fill_range(job, r, lo, hi, 1);
-    }
-    return NULL;
 }
 
 static PyObject *fill_columns(PyObject *self, PyObject *args)
@@ -802,27 +779,8 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
     job.val = (const float *)(uintptr_t)val_addr;
     job.obj = obj;
     job.sim = sim;
-    job.chunk = 8192;
-    job.n_chunks = (n + job.chunk - 1) / job.chunk;
-    job.next_task = 0;
-    const long n_tasks = (long)(job.n_chunks * top_n);
-    if (n_threads > 16) n_threads = 16;
-    if (n_threads > n_tasks) n_threads = (int)n_tasks;
-#if !PFZ_DIRECT_REFCNT
-    n_threads = 1;                             /* no atomic reference counts next to immortal objects */
-#endif
-    int started = 0;
-    pthread_t th[16];
-    if (n * top_n >= 65536 && n_threads > 1) {
-        for (; started < n_threads - 1; ++started)
-            if (pthread_create(&th[started], NULL, fill_worker, &job) != 0) break;
-    }
-    if (started > 0) {
-        fill_worker(&job);                     /* the calling thread works too (atomic adds, like the others) */
-        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
-    } else {
-        for (Py_ssize_t r = 0; r < top_n; ++r) fill_range(&job, r, 0, n, 0);
-    }
+    (void)n_threads;
+    for (Py_ssize_t r = 0; r < top_n; ++r) fill_range(&job, r, 0, n);
     release_overwritten_none(old_none);        /* the references the overwritten slots held */
     Py_DECREF(seq);
     free(heap);
@@ -834,7 +792,8 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
  *
  * The (To_r, Similarity_r) column pairs of a BIG match whose result arrives in ascending row ranges (pfz_cossim_topn_ranges with a
  * mirror: idx / val are the whole result in pinned host memory, range i = rows [ends[i-1], ends[i]) valid once
- * wait(ctx, first_slot + i) -- pfz_event_wait, a spin on a word in pinned memory -- has returned 0).  Same cells as fill_columns.
+ * wait(ctx, first_slot + i) -- pfz_event_wait, a spin on a word in pinned memory -- has returned 0; wait_addr 0: everything is
+ * there, any big result in ordinary memory).  Same cells as fill_columns.
  * from_obj_addr != 0: the match is a list against itself (n rows = len(names)) and the From column -- a fresh object array, slot
  * i <- a new reference to names[i] -- is filled in the same closing walk.
  *
@@ -974,7 +933,7 @@ static void rfill_run(void *arg, int tid)
         if (__atomic_load_n(&job->error, __ATOMIC_RELAXED) != 1) {
             while (t >= job->task_end[range]) ++range;
             int ok = 1;
-            if (!__atomic_load_n(&job->ready[range], __ATOMIC_ACQUIRE)) {
+            if (job->wait && !__atomic_load_n(&job->ready[range], __ATOMIC_ACQUIRE)) {
                 if (job->wait(job->ctx, job->first_slot + range) != 0) {
                     __atomic_store_n(&job->error, 1, __ATOMIC_RELAXED);
                     ok = 0;
@@ -1022,8 +981,8 @@ static PyObject *fill_ranges(PyObject *self, PyObject *args)
         return NULL;
     const Py_ssize_t n_ranges = PyTuple_GET_SIZE(ends_t);
     if (top_n < 1 || top_n > 1024 || PyTuple_GET_SIZE(obj_addrs) != top_n || PyTuple_GET_SIZE(sim_addrs) != top_n || n_ranges < 1 ||
-        n_ranges > 64 || !wait_addr || !idx_addr || !val_addr) {
-        PyErr_SetString(PyExc_ValueError, "fill_ranges(): need 1..1024 column pairs, 1..64 range ends, the result's addresses and a wait function");
+        n_ranges > 64 || !idx_addr || !val_addr) {
+        PyErr_SetString(PyExc_ValueError, "fill_ranges(): need 1..1024 column pairs, 1..64 range ends and the result's addresses");
         return NULL;
     }
     PyObject *seq = PySequence_Fast(names, "fill_ranges() expects a sequence of names");

@@ -70,7 +70,6 @@ def _clean_string(string: str) -> str:
 _TRACE = bool(os.environ.get("PFZ_MATCH_TRACE"))      # host-side stamps of a big match's ranges in .last_trace (tools/r6_match_ab.py)
 _DIRECT_PACK = os.environ.get("PFZ_DIRECT_PACK", "1") != "0"    # (A/B knob: 0 = pack into a bytes object, copy that into the staging buffer)
 _RANGE_FILL = os.environ.get("PFZ_RANGE_FILL", "1") != "0"      # (A/B knob: 0 = the ranges waited for and filled one by one from Python, round 6's first form)
-_FROM_IN_FILL = os.environ.get("PFZ_FROM_IN_FILL")      # (A/B knob: 1 / 0 = the From column of a big self-match in the range fill's closing walk / in the packer's walk; unset: in the fill exactly when the packer runs on threads, which touch no reference count)
 _FROM_IN_PACK = os.environ.get("PFZ_FROM_IN_PACK", "1") != "0"      # (A/B knob of tools/match_wall_probe.py; the frames are the same)
 
 
@@ -176,9 +175,9 @@ class TFIDF(BaseMatcher):
         ctx = _lib.Context.default()
         t0 = time.perf_counter()
         # the From column of the frame is filled by the string packer's own walk over from_list (a list): no second pass
-        # (a big match of a list: the threads of the frame's range fill take the From column too, _pack.fill_ranges -- PFZ_FROM_IN_FILL)
-        in_fill = _lib._PACK_INTO_THREADS > 1 if _FROM_IN_FILL is None else _FROM_IN_FILL != "0"
-        ranged = _RANGE_FILL and in_fill and to_list is None and isinstance(from_list, list) and len(from_list) >= _SPLIT_MIN_ROWS and \
+        # (a big list against itself whose packer runs on threads, which touch no reference count: the From column is filled in the
+        # closing walk of the frame's range fill, _pack.fill_ranges)
+        ranged = _RANGE_FILL and _lib._PACK_INTO_THREADS > 1 and to_list is None and isinstance(from_list, list) and len(from_list) >= _SPLIT_MIN_ROWS and \
             _lib._pack is not None and hasattr(_lib._pack, "fill_ranges")
         col = [np.empty(len(from_list), dtype=object)] if isinstance(from_list, list) and len(from_list) >= 1024 and _FROM_IN_PACK and not ranged else None
         from_dev, to_dev = self._extract_tf_idf(from_list, to_list, re_train, col)

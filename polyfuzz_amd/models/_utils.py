@@ -17,28 +17,8 @@ from scipy.sparse import issparse
 from .. import _lib
 
 _METHODS = ("sparse", "sklearn", "knn", "hip")
-# host threads that gather the To columns of a large result frame (_pack.fill_columns; PFZ_FRAME_THREADS overrides).
-# Measured on the MI355X host (EPYC 9575F, tools/host_glue_probe.py): the gathers are faster on ONE thread (3.0 ms for
-# 100k x top-5 against 3.9 ms on four) -- the atomic reference-count updates the workers need cost more than the
-# cache misses they overlap -- so the threaded path stays opt-in.
-def _fill_threads():
-    env = os.environ.get("PFZ_FRAME_THREADS")
-    return max(1, int(env)) if env else 1
-
-
-_FILL_THREADS = _fill_threads()
-
-
-# host threads of a BIG match's frame (_pack.fill_ranges: the result arrives in row ranges, the threads gather a range's columns as
-# soon as it is final; no reference count is touched while they run -- every thread counts what it stored, the counts are added at
-# the end; helpers run on the cores that share the caller's L3, nowhere else).  PFZ_RANGE_THREADS overrides (1 = the calling thread
-# alone); by default four where the process may use twice that many CPUs.
-def _range_threads():
-    env = os.environ.get("PFZ_RANGE_THREADS")
-    return max(1, min(16, int(env))) if env else max(1, min(4, _lib.usable_cpus() // 2))
-
-
-_RANGE_THREADS = _range_threads()
+# host threads of a big frame's gathers (_pack.fill_ranges), the calling thread included: _lib.host_threads() -- PFZ_HOST_THREADS
+_RANGE_THREADS = _lib.host_threads()
 
 
 def object_column(strings) -> np.ndarray:
@@ -163,12 +143,16 @@ class FrameBuilder:
 
     def fill_raw(self, idx_addr, val_addr, m, row0):
         """fill() from the addresses of int32 idx[m][top_n] / fp32 val[m][top_n] (the context's pinned staging: no copy between
-        the device's result and the columns)"""
+        the device's result and the columns).  A big stretch goes to the crew of host threads (_pack.fill_ranges, nothing to wait
+        for), a small one is filled by the calling thread (_pack.fill_columns)."""
         if not m or not self.top_n:
             return
         at = 8 * row0
-        _lib._pack.fill_columns(self.to_list, idx_addr, val_addr, m, self.top_n, tuple(b + at for b in self._name_at),
-                                tuple(b + at for b in self._sim_at), _FILL_THREADS)
+        names_at, sims_at = tuple(b + at for b in self._name_at), tuple(b + at for b in self._sim_at)
+        if _RANGE_THREADS > 1 and m * self.top_n >= 65536 and self.top_n <= 1024 and hasattr(_lib._pack, "fill_ranges"):
+            _lib._pack.fill_ranges(self.to_list, idx_addr, val_addr, self.top_n, names_at, sims_at, (int(m),), 0, 0, 0, _RANGE_THREADS)
+        else:
+            _lib._pack.fill_columns(self.to_list, idx_addr, val_addr, m, self.top_n, names_at, sims_at, 1)
 
     def fill_ranges(self, idx_addr, val_addr, ends, wait_addr, ctx_addr, first_slot, stamps=None):
         """every row range of a result that arrives in ascending ranges [0, ends[0]), [ends[0], ends[1]) ... at idx_addr / val_addr
@@ -189,7 +173,11 @@ class FrameBuilder:
             return
         idx = np.ascontiguousarray(idx, np.int32).reshape(m, self.top_n)
         val = np.ascontiguousarray(val, np.float32).reshape(m, self.top_n)
-        self.fill_raw(idx.ctypes.data, val.ctypes.data, m, row0)
+        if self.from_pending and row0 == 0 and m == self.n and self.from_list is self.to_list and _RANGE_THREADS > 1 and \
+                self.top_n <= 1024 and hasattr(_lib._pack, "fill_ranges"):
+            self.fill_ranges(idx.ctypes.data, val.ctypes.data, (m,), 0, 0, 0)       # (the whole frame of a list against itself: From column included)
+        else:
+            self.fill_raw(idx.ctypes.data, val.ctypes.data, m, row0)
 
     def _wrap(self):
         if self.top_n and self.n < 8192 and _fast_frame_ok():
@@ -218,7 +206,9 @@ def topn_to_frame(idx: np.ndarray, val: np.ndarray, from_list: List[str], to_lis
     names); without the helper the numpy twin below builds the same frame."""
     if _lib._pack is None or not isinstance(to_list, (list, tuple)):
         return _topn_to_frame_numpy(idx, val, from_list, to_list, top_n)
-    fb = FrameBuilder(from_list, to_list, top_n, from_col)
+    # (a big list against itself -- the sharded self-match's frame: the crew that gathers the To columns fills the From column too)
+    fb = FrameBuilder(from_list, to_list, top_n, from_col,
+                      from_pending=from_col is None and from_list is to_list and len(from_list) * top_n >= 65536)
     fb.fill(idx, val, 0)
     return fb.frame()
 
@@ -314,5 +304,5 @@ def cosine_similarity(from_vector,
         index = _lib.DeviceIndex.build(ctx, b)
         idx, val = _lib.cossim_topn(ctx, index, a, max(top_n, 1), lower, exclude_diag=self_match).download()
     if self_match:
-        to_list = list(from_list)
+        to_list = from_list if isinstance(from_list, (list, tuple)) else list(from_list)
     return topn_to_frame(idx, val, from_list, to_list, top_n)

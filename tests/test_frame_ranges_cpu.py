@@ -184,3 +184,23 @@ def test_pack_into_on_threads_equals_the_single_walk(threads):
                      (names, off_bytes + a - 1)):
         assert _lib._pack.pack_into(bad, 0, many.ctypes.data, (8 * (len(bad) + 1) + 255) & ~255, cap, threads) is None
     assert _lib._pack.pack_into(names, 0, many.ctypes.data, off_bytes, off_bytes + a, threads) == a          # (fits exactly)
+
+
+def test_a_whole_frame_of_a_list_against_itself_goes_through_the_crew(monkeypatch):
+    """topn_to_frame(idx, val, names, names, top_n) on a big list -- what pipeline.sharded_self_match builds on every rank -- fills
+    the To columns AND the From column through fill_ranges (nothing to wait for); same frame as the numpy twin, counts balanced"""
+    monkeypatch.setattr(_utils, "_RANGE_THREADS", 4)
+    n, top_n = 30000, 3
+    names = [f"name {i}" for i in range(n)]
+    rng = np.random.default_rng(8)
+    idx = np.clip(np.arange(n)[:, None] + rng.integers(-9, 10, (n, top_n)), -1, n).astype(np.int32)
+    val = rng.random((n, top_n)).astype(np.float32)
+    rc0 = [sys.getrefcount(s) for s in names[:50]]
+    a = _utils.topn_to_frame(idx, val, names, names, top_n)
+    b = _utils._topn_to_frame_numpy(idx, val, names, names, top_n)
+    assert list(a.columns) == list(b.columns) and a["From"].tolist() == names
+    for c in a.columns:
+        assert (np.array_equal(a[c].to_numpy(), b[c].to_numpy()) if c.startswith("Similarity") else a[c].tolist() == b[c].tolist()), c
+    del a, b
+    rc1 = [sys.getrefcount(s) for s in names[:50]]
+    assert rc1 == rc0

@@ -135,7 +135,7 @@ def test_synthetic_names_are_deterministic_and_name_like():
 
 @pytest.mark.parametrize("threads", [1, 4])
 def test_frame_helper_equals_numpy_twin(threads, monkeypatch):
-    """_pack.fill_columns (C, optionally threaded with atomic reference counts) builds exactly the frame of
+    """_pack.fill_columns (C, the calling thread) / _pack.fill_ranges (a big fill: the crew of host threads) build exactly the frame of
     the numpy twin -- np.round(., 3), the < 0.001 rule at the rounding boundary, -1 / out-of-range rows --
     and leaves every reference count balanced; a frame filled in row ranges from raw addresses (what TFIDF.match does under the
     device's work, from the context's pinned memory) is the same frame."""
@@ -144,7 +144,7 @@ def test_frame_helper_equals_numpy_twin(threads, monkeypatch):
     from polyfuzz_amd.models import _utils
     if _lib._pack is None:
         pytest.skip("_pack.so not built")
-    monkeypatch.setattr(_utils, "_FILL_THREADS", threads)
+    monkeypatch.setattr(_utils, "_RANGE_THREADS", threads)
     rng = np.random.default_rng(11)
     to_list = [f"name {i} é" for i in range(5000)]
     for n, top_n in ((0, 1), (7, 3), (30000, 5)):

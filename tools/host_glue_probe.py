@@ -19,7 +19,7 @@ def med(f, n=15):
 
 for th in (1, 2, 4, 8, 16):
     p = med(lambda: _lib._pack.pack(names, th))
-    _utils._FILL_THREADS = th
+    _utils._RANGE_THREADS = th
     fr = med(lambda: _utils.topn_to_frame(idx, val, names, names, 5))
     print(f"threads {th:2d}: pack {p:.3f} ms   frame(top-5, 100k) {fr:.3f} ms")
 print("from column", med(lambda: _utils.object_column(names)))

@@ -1,4 +1,4 @@
-for v in "" "PFZ_HOST_PIN=0" "PFZ_RANGE_THREADS=1" "PFZ_PACK_INTO_THREADS=1" "PFZ_RANGE_FILL=0 PFZ_PACK_INTO_THREADS=1" ""; do
+for v in "" "PFZ_HOST_PIN=0" "PFZ_HOST_THREADS=2" "PFZ_HOST_THREADS=8" "PFZ_RANGE_FILL=0 PFZ_HOST_THREADS=1" ""; do
   echo "== $v"
   env $v python bench.py --no-configs --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json

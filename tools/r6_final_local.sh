@@ -20,6 +20,7 @@ cp $O/gpu_tests.log profiles/r06_gpu_tests.log; cp $O/smoke.log profiles/r06_smo
 cp $O/match_ab.txt profiles/experiments/r06_match_streamed_ab.txt; grep "bench rank\|bench\]\|rc=" $O/gpus2_selflaunch.txt > profiles/r06_bench_gpus2_selflaunch.txt
 cp $O/profile/bench_under_rocprof.json profiles/r06_bench_under_rocprof.json 2>/dev/null || true
 cp $O/k7_fuzz.txt profiles/r06_k7_fuzz.txt
+cp $O/frame_fill_mt.txt profiles/experiments/r06_frame_fill_mt.txt
 [ -f $O/other/summary_other.txt ] && cp $O/other/summary_other.txt profiles/r06_other_kernels_rocprofv3_summary.txt
 python - <<PY
 import json

@@ -14,16 +14,16 @@ variants = []
 for a in sys.argv[1:] or ["default:"]:
     name, _, envs = a.partition(":")
     variants.append((name, {kv.split("=")[0]: kv.split("=")[1] for kv in envs.split(",") if kv}))
-KEYS = ("PFZ_RANGE_FILL", "PFZ_RANGE_THREADS", "PFZ_PACK_INTO_THREADS", "PFZ_FROM_IN_FILL", "PFZ_HOST_PIN")
+KEYS = ("PFZ_RANGE_FILL", "PFZ_RANGE_THREADS", "PFZ_PACK_INTO_THREADS", "PFZ_HOST_THREADS", "PFZ_HOST_PIN")
 m = TFIDF(min_similarity=0, top_n=5)
 for name, env in variants:
     for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
     _tfidf._RANGE_FILL = os.environ.get("PFZ_RANGE_FILL", "1") != "0"
-    _tfidf._FROM_IN_FILL = os.environ.get("PFZ_FROM_IN_FILL")
-    _utils._RANGE_THREADS = _utils._range_threads()
-    _lib._PACK_INTO_THREADS = _lib._pack_into_threads()
+    # (PFZ_RANGE_THREADS / PFZ_PACK_INTO_THREADS are names of THIS tool: the two crews' sizes apart; the library reads PFZ_HOST_THREADS for both)
+    _utils._RANGE_THREADS = int(os.environ.get("PFZ_RANGE_THREADS", _lib.host_threads()))
+    _lib._PACK_INTO_THREADS = int(os.environ.get("PFZ_PACK_INTO_THREADS", _lib.host_threads()))
     for _ in range(4):
         m.match(names)
     for mode in ("kept", "dropped"):

@@ -9,7 +9,7 @@ import numpy as np
 from polyfuzz_amd import datasets, _lib
 from polyfuzz_amd.models import TFIDF, _utils, _tfidf
 names = datasets.load_company_names()
-KEYS = ("PFZ_K3_NO_STREAMED", "PFZ_MATCH_SHARES", "PFZ_DIRECT_PACK", "PFZ_RANGE_FILL", "PFZ_RANGE_THREADS", "PFZ_PACK_INTO_THREADS", "PFZ_FROM_IN_FILL", "PFZ_HOST_PIN")
+KEYS = ("PFZ_K3_NO_STREAMED", "PFZ_MATCH_SHARES", "PFZ_DIRECT_PACK", "PFZ_RANGE_FILL", "PFZ_RANGE_THREADS", "PFZ_PACK_INTO_THREADS", "PFZ_HOST_THREADS", "PFZ_HOST_PIN")
 variants = [("r5form", {"PFZ_K3_NO_STREAMED": "1", "PFZ_MATCH_SHARES": "0.3,0.3,0.25,0.15"}),
             ("streamed5", {"PFZ_MATCH_SHARES": "0.2,0.2,0.2,0.2,0.2"}),
             ("streamed4", {"PFZ_MATCH_SHARES": "0.25,0.3,0.25,0.2"}),
@@ -26,10 +26,9 @@ def apply_env():
     # (knobs read at import: set as the variant says)
     _tfidf._DIRECT_PACK = os.environ.get("PFZ_DIRECT_PACK", "1") != "0"
     _tfidf._RANGE_FILL = os.environ.get("PFZ_RANGE_FILL", "1") != "0"
-    _tfidf._FROM_IN_FILL = os.environ.get("PFZ_FROM_IN_FILL")
-    _utils._RANGE_THREADS = _utils._range_threads()
-    if hasattr(_lib, "_pack_into_threads"):
-        _lib._PACK_INTO_THREADS = _lib._pack_into_threads()
+    # (PFZ_RANGE_THREADS / PFZ_PACK_INTO_THREADS are names of THIS tool: the two crews' sizes apart; the library reads PFZ_HOST_THREADS for both)
+    _utils._RANGE_THREADS = int(os.environ.get("PFZ_RANGE_THREADS", _lib.host_threads()))
+    _lib._PACK_INTO_THREADS = int(os.environ.get("PFZ_PACK_INTO_THREADS", _lib.host_threads()))
 
 
 first_sig = None
