@@ -471,12 +471,13 @@ def usable_cpus():
 def host_threads():
     """Host threads of the two big host-side walks of a match -- the string packer (pack_into / pack) and the frame's gathers
     (_pack.fill_ranges) -- the calling thread included.  PFZ_HOST_THREADS overrides (1 = everything on the calling thread); by
-    default four where the process may use at least twice that many CPUs.  The helpers run on the cores that share the calling
+    default eight -- a CCD of the MI355X host -- where the process may use twice that many CPUs, half its CPUs below that.  The helpers run on the cores that share the calling
     thread's L3 and nowhere else (_pack.c: the crew; PFZ_HOST_PIN=0 lets the scheduler place them -- measured 4 x slower on the
     two-socket MI355X host); a host that does not tell its cache topology gets none.
-    Measured there (tools/r6_match_ab.py): TFIDF(top_n=5).match(100 000 names) 3.2 - 3.3 -> 2.9 ms."""
+    Measured there (tools/r6_match_ab.py, one box): TFIDF(top_n=5).match(100 000 names) 3.31 ms on the calling thread alone,
+    3.20 / 3.02 / 2.82 / 2.79 with crews of 2 / 4 / 6 / 8."""
     env = os.environ.get("PFZ_HOST_THREADS")
-    return max(1, min(16, int(env))) if env else max(1, min(4, usable_cpus() // 2))
+    return max(1, min(16, int(env))) if env else max(1, min(8, usable_cpus() // 2))
 
 
 _PACK_THREADS = _PACK_INTO_THREADS = host_threads()       # (the general packer's walks / pack_into's: separate names for the A/B tools)

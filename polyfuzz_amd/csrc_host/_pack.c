@@ -795,28 +795,35 @@ static PyObject *fill_columns(PyObject *self, PyObject *args)
  * wait(ctx, first_slot + i) -- pfz_event_wait, a spin on a word in pinned memory -- has returned 0; wait_addr 0: everything is
  * there, any big result in ordinary memory).  Same cells as fill_columns.
  * from_obj_addr != 0: the match is a list against itself (n rows = len(names)) and the From column -- a fresh object array, slot
- * i <- a new reference to names[i] -- is filled in the same closing walk.
+ * i <- a new reference to names[i] -- is filled by the calling thread before it turns to the ranges.
  *
  * Round 6: the frame's gathers were the user-level call's tail -- from the seventh of twelve ranges on the host found the ranges
  * waiting, and the call ended 0.4 - 0.8 ms behind the device.  What was measured on the way here (the MI355X host, 2 x EPYC 9575F;
  * tools/ubench/frame_fill_mt.c is the model, tools/r6_match_ab.py the call):
  *   - threads with atomic reference counts in the gathers lose (3.9 ms on four against 3.0 on one);
  *   - helper threads the scheduler places lose whatever they do: 0.44 -> 0.95 ms for the bare STORES on two threads -- the names and
- *     the columns lie in the caller's caches, from another CCD or the other socket every line is a remote miss; pinned to the cores
+ *     the columns lie in the caller's caches, from another CCD or the other socket every line is a remote miss; confined to the cores
  *     that share the caller's L3 the same stores take 0.27 / 0.16 / 0.13 ms on 2 / 4 / 8 threads (the crew above, l3_local_cpus);
- *   - every object owned by one thread by its address, each thread scanning all cells for its own: 4 x slower than one thread.
- * So: NO thread touches a reference count while the gathers run.  A thread stores the pointers and counts, per list position,
- * how many it stored, in an array of its own; when every task is done, the positions are cut into chunks that the threads draw, and
- * whoever draws a chunk adds its counts to the objects' reference counts -- with ATOMIC adds, one per name: one object may sit at
- * several positions of a list, in two chunks.  The calling thread holds the GIL from the first store to the last add.
- * A task = (range, 1024 rows, every column); a thread that draws a task of a range nobody has seen final yet waits for it itself.
- * The slots' old contents (np.empty's None or NULL) are checked and counted by whoever overwrites them.
- * A wait that fails stops the draw; what was stored by then is counted like the rest (the columns stay consistent), then it raises.
- * Where reference counts cannot be edited directly (CPython >= 3.12: immortal objects) the closing walk is the calling thread's.
+ *   - every object owned by one thread by its address, each thread scanning all cells for its own: 4 x slower than one thread;
+ *   - threads that count what they store, per list position, in arrays of their own, the counts added to the objects in a closing
+ *     walk (atomic adds: one object may sit at several positions): the gathers keep up with the device, the walk is 0.10 ms behind
+ *     the last range -- and as much when it is taken early, in front of the last ranges.
+ * So the work is cut along what it touches.  **The helpers do everything that touches no reference count**: for a task (1024 rows,
+ * every column) the rounding, the similarity stores, the gather of the names' pointers and the pointer stores -- then they flag the
+ * task.  **The calling thread does nothing but reference counts**: it follows the flags in task order and takes one reference per
+ * pointer it finds in the task's column cells (plain Py_INCREF: it holds the GIL from the first store to the last count, nobody
+ * else edits a count, any CPython) -- the names' headers stay in ITS caches, where the packer's walk and the last frame's disposal
+ * left them, and its work per cell is a load and an increment.  When the last range's last task is flagged, the frame is 5 000
+ * increments away from done: no closing walk.
+ * A helper that draws a task of a range nobody has seen final yet waits for it itself; a task nobody has drawn when the caller
+ * gets to it is the caller's (no helper could be started, or none has been scheduled yet: the call does not depend on them).
+ * The slots' old contents (np.empty's None or NULL) are checked and counted by whoever overwrites them.  A wait that fails stops
+ * the work at that task: the tasks behind it are flagged as skipped, what was stored is counted (the columns stay consistent),
+ * then it raises.
  */
 typedef int (*pfz_wait_fn)(void *ctx, int32_t slot);
 
-enum { RFILL_ROWS = 1024, RFILL_WALK = 2048 };
+enum { RFILL_ROWS = 1024 };
 
 typedef struct {
     PyObject **items;
@@ -826,23 +833,18 @@ typedef struct {
     pfz_wait_fn wait;
     void *ctx;
     int first_slot;
-    int n_threads;           /* the caller + the helpers planned: the count arrays */
     int n_ranges;
     long n_tasks;
-    long n_walk;             /* chunks of the closing walk */
-    long next_task, tasks_done;      /* atomic */
-    long next_walk, walk_done;       /* atomic */
+    long next_ticket;        /* atomic */
     int error;               /* atomic: 1 = a wait failed, 2 = a slot was not fresh */
-    int32_t *cnt;            /* n_threads x n_names */
-    PyObject **from_obj;     /* the From column of a self-match, or NULL */
-    double *stamps;          /* 2 x n_ranges (seconds, CLOCK_MONOTONIC): range seen final / its last task done; or NULL */
-    long none_new[16], none_old[16];
+    double *stamps;          /* 2 x n_ranges (seconds, CLOCK_MONOTONIC): range seen final / its last task counted; or NULL */
+    long none_old[16];       /* per thread: overwritten slots that held None */
     int64_t ends[64];
     long task_end[64];       /* task_end[i] = number of tasks of ranges 0..i */
-    long left[64];           /* tasks of range i not finished yet (atomic): stamps */
     int ready[64];           /* range i has been seen final (atomic) */
     PyObject **obj[1024];
     double *sim[1024];
+    int done[];              /* per task (atomic): 0 not yet, 1 stored, 2 skipped */
 } rfill_job;
 
 static double mono_now(void)
@@ -852,13 +854,13 @@ static double mono_now(void)
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
-static void rfill_task(rfill_job *job, int tid, Py_ssize_t lo, Py_ssize_t hi)
+/* rows [lo, hi) of every column: similarities and pointers stored, no reference taken */
+static void rfill_store(rfill_job *job, int tid, Py_ssize_t lo, Py_ssize_t hi)
 {
     const Py_ssize_t top_n = job->top_n, n_names = job->n_names;
     PyObject *dummy = Py_None;
     PyObject **items = n_names ? job->items : &dummy;
-    int32_t *cnt = job->cnt + (size_t)tid * (size_t)(n_names ? n_names : 1);
-    long none_new = 0, none_old = 0;
+    long none_old = 0;
     int stale = 0;
     for (Py_ssize_t r = 0; r < top_n; ++r) {
         const int32_t *idx = job->idx + r;
@@ -869,11 +871,8 @@ static void rfill_task(rfill_job *job, int tid, Py_ssize_t lo, Py_ssize_t hi)
             const int32_t j = idx[i * top_n];
             const double t = rint((double)val[i * top_n] * 1000.0);       /* numpy's round(x, 3) = rint(x * 1000) / 1000 */
             const int keep = !(t < 1.0) & (j >= 0) & (j < n_names);       /* (rint(.) / 1000 < 0.001 exactly when rint(.) < 1) */
-            const Py_ssize_t jj = keep ? j : 0;
-            PyObject *o = items[jj];
+            PyObject *o = items[keep ? j : 0];
             o = keep ? o : Py_None;
-            cnt[jj] += keep;
-            none_new += !keep;
             PyObject *old = obj[i];
             none_old += old == Py_None;
             stale |= (old != NULL) & (old != Py_None);
@@ -881,93 +880,69 @@ static void rfill_task(rfill_job *job, int tid, Py_ssize_t lo, Py_ssize_t hi)
             obj[i] = o;
         }
     }
-    job->none_new[tid] += none_new;
     job->none_old[tid] += none_old;
     if (stale) __atomic_store_n(&job->error, 2, __ATOMIC_RELAXED);
 }
 
-/* the closing walk over list positions [lo, hi): the counts of every thread to the objects, the From column of a self-match */
-static void rfill_count(rfill_job *job, int tid, Py_ssize_t lo, Py_ssize_t hi, int atomic)
+/* task t, drawn by thread tid: wait for its range if nobody has seen it final, store, flag */
+static void rfill_ticket(rfill_job *job, int tid, long t)
 {
-    const Py_ssize_t n = job->n_names;
-    PyObject **items = job->items, **from = job->from_obj;
-    long none_old = 0;
-    int stale = 0;
-    for (Py_ssize_t j = lo; j < hi; ++j) {
-        if (j + 8 < hi) __builtin_prefetch(items[j + 8], 1, 1);
-        long c = from != NULL;
-        for (int u = 0; u < job->n_threads; ++u) {
-            int32_t *p = job->cnt + (size_t)u * (size_t)n + j;
-            c += *p;
-            *p = 0;               /* (the arrays are kept between calls: left zeroed) */
+    int state = 2;
+    if (__atomic_load_n(&job->error, __ATOMIC_RELAXED) != 1) {
+        int range = 0;
+        while (t >= job->task_end[range]) ++range;
+        int ok = 1;
+        if (job->wait && !__atomic_load_n(&job->ready[range], __ATOMIC_ACQUIRE)) {
+            if (job->wait(job->ctx, job->first_slot + range) != 0) {
+                __atomic_store_n(&job->error, 1, __ATOMIC_RELAXED);
+                ok = 0;
+            } else if (!__atomic_exchange_n(&job->ready[range], 1, __ATOMIC_ACQ_REL) && job->stamps) {
+                job->stamps[2 * range] = mono_now();
+            }
         }
-        PyObject *o = items[j];
-        if (from) {
-            PyObject *old = from[j];
-            none_old += old == Py_None;
-            stale |= (old != NULL) & (old != Py_None);
-            from[j] = o;
+        if (ok) {
+            const Py_ssize_t row0 = range ? (Py_ssize_t)job->ends[range - 1] : 0, row1 = (Py_ssize_t)job->ends[range];
+            const long k = t - (range ? job->task_end[range - 1] : 0);
+            const Py_ssize_t lo = row0 + k * RFILL_ROWS, hi = lo + RFILL_ROWS < row1 ? lo + RFILL_ROWS : row1;
+            rfill_store(job, tid, lo, hi);
+            state = 1;
         }
-        if (!c) continue;
-#if PFZ_DIRECT_REFCNT
-        if (atomic) __atomic_fetch_add(&o->ob_refcnt, (Py_ssize_t)c, __ATOMIC_RELAXED);
-        else o->ob_refcnt += c;
-#else
-        (void)atomic;
-        for (; c > 0; --c) Py_INCREF(o);
-#endif
     }
-    job->none_old[tid] += none_old;
-    if (stale) __atomic_store_n(&job->error, 2, __ATOMIC_RELAXED);
+    __atomic_store_n(&job->done[t], state, __ATOMIC_RELEASE);
 }
 
-static void rfill_run(void *arg, int tid)
+static void rfill_helper(void *arg, int tid)
 {
     rfill_job *job = (rfill_job *)arg;
-    const long n_tasks = job->n_tasks;
-    int range = 0;
     for (;;) {
-        const long t = __atomic_fetch_add(&job->next_task, 1, __ATOMIC_RELAXED);
-        if (t >= n_tasks) break;
-        /* (after a wait has failed the tasks left are drawn and counted without being done: the gathers' end is a count of tasks) */
-        if (__atomic_load_n(&job->error, __ATOMIC_RELAXED) != 1) {
-            while (t >= job->task_end[range]) ++range;
-            int ok = 1;
-            if (job->wait && !__atomic_load_n(&job->ready[range], __ATOMIC_ACQUIRE)) {
-                if (job->wait(job->ctx, job->first_slot + range) != 0) {
-                    __atomic_store_n(&job->error, 1, __ATOMIC_RELAXED);
-                    ok = 0;
-                } else if (!__atomic_exchange_n(&job->ready[range], 1, __ATOMIC_ACQ_REL) && job->stamps) {
-                    job->stamps[2 * range] = mono_now();
-                }
-            }
-            if (ok) {
-                const Py_ssize_t row0 = range ? (Py_ssize_t)job->ends[range - 1] : 0, row1 = (Py_ssize_t)job->ends[range];
-                const long k = t - (range ? job->task_end[range - 1] : 0);
-                const Py_ssize_t lo = row0 + k * RFILL_ROWS, hi = lo + RFILL_ROWS < row1 ? lo + RFILL_ROWS : row1;
-                rfill_task(job, tid, lo, hi);
-                if (__atomic_sub_fetch(&job->left[range], 1, __ATOMIC_ACQ_REL) == 0 && job->stamps) job->stamps[2 * range + 1] = mono_now();
-            }
-        }
-        __atomic_add_fetch(&job->tasks_done, 1, __ATOMIC_RELEASE);
-    }
-    if (__atomic_load_n(&job->next_walk, __ATOMIC_RELAXED) >= job->n_walk) return;        /* (a late-comer: nothing left to draw) */
-    /* every task done -- by whomever -- before anybody counts: the counts of a position come from all the threads */
-    while (__atomic_load_n(&job->tasks_done, __ATOMIC_ACQUIRE) < n_tasks) __builtin_ia32_pause();
-#if !PFZ_DIRECT_REFCNT
-    if (tid != 0) return;          /* (no atomic adds beside immortal objects: the closing walk is the caller's alone) */
-#endif
-    for (;;) {
-        const long w = __atomic_fetch_add(&job->next_walk, 1, __ATOMIC_RELAXED);
-        if (w >= job->n_walk) break;
-        const Py_ssize_t lo = (Py_ssize_t)w * RFILL_WALK, hi = lo + RFILL_WALK < job->n_names ? lo + RFILL_WALK : job->n_names;
-        rfill_count(job, tid, lo, hi, PFZ_DIRECT_REFCNT && job->n_threads > 1);
-        __atomic_add_fetch(&job->walk_done, 1, __ATOMIC_RELEASE);
+        const long t = __atomic_fetch_add(&job->next_ticket, 1, __ATOMIC_RELAXED);
+        if (t >= job->n_tasks) break;
+        rfill_ticket(job, tid, t);
     }
 }
 
-static int32_t *g_rfill_cnt = NULL;        /* the threads' count arrays, kept (and kept zeroed) between calls; GIL-protected */
-static size_t g_rfill_cap = 0;
+/* the calling thread: one reference per pointer the stored task holds; returns the cells that hold None */
+static long rfill_take(rfill_job *job, long t)
+{
+    enum { AHEAD = 8 };
+    int range = 0;
+    while (t >= job->task_end[range]) ++range;
+    const Py_ssize_t row0 = range ? (Py_ssize_t)job->ends[range - 1] : 0, row1 = (Py_ssize_t)job->ends[range];
+    const long k = t - (range ? job->task_end[range - 1] : 0);
+    const Py_ssize_t lo = row0 + k * RFILL_ROWS, hi = lo + RFILL_ROWS < row1 ? lo + RFILL_ROWS : row1;
+    long nones = 0;
+    for (Py_ssize_t r = 0; r < job->top_n; ++r) {
+        PyObject **obj = job->obj[r];
+        for (Py_ssize_t i = lo; i < hi; ++i) {
+            if (i + AHEAD < hi) __builtin_prefetch(obj[i + AHEAD], 1, 1);
+            PyObject *o = obj[i];
+            nones += o == Py_None;
+            Py_INCREF(o);                 /* (None's too: counted one by one like any other object's) */
+        }
+    }
+    if (job->stamps && t + 1 == job->task_end[range]) job->stamps[2 * range + 1] = mono_now();
+    return nones;
+}
 
 static PyObject *fill_ranges(PyObject *self, PyObject *args)
 {
@@ -987,13 +962,29 @@ static PyObject *fill_ranges(PyObject *self, PyObject *args)
     }
     PyObject *seq = PySequence_Fast(names, "fill_ranges() expects a sequence of names");
     if (!seq) return NULL;
+    int64_t ends[64], prev = 0;
+    long tasks = 0, task_end[64];
+    for (Py_ssize_t i = 0; i < n_ranges && !PyErr_Occurred(); ++i) {
+        ends[i] = (int64_t)PyLong_AsLongLong(PyTuple_GET_ITEM(ends_t, i));
+        if (!PyErr_Occurred() && ends[i] <= prev) PyErr_SetString(PyExc_ValueError, "fill_ranges(): range ends must ascend from above 0");
+        tasks += (long)((ends[i] - prev + RFILL_ROWS - 1) / RFILL_ROWS);
+        task_end[i] = tasks;
+        prev = ends[i];
+    }
+    if (!PyErr_Occurred() && from_obj_addr && PySequence_Fast_GET_SIZE(seq) != (Py_ssize_t)prev)
+        PyErr_SetString(PyExc_ValueError, "fill_ranges(): a From column needs a list against itself (as many rows as names)");
+    if (PyErr_Occurred()) {
+        Py_DECREF(seq);
+        return NULL;
+    }
     /* helpers only where they can sit on the caller's L3 (anywhere else they cost more than they do: see above) */
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
+    if (n_threads > tasks) n_threads = (int)tasks;
     int local[16];
     const int n_local = n_threads > 1 ? l3_local_cpus(local, 16) : 0;
     if (n_threads > 1 + n_local && !pin_is_off()) n_threads = 1 + n_local;
-    crew *c = crew_new(sizeof(rfill_job), n_threads - 1, rfill_run);
+    crew *c = crew_new(sizeof(rfill_job) + (size_t)tasks * sizeof(int), n_threads - 1, rfill_helper);
     if (!c) {
         Py_DECREF(seq);
         return PyErr_NoMemory();
@@ -1003,59 +994,51 @@ static PyObject *fill_ranges(PyObject *self, PyObject *args)
         job->obj[r] = (PyObject **)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(obj_addrs, r));
         job->sim[r] = (double *)(uintptr_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(sim_addrs, r));
     }
-    int64_t prev = 0;
-    long tasks = 0;
-    for (Py_ssize_t i = 0; i < n_ranges && !PyErr_Occurred(); ++i) {
-        job->ends[i] = (int64_t)PyLong_AsLongLong(PyTuple_GET_ITEM(ends_t, i));
-        if (!PyErr_Occurred() && job->ends[i] <= prev) PyErr_SetString(PyExc_ValueError, "fill_ranges(): range ends must ascend from above 0");
-        job->left[i] = (long)((job->ends[i] - prev + RFILL_ROWS - 1) / RFILL_ROWS);
-        tasks += job->left[i];
-        job->task_end[i] = tasks;
-        prev = job->ends[i];
-    }
-    if (!PyErr_Occurred() && from_obj_addr && PySequence_Fast_GET_SIZE(seq) != (Py_ssize_t)prev)
-        PyErr_SetString(PyExc_ValueError, "fill_ranges(): a From column needs a list against itself (as many rows as names)");
+    memcpy(job->ends, ends, sizeof ends);
+    memcpy(job->task_end, task_end, sizeof task_end);
     job->items = PySequence_Fast_ITEMS(seq);
     job->n_names = PySequence_Fast_GET_SIZE(seq);
-    const size_t need = (size_t)n_threads * (size_t)(job->n_names ? job->n_names : 1);
-    if (!PyErr_Occurred() && need > g_rfill_cap) {
-        free(g_rfill_cnt);
-        g_rfill_cnt = (int32_t *)calloc(need, sizeof(int32_t));
-        g_rfill_cap = g_rfill_cnt ? need : 0;
-        if (!g_rfill_cnt) PyErr_NoMemory();
-    }
-    if (PyErr_Occurred()) {
-        crew_release(c, c->refs);           /* (nobody was started) */
-        Py_DECREF(seq);
-        return NULL;
-    }
     job->top_n = top_n;
     job->idx = (const int32_t *)(uintptr_t)idx_addr;
     job->val = (const float *)(uintptr_t)val_addr;
     job->n_ranges = (int)n_ranges;
     job->n_tasks = tasks;
-    job->n_walk = (long)((job->n_names + RFILL_WALK - 1) / RFILL_WALK);
     job->wait = (pfz_wait_fn)(uintptr_t)wait_addr;
     job->ctx = (void *)(uintptr_t)ctx_addr;
     job->first_slot = first_slot;
-    job->n_threads = n_threads;
     job->stamps = (double *)(uintptr_t)stamps_addr;
-    job->from_obj = (PyObject **)(uintptr_t)from_obj_addr;
-    job->cnt = g_rfill_cnt;
     crew_spawn(c, 1);
-    rfill_run(job, 0);
-    /* the call is over when the WORK is: every chunk of the closing walk done, whoever did it */
-    while (__atomic_load_n(&job->walk_done, __ATOMIC_ACQUIRE) < job->n_walk) __builtin_ia32_pause();
-    long none_new = 0, none_old = 0;
-    for (int t = 0; t < n_threads; ++t) {
-        none_new += job->none_new[t];
-        none_old += job->none_old[t];
+    long none_old = 0, none_new = 0;
+    int stale = 0;
+    if (from_obj_addr) {          /* the From column, while the helpers wait for the first range */
+        PyObject **from = (PyObject **)(uintptr_t)from_obj_addr, **items = job->items;
+        for (Py_ssize_t i = 0; i < job->n_names; ++i) {
+            if (i + 16 < job->n_names) __builtin_prefetch(items[i + 16], 1, 1);
+            PyObject *old = from[i];
+            none_old += old == Py_None;
+            stale |= (old != NULL) & (old != Py_None);
+            Py_INCREF(items[i]);
+            from[i] = items[i];
+        }
     }
-    const int error = job->error;
+    for (long t = 0; t < tasks;) {
+        const int state = __atomic_load_n(&job->done[t], __ATOMIC_ACQUIRE);
+        if (state) {
+            if (state == 1) none_new += rfill_take(job, t);
+            ++t;
+            continue;
+        }
+        long cur = __atomic_load_n(&job->next_ticket, __ATOMIC_RELAXED);
+        if (cur == t && __atomic_compare_exchange_n(&job->next_ticket, &cur, cur + 1, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            rfill_ticket(job, 0, t);          /* (nobody has drawn it: no helper runs yet, or there is none) */
+            continue;
+        }
+        __builtin_ia32_pause();
+    }
+    for (int u = 0; u < 16; ++u) none_old += job->none_old[u];
+    const int error = stale ? 2 : job->error;
     crew_release(c, 1);
-#if PFZ_DIRECT_REFCNT
-    Py_None->ob_refcnt += none_new;
-#endif
+    (void)none_new;                            /* (None's references were taken one by one with the others) */
     release_overwritten_none(none_old);
     Py_DECREF(seq);
     if (error == 1) {

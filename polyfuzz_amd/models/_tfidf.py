@@ -175,8 +175,8 @@ class TFIDF(BaseMatcher):
         ctx = _lib.Context.default()
         t0 = time.perf_counter()
         # the From column of the frame is filled by the string packer's own walk over from_list (a list): no second pass
-        # (a big list against itself whose packer runs on threads, which touch no reference count: the From column is filled in the
-        # closing walk of the frame's range fill, _pack.fill_ranges)
+        # (a big list against itself whose packer runs on threads, which touch no reference count: the From column is filled by the
+        # frame's range fill, _pack.fill_ranges, while its helpers wait for the first range)
         ranged = _RANGE_FILL and _lib._PACK_INTO_THREADS > 1 and to_list is None and isinstance(from_list, list) and len(from_list) >= _SPLIT_MIN_ROWS and \
             _lib._pack is not None and hasattr(_lib._pack, "fill_ranges")
         col = [np.empty(len(from_list), dtype=object)] if isinstance(from_list, list) and len(from_list) >= 1024 and _FROM_IN_PACK and not ranged else None
@@ -221,6 +221,7 @@ class TFIDF(BaseMatcher):
                     for i in range(len(ends)):
                         trace += [(f"range {i} [{ends[i - 1] if i else 0}, {ends[i]}) here", stamps[2 * i] + off - t0),
                                   (f"range {i} filled", stamps[2 * i + 1] + off - t0)]
+                    trace.append(("fill returned", tb - t0))
                 framed, tp = framed + (tb - tp), tb
                 ends = ()
             for i, row1 in enumerate(ends):

@@ -156,12 +156,13 @@ class FrameBuilder:
 
     def fill_ranges(self, idx_addr, val_addr, ends, wait_addr, ctx_addr, first_slot, stamps=None):
         """every row range of a result that arrives in ascending ranges [0, ends[0]), [ends[0], ends[1]) ... at idx_addr / val_addr
-        (the whole result, pinned host memory): range i is filled once wait(ctx, first_slot + i) has returned -- on _RANGE_THREADS
-        threads that wait for the ranges themselves (_pack.fill_ranges).  stamps: float64[2 * len(ends)] or None (seconds on
-        time.monotonic's clock: range seen final / filled)"""
+        (the whole result, pinned host memory): range i is filled once wait(ctx, first_slot + i) has returned (wait_addr 0:
+        everything is there) -- _RANGE_THREADS - 1 helper threads wait for the ranges themselves and store similarities and
+        pointers, the calling thread takes the references (_pack.fill_ranges).  stamps: float64[2 * len(ends)] or None (seconds on
+        time.monotonic's clock: range seen final / filled and counted)"""
         if not self.top_n or not len(ends):
             return
-        pending = self.from_pending and self.from_list is self.to_list        # (the closing walk fills the From column of a list against itself)
+        pending = self.from_pending and self.from_list is self.to_list        # (the From column of a list against itself: filled in the same call)
         self.from_pending = self.from_pending and not pending
         _lib._pack.fill_ranges(self.to_list, idx_addr, val_addr, self.top_n, tuple(self._name_at), tuple(self._sim_at),
                                tuple(int(e) for e in ends), wait_addr, ctx_addr, first_slot, _RANGE_THREADS,

@@ -1,6 +1,6 @@
-"""_pack.fill_ranges (round 6): the (To, Similarity) columns of a big match filled by threads that wait for the result's row ranges
-themselves and touch no reference count while they gather -- every thread counts what it stored, the counts reach the names at the
-end.  No device here: `_pack.test_wait` stands in for pfz_event_wait (an int32 flag per range), `_pack.test_set_flags` raises the
+"""_pack.fill_ranges (round 6): the (To, Similarity) columns of a big match filled by helper threads that wait for the result's row
+ranges themselves and touch no reference count -- they store similarities and pointers and flag the task; the calling thread follows
+the flags and takes one reference per stored pointer.  No device here: `_pack.test_wait` stands in for pfz_event_wait (an int32 flag per range), `_pack.test_set_flags` raises the
 flags from a thread of its own while the caller sits inside fill_ranges with the GIL.
 
 Held against the single-threaded fill_columns cell by cell, and against the reference counts a frame must hold: exactly one per
@@ -65,8 +65,7 @@ def test_ranges_equal_the_single_threaded_fill(n, top_n, k, threads, monkeypatch
 
 
 def test_ranges_that_arrive_late_and_one_object_in_every_slot(monkeypatch):
-    """the flags are raised 300 us apart from another thread while four threads sit in fill_ranges; every cell points at ONE name
-    (the counts of four threads meet on one object)"""
+    """the flags are raised 300 us apart from another thread while four threads sit in fill_ranges; every cell points at ONE name"""
     n, top_n = 24000, 5
     names = ["the one"] + [f"other {i}" for i in range(99)]
     idx = np.zeros((n, top_n), np.int32)
@@ -93,8 +92,8 @@ def test_ranges_that_arrive_late_and_one_object_in_every_slot(monkeypatch):
 
 @pytest.mark.parametrize("threads", [1, 4])
 def test_the_from_column_and_one_object_at_many_list_positions(threads, monkeypatch):
-    """a self-match's frame: the From column is filled by the same threads (from_pending), and the list holds ONE object at fifty
-    positions -- the owner of a reference count is the object's address, not its position"""
+    """a self-match's frame: the From column is filled in the same call (from_pending), and the list holds ONE object at fifty
+    positions"""
     n, top_n = 30000, 4
     dup = "a name that is there fifty times"
     names = [f"name {i}" for i in range(n)]
@@ -130,13 +129,16 @@ def test_the_from_column_and_one_object_at_many_list_positions(threads, monkeypa
     assert fb.frame()["From"].tolist() == names[:9000]
 
 
-def test_a_failing_wait_leaves_consistent_columns(monkeypatch):
-    """range 2 of 4 never arrives (the wait returns an error): RuntimeError, and what had been stored by then holds exactly the
-    references it should -- dropping the columns brings every count back"""
+@pytest.mark.parametrize("k,fails_at", [(4, 2), (8, 1), (8, 6), (8, 7)])
+def test_a_failing_wait_leaves_consistent_columns(k, fails_at, monkeypatch):
+    """one of the ranges never arrives (the wait returns an error) -- an early one, a late one, the last one --:
+    RuntimeError, and what had been stored by then holds exactly the references it should: dropping the columns brings every
+    count back"""
     n, top_n = 20000, 3
     names, idx, val = _case(n, top_n, 3000, 5)
-    ends = _ends(n, 4)
-    flags = np.array([1, 1, -1, 1], np.int32)
+    ends = _ends(n, k)
+    flags = np.ones(k, np.int32)
+    flags[fails_at] = -1
     rc0 = [sys.getrefcount(s) for s in names]
     fb = _utils.FrameBuilder([f"q{i}" for i in range(n)], names, top_n)
     with pytest.raises(RuntimeError):
@@ -144,12 +146,12 @@ def test_a_failing_wait_leaves_consistent_columns(monkeypatch):
     held = np.zeros(len(names), np.int64)
     where = {id(s): i for i, s in enumerate(names)}
     for col in fb.names:
-        for o in col[:ends[1]]:
+        for o in col:
             if o is not None:
                 held[where[id(o)]] += 1
-        assert all(o is None for o in col[ends[2]:ends[2] + 5])           # (nothing of the range that failed)
+        assert all(o is None for o in col[ends[fails_at - 1]:ends[fails_at - 1] + 5])           # (nothing of the range that failed)
     rc1 = [sys.getrefcount(s) for s in names]
-    assert np.all(np.array(rc1) - np.array(rc0) >= held)                  # (ranges 0, 1 whole; range 3 as far as the draw got)
+    assert (np.array(rc1) - np.array(rc0) == held).all()                  # exactly one reference per stored pointer
     del fb, col, o
     assert [sys.getrefcount(s) for s in names] == rc0
 
