@@ -889,6 +889,8 @@ int pfz_cossim_topn_ranges(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
                 if (bytes > ctx->mirror_bytes) {
                     PFZ_HIP(hipStreamSynchronize(ctx->stream));
                     if (ctx->stream3) PFZ_HIP(hipStreamSynchronize(ctx->stream3));
+                    for (int q = 0; q < 3; ++q)
+                        if (ctx->stream3x[q]) PFZ_HIP(hipStreamSynchronize(ctx->stream3x[q]));
                     if (ctx->mirror) PFZ_HIP(hipHostFree(ctx->mirror));
                     ctx->mirror = nullptr;
                     ctx->mirror_bytes = 0;

@@ -67,6 +67,11 @@ constexpr int kSymKeep = 32;       // keys a row keeps between the passes at mos
 constexpr int kSymF = PFZ_K3_SYM_F;         // staged foreign candidates per wave (flushed above kSymF - 64)
 constexpr int kSymPush = PFZ_K3_SYM_PUSH;   // push slots per row; a row that is sent more is recomputed in full
 constexpr int kSymMergeCap = kSymPush + 64;
+#ifndef PFZ_K3_SYM_SIDE_STREAMS
+#define PFZ_K3_SYM_SIDE_STREAMS 2      // (tuning builds, tools/build_variant.sh: 1 = every range's chain on one side stream, round 6's first form; up to 4)
+#endif
+constexpr int kSymSides = PFZ_K3_SYM_SIDE_STREAMS;      // side streams of a streamed session (k3_sym_launch_streamed)
+static_assert(kSymSides >= 1 && kSymSides <= 4, "one to four side streams");
 constexpr int kSymSlices = 8;      // pass 2: a row that is recomputed in full is cut into at most this many slices of to-blocks ...
 constexpr int kSymSlicedRows = 4096;   // ... for the first so many rows of the list (a single wave takes ~100 us for a whole row)
 #ifndef PFZ_K3_SYM_EXP
@@ -758,6 +763,8 @@ struct K3SymState {
     uint64_t *push_buf = nullptr;
     int32_t *ovf = nullptr;
     uint64_t *part = nullptr;
+    int32_t *ovfx[3] = {nullptr, nullptr, nullptr};      // streamed sessions: the further side streams' lists of rows to recompute and partial lists
+    uint64_t *partx[3] = {nullptr, nullptr, nullptr};
     uint32_t *done = nullptr;            // [nb] streamed sessions: pass-1 items finished per block
     // the running session: the next range must start where the last one ended, with the same job
     int64_t next_row = -1;
@@ -772,7 +779,7 @@ void k3_sym_free(pfz_index *ix)
 {
     K3SymState *s = ix->sym;
     if (!s) return;
-    void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part, s->done};
+    void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part, s->ovfx[0], s->partx[0], s->ovfx[1], s->partx[1], s->ovfx[2], s->partx[2], s->done};
     for (void *p : bufs)
         if (p) pool_free(p);
     delete s;
@@ -826,6 +833,10 @@ static int sym_state_alloc(pfz_ctx *ctx, const pfz_index *ix, K3SymState *s)
     PFZ_TRY(pool_alloc(ctx, &s->push_buf, (size_t)n * kSymPush * sizeof(uint64_t)));
     PFZ_TRY(pool_alloc(ctx, &s->ovf, (size_t)(n + 1) * sizeof(int32_t)));
     PFZ_TRY(pool_alloc(ctx, &s->part, (size_t)kSymSlicedRows * kSymSlices * kSymKeep * sizeof(uint64_t)));
+    for (int q = 0; q + 1 < kSymSides; ++q) {
+        PFZ_TRY(pool_alloc(ctx, &s->ovfx[q], (size_t)(n + 1) * sizeof(int32_t)));
+        PFZ_TRY(pool_alloc(ctx, &s->partx[q], (size_t)kSymSlicedRows * kSymSlices * kSymKeep * sizeof(uint64_t)));
+    }
     PFZ_TRY(pool_alloc(ctx, &s->done, (size_t)(ix->n_blocks + 64) * kSymDoneStride * sizeof(uint32_t)));
     return PFZ_OK;
 }
@@ -841,7 +852,7 @@ static K3SymState *sym_state_of(pfz_ctx *ctx, const pfz_index *ix)
     s->n = ix->n_rows;
     ix->sym = s;      // (freed with the index, whatever happens below)
     if (getenv("PFZ_K3_SYM_FAIL_ALLOC") || sym_state_alloc(ctx, ix, s) != PFZ_OK) {      // (the knob: tests of this fallback)
-        void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part, s->done};
+        void *const bufs[] = {s->thrv, s->slot4, s->gmin, s->thr_slot, s->row_slot, s->mag, s->post_sym, s->keys, s->push_cnt, s->push_buf, s->ovf, s->part, s->ovfx[0], s->partx[0], s->ovfx[1], s->partx[1], s->ovfx[2], s->partx[2], s->done};
         for (void *p : bufs)
             if (p) pool_free(p);
         *s = K3SymState();
@@ -1045,6 +1056,10 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
         PFZ_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
         PFZ_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, pr_hi));
         PFZ_HIP(hipEventCreateWithFlags(&ctx->ev3, hipEventDisableTiming));
+        for (int q = 0; q + 1 < kSymSides; ++q) {
+            PFZ_HIP(hipStreamCreateWithPriority(&ctx->stream3x[q], hipStreamNonBlocking, pr_hi));
+            PFZ_HIP(hipEventCreateWithFlags(&ctx->ev3x[q], hipEventDisableTiming));
+        }
     }
     s->next_row = -1;
     K3SymArgs a;
@@ -1072,17 +1087,31 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
     hipLaunchKernelGGL((k3_sym_kernel<kSymC, 1>), dim3((unsigned)(a.row_end + a.n_mag_items)), dim3(64), 0, ctx->stream, a);
     PFZ_HIP(hipGetLastError());
     a.n_mag_items = 0;
-    // the ranges, on the side stream
-    hipStream_t side = ctx->stream3;
-    PFZ_HIP(hipStreamWaitEvent(side, ctx->ev3, 0));
+    // The ranges, on kSymSides side streams in turn.  A range's chain -- wait, merge, overflow pass in slices, their merge, the overflow
+    // pass of whole rows -- is ~0.1 ms of small kernels one behind the other, and the last ranges of a list become final within
+    // less than that of each other (a row walks the blocks from its own upwards: 1 - (1 - x)^2 of pass 1 is spent when a share x of
+    // the rows is done): on one stream the chains of the last three ranges queued up behind pass 1's end, 0.2 ms; going round
+    // several streams a chain runs beside its neighbours'.  Each stream has its own list of rows to recompute and its own partial
+    // lists; a range is announced by the wait kernel of the NEXT range on ITS stream (the stream is in order); a range's wait
+    // covers the blocks from the end of the range before it ON ITS STREAM (the ranges between wait on the other streams).
+    hipStream_t sides[4] = {ctx->stream3, ctx->stream3x[0], ctx->stream3x[1], ctx->stream3x[2]};
+    hipEvent_t side_ev[4] = {ctx->ev3, ctx->ev3x[0], ctx->ev3x[1], ctx->ev3x[2]};
+    const int n_sides = n_ranges < kSymSides ? n_ranges : kSymSides;
+    for (int q = 0; q < n_sides; ++q) PFZ_HIP(hipStreamWaitEvent(sides[q], ctx->ev3, 0));
     int64_t row0 = 0;
-    int32_t *flag = nullptr;
-    int32_t flag_value = 0;
+    int64_t covered[4] = {0, 0, 0, 0};        // per stream: the row its waits have covered the blocks up to
+    int32_t *flag[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t flag_value[4] = {0, 0, 0, 0};
     for (int32_t i = 0; i < n_ranges; ++i) {
+        const int q = i % n_sides;
+        hipStream_t side = sides[q];
         const int64_t row1 = ends[i];
-        a.blk_lo = (int32_t)(row0 / kSymC);
+        a.ovf = q ? s->ovfx[q - 1] : s->ovf;
+        a.part = q ? s->partx[q - 1] : s->part;
+        a.blk_lo = (int32_t)(covered[q] / kSymC);
         a.blk_hi = (int32_t)((row1 + kSymC - 1) / kSymC);
-        hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, side, a, flag, flag_value);
+        covered[q] = row1;
+        hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, side, a, flag[q], flag_value[q]);
         a.row_begin = (int32_t)row0;
         a.row_end = (int32_t)row1;
         hipLaunchKernelGGL(k3_sym_merge<PFZ_K3_SYM_MERGE_W>, dim3((unsigned)((row1 - row0 + PFZ_K3_SYM_MERGE_W - 1) / PFZ_K3_SYM_MERGE_W)),
@@ -1090,15 +1119,19 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
         sym_launch_pass2(ctx, a, side, 2);       // (a range's overflow rows are few: two workgroups per CU loop over them)
         PFZ_HIP(hipGetLastError());
         PFZ_HIP(hipEventRecord(ctx->events[first_event + i], side));
-        PFZ_TRY(event_flag_next(ctx, first_event + i, &flag, &flag_value));       // (... and as a word in pinned memory: pfz_topn_rows_begin / _finish)
+        PFZ_TRY(event_flag_next(ctx, first_event + i, &flag[q], &flag_value[q]));       // (... and as a word in pinned memory: pfz_topn_rows_begin / _finish)
         row0 = row1;
     }
     a.blk_lo = a.blk_hi = 0;
-    hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, side, a, flag, flag_value);      // (the last range's word)
-    PFZ_HIP(hipGetLastError());
-    PFZ_HIP(hipEventRecord(ctx->ev3, side));
+    a.ovf = s->ovf;
+    a.part = s->part;
+    for (int q = 0; q < n_sides; ++q) {
+        hipLaunchKernelGGL(k3_sym_wait, dim3(1), dim3(64), 0, sides[q], a, flag[q], flag_value[q]);      // (the stream's last range's word)
+        PFZ_HIP(hipGetLastError());
+        PFZ_HIP(hipEventRecord(side_ev[q], sides[q]));
+    }
     // whatever follows on the context's stream (and its timers) comes after the last range
-    PFZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev3, 0));      // (ev3: free again once pass 1 had been launched behind it)
+    for (int q = 0; q < n_sides; ++q) PFZ_HIP(hipStreamWaitEvent(ctx->stream, side_ev[q], 0));      // (ev3: free again once pass 1 had been launched behind it)
     s->next_row = n;
     s->launches += 1;
     s->rows += n;

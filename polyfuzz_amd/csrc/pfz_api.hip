@@ -612,6 +612,13 @@ void pfz_ctx_destroy(pfz_ctx *ctx)
         (void)hipStreamDestroy(ctx->stream3);
     }
     if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+    for (int q = 0; q < 3; ++q) {
+        if (ctx->stream3x[q]) {
+            (void)hipStreamSynchronize(ctx->stream3x[q]);
+            (void)hipStreamDestroy(ctx->stream3x[q]);
+        }
+        if (ctx->ev3x[q]) (void)hipEventDestroy(ctx->ev3x[q]);
+    }
     (void)pool_release(ctx);
     {   // blocks still owned by live handles of this context: free them, the handles become inert
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -659,8 +666,12 @@ static int event_flag_spin(pfz_ctx *ctx, int32_t slot, const char *who)
     const volatile int32_t *flag = ctx->evt_flag + slot;
     for (uint64_t spins = 0; *flag != want; ++spins) {
         __builtin_ia32_pause();
-        if ((spins & 0xffff) == 0xffff && ctx->stream3 && hipStreamQuery(ctx->stream3) == hipSuccess && *flag != want) {
+        bool dry = (spins & 0xffff) == 0xffff && ctx->stream3 && hipStreamQuery(ctx->stream3) == hipSuccess;
+        for (int q = 0; q < 3 && dry; ++q) dry = !ctx->stream3x[q] || hipStreamQuery(ctx->stream3x[q]) == hipSuccess;
+        if (dry && *flag != want) {
             PFZ_HIP(hipStreamSynchronize(ctx->stream3));
+            for (int q = 0; q < 3; ++q)
+                if (ctx->stream3x[q]) PFZ_HIP(hipStreamSynchronize(ctx->stream3x[q]));
             if (*flag != want) {
                 set_error("%s: event slot %d was never announced", who, slot);
                 return PFZ_ERR_HIP;

@@ -78,6 +78,8 @@ struct pfz_ctx {
     hipEvent_t side_events[4] = {};       // K5: panel ready x2, panel consumed x2
     hipStream_t stream3 = nullptr;        // K3's streamed self-match: the per-range merges beside the one pass-1 launch (k3_sym_launch_streamed)
     hipEvent_t ev3 = nullptr;             // ... "pass 1 is about to start" on the main stream
+    hipStream_t stream3x[3] = {nullptr, nullptr, nullptr};      // ... more side streams: the ranges' chains (wait, merge, overflow pass) go round them
+    hipEvent_t ev3x[3] = {nullptr, nullptr, nullptr};
     hipDeviceProp_t prop;
     hipEvent_t events[pfz::kEventSlots] = {};
     bool prof = false;
