@@ -20,9 +20,11 @@ timeout 300 python tools/k7_rowstats.py WRatio >> $O/k7_fuzz.txt 2>&1
 timeout 300 python tools/r6_match_ab.py "round 5 (launch per range, copying upload, one host thread):PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15,PFZ_DIRECT_PACK=0,PFZ_HOST_THREADS=1" "launch per range, direct pack, one host thread:PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15,PFZ_HOST_THREADS=1" "streamed12, copying upload, one host thread:PFZ_DIRECT_PACK=0,PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed5, one host thread:PFZ_MATCH_SHARES=1;1;1;1;1,PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed12, one host thread (round 6, first form):PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed12, range fill on one thread:PFZ_HOST_THREADS=1" "streamed12, crews of 2:PFZ_HOST_THREADS=2" "streamed12, crews of 4 (default):" "streamed12, crews of 8:PFZ_HOST_THREADS=8" "streamed12, packer alone on 4:PFZ_RANGE_THREADS=1" "streamed12, frame alone on 4:PFZ_PACK_INTO_THREADS=1" "streamed12, crews of 4 placed by the scheduler:PFZ_HOST_PIN=0" "streamed16, crews of 4:PFZ_MATCH_SHARES=1;1;1;1;1;1;1;1;1;1;1;1;1;1;1;1" > $O/match_ab.txt 2>&1
 # what the frame fill's variants cost on this host's CPU, on threads the scheduler places and on threads on the caller's L3
 (gcc -O3 -msse4.1 tools/ubench/frame_fill_mt.c -lpthread -lm -o /tmp/ffmt && /tmp/ffmt && /tmp/ffmt pin) > $O/frame_fill_mt.txt 2>&1
+# the streamed session's range chains on 1 / 2 (shipped) / 3 / 4 side streams: variants/sidesK.so, built by tools/r6_final_local.sh from this commit
+timeout 600 bash tools/r6_sides_ab.sh > $O/side_streams.txt 2>&1
 # `python bench.py --gpus 2` as the driver would call it, on a box with one device: launches itself, every rank says what is missing
 timeout 300 python bench.py --gpus 2 --steps 2 > $O/gpus2_selflaunch.txt 2>&1; echo "bench --gpus 2 rc=$? (expected: not 0 on a one-GPU box)" >> $O/gpus2_selflaunch.txt
-for f in $O/profile/summary.txt $O/profile/summary_headline.txt $O/profile/summary_match.txt $O/k7_fuzz.txt $O/match_ab.txt $O/frame_fill_mt.txt; do [ -f $f ] && sed -i "1i (source commit $HEAD_ID; tools/r6_final.sh)" $f; done
+for f in $O/profile/summary.txt $O/profile/summary_headline.txt $O/profile/summary_match.txt $O/k7_fuzz.txt $O/match_ab.txt $O/frame_fill_mt.txt $O/side_streams.txt; do [ -f $f ] && sed -i "1i (source commit $HEAD_ID; tools/r6_final.sh)" $f; done
 python - <<PY
 import json
 d=json.load(open("$O/bench.json"))

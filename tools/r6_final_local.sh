@@ -8,6 +8,7 @@ cd "$(dirname "$0")/.."
 if [ -n "$(git status --porcelain -- . ':!profiles' ':!DESIGN.md' ':!README.md' ':!tools/README.md' ':!INTEGRATION.md')" ]; then echo "working tree is not clean: commit first"; git status --short | head; exit 1; fi
 HEAD_ID=$(git rev-parse HEAD); echo "$HEAD_ID" > tools/.build_head
 python -c "import __graft_entry__ as g; g.build()" | tail -1
+mkdir -p variants; for k in 1 3 4; do bash tools/build_variant.sh "$PWD/variants/sides$k.so" -DPFZ_K3_SYM_SIDE_STREAMS=$k 2>&1 | grep -i " error" || true; done
 gpurun --timeout 5400 -- 'bash tools/r6_final.sh' 2>&1 | tail -60
 [ "$(git rev-parse HEAD)" = "$HEAD_ID" ] || { echo "HEAD moved while the call ran: results NOT filed"; exit 1; }
 [ "$(cat gpurun_out/r06_final/source_commit.txt)" = "$HEAD_ID" ] || { echo "the box profiled another build: results NOT filed"; exit 1; }
@@ -21,6 +22,7 @@ cp $O/match_ab.txt profiles/experiments/r06_match_streamed_ab.txt; grep "bench r
 cp $O/profile/bench_under_rocprof.json profiles/r06_bench_under_rocprof.json 2>/dev/null || true
 cp $O/k7_fuzz.txt profiles/r06_k7_fuzz.txt
 cp $O/frame_fill_mt.txt profiles/experiments/r06_frame_fill_mt.txt
+cp $O/side_streams.txt profiles/experiments/r06_k3_side_streams.txt
 [ -f $O/other/summary_other.txt ] && cp $O/other/summary_other.txt profiles/r06_other_kernels_rocprofv3_summary.txt
 python - <<PY
 import json
