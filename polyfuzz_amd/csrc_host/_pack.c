@@ -32,8 +32,8 @@
 
 /* Reference counts are only ever edited directly where that is exact: CPython < 3.12 (every object mortal, ob_refcnt a
  * plain Py_ssize_t).  From 3.12 on None and interned strings are IMMORTAL -- Py_INCREF / Py_DECREF of them are no-ops
- * and their count must not be touched -- so there the threaded fill is off (Py_INCREF under the GIL only) and the
- * references to None that np.empty(n, object) "held" need no release. */
+ * and their count must not be touched -- so there the references to None that np.empty(n, object) "held" need no release.
+ * (The only direct edit left is that release; every reference this file TAKES is a Py_INCREF by the thread that holds the GIL.) */
 #ifdef Py_GIL_DISABLED
 #error "_pack.c relies on the GIL (free-threaded CPython is not supported)"
 #endif
@@ -1058,10 +1058,9 @@ static PyObject *fill_ranges(PyObject *self, PyObject *args)
  * address; test_set_flags(addr, n, usec, value) sets flags[0..n) to value one by one, usec apart, from a detached thread. */
 static int test_wait(void *ctx, int32_t slot)
 {
-    volatile int32_t *flag = (volatile int32_t *)ctx + slot;
-    while (*flag == 0) __builtin_ia32_pause();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return *flag < 0 ? -1 : 0;
+    int32_t *flag = (int32_t *)ctx + slot, v;
+    while ((v = __atomic_load_n(flag, __ATOMIC_ACQUIRE)) == 0) __builtin_ia32_pause();
+    return v < 0 ? -1 : 0;
 }
 
 static PyObject *test_wait_addr(PyObject *self, PyObject *args)
