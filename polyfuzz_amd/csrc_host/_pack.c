@@ -91,6 +91,8 @@ static int parse_cpu_list(const char *path, cpu_set_t *set)
 /* the caller's L3 domain without the caller's own core, as an affinity mask (what l3_local_cpus counted the cores of) */
 static cpu_set_t g_l3_mask;
 static int g_l3_mask_for = -1;
+static cpu_set_t g_allowed_mask;            /* the calling thread's affinity when the L3 domain was looked up */
+static int g_allowed_known = 0;
 
 static int pin_is_off(void)
 {
@@ -115,6 +117,8 @@ static int l3_local_cpus(int *cpus, int max)
         snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", me);
         if (parse_cpu_list(path, &sib) != 0) CPU_ZERO(&sib);
         CPU_SET(me, &sib);
+        g_allowed_mask = allowed;
+        g_allowed_known = 1;
         CPU_ZERO(&g_l3_mask);
         g_l3_mask_for = -1;
         for (int c = 0; c < CPU_SETSIZE; ++c)
@@ -143,31 +147,42 @@ static int l3_local_cpus(int *cpus, int max)
     return k;
 }
 
-/* A crew: the helper threads of ONE call (pack_into on threads, fill_ranges).
- * - Confined to the caller's L3 domain minus the caller's own core -- to the whole domain, not to a core each: the scheduler picks
- *   idle cores among them (a helper nailed to one core waits whenever a neighbour on the host has that core).
- * - Started as a chain: the caller starts one helper, every helper starts the next before it takes work -- one pthread_create
- *   (20 - 30 us with the affinity attribute) on the caller's path instead of three.
- * - Detached, and NOBODY waits for a helper as such: the work is drawn from counters and the phases end when the work of the phase
- *   is done, whoever did it.  A helper the scheduler has not run yet (placed behind a spinning thread, on a core that sleeps) does not
- *   hold the call up -- with a barrier over the threads one call in ten took 6 - 13 ms instead of 3 on a freshly started box; it
- *   finds nothing left when it gets there and leaves.  The job lives on the heap behind the crew's header and is freed by whoever
- *   lets go of it last. */
-struct crew;
-typedef struct {
-    struct crew *c;
-    int tid;
-} crew_slot;
+/* A crew: the helper threads of ONE call (pack_into on threads, fill_ranges), taken from a POOL of parked threads.
+ * - The pool's threads are confined to the caller's L3 domain minus the caller's own core -- to the whole domain, not to a core
+ *   each: the scheduler picks idle cores among them (a helper nailed to one core waits whenever a neighbour on the host has that
+ *   core).  They are created on first use, detached, and sleep on a futex between calls: a call wakes as many as it wants with ONE
+ *   system call (started per call -- as a chain, each helper starting the next -- the eighth helper of the string packer was there
+ *   after 0.2 ms of a 0.3-ms job).  The caller's L3 domain is looked up again when the caller is found on another CPU, and the pool
+ *   re-confined; a forked child starts a pool of its own.
+ * - A woken thread JOINS the crew that is current, under the pool's lock, and takes a reference on it there: the job lives on the
+ *   heap behind the crew's header and is freed by whoever lets go of it last.  The caller closes the crew (nobody can join any more)
+ *   when the job's work is done.
+ * - NOBODY waits for a helper as such: the work is drawn from counters and the phases end when the work of the phase is done,
+ *   whoever did it.  A helper the scheduler has not run yet (placed behind a spinning thread, on a core that sleeps) does not hold
+ *   the call up -- with a barrier over the threads one call in ten took 6 - 13 ms instead of 3 on a freshly started box; it finds
+ *   the crew closed, or nothing left to draw, and goes back to sleep. */
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 typedef struct crew {
-    int refs;                               /* atomic: the caller + every helper planned */
-    int planned;
-    int confine;                            /* helpers get the L3 mask */
-    cpu_set_t mask;
-    void (*run)(void *job, int tid);        /* tid 1 .. planned (the caller is 0 and calls run itself) */
-    crew_slot slot[16];
+    int refs;                               /* atomic: the caller + every helper that has joined */
+    int planned;                            /* helpers wanted */
+    int joined;                             /* helpers that have joined (under the pool's lock): their tids are 1 .. joined */
+    void (*run)(void *job, int tid);        /* (the caller is tid 0 and does its part itself) */
     _Alignas(64) char job[];
 } crew;
+
+static struct {
+    pthread_mutex_t lock;
+    int n;                                  /* threads alive */
+    pid_t pid;                              /* the process they belong to (a forked child has none of them) */
+    int mask_for;                           /* what the pool is confined to: g_l3_mask_for's value then, -1 = not confined */
+    int mask_gen;                           /* bumped when `mask` changes: a thread that sees another value confines itself anew */
+    cpu_set_t mask;
+    uint32_t gen;                           /* futex word: bumped by every dispatch */
+    crew *current;                          /* the crew helpers may join, or NULL */
+} g_pool = {.lock = PTHREAD_MUTEX_INITIALIZER, .mask_for = -1};
 
 static crew *crew_new(size_t job_bytes, int helpers, void (*run)(void *, int))
 {
@@ -176,10 +191,8 @@ static crew *crew_new(size_t job_bytes, int helpers, void (*run)(void *, int))
     if (helpers > 15) helpers = 15;
     if (helpers < 0) helpers = 0;
     c->planned = helpers;
-    c->refs = 1 + helpers;
+    c->refs = 1;
     c->run = run;
-    c->confine = g_l3_mask_for >= 0 && !pin_is_off();
-    if (c->confine) c->mask = g_l3_mask;
     return c;
 }
 
@@ -188,41 +201,84 @@ static void crew_release(crew *c, int n)
     if (n > 0 && __atomic_sub_fetch(&c->refs, n, __ATOMIC_ACQ_REL) == 0) free(c);
 }
 
-static void *crew_helper(void *arg);
-
-/* start helper `tid` (and with it the chain behind it); a start that fails lets go of the references of every helper not started */
-static void crew_spawn(crew *c, int tid)
+static void *pool_thread(void *arg)
 {
-    if (tid > c->planned) return;
-    c->slot[tid].c = c;
-    c->slot[tid].tid = tid;
-    pthread_attr_t attr;
-    pthread_t th;
-    int rc = -1;
-    if (pthread_attr_init(&attr) == 0) {
-        pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);
-        if (c->confine) pthread_attr_setaffinity_np(&attr, sizeof c->mask, &c->mask);
-        rc = pthread_create(&th, &attr, crew_helper, &c->slot[tid]);
-        if (rc != 0 && c->confine) {            /* (an affinity the kernel refuses: anywhere, then) */
-            pthread_attr_destroy(&attr);
-            if (pthread_attr_init(&attr) == 0) {
-                pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);
-                rc = pthread_create(&th, &attr, crew_helper, &c->slot[tid]);
-            }
+    (void)arg;
+    uint32_t seen = 0;
+    int my_mask_gen = 0;
+    for (;;) {
+        /* sleep until a dispatch bumps the word (a bump between the load and the call makes the call return at once) */
+        while (__atomic_load_n(&g_pool.gen, __ATOMIC_ACQUIRE) == seen) syscall(SYS_futex, &g_pool.gen, FUTEX_WAIT_PRIVATE, seen, NULL, NULL, 0);
+        seen = __atomic_load_n(&g_pool.gen, __ATOMIC_ACQUIRE);
+        crew *c = NULL;
+        int tid = 0, confine_anew = 0;
+        cpu_set_t mask;
+        pthread_mutex_lock(&g_pool.lock);
+        if (my_mask_gen != g_pool.mask_gen) {
+            my_mask_gen = g_pool.mask_gen;
+            mask = g_pool.mask;
+            confine_anew = 1;
         }
-        pthread_attr_destroy(&attr);
+        if (g_pool.current && g_pool.current->joined < g_pool.current->planned) {
+            c = g_pool.current;
+            tid = ++c->joined;
+            __atomic_add_fetch(&c->refs, 1, __ATOMIC_ACQ_REL);
+        }
+        pthread_mutex_unlock(&g_pool.lock);
+        if (confine_anew) (void)sched_setaffinity(0, sizeof mask, &mask);      /* (refused: the thread stays where it may run) */
+        if (c) {
+            c->run(c->job, tid);
+            crew_release(c, 1);
+        }
     }
-    if (rc != 0) crew_release(c, c->planned - tid + 1);
+    return NULL;
 }
 
-static void *crew_helper(void *arg)
+/* make `c` the current crew and wake its helpers (the pool is grown to c->planned threads and confined to the caller's L3 first;
+ * threads that cannot be started are simply not there: the caller does their part) */
+static void crew_dispatch(crew *c)
 {
-    crew *c = ((crew_slot *)arg)->c;
-    const int tid = ((crew_slot *)arg)->tid;
-    crew_spawn(c, tid + 1);
-    c->run(c->job, tid);
-    crew_release(c, 1);
-    return NULL;
+    if (c->planned <= 0) return;
+    const int confine = g_l3_mask_for >= 0 && !pin_is_off();
+    if (g_pool.pid != getpid()) {           /* first use, or a forked child: no thread of the pool lives here (nor whoever held its lock) */
+        pthread_mutex_init(&g_pool.lock, NULL);
+        pthread_mutex_lock(&g_pool.lock);
+        g_pool.pid = getpid();
+        g_pool.n = 0;
+        g_pool.current = NULL;
+        g_pool.mask_for = -1;               /* (its threads will start unconfined, with mask_gen 0 behind the pool's) */
+    } else {
+        pthread_mutex_lock(&g_pool.lock);
+    }
+    while (g_pool.n < c->planned) {
+        pthread_attr_t attr;
+        pthread_t th;
+        if (pthread_attr_init(&attr) != 0) break;
+        pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);
+        pthread_attr_setstacksize(&attr, 256 * 1024);
+        const int rc = pthread_create(&th, &attr, pool_thread, NULL);
+        pthread_attr_destroy(&attr);
+        if (rc != 0) break;
+        ++g_pool.n;
+    }
+    const int want_mask = confine ? g_l3_mask_for : -1;
+    if (g_pool.mask_for != want_mask && (confine || g_allowed_known)) {
+        g_pool.mask = confine ? g_l3_mask : g_allowed_mask;      /* (the caller's L3 domain, or everything the process may use again) */
+        g_pool.mask_for = want_mask;
+        ++g_pool.mask_gen;
+    }
+    g_pool.current = c;
+    pthread_mutex_unlock(&g_pool.lock);
+    __atomic_add_fetch(&g_pool.gen, 1, __ATOMIC_RELEASE);
+    syscall(SYS_futex, &g_pool.gen, FUTEX_WAKE_PRIVATE, c->planned, NULL, NULL, 0);
+}
+
+/* nobody can join any more (the job's work is done) */
+static void crew_close(crew *c)
+{
+    pthread_mutex_lock(&g_pool.lock);
+    if (g_pool.current == c) g_pool.current = NULL;
+    pthread_mutex_unlock(&g_pool.lock);
 }
 
 typedef struct {
@@ -473,7 +529,7 @@ static Py_ssize_t pack_into_threads(PyObject **items, Py_ssize_t n, int64_t *op,
     job->room = room;
     job->n_chunks = n_chunks;
     op[0] = 0;
-    crew_spawn(c, 1);
+    crew_dispatch(c);
     pinto_run(job, 0);
     /* the call is over when the WORK is: every chunk of walk 2 done -- or walk 1 done and found wanting */
     Py_ssize_t got = -1;
@@ -486,6 +542,7 @@ static Py_ssize_t pack_into_threads(PyObject **items, Py_ssize_t n, int64_t *op,
             got = (Py_ssize_t)all;
         }
     }
+    crew_close(c);
     crew_release(c, 1);
     return got;
 }
@@ -1007,7 +1064,7 @@ static PyObject *fill_ranges(PyObject *self, PyObject *args)
     job->ctx = (void *)(uintptr_t)ctx_addr;
     job->first_slot = first_slot;
     job->stamps = (double *)(uintptr_t)stamps_addr;
-    crew_spawn(c, 1);
+    crew_dispatch(c);
     long none_old = 0, none_new = 0;
     int stale = 0;
     if (from_obj_addr) {          /* the From column, while the helpers wait for the first range */
@@ -1037,6 +1094,7 @@ static PyObject *fill_ranges(PyObject *self, PyObject *args)
     }
     for (int u = 0; u < 16; ++u) none_old += job->none_old[u];
     const int error = stale ? 2 : job->error;
+    crew_close(c);
     crew_release(c, 1);
     (void)none_new;                            /* (None's references were taken one by one with the others) */
     release_overwritten_none(none_old);

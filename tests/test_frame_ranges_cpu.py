@@ -206,3 +206,31 @@ def test_a_whole_frame_of_a_list_against_itself_goes_through_the_crew(monkeypatc
     del a, b
     rc1 = [sys.getrefcount(s) for s in names[:50]]
     assert rc1 == rc0
+
+
+def test_a_forked_child_starts_a_pool_of_its_own():
+    """the crews' threads are a pool that sleeps between calls; none of them lives in a forked child -- it must start its own (and
+    not wait for the parent's): pack on threads in the parent, fork, pack + fill on threads in the child"""
+    import os
+    names = [f"name {i} inc" for i in range(40000)]
+    n = len(names)
+    off_bytes = (8 * (n + 1) + 255) & ~255
+    buf = np.zeros(off_bytes + 48 * n, np.uint8)
+    want = _lib._pack.pack_into(names, 0, buf.ctypes.data, off_bytes, len(buf), 4)
+    assert want == sum(len(s) for s in names)
+    pid = os.fork()
+    if pid == 0:
+        ok = 1
+        try:
+            buf2 = np.zeros_like(buf)
+            got = _lib._pack.pack_into(names, 0, buf2.ctypes.data, off_bytes, len(buf2), 4)
+            idx = np.zeros((n, 2), np.int32)
+            val = np.full((n, 2), 0.5, np.float32)
+            _utils._RANGE_THREADS = 4
+            fb = _utils.FrameBuilder(names, names, 2, from_pending=True)
+            fb.fill_ranges(idx.ctypes.data, val.ctypes.data, [n], 0, 0, 0)
+            ok = 0 if got == want and np.array_equal(buf, buf2) and fb.names[1][n - 1] is names[0] and fb.from_col[5] is names[5] else 2
+        finally:
+            os._exit(ok)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
