@@ -17,7 +17,7 @@ timeout 300 python tools/k7_time.py 20000 WRatio,partial_ratio,token_ratio,parti
 timeout 300 python tools/k7_rowstats.py WRatio >> $O/k7_fuzz.txt 2>&1
 # the user-level call: round 5's form (a session launch per range) against the streamed session, then the host side on one thread
 # (round 6's first form) against the crews of host threads (packer + frame), one process, one box
-timeout 300 python tools/r6_match_ab.py "round 5 (launch per range, copying upload, one host thread):PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15,PFZ_DIRECT_PACK=0,PFZ_HOST_THREADS=1" "launch per range, direct pack, one host thread:PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15,PFZ_HOST_THREADS=1" "streamed12, copying upload, one host thread:PFZ_DIRECT_PACK=0,PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed5, one host thread:PFZ_MATCH_SHARES=1;1;1;1;1,PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed12, one host thread (round 6, first form):PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed12, range fill on one thread:PFZ_HOST_THREADS=1" "streamed12, crews of 2:PFZ_HOST_THREADS=2" "streamed12, crews of 4:PFZ_HOST_THREADS=4" "streamed12, crews of 8 (default):" "streamed12, packer alone on 8:PFZ_RANGE_THREADS=1" "streamed12, frame alone on 8:PFZ_PACK_INTO_THREADS=1" "streamed12, crews of 8 placed by the scheduler:PFZ_HOST_PIN=0" "streamed16, crews of 8:PFZ_MATCH_SHARES=1;1;1;1;1;1;1;1;1;1;1;1;1;1;1;1" > $O/match_ab.txt 2>&1
+timeout 300 python tools/r6_match_ab.py "round 5 (launch per range, copying upload, one host thread):PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15,PFZ_DIRECT_PACK=0,PFZ_HOST_THREADS=1" "launch per range, direct pack, one host thread:PFZ_K3_NO_STREAMED=1,PFZ_MATCH_SHARES=0.3;0.3;0.25;0.15,PFZ_HOST_THREADS=1" "streamed12, copying upload, one host thread:PFZ_DIRECT_PACK=0,PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed5, one host thread:PFZ_MATCH_SHARES=1;1;1;1;1,PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed12, one host thread (round 6, first form):PFZ_HOST_THREADS=1,PFZ_RANGE_FILL=0" "streamed12, range fill on one thread:PFZ_HOST_THREADS=1" "streamed12, crews of 2:PFZ_HOST_THREADS=2" "streamed12, crews of 4:PFZ_HOST_THREADS=4" "streamed12, crews of 8 (default):" "streamed12, packer alone on 8:PFZ_RANGE_THREADS=1" "streamed12, frame alone on 8:PFZ_PACK_INTO_THREADS=1" "streamed12, crews of 8, confinement lifted (the pool's threads stay where they last ran -- threads the scheduler places afresh: frame_fill_mt.txt):PFZ_HOST_PIN=0" "streamed16, crews of 8:PFZ_MATCH_SHARES=1;1;1;1;1;1;1;1;1;1;1;1;1;1;1;1" > $O/match_ab.txt 2>&1
 # what the frame fill's variants cost on this host's CPU, on threads the scheduler places and on threads on the caller's L3
 (gcc -O3 -msse4.1 tools/ubench/frame_fill_mt.c -lpthread -lm -o /tmp/ffmt && /tmp/ffmt && /tmp/ffmt pin) > $O/frame_fill_mt.txt 2>&1
 # the streamed session's range chains on 1 / 2 (shipped) / 3 / 4 side streams: variants/sidesK.so, built by tools/r6_final_local.sh from this commit
