@@ -235,7 +235,7 @@ def sharded_self_match(ctx, comm, names, top_n=1, min_similarity=0.0, n_gram_ran
     the rows (`TfidfMatchJob`: K3's symmetric form cut over the ranks where it applies, cost-balanced row shards otherwise), the
     exchange leaves the full result on every rank, and every rank builds the frame from it."""
     from .models._utils import topn_to_frame
-    names = list(names)
+    names = names if isinstance(names, list) else list(names)       # (no copy of a list: 100 000 references taken and dropped per call)
     # (row shards of equal ROWS up to the size K3's symmetric form takes -- it deals the rows r, r + world, ... itself and the cuts only
     # name what each rank uploads --, of equal characters beyond: balanced_bounds walks every string, 10 ms per 100 000 names, which
     # is three of these calls)
