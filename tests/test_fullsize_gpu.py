@@ -329,3 +329,46 @@ def test_headline_match_frame(headline):
         exp = [None if none[i] else names[j] for i, j in enumerate(idx[:, r].tolist())]
         assert df["To" if r == 0 else f"To_{r + 1}"].tolist() == exp
     assert set(m.last_timings) == {"upload_and_enqueue", "from_column", "wait_and_download", "frame"}
+
+
+@pytest.mark.parametrize("setting", ["one host thread, ranges filled from Python", "one host thread", "crews of 3",
+                                     "crews of 8, confinement lifted", "From column in the packer's walk"])
+def test_headline_match_frame_under_the_host_thread_settings(headline, monkeypatch, setting):
+    """Round 6, second half: the string packer and the frame's range fill on crews of host threads (PFZ_HOST_THREADS, PFZ_HOST_PIN,
+    PFZ_RANGE_FILL -- read at import: set on the modules here).  Every setting returns the frame of the default, cell for cell, and
+    leaves the names' reference counts where they were."""
+    import sys
+    from polyfuzz_amd import _lib
+    from polyfuzz_amd.models import TFIDF, _tfidf, _utils
+    names = headline[0]
+    m = TFIDF(min_similarity=0, top_n=5)
+    want = m.match(names)
+    rc0 = [sys.getrefcount(s) for s in names[:2000]]
+    if setting == "one host thread, ranges filled from Python":
+        monkeypatch.setattr(_tfidf, "_RANGE_FILL", False)
+        monkeypatch.setattr(_utils, "_RANGE_THREADS", 1)
+        monkeypatch.setattr(_lib, "_PACK_INTO_THREADS", 1)
+    elif setting == "one host thread":
+        monkeypatch.setattr(_utils, "_RANGE_THREADS", 1)
+        monkeypatch.setattr(_lib, "_PACK_INTO_THREADS", 1)
+    elif setting == "crews of 3":
+        monkeypatch.setattr(_utils, "_RANGE_THREADS", 3)
+        monkeypatch.setattr(_lib, "_PACK_INTO_THREADS", 3)
+    elif setting == "crews of 8, confinement lifted":
+        monkeypatch.setattr(_utils, "_RANGE_THREADS", 8)
+        monkeypatch.setattr(_lib, "_PACK_INTO_THREADS", 8)
+        monkeypatch.setenv("PFZ_HOST_PIN", "0")
+    else:
+        monkeypatch.setattr(_lib, "_PACK_INTO_THREADS", 1)          # (the From column rides on the single walk again)
+    for _ in range(3):
+        got = m.match(names)
+        assert list(got.columns) == list(want.columns)
+        for c in want.columns:
+            if c.startswith("Similarity"):
+                np.testing.assert_array_equal(got[c].to_numpy(), want[c].to_numpy())
+            else:
+                a, b = got[c].to_numpy(), want[c].to_numpy()
+                assert all(x is y for x, y in zip(a, b)), c
+        del got, a, b
+    rc1 = [sys.getrefcount(s) for s in names[:2000]]
+    assert rc1 == rc0
