@@ -148,10 +148,14 @@ __global__ __launch_bounds__(1024) void k3_sym_order(const K3SymArgs a)
     __shared__ int s_gmin[256];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 256) s_gmin[threadIdx.x] = kNoThr;
+    if (threadIdx.x == 0 && a.done) a.done[b * kSymDoneStride] = 0u;
     __syncthreads();
     for (int rho = wave * 2; rho < wave * 2 + 2; ++rho) {
         const int r = rho + 32 * lane;
         const int row = b * kSymC + r;
+        // (the chores that were memsets of their own in front of pass 0, ~6 us each on the stream: nobody has pushed anything to a
+        // row yet -- pass 0 hands nothing over --, and no pass-1 item has counted itself)
+        if (row < a.n) a.push_cnt[row] = 0;
         const int thr = row < a.n ? a.thrv[thr_pos(a, row)] : kNoThr;
         // (thresholds are >= 0: they start at thr0 >= 0 and only rise)
         const uint64_t key = ((uint64_t)(uint32_t)thr << 6) | (uint32_t)lane;
@@ -967,8 +971,7 @@ int k3_sym_launch(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, int64_t r
     a.out_val = out->val;
     if (start) {
         // pass 0 over ALL rows: every row's first threshold is there before anybody hands anything over; then the re-deal of
-        // every block's rows to the accumulator slots and the re-dealt copy of the postings
-        PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
+        // every block's rows to the accumulator slots and the re-dealt copy of the postings (k3_sym_order also clears push_cnt)
         a.row_begin = 0;
         a.row_end = (int32_t)n;
         // (workgroups that loop over a few rows each: the loop is what lets a row's loads be fetched under the row before it.
@@ -1068,8 +1071,7 @@ int k3_sym_launch_streamed(pfz_ctx *ctx, const pfz_index *ix, const pfz_csr *A, 
     a.out_val = out->val;
     a.host_idx = host_idx;
     a.host_val = host_val;
-    PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
-    PFZ_HIP(hipMemsetAsync(s->done, 0, (size_t)nb * kSymDoneStride * sizeof(uint32_t), ctx->stream));
+    a.done = s->done;          // (k3_sym_order clears push_cnt and the blocks' counters: no memset of their own in front of pass 0)
     const unsigned grid0 = (unsigned)std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * kSymP0PerCu);
     hipLaunchKernelGGL((k3_sym_kernel<kSymC, 0>), dim3(grid0), dim3(64), 0, ctx->stream, a);
     hipLaunchKernelGGL(k3_sym_order, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, a);
@@ -1234,8 +1236,7 @@ static int k3_sym_sharded_body(pfz_ctx *ctx, pfz_comm *comm, const pfz_index *ix
     a.per = (int32_t)((n + n_parts - 1) / n_parts);
     a.thr_by_part = 1;
     a.keys_out = mine.p;
-    PFZ_HIP(hipMemsetAsync(s->push_cnt, 0, (size_t)n * sizeof(int32_t), ctx->stream));
-    PFZ_HIP(hipMemsetAsync(s->ovf, 0, sizeof(int32_t), ctx->stream));
+    PFZ_HIP(hipMemsetAsync(s->ovf, 0, sizeof(int32_t), ctx->stream));      // (push_cnt: cleared by k3_sym_order)
     // pass 0 of this part's rows; the parts' thresholds, stretch by stretch, complete thrv on every GPU
     a.row_begin = part;
     a.row_end = (int32_t)n;
