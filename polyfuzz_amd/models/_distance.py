@@ -17,7 +17,7 @@ import pandas as pd
 
 from .. import _lib
 from ._base import BaseMatcher
-from ._utils import gather_column, object_column
+from ._utils import pair_frame, pair_frame_blocks
 
 
 def _device_scorer(scorer) -> str:
@@ -79,11 +79,10 @@ class EditDistance(BaseMatcher):
         packed groups) are used again -- no upload, no preparation.  Any other list is uploaded. """
         t0 = time.perf_counter()
         pending, names = self._best(from_list, to_list, reuse_to=kwargs.get("re_train", True) is False)
-        from_col = object_column(from_list)          # host work while the device scores
+        blocks = pair_frame_blocks(from_list)        # (the From column: host work while the device scores)
         idx, score = pending.result()
         t1 = time.perf_counter()
-        to_col = gather_column(names, idx)
-        matches = pd.DataFrame({"From": from_col, "To": to_col, "Similarity": score}, copy=False)
+        matches = pair_frame(from_list, names, idx, score, blocks=blocks)
         if self.normalize:      # global min-max over the best scores, _distance.py:83-86
             matches["Similarity"] = (matches["Similarity"] -
                                      matches["Similarity"].min()) / (matches["Similarity"].max() -

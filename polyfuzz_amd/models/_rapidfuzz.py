@@ -34,7 +34,7 @@ import pandas as pd
 
 from .. import _lib
 from ._base import BaseMatcher
-from ._utils import gather_column, object_column
+from ._utils import pair_frame, pair_frame_blocks
 
 _K4_SCORERS = ("ratio", "QRatio", "token_sort_ratio")
 _DEVICE_SCORERS = _K4_SCORERS + tuple(_lib.FUZZ_SCORERS)
@@ -175,21 +175,20 @@ class RapidFuzz(BaseMatcher):
             for j, s in enumerate(names):
                 first.setdefault(s, j)
             skip = np.fromiter((first[s] for s in from_list), np.int32, n)
-        from_col = None
+        blocks = None
         if n == 0 or len(names) - (1 if self_match else 0) <= 0:
             idx, score = np.full(n, -1, np.int32), np.zeros(n)             # extractOne over no choices: None
-            from_col = object_column(from_list)
+            blocks = pair_frame_blocks(from_list)
         else:
             if not self_match:
                 self._to_dev, self._to_names = (held if reuse else upload_for(ctx, self._scorer_name, names)), snap
             pending = best_choice_async(ctx, self._scorer_name, from_list, names, skip, self_match,
                                         to_dev=None if self_match else self._to_dev)
-            from_col = object_column(from_list)                              # (host work while the device scores)
+            blocks = pair_frame_blocks(from_list)                            # (the From column: host work while the device scores)
             idx, score = pending.result()
         hit = (idx >= 0) & (score >= self.score_cutoff)                       # extractOne: best score >= score_cutoff
-        to_col = gather_column(names, idx, hit)
         sim = np.where(hit, score / 100, 0.0)
-        return pd.DataFrame({"From": from_col, "To": to_col, "Similarity": sim}, copy=False)
+        return pair_frame(from_list, names, idx, sim, keep=hit, blocks=blocks)
 
     # a matcher is pickled by joblib (reference polyfuzz.py:429-457): device handles stay behind
     def __getstate__(self):

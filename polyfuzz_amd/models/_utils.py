@@ -21,9 +21,13 @@ _METHODS = ("sparse", "sklearn", "knn", "hip")
 _RANGE_THREADS = _lib.host_threads()
 
 
-def object_column(strings) -> np.ndarray:
-    """list[str] -> 1-D object ndarray (the From column; built while the GPU is still busy)."""
-    arr = np.empty(len(strings), dtype=object)
+_BLOCK_FRAME_ROWS = 20000       # frames of fewer rows live in their two blocks from the start (FrameBuilder); = TFIDF's _SPLIT_MIN_ROWS
+
+
+def object_column(strings, out=None) -> np.ndarray:
+    """list[str] -> 1-D object ndarray (the From column; built while the GPU is still busy).  out: a fresh, contiguous object array
+    of that length to fill instead"""
+    arr = np.empty(len(strings), dtype=object) if out is None else out
     if _lib._pack is not None and isinstance(strings, (list, tuple)) and hasattr(_lib._pack, "fill_objects"):
         _lib._pack.fill_objects(strings, arr.ctypes.data, len(strings))      # (numpy's own assignment is 10x slower)
     else:
@@ -31,12 +35,13 @@ def object_column(strings) -> np.ndarray:
     return arr
 
 
-def gather_column(names, idx, keep=None) -> np.ndarray:
+def gather_column(names, idx, keep=None, out=None) -> np.ndarray:
     """object column of names[idx[i]] (None where `keep[i]` is false or idx[i] < 0): one pass of the CPython helper
-    (prefetched gathers of the names), or -- without it -- one fancy-index over an object pool"""
+    (prefetched gathers of the names), or -- without it -- one fancy-index over an object pool.  out: a fresh, contiguous object
+    array of len(idx) to fill instead"""
     if _lib._pack is not None and isinstance(names, (list, tuple)) and hasattr(_lib._pack, "gather_objects"):
         j = np.ascontiguousarray(idx, np.int32)
-        out = np.empty(len(j), dtype=object)
+        out = np.empty(len(j), dtype=object) if out is None else out
         k = None if keep is None else np.ascontiguousarray(keep, np.uint8)
         _lib._pack.gather_objects(names, j.ctypes.data, len(j), out.ctypes.data, 0 if k is None else k.ctypes.data)
         return out
@@ -45,7 +50,37 @@ def gather_column(names, idx, keep=None) -> np.ndarray:
     pool[len(names)] = None
     j = np.asarray(idx, np.int64)
     bad = j < 0 if keep is None else (j < 0) | ~np.asarray(keep, bool)
-    return pool[np.where(bad, len(names), j)]
+    col = pool[np.where(bad, len(names), j)]
+    if out is None:
+        return col
+    out[:] = col
+    return out
+
+
+def pair_frame(from_list, names, idx, sim, keep=None, from_col=None, blocks=None) -> pd.DataFrame:
+    """The From / To / Similarity frame of the best-match matchers (reference _distance.py:77-81, _rapidfuzz.py:84-91): To = names[idx]
+    (None where idx < 0 or `keep` is false), Similarity = sim.  blocks: what pair_frame_blocks() returned -- the From column is
+    in its place already (blocks[0][0], filled while the device worked) and the frame is put together from the two blocks without
+    pandas' constructor and without a copy; None: the constructor's frame."""
+    if blocks is None:
+        if from_col is None:
+            from_col = object_column(from_list)
+        return pd.DataFrame({"From": from_col, "To": gather_column(names, idx, keep), "Similarity": sim}, copy=False)
+    obj, flt = blocks
+    gather_column(names, idx, keep, out=obj[1])
+    flt[0] = sim
+    return _fast_frame_of_blocks(obj, flt)
+
+
+def pair_frame_blocks(from_list):
+    """the two blocks of a From / To / Similarity frame with the From column filled in -- (object[2][n], float64[1][n]) --, or None
+    where the block shortcut does not apply (no CPython helper, a from-list that is no list, a pandas whose parts differ)"""
+    if _lib._pack is None or not isinstance(from_list, (list, tuple)) or not _fast_frame_ok():
+        return None
+    n = len(from_list)
+    obj, flt = np.empty((2, n), dtype=object), np.empty((1, n), np.float64)
+    object_column(from_list, out=obj[0])
+    return obj, flt
 
 
 # ---- a small result frame without pandas' constructor -----------------------------------------------------------------
@@ -86,6 +121,15 @@ def _fast_frame(from_col, names, sims):
     return pd.DataFrame._from_mgr(mgr, axes=mgr.axes)
 
 
+def _fast_frame_of_blocks(obj, flt):
+    """_fast_frame() around blocks that exist already: obj[0] = From, obj[1 + r] = To_r, flt[r] = Similarity_r (no copy)"""
+    from pandas.core.internals.blocks import new_block_2d
+    from pandas.core.internals.managers import BlockManager
+    cols, obj_at, flt_at = _fast_frame_parts(len(flt))
+    mgr = BlockManager((new_block_2d(obj, obj_at), new_block_2d(flt, flt_at)), [cols, pd.RangeIndex(obj.shape[1])], verify_integrity=False)
+    return pd.DataFrame._from_mgr(mgr, axes=mgr.axes)
+
+
 def _fast_frame_ok():
     if _FAST_FRAME["ok"] is None:
         ok = False
@@ -117,9 +161,26 @@ class FrameBuilder:
         self.n, self.top_n, self.to_list = len(from_list), top_n, to_list
         self.from_list = from_list
         self.from_pending = bool(from_pending and from_col is None)
-        self.from_col = np.empty(self.n, dtype=object) if self.from_pending else object_column(from_list) if from_col is None else from_col
-        self.names = [np.empty(self.n, dtype=object) for _ in range(top_n)]
-        self.sims = [np.empty(self.n, np.float64) for _ in range(top_n)]
+        # A frame that is not built under the device's work (fewer rows than a split match has) lives in its two BLOCKS from the start
+        # -- one object array (From, To, To_2 ...) x rows, one float64 array (the similarities) x rows: the columns below are rows of
+        # them, the fills write there, and frame() puts the DataFrame together from the blocks (_fast_frame_of_blocks) without
+        # pandas' constructor looking at eleven columns (0.3 ms of a 0.75-ms match of 10 000 x 10 000 names) and without a copy.
+        self._blocks = None
+        if top_n >= 1 and self.n < _BLOCK_FRAME_ROWS and _fast_frame_ok():
+            obj = np.empty((1 + top_n, self.n), dtype=object)
+            flt = np.empty((top_n, self.n), np.float64)
+            self._blocks = (obj, flt)
+            if from_col is not None:
+                obj[0] = from_col
+            elif not self.from_pending:
+                object_column(from_list, out=obj[0])
+            self.from_col = obj[0]
+            self.names = [obj[1 + r] for r in range(top_n)]
+            self.sims = [flt[r] for r in range(top_n)]
+        else:
+            self.from_col = np.empty(self.n, dtype=object) if self.from_pending else object_column(from_list) if from_col is None else from_col
+            self.names = [np.empty(self.n, dtype=object) for _ in range(top_n)]
+            self.sims = [np.empty(self.n, np.float64) for _ in range(top_n)]
         # (the columns' data addresses, taken ONCE: `ndarray.ctypes` builds a helper object on every access -- ten of them per
         # filled row range were 10 - 18 us of a range's 80)
         self._name_at = [a.ctypes.data for a in self.names]
@@ -128,7 +189,7 @@ class FrameBuilder:
         # pandas takes ~0.5 ms to look at eleven 100 000-element columns -- and `fill` writes through the arrays it shares
         # with them.  Only if this pandas really shares them (copy=False is a request): otherwise frame() builds it at the end.
         self._frame = None
-        if self.n >= 8192 and top_n and os.environ.get("PFZ_EARLY_FRAME", "1") != "0":     # (a small frame is made in no time, and the sharing checks below would be most of a single query's host time)
+        if self._blocks is None and self.n >= 8192 and top_n and os.environ.get("PFZ_EARLY_FRAME", "1") != "0":     # (a small frame is made in no time, and the sharing checks below would be most of a single query's host time)
             # (pandas scans an object column for date-likes until it meets a non-null: an all-None column is scanned to its end.
             # The first slot holds a string while the frame is made, and None again before anything is filled in)
             empty = self.names + ([self.from_col] if self.from_pending else [])
@@ -181,6 +242,8 @@ class FrameBuilder:
             self.fill_raw(idx.ctypes.data, val.ctypes.data, m, row0)
 
     def _wrap(self):
+        if self._blocks is not None:
+            return _fast_frame_of_blocks(*self._blocks)
         if self.top_n and self.n < 8192 and _fast_frame_ok():
             return _fast_frame(self.from_col, self.names, self.sims)
         data = {"From": self.from_col}

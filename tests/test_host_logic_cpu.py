@@ -324,3 +324,48 @@ def test_pack_into_a_caller_s_buffer_equals_pack():
         assert all(c is None for c in col) and rc1 == rc0
     with pytest.raises(ValueError):
         _lib._pack.pack_into(names, 0, buf.ctypes.data, 8, len(buf))
+
+
+def test_pair_frames_from_their_blocks_equal_the_constructor_s():
+    """The From / To / Similarity frame of EditDistance / RapidFuzz put together from two blocks that exist before the device's result
+    does (pair_frame_blocks / pair_frame: no pandas constructor, no copy), and a TFIDF frame of fewer rows than a split match has
+    living in its blocks from the start (FrameBuilder): equal to the constructor's frames -- values, dtypes, columns, index --,
+    ordinary frames afterwards, the names' reference counts balanced."""
+    import sys
+    import pandas as pd
+    from polyfuzz_amd import _lib
+    from polyfuzz_amd.models import _utils
+    if _lib._pack is None or not _utils._fast_frame_ok():
+        pytest.skip("_pack.so not built / this pandas' parts differ")
+    rng = np.random.default_rng(5)
+    names = [f"name {i}" for i in range(300)]
+    from_list = [f"q{i}" for i in range(12000)]
+    n = len(from_list)
+    idx = rng.integers(-1, len(names), n).astype(np.int32)
+    sim = rng.random(n)
+    keep = rng.random(n) < 0.8
+    rc0 = sys.getrefcount(names[7])
+    for k in (None, keep):
+        fast = _utils.pair_frame(from_list, names, idx, sim, keep=k, blocks=_utils.pair_frame_blocks(from_list))
+        slow = _utils.pair_frame(from_list, names, idx, sim, keep=k)
+        pd.testing.assert_frame_equal(fast, slow)
+        assert list(fast.columns) == ["From", "To", "Similarity"] and isinstance(fast.index, pd.RangeIndex)
+        fast["Similarity"] = (fast["Similarity"] - fast["Similarity"].min()) / (fast["Similarity"].max() - fast["Similarity"].min())
+        assert fast["Similarity"].max() == 1.0 and fast["To"].isna().sum() == int(((idx < 0) | (~k if k is not None else False)).sum())
+        del fast, slow
+    rc1 = sys.getrefcount(names[7])
+    assert rc1 == rc0
+    assert _utils.pair_frame_blocks(tuple(from_list)) is not None and _utils.pair_frame_blocks(np.array(from_list, dtype=object)) is None
+    # a TFIDF frame of 12 000 rows: blocks from the start
+    top_n = 3
+    i2 = rng.integers(-1, len(names) + 1, (n, top_n)).astype(np.int32)
+    v2 = rng.random((n, top_n)).astype(np.float32)
+    fb = _utils.FrameBuilder(from_list, names, top_n)
+    assert fb._blocks is not None and fb.names[0].base is fb._blocks[0]
+    fb.fill(i2, v2, 0)
+    a, b = fb.frame(), _utils._topn_to_frame_numpy(i2, v2, from_list, names, top_n)
+    pd.testing.assert_frame_equal(a, b)
+    assert np.shares_memory(a["To_2"].to_numpy(), fb._blocks[0])
+    del a, b, fb
+    rc2 = sys.getrefcount(names[7])
+    assert rc2 == rc0
