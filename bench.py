@@ -774,6 +774,11 @@ def headline(world, ctx, args):
         return None
     if user_step is not None:
         out["config"]["timed_step"] = user_what
+        # what the user-level call runs on beside the GPU: the string packer and the frame's range fill work on a pool of host threads
+        # confined to the cores that share the calling thread's L3 (polyfuzz_amd/csrc_host/_pack.c); PFZ_HOST_THREADS=1 = the calling thread alone
+        from polyfuzz_amd import _lib as _pl
+        out["config"]["host_threads"] = {"per_call": int(_pl.host_threads()), "usable_cpus": int(_pl.usable_cpus()),
+                                         "confined_to_the_callers_l3": os.environ.get("PFZ_HOST_PIN", "1") != "0"}
         if size == 1 and len(step_walls) >= args.steps:
             # every timed call under its own clock (the region's clock is what `ms_per_step` comes from): one slow call -- a helper
             # thread's core waking up, a neighbour on the host -- shows here instead of hiding in the mean
